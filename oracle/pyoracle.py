@@ -1,0 +1,154 @@
+"""ctypes binding of oracle/_build/liboracle.so (test infrastructure only)."""
+
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "_build" / "liboracle.so"
+_lib = None
+
+_u8p = C.POINTER(C.c_uint8)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+
+
+def build(force: bool = False) -> Path:
+    """Compile the C restatement with gcc (a few hundred ms)."""
+    src = _HERE / "sourmash_oracle.c"
+    if force or not _LIB_PATH.is_file() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+        subprocess.run(["make", "-C", str(_HERE), "-s", "-B"], check=True)
+    return _LIB_PATH
+
+
+def _load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(str(_LIB_PATH))
+        lib.orc_murmur3_h1.restype = C.c_uint64
+        lib.orc_murmur3_h1.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32]
+        lib.orc_max_hash.restype = C.c_uint64
+        lib.orc_max_hash.argtypes = [C.c_uint64]
+        lib.orc_sketch_fasta.restype = C.c_int64
+        lib.orc_sketch_fasta.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, _u64p, C.c_uint64, _u64p]
+        lib.orc_sketch_seq.restype = C.c_int64
+        lib.orc_sketch_seq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, _u64p, C.c_uint64]
+        lib.orc_sketch_many.restype = C.c_int
+        lib.orc_sketch_many.argtypes = [_u8p, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _u64p, _u64p, _i64p, C.c_int]
+        lib.orc_intersect.restype = C.c_uint32
+        lib.orc_intersect.argtypes = [_u64p, C.c_uint64, _u64p, C.c_uint64]
+        lib.orc_pair_counts.restype = None
+        lib.orc_pair_counts.argtypes = [_u64p, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, C.c_int]
+        lib.orc_ani.restype = None
+        lib.orc_ani.argtypes = [_u32p, _u64p, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _f64p, _f64p, _u8p]
+        _lib = lib
+    return _lib
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(t)
+
+
+def murmur3_h1(data: bytes, seed: int = 42) -> int:
+    return int(_load().orc_murmur3_h1(data, len(data), seed))
+
+
+def max_hash(scaled: int) -> int:
+    return int(_load().orc_max_hash(scaled))
+
+
+def sketch_fasta_text(text: bytes, k: int, scaled: int) -> tuple[np.ndarray, int]:
+    """(sorted unique hashes, total residues) of a decompressed FASTA text."""
+    lib = _load()
+    cap = max(1024, len(text) // max(1, scaled) * 2 + 1024)
+    total = C.c_uint64(0)
+    while True:
+        out = np.empty(cap, dtype=np.uint64)
+        n = lib.orc_sketch_fasta(text, len(text), k, max_hash(scaled), _p(out, _u64p), cap, C.byref(total))
+        if n < 0:
+            raise MemoryError("oracle allocation failed")
+        if n <= cap:
+            return out[:n].copy(), int(total.value)
+        cap = int(n)
+
+
+def sketch_seq(seq: bytes, k: int, scaled: int) -> np.ndarray:
+    lib = _load()
+    cap = max(1024, len(seq) // max(1, scaled) * 2 + 1024)
+    while True:
+        out = np.empty(cap, dtype=np.uint64)
+        n = lib.orc_sketch_seq(seq, len(seq), k, max_hash(scaled), _p(out, _u64p), cap)
+        if n < 0:
+            raise MemoryError("oracle allocation failed")
+        if n <= cap:
+            return out[:n].copy()
+        cap = int(n)
+
+
+def sketch_many(seqs: list[bytes] | list[np.ndarray], k: int, scaled: int, threads: int = 1) -> list[np.ndarray]:
+    """Sketch bare residue strings, one OpenMP task each."""
+    lib = _load()
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    flat = np.empty(int(off[-1]), dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        flat[int(off[i]) : int(off[i + 1])] = np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else s
+    caps = np.maximum(1024, lens // max(1, scaled) * 2 + 1024).astype(np.uint64)
+    while True:
+        ooff = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(caps, out=ooff[1:])
+        out = np.empty(int(ooff[-1]), dtype=np.uint64)
+        sizes = np.zeros(len(seqs), dtype=np.int64)
+        rc = lib.orc_sketch_many(_p(flat, _u8p), _p(off, _u64p), len(seqs), k, max_hash(scaled), _p(out, _u64p), _p(ooff, _u64p), _p(sizes, _i64p), threads)
+        if (sizes < 0).any():
+            raise MemoryError("oracle allocation failed")
+        if rc == 0:
+            return [out[int(ooff[i]) : int(ooff[i]) + int(sizes[i])].copy() for i in range(len(seqs))]
+        caps = np.maximum(caps, sizes.astype(np.uint64))
+
+
+def intersect(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    return int(_load().orc_intersect(_p(a, _u64p), len(a), _p(b, _u64p), len(b)))
+
+
+def _csr(sketches: list[np.ndarray]) -> tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(sketches) + 1, dtype=np.uint64)
+    np.cumsum([len(s) for s in sketches], out=off[1:])
+    flat = np.concatenate([np.asarray(s, dtype=np.uint64) for s in sketches]) if sketches else np.empty(0, np.uint64)
+    return np.ascontiguousarray(flat, dtype=np.uint64), off
+
+
+def pair_counts(sketches: list[np.ndarray], q_range=None, s_range=None, threads: int = 1) -> np.ndarray:
+    """counts[q, s] = |sketch q ∩ sketch s| for the given index ranges (default all)."""
+    flat, off = _csr(sketches)
+    n = len(sketches)
+    q0, q1 = q_range or (0, n)
+    s0, s1 = s_range or (0, n)
+    counts = np.zeros((q1 - q0, s1 - s0), dtype=np.uint32)
+    if flat.size == 0:
+        flat = np.zeros(1, dtype=np.uint64)
+    _load().orc_pair_counts(_p(flat, _u64p), _p(off, _u64p), q0, q1, s0, s1, _p(counts, _u32p), threads)
+    return counts
+
+
+def ani(counts: np.ndarray, q_sizes, s_sizes, k: int) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(identity, cov_query, is_null) as the reference maps manysearch rows."""
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    nq, ns = counts.shape
+    q_sizes = np.ascontiguousarray(q_sizes, dtype=np.uint64)
+    s_sizes = np.ascontiguousarray(s_sizes, dtype=np.uint64)
+    ident = np.empty((nq, ns), dtype=np.float64)
+    cov = np.empty((nq, ns), dtype=np.float64)
+    null = np.empty((nq, ns), dtype=np.uint8)
+    _load().orc_ani(_p(counts, _u32p), _p(q_sizes, _u64p), _p(s_sizes, _u64p), nq, ns, k, _p(ident, _f64p), _p(cov, _f64p), _p(null, _u8p))
+    return ident, cov, null.astype(bool)
