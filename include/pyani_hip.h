@@ -1,0 +1,166 @@
+/*
+ * pyani_hip.h -- C ABI of libpyani_hip.so, the MI355X (gfx950) compute backend
+ * for pyani-plus's all-vs-all sketch -> ANI path.
+ *
+ * pyani-plus has no FFI of its own: its sourmash method shells out to
+ * third-party tools.  Each entry point below therefore
+ * replaces one *process launch* on that path, and the Python method module
+ * (pyani_plus_amd/methods/sourmash_hip.py) binds them with ctypes exactly as a
+ * maintainer would from pyani_plus/methods/ (stub shown in INTEGRATION.md).
+ *
+ *   pa_pack_fasta / pa_pack_seq   FASTA text -> 2-bit arena
+ *        replaces the FASTA reader inside `sourmash scripts singlesketch`
+ *        (pyani_plus/methods/sourmash.py:67-83); record/whitespace semantics of
+ *        pyani_plus/utils.py:67-90.
+ *   pa_sketch                     arena -> FracMinHash sketches (CSR of u64)
+ *        replaces `sourmash scripts singlesketch -I DNA -p k=K,scaled=S`
+ *        (pyani_plus/methods/sourmash.py:62-84).
+ *   pa_pair_counts                sketches -> |Q n S| for a query x subject tile
+ *        replaces `sourmash sig collect` x2 + `sourmash scripts manysearch`
+ *        (pyani_plus/methods/sourmash.py:162-200).
+ *   pa_ani / pa_ani_host          counts -> (identity, cov_query)
+ *        replaces the manysearch CSV columns read at
+ *        pyani_plus/methods/sourmash.py:107-110 and their mapping at
+ *        pyani_plus/private_cli.py:1879-1880.
+ *
+ * Conventions: plain pointers and sizes only.  `d_` arguments are DEVICE
+ * pointers (hipMalloc / torch storage), `h_` are host pointers.  Every function
+ * returns 0 on success or a negative pa_status; pa_last_error() gives the
+ * message of the calling thread's last failure.  A context is bound to one GPU
+ * and one HIP stream and is not thread-safe.  Work is enqueued on the context's
+ * stream; functions that return sizes to the host synchronise that stream.
+ * There is NO CPU fallback: without a usable HIP device pa_ctx_create fails.
+ */
+#ifndef PYANI_HIP_H
+#define PYANI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1
+
+/* every entry point below is exported with default visibility */
+#define PA_API __attribute__((visibility("default")))
+
+typedef enum pa_status {
+  PA_OK = 0,
+  PA_E_INVALID = -1,   /* bad argument */
+  PA_E_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+  PA_E_NOMEM = -3,     /* host or device allocation failed */
+  PA_E_CAPACITY = -4,  /* caller buffer too small; required size reported */
+  PA_E_NODEVICE = -5   /* no usable gfx950 device */
+} pa_status;
+
+typedef struct pa_ctx pa_ctx;
+
+/* Arena geometry: every genome starts at a multiple of PA_ALIGN_BASES bases. */
+#define PA_ALIGN_BASES 64u
+#define PA_MAX_K 32u
+
+/* ---- library / context ---- */
+PA_API int pa_abi_version(void);
+PA_API const char *pa_last_error(void);
+/* number of HIP devices visible (0 if none; never initialises a context) */
+PA_API int pa_device_count(void);
+PA_API int pa_ctx_create(int device, pa_ctx **out);
+PA_API void pa_ctx_destroy(pa_ctx *ctx);
+/* Adopt an existing hipStream_t (e.g. torch's current stream).  NULL is HIP's default
+ * (null) stream, which is what torch uses unless told otherwise.  A new context starts
+ * on a private non-blocking stream; pa_ctx_own_stream() returns to it. */
+PA_API int pa_ctx_set_stream(pa_ctx *ctx, void *hip_stream);
+PA_API int pa_ctx_own_stream(pa_ctx *ctx);
+PA_API int pa_ctx_sync(pa_ctx *ctx);
+/* Device properties: name (<=255 chars), CU count, bytes of global memory. */
+PA_API int pa_ctx_device_info(pa_ctx *ctx, char *name256, int *compute_units, uint64_t *global_mem);
+
+/* ---- raw device memory, for callers without their own allocator ---- */
+PA_API int pa_dev_alloc(pa_ctx *ctx, uint64_t bytes, void **d_out);
+PA_API int pa_dev_free(pa_ctx *ctx, void *d_ptr);
+PA_API int pa_memcpy_h2d(pa_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+PA_API int pa_memcpy_d2h(pa_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+PA_API int pa_memset_d(pa_ctx *ctx, void *d_dst, int value, uint64_t bytes);
+
+/* ---- host side: text -> 2-bit arena (no GPU needed) ----
+ * Arena layout (DESIGN.md "Data layout"):
+ *   packed: uint32 words, 16 bases/word, base i in bits [2*(i%16), 2*(i%16)+1],
+ *           A=0 C=1 G=2 T=3 (case-insensitive); invalid positions hold 0.
+ *   mask:   uint32 words, 32 bases/word, bit (i%32) = 1 when position i is NOT
+ *           a usable base: non-ACGT residue, the one-position separator written
+ *           between FASTA records, or padding up to PA_ALIGN_BASES.
+ * `packed`/`mask` point at the genome's first word inside the arena; `cap_bases`
+ * (multiple of 64) is the room available.  An upper bound for any FASTA text of
+ * n bytes is pa_pack_bound(n).
+ * Outputs: n_bases = positions written incl. separators and padding (multiple
+ * of 64), n_residues = sum of record lengths (the reference's Genome.length,
+ * db_orm.py:832-866), n_records, n_invalid = non-ACGT residues.
+ * FASTA semantics follow pyani_plus/utils.py:67-90: text before the first '>'
+ * is ignored; " \t\r\n" are removed from sequence lines. */
+PA_API uint64_t pa_pack_bound(uint64_t n_text_bytes);
+PA_API int pa_pack_fasta(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask,
+                  uint64_t cap_bases, uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records,
+                  uint64_t *n_invalid);
+/* One bare residue string (no FASTA framing) = one record. */
+PA_API int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_packed, uint32_t *h_mask,
+                uint64_t cap_bases, uint64_t *n_bases, uint64_t *n_invalid);
+
+/* FracMinHash threshold for `scaled` (sourmash max_hash; fixtures pin
+ * 61489146912365176 @300 and 18446744073709552 @1000). */
+PA_API uint64_t pa_max_hash(uint64_t scaled);
+
+/* ---- sketch: arena -> sorted unique hashes per genome ----
+ * d_packed/d_mask: arena of `arena_bases` positions (multiple of 64).
+ * h_genome_start[n_genomes+1]: first position of each genome (multiples of 64,
+ * ascending; last entry = arena_bases).
+ * For every window of k valid bases inside one record: canonical k-mer ->
+ * MurmurHash3_x64_128(seed 42).h1; kept when <= max_hash.
+ * Outputs (device): d_hashes[cap_hashes] genome-major ascending duplicate-free,
+ * d_off[n_genomes+1] CSR offsets.  *h_total = total hashes.  If the total
+ * exceeds cap_hashes the call returns PA_E_CAPACITY with *h_total = required
+ * size and writes nothing to d_hashes. */
+PA_API int pa_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+              const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
+              uint64_t *d_hashes, uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total);
+
+/* ---- pairs: CSR sketches -> intersection counts ----
+ * d_hashes/d_off describe n sketches (any source: pa_sketch, a `.sig` cache,
+ * an all-gather).  Computes d_counts[(q-q0)*(s1-s0) + (s-s0)] = |S_q n S_s| for
+ * q in [q0,q1), s in [s0,s1).  algo: PA_PAIRS_AUTO, or force one kernel. */
+#define PA_PAIRS_AUTO 0
+#define PA_PAIRS_BITROW 1 /* dictionary + bit-row column sums (default) */
+#define PA_PAIRS_MERGE 2  /* per-pair LDS merge-path intersection */
+PA_API int pa_pair_counts(pa_ctx *ctx, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n,
+                   uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts, int algo);
+
+/* ---- counts -> ANI ----
+ * cov_query = (I/|Q|)^(1/k), identity = max(cov_query, (I/|S|)^(1/k));
+ * I == 0 -> NaN in both (the reference's NULL, sourmash.py:141-144).
+ * pa_ani runs on the device (f64; <= 1 ulp from libm);
+ * pa_ani_host uses the host libm `pow`, which reproduces every reference
+ * fixture bit for bit, and is what the JSON/DB boundary uses. */
+PA_API int pa_ani(pa_ctx *ctx, const uint32_t *d_counts, const uint64_t *d_off, uint32_t q0, uint32_t q1,
+           uint32_t s0, uint32_t s1, uint32_t k, double *d_identity, double *d_cov_query);
+PA_API int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, const uint64_t *h_s_sizes,
+                uint32_t nq, uint32_t ns, uint32_t k, double *h_identity, double *h_cov_query,
+                uint8_t *h_is_null);
+
+/* ---- in-library HIP-event timing of the kernels (bench.py roofline) ----
+ * Phases are timed with hipEvents on the context's stream when enabled. */
+#define PA_PROF_KMER_HASH 0   /* k-mer hash + threshold filter kernel */
+#define PA_PROF_SKETCH_SORT 1 /* radix sort + unique of candidates */
+#define PA_PROF_PAIR_DICT 2   /* dictionary sort + ids + bit-row build */
+#define PA_PROF_PAIR_COUNT 3  /* bit-row column-sum / merge kernel */
+#define PA_PROF_ANI 4
+#define PA_PROF_NPHASES 5
+PA_API int pa_prof_enable(pa_ctx *ctx, int on);
+PA_API int pa_prof_reset(pa_ctx *ctx);
+/* total milliseconds and number of timed launches of a phase (syncs the stream) */
+PA_API int pa_prof_get(pa_ctx *ctx, int phase, double *total_ms, uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYANI_HIP_H */

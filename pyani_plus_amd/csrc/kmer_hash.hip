@@ -1,0 +1,240 @@
+// kmer_hash.hip -- kernel 1 of the sketch phase (gfx950).
+//
+// Replaces the k-mer loop inside `sourmash scripts singlesketch`
+// (call site pyani_plus/methods/sourmash.py:67-83): for every window of K valid
+// bases, hash the canonical k-mer (upper-case ASCII) with MurmurHash3_x64_128,
+// seed 42, keep the first word when it is <= max_hash.
+//
+// Work decomposition: one thread per 64-base arena block (one 16-byte packed
+// load + one 8-byte mask load, both perfectly coalesced), plus a 32-base
+// look-back into the previous block to warm the rolling k-mer registers.
+// The kernel is integer-VALU bound (12 64-bit multiplies + ~170 other VALU per
+// window against 0.375 byte of HBM input), so there is no LDS tiling of the
+// input; LDS only stages the rare survivors (1 in `scaled`) so that the global
+// append is one atomic per workgroup and the stores are coalesced.
+#include "pa_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint32_t kStageCap = 1024;  // LDS staging slots per workgroup
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// 4 bases (8 bits, base j at bits 2j) -> 4 ASCII bytes (base j in byte j).
+// spread the 2-bit codes to one per byte, then use v_perm_b32 as a 4-entry LUT.
+__device__ __forceinline__ uint32_t ascii4(uint32_t b8) {
+  uint32_t u = (b8 | (b8 << 12)) & 0x000F000Fu;
+  uint32_t v = (u | (u << 6)) & 0x03030303u;
+  // selector byte value 0..3 picks that byte of the second source: "ACGT" little-endian
+  return __builtin_amdgcn_perm(0u, 0x54474341u, v);
+}
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// MurmurHash3_x64_128(seed 42).h1 of the K ASCII bytes held little-endian in w[0..7]
+// (bytes beyond K are zero).
+template <int K>
+__device__ __forceinline__ uint64_t murmur3_h1(const uint32_t (&w)[8]) {
+  constexpr uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = 42, h2 = 42;
+  constexpr int nblocks = K / 16;
+  constexpr int tail = K % 16;
+#pragma unroll
+  for (int i = 0; i < nblocks; ++i) {
+    uint64_t k1 = u64_of(w[4 * i], w[4 * i + 1]);
+    uint64_t k2 = u64_of(w[4 * i + 2], w[4 * i + 3]);
+    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  if constexpr (tail > 8) {
+    uint64_t k2 = u64_of(w[4 * nblocks + 2], w[4 * nblocks + 3]);
+    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+  }
+  if constexpr (tail > 0) {
+    uint64_t k1 = u64_of(w[4 * nblocks], w[4 * nblocks + 1]);
+    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+  }
+  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2;
+  return h1;
+}
+
+// largest g with genome_blk[g] <= blk   (genome_blk has n+1 ascending entries)
+__device__ __forceinline__ uint32_t find_genome(const uint32_t *__restrict__ genome_blk, uint32_t n, uint32_t blk) {
+  uint32_t lo = 0, hi = n;  // invariant: genome_blk[lo] <= blk < genome_blk[hi]
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (genome_blk[mid] <= blk) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <int K>
+__global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
+    const uint4 *__restrict__ packed, const uint2 *__restrict__ mask, uint32_t n_blocks64,
+    const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash,
+    uint64_t *__restrict__ cand_hash, uint32_t *__restrict__ cand_genome, uint64_t cap,
+    unsigned long long *__restrict__ count) {
+  static_assert(K >= 4 && K <= 32, "k-mer state is one 64-bit register pair");
+  __shared__ uint64_t s_hash[kStageCap];
+  __shared__ uint32_t s_blk[kStageCap];
+  __shared__ uint32_t s_n;
+  __shared__ unsigned long long s_base;
+
+  const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+
+  const uint32_t t = blockIdx.x * kThreads + tid;
+  if (t < n_blocks64) {
+    const uint4 cur = packed[t];
+    const uint2 m = mask[t];
+    uint2 pw = make_uint2(0u, 0u);
+    uint32_t pm = 0xffffffffu;
+    if (t > 0) {
+      pw = reinterpret_cast<const uint2 *>(packed)[2 * (uint64_t)t - 1];  // bases -32..-1
+      pm = mask[t - 1].y;
+    }
+    // ---- which windows are usable: dilate the invalid-position bitset by K ----
+    // bit i of (d0,d1,d2) <-> base i-32; window ending at base e is bad iff any of
+    // bases e-K+1..e is invalid, i.e. bit (32+e) of OR_{s<K} (M << s).
+    uint32_t d0 = pm, d1 = m.x, d2 = m.y;
+    {
+      int c = 1;
+#pragma unroll
+      for (; 2 * c <= K; c *= 2) {
+        d2 |= alignbit(d2, d1, 32 - c);
+        d1 |= alignbit(d1, d0, 32 - c);
+        d0 |= d0 << c;
+      }
+      constexpr int cc = (K >= 32) ? 32 : (K >= 16) ? 16 : (K >= 8) ? 8 : 4;
+      constexpr int r = K - cc;
+      if constexpr (r > 0) {
+        d2 |= alignbit(d2, d1, 32 - r);
+        d1 |= alignbit(d1, d0, 32 - r);
+      }
+    }
+    const uint32_t bad[2] = {d1, d2};
+    if ((d1 & d2) != 0xffffffffu) {  // at least one usable window in this block
+      constexpr uint64_t kMask = (K == 32) ? ~0ULL : ((1ULL << (2 * K)) - 1);
+      constexpr uint32_t kMaskHi = (uint32_t)(kMask >> 32);
+      constexpr int kTopShift = 2 * (K - 1);  // where a new base enters the LSB-first register
+      // F_msb: base 0 of the window in the top bits (lexicographic order == integer order)
+      // F_lsb: base j of the window at bits 2j (== the packed stream layout)
+      // revcomp in MSB-first form is ~F_lsb, in LSB-first form ~F_msb.
+      uint64_t f_msb = 0, f_lsb = 0;
+      // warm-up: the K-1 bases before this block
+#pragma unroll
+      for (int j = 32 - (K - 1); j < 32; ++j) {
+        const uint32_t word = (j < 16) ? pw.x : pw.y;
+        const uint64_t b = (word >> (2 * (j & 15))) & 3u;
+        f_msb = ((f_msb << 2) | b) & kMask;
+        f_lsb = (f_lsb >> 2) | (b << kTopShift);
+      }
+      const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll 1
+      for (int wi = 0; wi < 4; ++wi) {
+        uint32_t word = words[wi];
+        uint32_t badw = (bad[wi >> 1] >> (16 * (wi & 1))) & 0xffffu;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+          const uint64_t b = word & 3u;
+          word >>= 2;
+          f_msb = ((f_msb << 2) | b) & kMask;
+          f_lsb = (f_lsb >> 2) | (b << kTopShift);
+          const uint64_t r_msb = f_lsb ^ kMask;
+          const uint64_t canon = (f_msb <= r_msb) ? f_lsb : (f_msb ^ kMask);
+          const uint32_t clo = (uint32_t)canon, chi = (uint32_t)(canon >> 32);
+          uint32_t w[8];
+#pragma unroll
+          for (int d = 0; d < 8; ++d) {
+            if (4 * d >= K) { w[d] = 0; continue; }
+            const uint32_t src = d < 4 ? clo : chi;
+            uint32_t a = ascii4((src >> (8 * (d & 3))) & 0xffu);
+            if (4 * d + 4 > K) a &= (1u << (8 * (K - 4 * d))) - 1u;  // bytes beyond K are zero
+            w[d] = a;
+          }
+          (void)kMaskHi;
+          const uint64_t h = murmur3_h1<K>(w);
+          const bool ok = (h <= max_hash) && !((badw >> i) & 1u);
+          if (ok) {
+            const uint32_t slot = atomicAdd(&s_n, 1u);
+            if (slot < kStageCap) {
+              s_hash[slot] = h;
+              s_blk[slot] = t;
+            } else {  // staging full (tiny `scaled`): append straight to global
+              const unsigned long long g = atomicAdd(count, 1ULL);
+              if (g < cap) {
+                cand_hash[g] = h;
+                cand_genome[g] = find_genome(genome_blk, n_genomes, t);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n = min(s_n, kStageCap);
+  if (n == 0) return;
+  if (tid == 0) s_base = atomicAdd(count, (unsigned long long)n);
+  __syncthreads();
+  const unsigned long long base = s_base;
+  for (uint32_t i = tid; i < n; i += kThreads) {
+    const unsigned long long g = base + i;
+    if (g < cap) {
+      cand_hash[g] = s_hash[i];
+      cand_genome[g] = find_genome(genome_blk, n_genomes, s_blk[i]);
+    }
+  }
+}
+
+template <int K>
+int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+           const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
+           uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count) {
+  const uint32_t grid = ceil_div_u64(n_blocks64, kThreads);
+  hipLaunchKernelGGL(kmer_hash_kernel<K>, dim3(grid), dim3(kThreads), 0, c->stream,
+                     reinterpret_cast<const uint4 *>(d_packed), reinterpret_cast<const uint2 *>(d_mask),
+                     (uint32_t)n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap,
+                     reinterpret_cast<unsigned long long *>(d_count));
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+}  // namespace
+
+int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+                        const uint32_t *d_genome_blk, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
+                        uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count) {
+  PA_REQUIRE(n_blocks64 < (1ULL << 32), "arena too large: %llu blocks of 64 bases", (unsigned long long)n_blocks64);
+  if (n_blocks64 == 0) return PA_OK;
+#define PA_K_CASE(KK) \
+  case KK: return launch<KK>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap, d_count);
+  switch (k) {
+    PA_K_CASE(15) PA_K_CASE(16) PA_K_CASE(17) PA_K_CASE(19) PA_K_CASE(21) PA_K_CASE(23) PA_K_CASE(25)
+    PA_K_CASE(27) PA_K_CASE(29) PA_K_CASE(31) PA_K_CASE(32)
+    default:
+      pa_set_error("k=%u is not compiled in (supported: 15,16,17,19,21,23,25,27,29,31,32)", k);
+      return PA_E_INVALID;
+  }
+#undef PA_K_CASE
+}

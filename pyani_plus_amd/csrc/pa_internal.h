@@ -1,0 +1,138 @@
+// pa_internal.h -- shared internals of libpyani_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pyani_hip.h"
+
+// ---- error plumbing -------------------------------------------------------
+void pa_set_error(const char *fmt, ...);
+
+#define PA_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      pa_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return PA_E_HIP;                                                                        \
+    }                                                                                         \
+  } while (0)
+
+#define PA_TRY(call)          \
+  do {                        \
+    int _s = (call);          \
+    if (_s != PA_OK) return _s; \
+  } while (0)
+
+#define PA_REQUIRE(cond, ...)   \
+  do {                          \
+    if (!(cond)) {              \
+      pa_set_error(__VA_ARGS__); \
+      return PA_E_INVALID;      \
+    }                           \
+  } while (0)
+
+// ---- growable device buffer owned by the context ---------------------------
+struct DevBuf {
+  void *p = nullptr;
+  uint64_t bytes = 0;
+  int reserve(uint64_t want) {
+    if (want <= bytes) return PA_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    // grow geometrically so steady-state calls never allocate
+    uint64_t sz = want + want / 4 + 256;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+      pa_set_error("hipMalloc(%llu) failed: %s", (unsigned long long)sz, hipGetErrorString(e));
+      p = nullptr;
+      return PA_E_NOMEM;
+    }
+    bytes = sz;
+    return PA_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct ProfPhase {
+  double total_ms = 0.0;
+  uint64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct pa_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipDeviceProp_t prop;
+  // workspaces (sketch phase)
+  DevBuf cand_keys[2], cand_vals[2];  // double-buffered radix sort storage
+  DevBuf genome_blk;                  // genome start block index (u32[n+1])
+  DevBuf counters;                    // small device scalars
+  DevBuf hist;                        // radix histograms / scan scratch
+  DevBuf flags, scan_tmp;             // compaction
+  // workspaces (pair phase)
+  DevBuf dict_keys[2], dict_vals[2];
+  DevBuf ids, post_genome, bitrows;
+  // pinned host scalars
+  uint64_t *h_pinned = nullptr;
+  // profiling
+  bool prof_on = false;
+  ProfPhase prof[PA_PROF_NPHASES];
+  std::vector<hipEvent_t> event_pool;
+};
+
+// RAII-ish phase timer: records events around a group of launches when enabled.
+struct ProfScope {
+  pa_ctx *c;
+  int phase;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(pa_ctx *ctx, int ph);
+  ~ProfScope();
+};
+
+// ---- launch geometry helpers ----------------------------------------------
+static inline uint32_t ceil_div_u64(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// ---- device primitives implemented in the .hip files -----------------------
+// radix_sort.hip
+// Stable LSD radix sort of (u64 key, u32 val) pairs on bits [bit_lo, bit_hi) of the key
+// (or of the value when by_val).  keys/vals are double buffers: *which says which one holds
+// the input on entry and the result on return.
+int pa_radix_sort_pairs(pa_ctx *c, uint64_t *keys[2], uint32_t *vals[2], uint64_t n, int bit_lo,
+                        int bit_hi, bool by_val, int *which);
+// Exclusive prefix sum of u32 -> u32 (n up to 2^32-1 elements, total must fit u32... u64 total out).
+int pa_exclusive_scan_u32(pa_ctx *c, const uint32_t *d_in, uint32_t *d_out, uint64_t n,
+                          uint64_t *d_total_u64 /*nullable device ptr*/);
+
+// kmer_hash.hip
+int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+                        const uint32_t *d_genome_blk, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
+                        uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count);
+
+// sketch_build.hip
+int pa_build_sketch_csr(pa_ctx *c, const uint64_t *d_sorted_hash, const uint32_t *d_sorted_genome,
+                        uint64_t n_cand, uint32_t n_genomes, uint64_t *d_hashes, uint64_t cap_hashes,
+                        uint64_t *d_off, uint64_t *h_total);
+
+// pairs_bitrow.hip / pairs_merge.hip
+int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t total,
+                    uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts);
+int pa_pairs_merge(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint32_t q0,
+                   uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts);
+
+// ani.hip
+int pa_launch_ani(pa_ctx *c, const uint32_t *d_counts, const uint64_t *d_off, uint32_t q0, uint32_t q1,
+                  uint32_t s0, uint32_t s1, uint32_t k, double *d_identity, double *d_cov_query);

@@ -1,0 +1,254 @@
+"""Host driver of the MI355X sketch -> pair-count -> ANI pipeline.
+
+Everything numeric happens inside ``libpyani_hip.so`` (``include/pyani_hip.h``);
+this module only owns buffers.  PyTorch is used for device memory, the HIP
+stream and (in ``distributed.py``) RCCL -- never for arithmetic on the path.
+
+Reference steps replaced:
+  A2  ``sourmash scripts singlesketch``  (pyani_plus/methods/sourmash.py:67-83)
+  A5  ``sourmash scripts manysearch``    (pyani_plus/methods/sourmash.py:184-200)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _capi
+from ._capi import HipBackendError, check
+
+
+def max_hash_for_scaled(scaled: int) -> int:
+    """sourmash's ``max_hash`` for a ``scaled`` value (double-rounded 2**64/scaled)."""
+    return int(_capi.load_library().pa_max_hash(int(scaled)))
+
+
+# --------------------------------------------------------------------------- host arena
+@dataclass
+class HostArena:
+    """2-bit packed genomes + invalid-position mask (layout: DESIGN.md, "Data layout")."""
+
+    packed: np.ndarray  # uint32, 16 bases / word
+    mask: np.ndarray  # uint32, 32 positions / word, bit=1 -> not a usable base
+    genome_start: np.ndarray  # uint64 [n+1], multiples of 64
+    residues: list[int] = field(default_factory=list)  # Genome.length per genome
+    records: list[int] = field(default_factory=list)
+    invalid: list[int] = field(default_factory=list)
+
+    @property
+    def n_genomes(self) -> int:
+        return len(self.genome_start) - 1
+
+    @property
+    def arena_bases(self) -> int:
+        return int(self.genome_start[-1])
+
+
+def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
+    """Pack decompressed FASTA texts (or bare residue strings) into one arena (host only)."""
+    lib = _capi.load_library()
+    bounds = [int(lib.pa_pack_bound(len(t))) for t in texts]
+    total = sum(bounds)
+    packed = np.zeros(total // 16, dtype=np.uint32)
+    mask = np.zeros(total // 32, dtype=np.uint32)
+    starts = np.zeros(len(texts) + 1, dtype=np.uint64)
+    residues, records, invalid = [], [], []
+    pos = 0
+    for g, text in enumerate(texts):
+        nb, nr, nrec, ninv = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        buf = bytes(text) if len(text) else None
+        p_ptr = packed.ctypes.data + (pos // 16) * 4
+        m_ptr = mask.ctypes.data + (pos // 32) * 4
+        if fasta:
+            st = lib.pa_pack_fasta(buf, len(text), p_ptr, m_ptr, bounds[g], C.byref(nb), C.byref(nr), C.byref(nrec), C.byref(ninv))
+        else:
+            st = lib.pa_pack_seq(buf, len(text), p_ptr, m_ptr, bounds[g], C.byref(nb), C.byref(ninv))
+            nr.value, nrec.value = len(text), 1
+        check(st, "pa_pack_fasta" if fasta else "pa_pack_seq")
+        starts[g] = pos
+        pos += int(nb.value)
+        residues.append(int(nr.value))
+        records.append(int(nrec.value))
+        invalid.append(int(ninv.value))
+    starts[len(texts)] = pos
+    return HostArena(packed[: pos // 16].copy(), mask[: pos // 32].copy(), starts, residues, records, invalid)
+
+
+# --------------------------------------------------------------------------- device objects
+@dataclass
+class DeviceArena:
+    packed: "object"  # torch.int32 tensor
+    mask: "object"
+    genome_start: np.ndarray  # host uint64 [n+1]
+
+    @property
+    def n_genomes(self) -> int:
+        return len(self.genome_start) - 1
+
+    @property
+    def arena_bases(self) -> int:
+        return int(self.genome_start[-1])
+
+
+@dataclass
+class DeviceSketches:
+    """CSR of ascending duplicate-free u64 hashes, resident in HBM."""
+
+    hashes: "object"  # torch.int64 tensor (bit pattern of uint64), length >= total
+    off: "object"  # torch.int64 tensor [n+1]
+    n: int
+    total: int
+
+    def sizes(self) -> np.ndarray:
+        off = self.off.cpu().numpy().astype(np.uint64)
+        return (off[1:] - off[:-1]).astype(np.uint64)
+
+    def to_host(self) -> list[np.ndarray]:
+        off = self.off.cpu().numpy()
+        flat = self.hashes[: self.total].cpu().numpy().view(np.uint64)
+        return [flat[int(off[g]) : int(off[g + 1])].copy() for g in range(self.n)]
+
+
+class HipEngine:
+    """One HIP context on one GPU.  Raises ``HipBackendError`` when no MI355X is usable."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _capi.load_library()
+        try:
+            import torch
+        except ImportError as err:  # pragma: no cover
+            raise HipBackendError("PyTorch (ROCm build) is required for device memory") from err
+        if not torch.cuda.is_available():
+            raise HipBackendError("no HIP device visible to PyTorch; the HIP path has no CPU fallback")
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        ctx = C.c_void_p()
+        check(self.lib.pa_ctx_create(device, C.byref(ctx)), "pa_ctx_create")
+        self.ctx = ctx
+        self.use_torch_stream()
+
+    # -- plumbing
+    def use_torch_stream(self) -> None:
+        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        check(self.lib.pa_ctx_set_stream(self.ctx, C.c_void_p(stream)), "pa_ctx_set_stream")
+
+    def close(self) -> None:
+        if getattr(self, "ctx", None):
+            self.lib.pa_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self) -> dict:
+        name = C.create_string_buffer(256)
+        cus, mem = C.c_int(0), C.c_uint64(0)
+        check(self.lib.pa_ctx_device_info(self.ctx, name, C.byref(cus), C.byref(mem)), "pa_ctx_device_info")
+        return {"name": name.value.decode(), "compute_units": cus.value, "global_mem": mem.value}
+
+    def sync(self) -> None:
+        check(self.lib.pa_ctx_sync(self.ctx), "pa_ctx_sync")
+
+    # -- data movement
+    def upload(self, arena: HostArena) -> DeviceArena:
+        t = self.torch
+        packed = t.from_numpy(arena.packed.view(np.int32)).to(self.device)
+        mask = t.from_numpy(arena.mask.view(np.int32)).to(self.device)
+        return DeviceArena(packed, mask, arena.genome_start.copy())
+
+    def sketches_from_host(self, sketches: list[np.ndarray]) -> DeviceSketches:
+        t = self.torch
+        off = np.zeros(len(sketches) + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in sketches], out=off[1:])
+        flat = np.concatenate([np.asarray(s, dtype=np.uint64) for s in sketches]) if sketches else np.empty(0, np.uint64)
+        if flat.size == 0:
+            flat = np.zeros(1, dtype=np.uint64)
+        return DeviceSketches(
+            t.from_numpy(flat.view(np.int64).copy()).to(self.device), t.from_numpy(off).to(self.device), len(sketches), int(off[-1])
+        )
+
+    # -- the three device steps
+    def sketch(self, arena: DeviceArena, k: int, scaled: int, *, max_hash: int | None = None) -> DeviceSketches:
+        t = self.torch
+        mh = int(max_hash) if max_hash is not None else max_hash_for_scaled(scaled)
+        n = arena.n_genomes
+        frac = 1.0 if mh >= 2**64 - 1 else (mh + 1) / 2.0**64
+        cap = int(arena.arena_bases * frac * 1.25) + 4096
+        off = t.empty(n + 1, dtype=t.int64, device=self.device)
+        gs = np.ascontiguousarray(arena.genome_start, dtype=np.uint64)
+        total = C.c_uint64(0)
+        for _attempt in range(2):
+            hashes = t.empty(max(cap, 1), dtype=t.int64, device=self.device)
+            st = self.lib.pa_sketch(
+                self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases,
+                gs.ctypes.data_as(C.POINTER(C.c_uint64)), n, k, mh, hashes.data_ptr(), cap, off.data_ptr(), C.byref(total),
+            )  # fmt: skip
+            if st == _capi.PA_E_CAPACITY:
+                cap = int(total.value)
+                continue
+            check(st, "pa_sketch")
+            return DeviceSketches(hashes, off, n, int(total.value))
+        raise HipBackendError("pa_sketch: capacity retry failed")
+
+    def pair_counts(self, sk: DeviceSketches, q_range=None, s_range=None, algo: int = _capi.PA_PAIRS_AUTO):
+        """uint32 |S_q n S_s| for q in q_range, s in s_range -> torch.int32 [nq, ns] on the GPU."""
+        t = self.torch
+        q0, q1 = q_range or (0, sk.n)
+        s0, s1 = s_range or (0, sk.n)
+        counts = t.empty((q1 - q0, s1 - s0), dtype=t.int32, device=self.device)
+        check(
+            self.lib.pa_pair_counts(self.ctx, sk.hashes.data_ptr(), sk.off.data_ptr(), sk.n, q0, q1, s0, s1, counts.data_ptr(), algo),
+            "pa_pair_counts",
+        )
+        return counts
+
+    def ani(self, counts, sk: DeviceSketches, k: int, q_range=None, s_range=None):
+        """Device f64 (identity, cov_query); NaN marks the reference's NULL."""
+        t = self.torch
+        q0, q1 = q_range or (0, sk.n)
+        s0, s1 = s_range or (0, sk.n)
+        ident = t.empty((q1 - q0, s1 - s0), dtype=t.float64, device=self.device)
+        cov = t.empty_like(ident)
+        check(
+            self.lib.pa_ani(self.ctx, counts.data_ptr(), sk.off.data_ptr(), q0, q1, s0, s1, k, ident.data_ptr(), cov.data_ptr()),
+            "pa_ani",
+        )
+        return ident, cov
+
+    # -- profiling
+    def prof_enable(self, on: bool = True) -> None:
+        check(self.lib.pa_prof_enable(self.ctx, int(on)), "pa_prof_enable")
+
+    def prof_reset(self) -> None:
+        check(self.lib.pa_prof_reset(self.ctx), "pa_prof_reset")
+
+    def prof_get(self) -> dict[str, tuple[float, int]]:
+        out = {}
+        for name, idx in _capi.PROF_PHASES.items():
+            ms, n = C.c_double(0), C.c_uint64(0)
+            check(self.lib.pa_prof_get(self.ctx, idx, C.byref(ms), C.byref(n)), "pa_prof_get")
+            out[name] = (ms.value, int(n.value))
+        return out
+
+
+def ani_host(counts: np.ndarray, q_sizes, s_sizes, k: int) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Strict (host libm ``pow``) containment-ANI transform used at the JSON/DB boundary."""
+    lib = _capi.load_library()
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    nq, ns = counts.shape
+    q_sizes = np.ascontiguousarray(q_sizes, dtype=np.uint64)
+    s_sizes = np.ascontiguousarray(s_sizes, dtype=np.uint64)
+    ident = np.empty((nq, ns), dtype=np.float64)
+    cov = np.empty((nq, ns), dtype=np.float64)
+    null = np.empty((nq, ns), dtype=np.uint8)
+    check(
+        lib.pa_ani_host(counts.ctypes.data, q_sizes.ctypes.data, s_sizes.ctypes.data, nq, ns, k, ident.ctypes.data, cov.ctypes.data, null.ctypes.data),
+        "pa_ani_host",
+    )
+    return ident, cov, null.astype(bool)
