@@ -90,7 +90,10 @@ PA_API int pa_memset_d(pa_ctx *ctx, void *d_dst, int value, uint64_t bytes);
  *           A=0 C=1 G=2 T=3 (case-insensitive); invalid positions hold 0.
  *   mask:   uint32 words, 32 bases/word, bit (i%32) = 1 when position i is NOT
  *           a usable base: non-ACGT residue, the one-position separator written
- *           between FASTA records, or padding up to PA_ALIGN_BASES.
+ *           between FASTA records, or the padding after the last residue.  Every
+ *           genome ends with AT LEAST ONE invalid position (then padding up to
+ *           PA_ALIGN_BASES) so that no k-mer window can span two genomes; arenas
+ *           built by other means must keep that invariant.
  * `packed`/`mask` point at the genome's first word inside the arena; `cap_bases`
  * (multiple of 64) is the room available.  An upper bound for any FASTA text of
  * n bytes is pa_pack_bound(n).

@@ -41,7 +41,7 @@ def _load() -> C.CDLL:
         lib.orc_sketch_seq.restype = C.c_int64
         lib.orc_sketch_seq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, _u64p, C.c_uint64]
         lib.orc_sketch_many.restype = C.c_int
-        lib.orc_sketch_many.argtypes = [_u8p, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _u64p, _u64p, _i64p, C.c_int]
+        lib.orc_sketch_many.argtypes = [_u8p, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _u64p, _u64p, _i64p, C.c_int, C.c_int]
         lib.orc_intersect.restype = C.c_uint32
         lib.orc_intersect.argtypes = [_u64p, C.c_uint64, _u64p, C.c_uint64]
         lib.orc_pair_counts.restype = None
@@ -92,8 +92,8 @@ def sketch_seq(seq: bytes, k: int, scaled: int) -> np.ndarray:
         cap = int(n)
 
 
-def sketch_many(seqs: list[bytes] | list[np.ndarray], k: int, scaled: int, threads: int = 1) -> list[np.ndarray]:
-    """Sketch bare residue strings, one OpenMP task each."""
+def sketch_many(seqs: list[bytes] | list[np.ndarray], k: int, scaled: int, threads: int = 1, fast: bool = False) -> list[np.ndarray]:
+    """Sketch bare residue strings, one OpenMP task each (fast=True: the tuned scalar form)."""
     lib = _load()
     lens = np.array([len(s) for s in seqs], dtype=np.uint64)
     off = np.zeros(len(seqs) + 1, dtype=np.uint64)
@@ -107,7 +107,7 @@ def sketch_many(seqs: list[bytes] | list[np.ndarray], k: int, scaled: int, threa
         np.cumsum(caps, out=ooff[1:])
         out = np.empty(int(ooff[-1]), dtype=np.uint64)
         sizes = np.zeros(len(seqs), dtype=np.int64)
-        rc = lib.orc_sketch_many(_p(flat, _u8p), _p(off, _u64p), len(seqs), k, max_hash(scaled), _p(out, _u64p), _p(ooff, _u64p), _p(sizes, _i64p), threads)
+        rc = lib.orc_sketch_many(_p(flat, _u8p), _p(off, _u64p), len(seqs), k, max_hash(scaled), _p(out, _u64p), _p(ooff, _u64p), _p(sizes, _i64p), threads, int(fast))
         if (sizes < 0).any():
             raise MemoryError("oracle allocation failed")
         if rc == 0:

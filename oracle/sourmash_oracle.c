@@ -202,16 +202,64 @@ ORC_API int64_t orc_sketch_seq(const uint8_t *seq, uint64_t len, uint32_t k, uin
   return (int64_t)m;
 }
 
+/* A tuned scalar CPU form of the same function, used ONLY as the timed
+ * `cpu_baseline` ("port") in bench.py so that the GPU is compared with a
+ * reasonable CPU implementation rather than with the deliberately naive one
+ * above: rolling 2-bit forward / reverse-complement registers, integer
+ * canonical compare, ASCII expansion through a 256-entry table.  k <= 32.
+ * tests/test_oracle_golden.py checks it equals orc_sketch_seq on every fixture. */
+static uint32_t g_ascii4[256];
+static int g_ascii4_ready = 0;
+static void init_ascii4(void) {
+  static const char up[4] = {'A', 'C', 'G', 'T'};
+  for (int v = 0; v < 256; ++v) {
+    uint32_t w = 0;
+    for (int j = 0; j < 4; ++j) w |= (uint32_t)(uint8_t)up[(v >> (2 * j)) & 3] << (8 * j);
+    g_ascii4[v] = w;
+  }
+  g_ascii4_ready = 1;
+}
+
+ORC_API int64_t orc_sketch_seq_fast(const uint8_t *seq, uint64_t len, uint32_t k, uint64_t max_hash,
+                                    uint64_t *out, uint64_t cap) {
+  if (k == 0 || k > 32) return -2;
+  if (!g_ascii4_ready) init_ascii4();
+  u64vec hashes = {0, 0, 0};
+  const uint64_t kmask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  const int top = 2 * ((int)k - 1);
+  uint64_t f_msb = 0, f_lsb = 0, run = 0;
+  uint8_t buf[32] __attribute__((aligned(8)));
+  for (uint64_t i = 0; i < len; ++i) {
+    const int c = base_code(seq[i]);
+    if (c < 0) { run = 0; f_msb = f_lsb = 0; continue; }
+    f_msb = ((f_msb << 2) | (uint64_t)c) & kmask;   /* base 0 of the window in the top bits */
+    f_lsb = (f_lsb >> 2) | ((uint64_t)c << top);    /* base j of the window at bits 2j */
+    if (++run < k) continue;
+    /* revcomp: MSB-first form is ~f_lsb, LSB-first form is ~f_msb */
+    const uint64_t canon = f_msb <= (f_lsb ^ kmask) ? f_lsb : (f_msb ^ kmask);
+    uint32_t w[8];
+    for (int d = 0; d < 8; ++d) w[d] = g_ascii4[(canon >> (8 * d)) & 0xff];
+    memcpy(buf, w, 32);
+    const uint64_t h = orc_murmur3_h1(buf, k, 42);
+    if (h <= max_hash && vec_push(&hashes, h)) { free(hashes.v); return -1; }
+  }
+  uint64_t m = sort_unique(hashes.v, hashes.n);
+  for (uint64_t i = 0; i < m && i < cap; ++i) out[i] = hashes.v[i];
+  free(hashes.v);
+  return (int64_t)m;
+}
+
 /* Many bare sequences, one OpenMP task per sequence (cpu_baseline leg).
  * seqs = concatenated residues, seq_off[n+1]; out = caller buffer with
  * out_off[n+1] capacities; sizes[n] receives the sketch sizes. */
 ORC_API int orc_sketch_many(const uint8_t *seqs, const uint64_t *seq_off, uint32_t n, uint32_t k,
                             uint64_t max_hash, uint64_t *out, const uint64_t *out_off, int64_t *sizes,
-                            int threads) {
+                            int threads, int fast) {
   int bad = 0;
+  if (!g_ascii4_ready) init_ascii4();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
   for (uint32_t g = 0; g < n; ++g) {
-    sizes[g] = orc_sketch_seq(seqs + seq_off[g], seq_off[g + 1] - seq_off[g], k, max_hash,
+    sizes[g] = (fast ? orc_sketch_seq_fast : orc_sketch_seq)(seqs + seq_off[g], seq_off[g + 1] - seq_off[g], k, max_hash,
                               out + out_off[g], out_off[g + 1] - out_off[g]);
     if (sizes[g] < 0 || (uint64_t)sizes[g] > out_off[g + 1] - out_off[g]) bad = 1;
   }

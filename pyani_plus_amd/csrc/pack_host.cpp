@@ -30,7 +30,10 @@ struct ArenaWriter {
     if ((pos & 15) == 0) { packed[(pos >> 4) - 1] = pw; pw = 0; }
     if ((pos & 31) == 0) { mask[(pos >> 5) - 1] = mw; mw = 0; }
   }
+  // Always at least one invalid position, then up to the next multiple of 64: the kernel's
+  // 32-base look-back into the previous block must never see a neighbouring genome's bases.
   inline void pad64() {
+    put(0, 1);
     while (pos & 63) put(0, 1);
   }
 };
@@ -50,7 +53,7 @@ constexpr Lut kLut;
 
 }  // namespace
 
-extern "C" uint64_t pa_pack_bound(uint64_t n_text_bytes) { return ((n_text_bytes + 63) & ~63ULL) + 64; }
+extern "C" uint64_t pa_pack_bound(uint64_t n_text_bytes) { return (n_text_bytes / 64 + 1) * 64 + 64; }
 
 extern "C" uint64_t pa_max_hash(uint64_t scaled) {
   if (scaled == 0) return 0;

@@ -1,0 +1,307 @@
+"""The ``sourmash-hip`` method: pyani-plus's sourmash path on an MI355X.
+
+Drop-in shaped like ``pyani_plus/methods/sourmash.py`` plus its column worker
+``private_cli.compute_sourmash`` (pyani_plus/private_cli.py:1803-1902):
+
+* module constants ``SCALED`` / ``KMER_SIZE`` read by the CLI for its defaults
+  (pyani_plus/public_cli.py:58, 612-613);
+* ``prepare_genomes(logger, run, cache)`` -- the hook ``private_cli.prepare`` finds by
+  importing ``pyani_plus.methods.<method>`` (pyani_plus/private_cli.py:725-752);
+* ``compute_sourmash_hip(...)`` -- same positional signature, return codes, JSON file and
+  interrupt behaviour as the ``compute`` dict entries (pyani_plus/private_cli.py:906-968).
+
+``run`` / ``session`` are duck-typed (``run.configuration.{method,program,version,kmersize,
+extra}``, ``run.fasta_directory``, ``run.fasta_hashes[*].{fasta_filename,genome_hash}``,
+``run.status``, ``session.commit()``): the reference's SQLAlchemy objects satisfy this,
+and so do the plain dataclasses of ``pyani_plus_amd.rundb``.
+
+Where the reference launches processes, this module makes library calls:
+``sourmash scripts singlesketch`` -> ``HipEngine.sketch`` (one batched launch for all
+missing genomes), ``sig collect`` + ``manysearch`` -> ``HipEngine.pair_counts``, and the
+CSV columns -> ``ani_host`` (host libm ``pow``: bit-identical to the reference fixtures).
+"""
+
+from __future__ import annotations
+
+import gzip
+import logging
+import platform
+import sys
+from collections.abc import Iterator
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from .. import __version__, _capi, sig, wire
+
+METHOD = "sourmash-hip"
+SCALED = 1000  # same defaults as pyani_plus/methods/sourmash.py:30-31
+KMER_SIZE = 31
+RECORDING_FAILED = 2  # pyani_plus/private_cli.py:188
+PREPARE_BATCH_BASES = 2_000_000_000  # residues sketched per launch by prepare_genomes
+
+
+def log_sys_exit(logger: logging.Logger, msg: str):
+    """Log the message as an error and exit with it (pyani_plus/__init__.py:120-126)."""
+    logger.error(msg)
+    sys.exit(msg)
+
+
+@dataclass(frozen=True)
+class ExternalToolData:
+    """Same two fields as pyani_plus/tools.py:39-43; ``exe_path.stem`` and ``version`` are what
+    the reference stores as ``Configuration.program`` / ``.version`` (public_cli.py:145-146)."""
+
+    exe_path: Path
+    version: str
+
+
+def get_sourmash_hip() -> ExternalToolData:
+    """The "tool" of this method is the HIP shared library (counterpart of tools.get_sourmash)."""
+    _capi.load_library()  # raises HipBackendError when the extension is missing
+    return ExternalToolData(_capi.LIB_PATH, __version__)
+
+
+def _check_tool_version(logger: logging.Logger, tool: ExternalToolData, configuration) -> None:
+    """Abort when the run was recorded with another program/version (private_cli.py:191-223)."""
+    if configuration.program != tool.exe_path.stem or configuration.version != tool.version:
+        msg = (
+            f"Run configuration was {configuration.program} {configuration.version}"
+            f" but we have {tool.exe_path.stem} {tool.version}"
+        )
+        log_sys_exit(logger, msg)
+
+
+def parse_scaled(extra: str) -> int:
+    """``extra`` is spliced into the sketch parameters as ``scaled=N`` (sourmash.py:75-76)."""
+    if not extra.startswith("scaled="):
+        msg = f"sourmash-hip supports extra='scaled=N' only, not {extra!r}"
+        raise ValueError(msg)
+    try:
+        scaled = int(extra[len("scaled=") :])
+    except ValueError:
+        msg = f"sourmash-hip supports extra='scaled=N' only, not {extra!r}"
+        raise ValueError(msg) from None
+    if scaled < 1:
+        msg = f"scaled must be a positive integer, not {scaled}"
+        raise ValueError(msg)
+    return scaled
+
+
+def sig_cache_dir(cache: Path, kmersize: int, extra: str) -> Path:
+    """Same sub-directory as the reference so both backends share signatures (sourmash.py:57)."""
+    return Path(cache) / f"sourmash_k={kmersize}_{extra}"
+
+
+def read_fasta_file(path: Path) -> bytes:
+    """Decompressed file content; gzip detected by content like utils.file_md5sum (utils.py:178-190)."""
+    raw = Path(path).read_bytes()
+    if raw[:2] == b"\x1f\x8b":
+        return gzip.decompress(raw)
+    return raw
+
+
+_ENGINE = None
+
+
+def get_engine(device: int = 0):
+    """Process-wide HipEngine (created on first use; raises HipBackendError without a GPU)."""
+    global _ENGINE
+    if _ENGINE is None:
+        from ..engine import HipEngine
+
+        _ENGINE = HipEngine(device)
+    return _ENGINE
+
+
+def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None) -> Iterator:
+    """Build the sketch signatures in ``cache/sourmash_k={kmersize}_scaled={N}``.
+
+    Yields the run's FASTA entries as their signatures are completed (progress bar),
+    skipping genomes whose ``.sig`` already exists -- the contract of
+    pyani_plus/methods/sourmash.py:34-84.
+    """
+    config = run.configuration
+    if config.method != METHOD:
+        log_sys_exit(logger, f"Expected run to be for {METHOD}, not method {config.method}")
+    if not config.kmersize:
+        log_sys_exit(logger, f"{METHOD} requires a k-mer size, default is {KMER_SIZE}")
+    if not config.extra:
+        log_sys_exit(logger, f"{METHOD} requires extra setting, default is scaled={SCALED}")
+    scaled = parse_scaled(config.extra)
+    if not Path(cache).is_dir():
+        msg = f"Cache directory '{cache}' does not exist"
+        raise ValueError(msg)
+    sig_dir = sig_cache_dir(cache, config.kmersize, config.extra)
+    logger.debug("Preparing %s signatures in '%s'", METHOD, sig_dir)
+    sig_dir.mkdir(exist_ok=True)
+    fasta_dir = Path(run.fasta_directory)
+
+    from ..engine import max_hash_for_scaled, pack_genomes
+
+    max_hash = max_hash_for_scaled(scaled)
+    batch: list = []
+    batch_texts: list[bytes] = []
+    batch_bases = 0
+
+    def flush() -> None:
+        nonlocal batch, batch_texts, batch_bases
+        if not batch:
+            return
+        eng = engine or get_engine()
+        arena = pack_genomes(batch_texts)
+        sketches = eng.sketch(eng.upload(arena), config.kmersize, scaled, max_hash=max_hash).to_host()
+        for entry, mins in zip(batch, sketches):
+            sig.write_sig(
+                sig_dir / f"{entry.genome_hash}.sig",
+                name=entry.genome_hash,
+                filename=str(fasta_dir / entry.fasta_filename),
+                ksize=config.kmersize,
+                max_hash=max_hash,
+                mins=mins,
+            )
+        batch, batch_texts, batch_bases = [], [], 0
+
+    pending: list = []
+    for entry in run.fasta_hashes:
+        if not (sig_dir / f"{entry.genome_hash}.sig").is_file():
+            text = read_fasta_file(fasta_dir / entry.fasta_filename)
+            batch.append(entry)
+            batch_texts.append(text)
+            batch_bases += len(text)
+        pending.append(entry)
+        if batch_bases >= PREPARE_BATCH_BASES:
+            flush()
+            yield from pending
+            pending = []
+    flush()
+    yield from pending
+
+
+def compute_sourmash_tile(
+    logger: logging.Logger,
+    subject_hashes,
+    query_hashes,
+    cache: Path,
+    *,
+    kmersize: int,
+    scaled: int,
+    engine=None,
+    algo: int = _capi.PA_PAIRS_AUTO,
+) -> Iterator[tuple[str, str, float | None, float | None]]:
+    """Yield ``(query_hash, subject_hash, query_containment_ani, max_containment_ani)`` for every
+    query x subject pair, ``None, None`` where the sketches share no hash -- what
+    ``compute_sourmash_tile`` + ``parse_sourmash_manysearch_csv`` yield in the reference
+    (pyani_plus/methods/sourmash.py:87-206).  Row order is deterministic here (query-major)."""
+    cache = Path(cache)
+    if not cache.is_dir():
+        msg = f"Given cache directory '{cache}' does not exist"
+        raise ValueError(msg)
+    from ..engine import ani_host, max_hash_for_scaled
+
+    queries = sorted(query_hashes)
+    extra_subjects = sorted(set(subject_hashes) - set(queries))
+    order = queries + extra_subjects  # CSR order: queries first, then subjects not among them
+    index = {h: i for i, h in enumerate(order)}
+    max_hash = max_hash_for_scaled(scaled)
+    sketches = []
+    for genome_hash in order:
+        sig_file = cache / f"{genome_hash}.sig"
+        if not sig_file.is_file():
+            log_sys_exit(logger, f"Missing sourmash signature file '{sig_file}'")
+        mins, _ = sig.read_sig(sig_file, ksize=kmersize, max_hash=max_hash)
+        sketches.append(mins)
+    eng = engine or get_engine()
+    dsk = eng.sketches_from_host(sketches)
+    subjects = sorted(subject_hashes)
+    sub_idx = [index[s] for s in subjects]
+    nq = len(queries)
+    # contiguous subject range if possible (all-vs-all, or a single subject column)
+    lo, hi = min(sub_idx), max(sub_idx) + 1
+    if hi - lo != len(sub_idx):
+        lo, hi = 0, len(order)  # scattered subjects: compute the covering block, pick columns below
+    counts = eng.pair_counts(dsk, (0, nq), (lo, hi), algo=algo).cpu().numpy().view(np.uint32)
+    sizes = np.array([len(s) for s in sketches], dtype=np.uint64)
+    cols = np.array(sub_idx) - lo
+    counts = np.ascontiguousarray(counts[:, cols])
+    ident, cov, null = ani_host(counts, sizes[:nq], sizes[np.array(sub_idx)], kmersize)
+    for qi, q in enumerate(queries):
+        for si, s in enumerate(subjects):
+            if null[qi, si]:
+                yield q, s, None, None
+                continue
+            if q == s and ident[qi, si] != 1.0:
+                # the reference refuses a self-comparison that is not exactly one (sourmash.py:119-127)
+                msg = f"Expected {METHOD} {q} vs self to be one, not {ident[qi, si]!r}"
+                raise ValueError(msg)
+            yield q, s, float(cov[qi, si]), float(ident[qi, si])
+
+
+def compute_sourmash_hip(  # noqa: PLR0913
+    logger: logging.Logger,
+    tmp_dir: Path,  # noqa: ARG001 - no intermediate files are needed
+    session,
+    run,
+    json_filename: Path,
+    fasta_dir: Path,  # noqa: ARG001
+    hash_to_filename: dict[str, str],  # noqa: ARG001
+    filename_to_hash: dict[str, str],  # noqa: ARG001
+    query_hashes: dict[str, int],
+    subject_hash: str,
+    *,
+    cache: Path = Path(),
+    engine=None,
+) -> int:
+    """Run many-vs-subject (or all-vs-all when ``subject_hash == ""``) and log to JSON.
+
+    Field mapping as private_cli.py:1875-1887: ``identity`` <- max-containment ANI,
+    ``cov_query`` <- query-containment ANI; ``aln_length``/``sim_errors``/``cov_subject`` unset.
+    """
+    uname = platform.uname()
+    configuration = run.configuration
+    tool = get_sourmash_hip()
+    _check_tool_version(logger, tool, configuration)
+    config_id = getattr(configuration, "configuration_id", None)
+
+    sig_cache = sig_cache_dir(cache, configuration.kmersize, configuration.extra)
+    if not sig_cache.is_dir():
+        log_sys_exit(
+            logger,
+            f"Missing sourmash signatures directory '{sig_cache}' - check cache setting '{cache}'.",
+        )
+    scaled = parse_scaled(configuration.extra)
+    db_entries: list[dict] = []
+    try:
+        for q, s, q_containment, max_containment in compute_sourmash_tile(
+            logger,
+            {subject_hash} if subject_hash else set(query_hashes),
+            set(query_hashes),
+            sig_cache,
+            kmersize=configuration.kmersize,
+            scaled=scaled,
+            engine=engine,
+        ):
+            db_entries.append(
+                {
+                    "query_hash": q,
+                    "subject_hash": s,
+                    "identity": max_containment,
+                    "cov_query": q_containment,
+                    "configuration_id": config_id,
+                    "uname_system": uname.system,
+                    "uname_release": uname.release,
+                    "uname_machine": uname.machine,
+                }
+            )
+    except KeyboardInterrupt:  # pragma: no cover
+        # abort gracefully without wasting the work done (private_cli.py:1889-1894)
+        logger.error("Interrupted with %d completed %s comparisons", len(db_entries), METHOD)  # noqa: TRY400
+        run.status = "Worker interrupted"
+        session.commit()
+    try:
+        wire.export_json_db_entries(logger, json_filename, configuration, db_entries)
+    except Exception:  # pragma: no cover
+        logger.exception("Unexpected exception saving JSON:")
+        return RECORDING_FAILED
+    return 0

@@ -1,0 +1,395 @@
+"""Run driver and persistence for the ``sourmash-hip`` method (stdlib ``sqlite3``).
+
+The reference's Python (Typer CLI, SQLAlchemy ORM, snakemake) does not travel to the GPU
+box, so this module is the build's own counterpart of ``cli_sourmash`` +
+``start_and_run_method`` + ``run_method`` minus snakemake (pyani_plus/public_cli.py:115-329,
+598-639) and of the parts of ``db_orm`` they use (last row):
+
+* FASTA enumeration by the four extensions +- ``.gz`` (pyani_plus/utils.py:226-242)
+* genome identity = md5 of the decompressed bytes (utils.py:142-196); length = sum of
+  residues, description = first title (db_orm.py:832-866); duplicate md5 aborts
+  (public_cli.py:165-171)
+* the same tables / constraints as ``Base.metadata.create_all``
+* JSON column import with INSERT OR IGNORE (private_cli.py:507-614, db_orm.py:1076)
+* ``cache_comparisons``: N x N matrices over sorted md5, pandas ``to_json(orient="split")``
+  (db_orm.py:393-466) -- built without the reference's O(N^3) ``hashes.index`` loop.
+
+Databases written here can be opened by the reference and vice versa.
+"""
+
+from __future__ import annotations
+
+import datetime
+import gzip
+import hashlib
+import json
+import logging
+import sqlite3
+import sys
+import tempfile
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from . import wire
+from .methods import sourmash_hip
+
+FASTA_EXTENSIONS = {".fasta", ".fas", ".fna", ".fa"}  # pyani_plus/__init__.py:48
+
+SCHEMA = """
+CREATE TABLE IF NOT EXISTS genomes (
+    genome_hash VARCHAR NOT NULL, path VARCHAR NOT NULL, length INTEGER NOT NULL, description VARCHAR NOT NULL,
+    CONSTRAINT pk_genomes PRIMARY KEY (genome_hash));
+CREATE TABLE IF NOT EXISTS configurations (
+    configuration_id INTEGER NOT NULL, method VARCHAR NOT NULL, program VARCHAR NOT NULL, version VARCHAR NOT NULL,
+    fragsize INTEGER, mode VARCHAR, kmersize INTEGER, minmatch FLOAT, extra VARCHAR,
+    CONSTRAINT pk_configurations PRIMARY KEY (configuration_id),
+    CONSTRAINT uq_configurations_method UNIQUE (method, program, version, fragsize, mode, kmersize, minmatch, extra));
+CREATE TABLE IF NOT EXISTS comparisons (
+    comparison_id INTEGER NOT NULL, query_hash VARCHAR NOT NULL, subject_hash VARCHAR NOT NULL,
+    configuration_id INTEGER NOT NULL, identity FLOAT, aln_length INTEGER, sim_errors INTEGER, cov_query FLOAT,
+    cov_subject FLOAT, uname_system VARCHAR NOT NULL, uname_release VARCHAR NOT NULL, uname_machine VARCHAR NOT NULL,
+    CONSTRAINT pk_comparisons PRIMARY KEY (comparison_id),
+    CONSTRAINT uq_comparisons_query_hash UNIQUE (query_hash, subject_hash, configuration_id),
+    CONSTRAINT fk_comparisons_query_hash_genomes FOREIGN KEY(query_hash) REFERENCES genomes (genome_hash),
+    CONSTRAINT fk_comparisons_subject_hash_genomes FOREIGN KEY(subject_hash) REFERENCES genomes (genome_hash),
+    CONSTRAINT fk_comparisons_configuration_id_configurations FOREIGN KEY(configuration_id)
+        REFERENCES configurations (configuration_id));
+CREATE TABLE IF NOT EXISTS runs (
+    run_id INTEGER NOT NULL, configuration_id INTEGER NOT NULL, cmdline VARCHAR NOT NULL,
+    fasta_directory VARCHAR NOT NULL, date DATETIME NOT NULL, status VARCHAR NOT NULL, name VARCHAR NOT NULL,
+    df_identity VARCHAR, df_cov_query VARCHAR, df_aln_length VARCHAR, df_sim_errors VARCHAR, df_hadamard VARCHAR,
+    CONSTRAINT pk_runs PRIMARY KEY (run_id),
+    CONSTRAINT fk_runs_configuration_id_configurations FOREIGN KEY(configuration_id)
+        REFERENCES configurations (configuration_id));
+CREATE TABLE IF NOT EXISTS runs_genomes (
+    genome_hash VARCHAR NOT NULL, run_id INTEGER NOT NULL, fasta_filename VARCHAR NOT NULL,
+    CONSTRAINT pk_runs_genomes PRIMARY KEY (genome_hash, run_id),
+    CONSTRAINT fk_runs_genomes_genome_hash_genomes FOREIGN KEY(genome_hash) REFERENCES genomes (genome_hash),
+    CONSTRAINT fk_runs_genomes_run_id_runs FOREIGN KEY(run_id) REFERENCES runs (run_id));
+"""
+
+
+# ------------------------------------------------------------------ plain-object mirrors of the ORM rows
+@dataclass
+class Configuration:
+    configuration_id: int
+    method: str
+    program: str
+    version: str
+    fragsize: int | None = None
+    mode: str | None = None
+    kmersize: int | None = None
+    minmatch: float | None = None
+    extra: str | None = None
+
+
+@dataclass
+class RunGenomeAssociation:
+    genome_hash: str
+    fasta_filename: str
+
+
+@dataclass
+class Run:
+    """Duck-type of ``db_orm.Run`` as far as the method module reads it."""
+
+    run_id: int
+    configuration: Configuration
+    fasta_directory: str
+    fasta_hashes: list[RunGenomeAssociation]
+    status: str
+    name: str = ""
+
+    @property
+    def configuration_id(self) -> int:
+        return self.configuration.configuration_id
+
+
+class Session:
+    """Minimal session: ``commit()`` persists ``run.status`` (what the worker's interrupt path needs)."""
+
+    def __init__(self, conn: sqlite3.Connection, run: Run | None = None):
+        self.conn = conn
+        self.run = run
+
+    def commit(self) -> None:
+        if self.run is not None:
+            self.conn.execute("UPDATE runs SET status=? WHERE run_id=?", (self.run.status, self.run.run_id))
+        self.conn.commit()
+
+
+# ------------------------------------------------------------------ FASTA bookkeeping
+def check_fasta(logger: logging.Logger, fasta: Path) -> list[Path]:
+    """FASTA files of a directory by extension (pyani_plus/utils.py:226-242)."""
+    fasta = Path(fasta)
+    if not fasta.is_dir():
+        sourmash_hip.log_sys_exit(logger, f"FASTA input {fasta} is not a directory")
+    names: list[Path] = []
+    for ext in sorted(FASTA_EXTENSIONS):
+        names.extend(fasta.glob("*" + ext))
+        names.extend(fasta.glob("*" + ext + ".gz"))
+    if not names:
+        sourmash_hip.log_sys_exit(
+            logger, f"No FASTA input genomes under {fasta} with extensions {', '.join(sorted(FASTA_EXTENSIONS))}"
+        )
+    return sorted(names)
+
+
+def read_genome(logger: logging.Logger, path: Path) -> tuple[bytes, str]:
+    """(decompressed bytes, md5).  A ``.gz`` suffix that disagrees with the content is an error
+    (pyani_plus/db_orm.py:846-854)."""
+    path = Path(path)
+    if not path.is_file():
+        msg = f"Input {path} is a broken symlink" if path.is_symlink() else f"Input {path} not found"
+        raise ValueError(msg)
+    raw = path.read_bytes()
+    is_gz = raw[:2] == b"\x1f\x8b"
+    if is_gz and not str(path).endswith(".gz"):
+        sourmash_hip.log_sys_exit(logger, f"No .gz ending, but {path.name} is gzip compressed")
+    if not is_gz and str(path).endswith(".gz"):
+        sourmash_hip.log_sys_exit(logger, f"Has .gz ending, but {path.name} is NOT gzip compressed")
+    data = gzip.decompress(raw) if is_gz else raw
+    return data, hashlib.md5(data).hexdigest()  # noqa: S324 - content fingerprint
+
+
+def fasta_length_and_description(text: bytes) -> tuple[int, str | None]:
+    """Sum of residues and first title, as fasta_bytes_iterator sees them (utils.py:67-90)."""
+    length = 0
+    description = None
+    in_record = False
+    for line in text.split(b"\n"):
+        if line[:1] == b">":
+            in_record = True
+            if description is None:
+                description = line[1:].rstrip().decode()
+            continue
+        if in_record:
+            length += len(line.translate(None, b" \t\r\n"))
+    return length, description
+
+
+# ------------------------------------------------------------------ database
+def connect_to_db(database: Path | str) -> sqlite3.Connection:
+    conn = sqlite3.connect(str(database), timeout=30.0)
+    conn.executescript(SCHEMA)
+    conn.commit()
+    return conn
+
+
+def db_configuration(conn, method, program, version, fragsize=None, mode=None, kmersize=None, minmatch=None,
+                     extra=None) -> Configuration:
+    """Return the matching configuration row, creating it if needed (db_orm.py:705-782)."""
+    row = conn.execute(
+        "SELECT configuration_id FROM configurations WHERE method=? AND program=? AND version=? AND fragsize IS ? "
+        "AND mode IS ? AND kmersize IS ? AND minmatch IS ? AND extra IS ?",
+        (method, program, version, fragsize, mode, kmersize, minmatch, extra),
+    ).fetchone()
+    if row is None:
+        cur = conn.execute(
+            "INSERT INTO configurations (method, program, version, fragsize, mode, kmersize, minmatch, extra) "
+            "VALUES (?,?,?,?,?,?,?,?)",
+            (method, program, version, fragsize, mode, kmersize, minmatch, extra),
+        )
+        conn.commit()
+        cid = cur.lastrowid
+    else:
+        cid = row[0]
+    return Configuration(cid, method, program, version, fragsize, mode, kmersize, minmatch, extra)
+
+
+def db_genome(conn, path: Path, md5: str, length: int, description: str) -> None:
+    conn.execute(
+        "INSERT OR IGNORE INTO genomes (genome_hash, path, length, description) VALUES (?,?,?,?)",
+        (md5, str(path), length, description),
+    )
+
+
+def add_run(conn, config: Configuration, cmdline: str, fasta_directory: Path, status: str, name: str,
+            fasta_to_hash: dict[Path, str]) -> Run:
+    now = datetime.datetime.now(datetime.timezone.utc).replace(tzinfo=None).isoformat(sep=" ")
+    cur = conn.execute(
+        "INSERT INTO runs (configuration_id, cmdline, fasta_directory, date, status, name) VALUES (?,?,?,?,?,?)",
+        (config.configuration_id, cmdline, str(fasta_directory), now, status, name),
+    )
+    run_id = cur.lastrowid
+    assoc = []
+    for filename, md5 in fasta_to_hash.items():
+        conn.execute(
+            "INSERT INTO runs_genomes (genome_hash, run_id, fasta_filename) VALUES (?,?,?)",
+            (md5, run_id, Path(filename).name),
+        )
+        assoc.append(RunGenomeAssociation(md5, Path(filename).name))
+    conn.commit()
+    return Run(run_id, config, str(fasta_directory), assoc, status, name)
+
+
+def load_run(conn, run_id: int) -> Run:
+    row = conn.execute(
+        "SELECT configuration_id, fasta_directory, status, name FROM runs WHERE run_id=?", (run_id,)
+    ).fetchone()
+    if row is None:
+        msg = f"Database has no run {run_id}"
+        raise ValueError(msg)
+    crow = conn.execute(
+        "SELECT configuration_id, method, program, version, fragsize, mode, kmersize, minmatch, extra "
+        "FROM configurations WHERE configuration_id=?",
+        (row[0],),
+    ).fetchone()
+    assoc = [
+        RunGenomeAssociation(h, f)
+        for h, f in conn.execute("SELECT genome_hash, fasta_filename FROM runs_genomes WHERE run_id=?", (run_id,))
+    ]
+    return Run(run_id, Configuration(*crow), row[1], assoc, row[2], row[3])
+
+
+def count_run_comparisons(conn, run: Run) -> int:
+    """Comparisons among this run's genomes under its configuration (Run.comparisons(), db_orm.py:353-391)."""
+    return conn.execute(
+        "SELECT COUNT(*) FROM comparisons c "
+        "JOIN runs_genomes q ON c.query_hash = q.genome_hash AND q.run_id = ? "
+        "JOIN runs_genomes s ON c.subject_hash = s.genome_hash AND s.run_id = ? "
+        "WHERE c.configuration_id = ?",
+        (run.run_id, run.run_id, run.configuration_id),
+    ).fetchone()[0]
+
+
+def import_json_comparisons(logger: logging.Logger, conn, json_filename: Path) -> int:
+    """Import one column file; the configuration must already exist; ``cov_subject`` is ignored
+    (pyani_plus/private_cli.py:507-614)."""
+    data = wire.load_json_comparisons(json_filename)
+    cfg = data["configuration"]
+    row = conn.execute(
+        "SELECT configuration_id FROM configurations WHERE method=? AND program=? AND version=? AND fragsize IS ? "
+        "AND mode IS ? AND kmersize IS ? AND minmatch IS ? AND extra IS ?",
+        tuple(cfg[k] for k in wire.CONFIG_FIELDS),
+    ).fetchone()
+    if row is None:
+        sourmash_hip.log_sys_exit(logger, f"JSON file {json_filename} configuration not in database")
+    cid = row[0]
+    uname = data["uname"]
+    rows = [
+        (
+            e["query_hash"], e["subject_hash"], cid, e["identity"], e.get("aln_length"), e.get("sim_errors"),
+            e.get("cov_query"), uname["system"], uname["release"], uname["machine"],
+        )  # fmt: skip
+        for e in data["comparisons"]
+    ]
+    conn.executemany(
+        "INSERT OR IGNORE INTO comparisons (query_hash, subject_hash, configuration_id, identity, aln_length, "
+        "sim_errors, cov_query, uname_system, uname_release, uname_machine) VALUES (?,?,?,?,?,?,?,?,?,?)",
+        rows,
+    )
+    conn.commit()
+    return len(rows)
+
+
+def cache_comparisons(conn, run: Run) -> dict[str, str]:
+    """Fill runs.df_* with the N x N matrices (rows = query, columns = subject, sorted md5)."""
+    import pandas as pd
+
+    hashes = sorted(a.genome_hash for a in run.fasta_hashes)
+    index = {h: i for i, h in enumerate(hashes)}
+    n = len(hashes)
+    mats = {k: np.full((n, n), np.nan, float) for k in ("identity", "cov_query", "aln_length", "sim_errors")}
+    for q, s, ident, cov, aln, sim in conn.execute(
+        "SELECT c.query_hash, c.subject_hash, c.identity, c.cov_query, c.aln_length, c.sim_errors FROM comparisons c "
+        "JOIN runs_genomes rq ON c.query_hash = rq.genome_hash AND rq.run_id = ? "
+        "JOIN runs_genomes rs ON c.subject_hash = rs.genome_hash AND rs.run_id = ? WHERE c.configuration_id = ?",
+        (run.run_id, run.run_id, run.configuration_id),
+    ):
+        r, c = index[q], index[s]
+        for key, val in (("identity", ident), ("cov_query", cov), ("aln_length", aln), ("sim_errors", sim)):
+            mats[key][r, c] = np.nan if val is None else val
+    mats["hadamard"] = mats["identity"] * mats["cov_query"]
+    out = {
+        f"df_{key}": pd.DataFrame(data=mat, index=hashes, columns=hashes, dtype=float).to_json(orient="split")
+        for key, mat in mats.items()
+    }
+    conn.execute(
+        "UPDATE runs SET df_identity=?, df_cov_query=?, df_aln_length=?, df_sim_errors=?, df_hadamard=? WHERE run_id=?",
+        (out["df_identity"], out["df_cov_query"], out["df_aln_length"], out["df_sim_errors"], out["df_hadamard"],
+         run.run_id),
+    )
+    conn.commit()
+    return out
+
+
+# ------------------------------------------------------------------ the run itself
+def run_sourmash_hip(  # noqa: PLR0913
+    fasta: Path,
+    database: Path | str,
+    *,
+    cache: Path | None = None,
+    name: str | None = None,
+    kmersize: int = sourmash_hip.KMER_SIZE,
+    scaled: int = sourmash_hip.SCALED,
+    temp: Path | None = None,
+    logger: logging.Logger | None = None,
+    engine=None,
+) -> Run:
+    """FASTA directory -> database with all N^2 comparisons and cached matrices.
+
+    Counterpart of ``pyani-plus sourmash <fasta> -d <db> --create-db`` (call stack in
+    SURVEY.md section 3.1) with the snakemake layer replaced by one in-process call."""
+    logger = logger or logging.getLogger("pyani_plus_amd")
+    fasta = Path(fasta)
+    fasta_names = check_fasta(logger, fasta)
+    tool = sourmash_hip.get_sourmash_hip()
+    conn = connect_to_db(database)
+    config = db_configuration(
+        conn, sourmash_hip.METHOD, tool.exe_path.stem, tool.version, kmersize=kmersize, extra=f"scaled={scaled}"
+    )
+    filename_to_md5: dict[Path, str] = {}
+    seen: set[str] = set()
+    for filename in fasta_names:
+        try:
+            text, md5 = read_genome(logger, filename)
+        except ValueError as err:
+            sourmash_hip.log_sys_exit(logger, str(err))
+        if md5 in seen:
+            dups = "\n" + "\n".join(sorted({str(k) for k, v in filename_to_md5.items() if v == md5} | {str(filename)}))
+            sourmash_hip.log_sys_exit(logger, f"Multiple genomes with same MD5 checksum {md5}:{dups}")
+        seen.add(md5)
+        filename_to_md5[filename] = md5
+        length, description = fasta_length_and_description(text)
+        if description is None:
+            sourmash_hip.log_sys_exit(logger, f"File {filename.name} is not recognised as a FASTA record")
+        db_genome(conn, filename, md5, length, description)
+    run = add_run(
+        conn, config, " ".join(sys.argv), fasta, "Initialising",
+        f"{len(filename_to_md5)} genomes using {sourmash_hip.METHOD}" if name is None else name, filename_to_md5,
+    )  # fmt: skip
+    session = Session(conn, run)
+    n = len(filename_to_md5)
+    if count_run_comparisons(conn, run) == n * n:
+        logger.info("Database already has all %d=%d^2 comparisons", n * n, n)
+    else:
+        run.status = "Running"
+        session.commit()
+        own_cache = cache is None
+        cache_dir = Path(tempfile.mkdtemp(prefix="pyani_hip_cache_")) if own_cache else Path(cache)
+        cache_dir.mkdir(parents=True, exist_ok=True)
+        for _ in sourmash_hip.prepare_genomes(logger, run, cache_dir, engine=engine):
+            pass
+        tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
+        json_file = tmp_dir / f"{sourmash_hip.METHOD}.run_{run.run_id}.column_0.json"
+        hash_to_filename = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}
+        lengths = dict(conn.execute("SELECT genome_hash, length FROM genomes"))
+        status = sourmash_hip.compute_sourmash_hip(
+            logger, tmp_dir, session, run, json_file, fasta, hash_to_filename,
+            {v: k for k, v in hash_to_filename.items()}, {h: lengths[h] for h in hash_to_filename}, "",
+            cache=cache_dir, engine=engine,
+        )  # fmt: skip
+        if status:
+            sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
+        import_json_comparisons(logger, conn, json_file)
+    done = count_run_comparisons(conn, run)
+    if done != n * n:
+        sourmash_hip.log_sys_exit(logger, f"Only have {done} of {n}^2={n * n} {sourmash_hip.METHOD} comparisons needed")
+    cache_comparisons(conn, run)
+    run.status = "Done"
+    session.commit()
+    conn.close()
+    return run

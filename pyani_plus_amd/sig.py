@@ -1,0 +1,78 @@
+"""sourmash-compatible ``.sig`` files.
+
+The reference caches one signature per genome as
+``<cache>/sourmash_k=<K>_<extra>/<md5>.sig`` (pyani_plus/methods/sourmash.py:57-66)
+and its tests compare every JSON key of those files
+(tests/snakemake/test_sourmash_workflow.py:43-67).  Writing the same format lets
+the HIP backend and the sourmash backend share a cache and resume each other's runs.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
+
+
+def signature_md5(ksize: int, mins) -> str:
+    """sourmash's ``md5sum`` of a MinHash: md5(str(ksize) + concatenated decimal hashes)."""
+    digest = hashlib.md5(str(int(ksize)).encode())  # noqa: S324 - fingerprint, not security
+    digest.update("".join(str(int(h)) for h in mins).encode())
+    return digest.hexdigest()
+
+
+def write_sig(path: Path, *, name: str, filename: str, ksize: int, max_hash: int, mins) -> None:
+    """Write a single-sketch DNA signature exactly as ``sourmash scripts singlesketch`` lays it out."""
+    mins_list = [int(h) for h in mins]
+    obj = [
+        {
+            "class": "sourmash_signature",
+            "email": "",
+            "hash_function": "0.murmur64",
+            "filename": filename,
+            "name": name,
+            "license": "CC0",
+            "signatures": [
+                {
+                    "num": 0,
+                    "ksize": int(ksize),
+                    "seed": 42,
+                    "max_hash": int(max_hash),
+                    "mins": mins_list,
+                    "md5sum": signature_md5(ksize, mins_list),
+                    "molecule": "DNA",
+                }
+            ],
+            "version": 0.4,
+        }
+    ]
+    tmp = Path(str(path) + ".tmp")
+    tmp.write_text(json.dumps(obj, separators=(",", ":")))  # single line, no trailing newline
+    tmp.replace(path)
+
+
+def read_sig(path: Path, *, ksize: int | None = None, max_hash: int | None = None) -> tuple[np.ndarray, dict]:
+    """Return (ascending uint64 hashes, sketch dict) of the DNA sketch with the wanted k."""
+    data = json.loads(Path(path).read_text())
+    if not isinstance(data, list) or not data:
+        msg = f"{path} is not a sourmash signature file"
+        raise ValueError(msg)
+    for entry in data:
+        for sketch in entry.get("signatures", []):
+            if sketch.get("molecule", "DNA") != "DNA":
+                continue
+            if ksize is not None and sketch.get("ksize") != ksize:
+                continue
+            if max_hash is not None and sketch.get("max_hash") != max_hash:
+                continue
+            if sketch.get("num", 0) != 0:
+                msg = f"{path}: only scaled (num=0) sketches are supported, found num={sketch['num']}"
+                raise ValueError(msg)
+            mins = np.array(sketch["mins"], dtype=np.uint64)
+            if mins.size > 1 and not bool(np.all(mins[1:] > mins[:-1])):
+                mins = np.unique(mins)
+            return mins, sketch
+    msg = f"{path} has no DNA sketch with ksize={ksize} max_hash={max_hash}"
+    raise ValueError(msg)

@@ -1,0 +1,283 @@
+"""CPU tests: C-ABI surface, host packer, .sig / JSON / DB boundary (no GPU compute calls)."""
+
+from __future__ import annotations
+
+import json
+import logging
+import re
+import sqlite3
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from pyani_plus_amd import _capi, rundb, sig, wire
+from pyani_plus_amd.engine import ani_host, max_hash_for_scaled, pack_genomes
+from pyani_plus_amd.methods import sourmash_hip
+from pyani_plus_amd.synth import arena_to_ascii, synth_arena_numpy
+from tests.fake_engine import OracleEngine
+from tests.helpers import FIXTURE_SETS, GOLDEN, load_sig, read_fasta_bytes, sig_mins
+
+ROOT = Path(__file__).resolve().parent.parent
+LOGGER = logging.getLogger("test")
+K = 31
+
+
+# ------------------------------------------------------------------ C ABI surface
+def test_library_exports_every_header_symbol():
+    header = (ROOT / "include" / "pyani_hip.h").read_text()
+    declared = set(re.findall(r"^PA_API [^;(]*?\b(pa_[a-z0-9_]+)\(", header, flags=re.M))
+    assert len(declared) >= 20
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = _capi.load_library()  # raises if the .so is missing or lacks a symbol
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.pa_abi_version() == 1
+    assert lib.pa_max_hash(300) == 61489146912365176 and lib.pa_max_hash(1000) == 18446744073709552
+    assert max_hash_for_scaled(1) == 2**64 - 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pyani_plus_amd.engine import HipEngine
+
+    with pytest.raises(_capi.HipBackendError):
+        HipEngine(0)
+    with pytest.raises(_capi.HipBackendError):
+        sourmash_hip.get_engine()
+
+
+def test_product_never_imports_the_oracle():
+    for path in (ROOT / "pyani_plus_amd").rglob("*"):
+        if path.suffix in {".py", ".hip", ".cpp", ".h"} and "_build" not in path.parts:
+            text = path.read_text()
+            assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), path
+            assert "liboracle" not in text and "oracle/" not in text.replace("no oracle/_ref", ""), path
+
+
+# ------------------------------------------------------------------ host packer
+def test_pack_fasta_semantics():
+    text = b"junk before\n>r1 first title  \nACGTN\nacgt\r\n  \n>r2\nGG TT\tAA\n"
+    arena = pack_genomes([text])
+    assert arena.records == [2] and arena.residues == [15] and arena.invalid == [1]
+    # r1 = ACGTNACGT (lower-case folded), one separator, r2 = GGTTAA; then padding
+    assert arena_to_ascii(arena, 0)[: 9 + 1 + 6] == b"ACGTNACGTNGGTTAA"
+    assert arena.arena_bases == 64 and rundb.fasta_length_and_description(text) == (15, "r1 first title")
+    empty = pack_genomes([b"", b">only title\n"])
+    assert empty.residues == [0, 0] and empty.records == [0, 1]
+    bare = pack_genomes([b"ACGTX" * 20], fasta=False)
+    assert bare.residues == [100] and bare.invalid == [20] and bare.arena_bases == 128
+    # a genome whose length is a multiple of 64 still ends with an invalid position (then padding)
+    exact = pack_genomes([b"ACGT" * 16, b"ACGT" * 16], fasta=False)
+    assert exact.genome_start.tolist() == [0, 128, 256]
+    assert arena_to_ascii(exact, 0) == b"ACGT" * 16 and (int(exact.mask[2]) & 1) == 1
+
+
+@pytest.mark.parametrize("name", ["viral_example", "bad_alignments"])
+def test_pack_matches_reference_lengths(name, golden):
+    boundary = json.loads((golden / name / "boundary.json").read_text())
+    for g in boundary["genomes"]:
+        text = read_fasta_bytes(golden / name / g["fasta_filename"])
+        arena = pack_genomes([text])
+        assert arena.residues[0] == g["length"]
+        assert rundb.fasta_length_and_description(text) == (g["length"], g["description"])
+
+
+def test_capacity_and_argument_errors():
+    import ctypes as C
+
+    lib = _capi.load_library()
+    packed = np.zeros(4, dtype=np.uint32)
+    mask = np.zeros(2, dtype=np.uint32)
+    nb = C.c_uint64(0)
+    st = lib.pa_pack_seq(b"A" * 100, 100, packed.ctypes.data, mask.ctypes.data, 64, C.byref(nb), None)
+    assert st == _capi.PA_E_CAPACITY and nb.value == 128 and b"too small" in lib.pa_last_error()
+    assert lib.pa_pack_seq(b"A", 1, packed.ctypes.data, mask.ctypes.data, 63, C.byref(nb), None) == -1
+    if lib.pa_device_count() == 0:
+        ctx = C.c_void_p()
+        assert lib.pa_ctx_create(0, C.byref(ctx)) == -5 and b"no CPU fallback" in lib.pa_last_error()
+
+
+# ------------------------------------------------------------------ ANI transform
+def test_ani_host_equals_oracle_and_fixture_strings():
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 6000, size=40).astype(np.uint64)
+    counts = np.minimum(rng.integers(0, 6000, size=(40, 40)), np.minimum.outer(sizes, sizes)).astype(np.uint32)
+    np.fill_diagonal(counts, sizes)
+    a = ani_host(counts, sizes, sizes, K)
+    b = oracle.ani(counts, sizes, sizes, K)
+    assert np.array_equal(a[2], b[2])
+    assert np.array_equal(a[0][~a[2]], b[0][~b[2]]) and np.array_equal(a[1][~a[2]], b[1][~b[2]])
+    assert np.all(np.diag(a[0]) == 1.0) and np.all(np.isnan(a[0][a[2]]))
+
+
+# ------------------------------------------------------------------ .sig files
+@pytest.mark.parametrize("name", list(FIXTURE_SETS))
+def test_sig_writer_reproduces_fixture_files(name, tmp_path):
+    scaled, genomes = FIXTURE_SETS[name]
+    for md5, fasta in genomes.items():
+        ref = GOLDEN / name / "sourmash" / f"{md5}.sig"
+        want = load_sig(ref)
+        out = tmp_path / f"{md5}.sig"
+        sig.write_sig(out, name=md5, filename=f"somewhere/{fasta}", ksize=K, max_hash=max_hash_for_scaled(scaled), mins=sig_mins(ref))
+        got = load_sig(out)
+        for key in set(got) | set(want):  # the reference's own comparison: every key, filename by basename
+            if key == "filename":
+                assert Path(got[key]).name == Path(want[key]).name
+            else:
+                assert got[key] == want[key], key
+        # byte layout: single line, compact separators, same key order as sourmash writes
+        ref_text = ref.read_text()
+        assert out.read_text().replace(f"somewhere/{fasta}", want["filename"]) == ref_text
+        mins, sketch = sig.read_sig(out, ksize=K, max_hash=max_hash_for_scaled(scaled))
+        assert np.array_equal(mins, sig_mins(ref)) and sketch["md5sum"] == want["signatures"][0]["md5sum"]
+    with pytest.raises(ValueError, match="no DNA sketch"):
+        sig.read_sig(out, ksize=21)
+
+
+# ------------------------------------------------------------------ plugin + driver (host logic, oracle-backed engine)
+def _make_run(fasta_dir: Path, genomes: dict[str, str], scaled: int, method=sourmash_hip.METHOD):
+    tool = sourmash_hip.get_sourmash_hip()
+    config = rundb.Configuration(1, method, tool.exe_path.stem, tool.version, kmersize=K, extra=f"scaled={scaled}")
+    assoc = [rundb.RunGenomeAssociation(md5, fasta) for md5, fasta in genomes.items()]
+    return rundb.Run(1, config, str(fasta_dir), assoc, "Testing")
+
+
+class _Session:
+    commits = 0
+
+    def commit(self):
+        self.commits += 1
+
+
+@pytest.mark.parametrize("name", list(FIXTURE_SETS))
+def test_prepare_and_compute_match_reference_boundary(name, tmp_path):
+    scaled, genomes = FIXTURE_SETS[name]
+    boundary = json.loads((GOLDEN / name / "boundary.json").read_text())
+    run = _make_run(GOLDEN / name, genomes, scaled)
+    cache = tmp_path / "cache"
+    with pytest.raises(ValueError, match="does not exist"):
+        list(sourmash_hip.prepare_genomes(LOGGER, run, cache, engine=OracleEngine()))
+    cache.mkdir()
+    done = list(sourmash_hip.prepare_genomes(LOGGER, run, cache, engine=OracleEngine()))
+    assert [e.genome_hash for e in done] == list(genomes)
+    sig_dir = cache / f"sourmash_k={K}_scaled={scaled}"
+    for md5 in genomes:
+        got, want = load_sig(sig_dir / f"{md5}.sig"), load_sig(GOLDEN / name / "sourmash" / f"{md5}.sig")
+        for key in set(got) | set(want):
+            if key == "filename":
+                assert Path(got[key]).name == Path(want[key]).name
+            else:
+                assert got[key] == want[key], key
+    # idempotent: existing signatures are not recomputed (engine=None would raise without a GPU)
+    stamp = {p.name: p.stat().st_mtime_ns for p in sig_dir.glob("*.sig")}
+    assert len(list(sourmash_hip.prepare_genomes(LOGGER, run, cache, engine=None))) == len(genomes)
+    assert stamp == {p.name: p.stat().st_mtime_ns for p in sig_dir.glob("*.sig")}
+
+    json_file = tmp_path / "sourmash-hip.run_1.column_0.json"
+    query_hashes = {g["genome_hash"]: g["length"] for g in boundary["genomes"]}
+    rc = sourmash_hip.compute_sourmash_hip(
+        LOGGER, tmp_path, _Session(), run, json_file, GOLDEN / name, {}, {}, query_hashes, "", cache=cache, engine=OracleEngine()
+    )
+    assert rc == 0
+    data = wire.load_json_comparisons(json_file)
+    assert set(data["configuration"]) == set(boundary["column_json"]["configuration"])
+    assert data["configuration"]["method"] == "sourmash-hip" and data["configuration"]["extra"] == f"scaled={scaled}"
+    assert set(data["uname"]) == {"system", "release", "machine"}
+    key = lambda e: (e["query_hash"], e["subject_hash"])  # noqa: E731
+    got = sorted(data["comparisons"], key=key)
+    want = sorted(boundary["column_json"]["comparisons"], key=key)
+    assert got == want  # same keys, None where NULL, bit-identical floats
+
+    # single subject column (compute-column --subject <hash>)
+    subject = sorted(genomes)[-1]
+    rc = sourmash_hip.compute_sourmash_hip(
+        LOGGER, tmp_path, _Session(), run, json_file, GOLDEN / name, {}, {}, query_hashes, subject, cache=cache, engine=OracleEngine()
+    )
+    col = sorted(wire.load_json_comparisons(json_file)["comparisons"], key=key)
+    assert rc == 0 and col == [e for e in want if e["subject_hash"] == subject]
+
+
+def test_compute_error_paths(tmp_path):
+    scaled, genomes = FIXTURE_SETS["viral_example"]
+    run = _make_run(GOLDEN / "viral_example", genomes, scaled)
+    with pytest.raises(SystemExit, match="Missing sourmash signatures directory"):
+        sourmash_hip.compute_sourmash_hip(LOGGER, tmp_path, _Session(), run, tmp_path / "x.json", tmp_path, {}, {}, {}, "", cache=tmp_path)
+    bad = _make_run(GOLDEN / "viral_example", genomes, scaled, method="sourmash")
+    with pytest.raises(SystemExit, match="Expected run to be for sourmash-hip"):
+        list(sourmash_hip.prepare_genomes(LOGGER, bad, tmp_path))
+    run.configuration.version = "0.0.0"
+    with pytest.raises(SystemExit, match="Run configuration was"):
+        sourmash_hip.compute_sourmash_hip(LOGGER, tmp_path, _Session(), run, tmp_path / "x.json", tmp_path, {}, {}, {}, "", cache=tmp_path)
+    run = _make_run(GOLDEN / "viral_example", genomes, scaled)
+    run.configuration.extra = "num=500"
+    with pytest.raises(ValueError, match="scaled=N"):
+        list(sourmash_hip.prepare_genomes(LOGGER, run, tmp_path))
+    run.configuration.extra = None
+    with pytest.raises(SystemExit, match="requires extra setting"):
+        list(sourmash_hip.prepare_genomes(LOGGER, run, tmp_path))
+    run.configuration.kmersize = None
+    with pytest.raises(SystemExit, match="requires a k-mer size"):
+        list(sourmash_hip.prepare_genomes(LOGGER, run, tmp_path))
+    (tmp_path / "sourmash_k=31_scaled=300").mkdir()
+    run = _make_run(GOLDEN / "viral_example", genomes, scaled)
+    with pytest.raises(SystemExit, match="Missing sourmash signature file"):
+        sourmash_hip.compute_sourmash_hip(
+            LOGGER, tmp_path, _Session(), run, tmp_path / "x.json", tmp_path, {}, {}, {h: 1 for h in genomes}, "", cache=tmp_path, engine=OracleEngine()
+        )
+
+
+@pytest.mark.parametrize("name", list(FIXTURE_SETS))
+def test_run_driver_database_matches_reference(name, tmp_path):
+    scaled, genomes = FIXTURE_SETS[name]
+    boundary = json.loads((GOLDEN / name / "boundary.json").read_text())
+    db = tmp_path / "run.sqlite"
+    run = rundb.run_sourmash_hip(GOLDEN / name, db, cache=tmp_path / "cache", scaled=scaled, engine=OracleEngine(), temp=tmp_path)
+    assert run.status == "Done"
+    conn = sqlite3.connect(db)
+    row = conn.execute("SELECT status, df_identity, df_cov_query, df_hadamard, df_aln_length, df_sim_errors FROM runs").fetchone()
+    assert row[0] == "Done"
+    for got, key in zip(row[1:], ("df_identity", "df_cov_query", "df_hadamard", "df_aln_length", "df_sim_errors")):
+        assert got == boundary[key], key  # identical strings, incl. pandas' 10-decimal rounding and nulls
+    rows = conn.execute(
+        "SELECT query_hash, subject_hash, identity, aln_length, sim_errors, cov_query, cov_subject FROM comparisons ORDER BY 1, 2"
+    ).fetchall()
+    want = [(c["query_hash"], c["subject_hash"], c["identity"], c["aln_length"], c["sim_errors"], c["cov_query"], c["cov_subject"]) for c in boundary["comparisons"]]
+    assert rows == want
+    g_rows = conn.execute("SELECT genome_hash, length, description FROM genomes ORDER BY 1").fetchall()
+    assert g_rows == [(g["genome_hash"], g["length"], g["description"]) for g in boundary["genomes"]]
+    conn.close()
+    # a second run over the same inputs re-uses every comparison (no engine needed)
+    again = rundb.run_sourmash_hip(GOLDEN / name, db, cache=tmp_path / "cache", scaled=scaled, engine=None)
+    assert again.run_id == 2 and again.status == "Done"
+
+
+def test_driver_rejects_duplicates_and_bad_gzip(tmp_path):
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "a.fasta").write_bytes(b">a\nACGT\n")
+    (d / "b.fna").write_bytes(b">a\nACGT\n")
+    with pytest.raises(SystemExit, match="Multiple genomes with same MD5"):
+        rundb.run_sourmash_hip(d, tmp_path / "x.sqlite", engine=OracleEngine())
+    (d / "b.fna").unlink()
+    (d / "c.fa.gz").write_bytes(b">c\nACGT\n")
+    with pytest.raises(SystemExit, match="NOT gzip compressed"):
+        rundb.run_sourmash_hip(d, tmp_path / "y.sqlite", engine=OracleEngine())
+    with pytest.raises(SystemExit, match="No FASTA input genomes"):
+        rundb.run_sourmash_hip(tmp_path, tmp_path / "z.sqlite", engine=OracleEngine())
+
+
+def test_synthetic_generator_roundtrip():
+    arena = synth_arena_numpy(5, [1000, 64, 777, 1000, 1000], n_species=2)
+    assert arena.arena_bases % 64 == 0 and arena.n_genomes == 5
+    a0, a2, a4 = (arena_to_ascii(arena, g) for g in (0, 2, 4))
+    assert len(a0) == 1000 and len(a2) == 777 and set(a0) <= set(b"ACGT")
+    # same species (0, 2, 4 -> species 0): mostly identical prefixes
+    same = sum(x == y for x, y in zip(a0, a4))
+    assert same > 900
+    again = synth_arena_numpy(5, [1000, 64, 777, 1000, 1000], n_species=2)
+    assert np.array_equal(again.packed, arena.packed) and np.array_equal(again.mask, arena.mask)

@@ -138,3 +138,20 @@ def test_empty_short_and_lowercase():
     a = oracle.sketch_seq(withn, K, 1)
     b = np.union1d(oracle.sketch_seq(seq[:40], K, 1), oracle.sketch_seq(seq[41:], K, 1))
     assert np.array_equal(a, b)
+
+
+def test_fast_cpu_form_equals_naive_form():
+    """The tuned scalar form timed as cpu_baseline must equal the pinned naive form."""
+    for name, (scaled, genomes) in FIXTURE_SETS.items():
+        if name == "bacterial_example":
+            genomes = dict(list(genomes.items())[:1])
+        for md5, fasta in genomes.items():
+            text = read_fasta_bytes(GOLDEN / name / fasta)
+            # one record per fixture file here except NC_002696 (2 records): sketch record-wise
+            seqs = [b"".join(rec.split(b"\n")[1:]) for rec in text.split(b">")[1:]]
+            slow = oracle.sketch_many(seqs, K, scaled, threads=2, fast=False)
+            fast = oracle.sketch_many(seqs, K, scaled, threads=2, fast=True)
+            for a, b in zip(slow, fast):
+                assert np.array_equal(a, b)
+    withn = b"ACGTTGCAAGCTTGCATGCCTGCAGGTCGACTCTAGNNAGGATCCCCGGGTACCGAGCTCGAATTCACTGGCCGTCGTTTTACAACGTCGTGACTGGGAAAACCCTGGCG"
+    assert np.array_equal(oracle.sketch_many([withn], K, 1, fast=True)[0], oracle.sketch_seq(withn, K, 1))
