@@ -12,6 +12,8 @@
 // window against 0.375 byte of HBM input), so there is no LDS tiling of the
 // input; LDS only stages the rare survivors (1 in `scaled`) so that the global
 // append is one atomic per workgroup and the stores are coalesced.
+#include <cstdlib>
+
 #include "pa_internal.h"
 
 namespace {
@@ -45,36 +47,50 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
 
 __device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-// MurmurHash3_x64_128(seed 42).h1 of the K ASCII bytes held little-endian in w[0..7]
-// (bytes beyond K are zero).
+// ---- MurmurHash3_x64_128(seed 42).h1, split at the first multiply -----------------
+// The K ASCII bytes form up to four little-endian 64-bit words; word j is a "k1" word
+// (j even: k*c1, rotl 31, *c2, xor into h1) or a "k2" word (j odd: k*c2, rotl 33, *c1,
+// xor into h2), in the 16-byte blocks and in the tail alike.  P[j] is the FIRST product
+// (word * c1 or c2); everything after it is computed here.
+constexpr uint64_t kC1 = 0x87c37b91114253d5ULL, kC2 = 0x4cf5ad432745937fULL;
+
+// h*5 + c as shift-and-add.  Left to itself hipcc turns this back into two quarter-rate
+// v_mad_u64_u32; the empty asm keeps the shifted value opaque so it stays three full-rate ops.
+__device__ __forceinline__ uint64_t times5_plus(uint64_t h, uint64_t c) {
+  uint64_t t = h << 2;
+  asm volatile("" : "+v"(t));
+  return t + h + c;
+}
+
 template <int K>
-__device__ __forceinline__ uint64_t murmur3_h1(const uint32_t (&w)[8]) {
-  constexpr uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+__device__ __forceinline__ uint64_t murmur3_from_products(const uint64_t (&P)[4]) {
   uint64_t h1 = 42, h2 = 42;
   constexpr int nblocks = K / 16;
   constexpr int tail = K % 16;
 #pragma unroll
   for (int i = 0; i < nblocks; ++i) {
-    uint64_t k1 = u64_of(w[4 * i], w[4 * i + 1]);
-    uint64_t k2 = u64_of(w[4 * i + 2], w[4 * i + 3]);
-    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    const uint64_t k1 = rotl64(P[2 * i], 31) * kC2;
+    h1 ^= k1;
+    h1 = rotl64(h1, 27) + h2;
+    h1 = times5_plus(h1, 0x52dce729ULL);
+    const uint64_t k2 = rotl64(P[2 * i + 1], 33) * kC1;
+    h2 ^= k2;
+    h2 = rotl64(h2, 31) + h1;
+    h2 = times5_plus(h2, 0x38495ab5ULL);
   }
-  if constexpr (tail > 8) {
-    uint64_t k2 = u64_of(w[4 * nblocks + 2], w[4 * nblocks + 3]);
-    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
-  }
-  if constexpr (tail > 0) {
-    uint64_t k1 = u64_of(w[4 * nblocks], w[4 * nblocks + 1]);
-    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
-  }
+  if constexpr (tail > 8) h2 ^= rotl64(P[2 * nblocks + 1], 33) * kC1;
+  if constexpr (tail > 0) h1 ^= rotl64(P[2 * nblocks], 31) * kC2;
   h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
   h1 += h2; h2 += h1;
   h1 = fmix64(h1); h2 = fmix64(h2);
   h1 += h2;
   return h1;
+}
+
+// the 4-base group `b8` (base j at bits 2j) as ASCII, keeping only its first `nv` bytes
+__device__ __forceinline__ uint32_t ascii_group(uint32_t b8, int nv) {
+  const uint32_t a = ascii4(b8);
+  return nv >= 4 ? a : (nv <= 0 ? 0u : (a & ((1u << (8 * nv)) - 1u)));
 }
 
 // largest g with genome_blk[g] <= blk   (genome_blk has n+1 ascending entries)
@@ -87,7 +103,13 @@ __device__ __forceinline__ uint32_t find_genome(const uint32_t *__restrict__ gen
   return lo;
 }
 
-template <int K>
+// LUT = true (default): the first multiply of every murmur word is looked up.  A word is
+// two 4-base groups (lo, hi); word*c = (ascii(lo) + ascii(hi)*2^32)*c
+//                                    = s_lo[j][lo] + (s_hi[j][hi] << 32)   (mod 2^64)
+// with s_lo[j][b] = ascii(b)*c_j (64 bit) and s_hi[j][b] = low32(ascii(b)*c_j): two LDS reads and
+// one add replace the ASCII expansion (8 VALU) and a 64-bit multiply (3 quarter-rate VALU).
+// LUT = false keeps the arithmetic form (ablation / cross-check, PA_KMER_VARIANT=0).
+template <int K, bool LUT>
 __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
     const uint4 *__restrict__ packed, const uint2 *__restrict__ mask, uint32_t n_blocks64,
     const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash,
@@ -98,9 +120,20 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
   __shared__ uint32_t s_blk[kStageCap];
   __shared__ uint32_t s_n;
   __shared__ unsigned long long s_base;
+  constexpr int kWords = (K + 7) / 8;
+  __shared__ uint64_t s_lo[LUT ? kWords : 1][256];
+  __shared__ uint32_t s_hi[LUT ? kWords : 1][256];
 
   const uint32_t tid = threadIdx.x;
   if (tid == 0) s_n = 0;
+  if constexpr (LUT) {
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+      const uint64_t cj = (j & 1) ? kC2 : kC1;
+      s_lo[j][tid] = (uint64_t)ascii_group(tid, K - 8 * j) * cj;
+      s_hi[j][tid] = (uint32_t)((uint64_t)ascii_group(tid, K - 8 * j - 4) * cj);
+    }
+  }
   __syncthreads();
 
   const uint32_t t = blockIdx.x * kThreads + tid;
@@ -163,17 +196,22 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
           const uint64_t r_msb = f_lsb ^ kMask;
           const uint64_t canon = (f_msb <= r_msb) ? f_lsb : (f_msb ^ kMask);
           const uint32_t clo = (uint32_t)canon, chi = (uint32_t)(canon >> 32);
-          uint32_t w[8];
+          uint64_t P[4] = {0, 0, 0, 0};
 #pragma unroll
-          for (int d = 0; d < 8; ++d) {
-            if (4 * d >= K) { w[d] = 0; continue; }
-            const uint32_t src = d < 4 ? clo : chi;
-            uint32_t a = ascii4((src >> (8 * (d & 3))) & 0xffu);
-            if (4 * d + 4 > K) a &= (1u << (8 * (K - 4 * d))) - 1u;  // bytes beyond K are zero
-            w[d] = a;
+          for (int j = 0; j < kWords; ++j) {
+            const uint32_t src = j < 2 ? clo : chi;
+            const uint32_t glo = (src >> (16 * (j & 1))) & 0xffu, ghi = (src >> (16 * (j & 1) + 8)) & 0xffu;
+            if constexpr (LUT) {
+              const uint64_t lo = s_lo[j][glo];
+              const uint32_t hi = (uint32_t)(lo >> 32) + s_hi[j][ghi];
+              P[j] = u64_of((uint32_t)lo, hi);
+            } else {
+              const uint64_t word = u64_of(ascii_group(glo, K - 8 * j), ascii_group(ghi, K - 8 * j - 4));
+              P[j] = word * ((j & 1) ? kC2 : kC1);
+            }
           }
           (void)kMaskHi;
-          const uint64_t h = murmur3_h1<K>(w);
+          const uint64_t h = murmur3_from_products<K>(P);
           const bool ok = (h <= max_hash) && !((badw >> i) & 1u);
           if (ok) {
             const uint32_t slot = atomicAdd(&s_n, 1u);
@@ -207,17 +245,32 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
   }
 }
 
-template <int K>
-int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+template <int K, bool LUT>
+int launch_variant(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
            const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
            uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count) {
   const uint32_t grid = ceil_div_u64(n_blocks64, kThreads);
-  hipLaunchKernelGGL(kmer_hash_kernel<K>, dim3(grid), dim3(kThreads), 0, c->stream,
+  hipLaunchKernelGGL((kmer_hash_kernel<K, LUT>), dim3(grid), dim3(kThreads), 0, c->stream,
                      reinterpret_cast<const uint4 *>(d_packed), reinterpret_cast<const uint2 *>(d_mask),
                      (uint32_t)n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap,
                      reinterpret_cast<unsigned long long *>(d_count));
   PA_HIP(hipGetLastError());
   return PA_OK;
+}
+
+template <int K>
+int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+           const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
+           uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count) {
+  static const bool arithmetic = [] {
+    const char *v = getenv("PA_KMER_VARIANT");
+    return v && v[0] == '0';
+  }();
+  if (arithmetic)
+    return launch_variant<K, false>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
+                                    d_cand_genome, cap, d_count);
+  return launch_variant<K, true>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
+                                 d_cand_genome, cap, d_count);
 }
 
 }  // namespace

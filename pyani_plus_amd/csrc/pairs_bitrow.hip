@@ -25,16 +25,19 @@ constexpr int kThreads = 256;
 constexpr int kPlanes = 8;                       // vertical counter planes -> flush every 255 rows
 constexpr uint32_t kMaxTileSubjects = 2048;      // widest bit row: 64 words = 256 bytes
 
-__global__ __launch_bounds__(kThreads) void iota_or_kernel(const uint64_t *__restrict__ keys, uint64_t n,
-                                                           uint32_t *__restrict__ vals,
-                                                           unsigned long long *__restrict__ or_out) {
+__global__ __launch_bounds__(kThreads) void iota_kernel(uint32_t *__restrict__ vals, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n) vals[i] = (uint32_t)i;
+}
+
+// OR of every sketch's largest hash (its last entry): the highest set bit of that OR is the
+// highest set bit of any key, which bounds the radix passes.  One thread per genome.
+__global__ __launch_bounds__(kThreads) void last_or_kernel(const uint64_t *__restrict__ hashes,
+                                                           const uint64_t *__restrict__ off, uint32_t n,
+                                                           unsigned long long *__restrict__ or_out) {
+  const uint32_t g = blockIdx.x * kThreads + threadIdx.x;
   uint64_t k = 0;
-  if (i < n) {
-    vals[i] = (uint32_t)i;
-    k = keys[i];
-  }
-  // wave OR, one atomic per wave
+  if (g < n && off[g + 1] > off[g]) k = hashes[off[g + 1] - 1];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) k |= __shfl_xor(k, o, 64);
   if ((threadIdx.x & 63u) == 0 && k) atomicOr(or_out, (unsigned long long)k);
@@ -191,8 +194,9 @@ int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, 
     const uint32_t grid = ceil_div_u64(P, kThreads);
     PA_HIP(hipMemcpyAsync(keys[0], d_hashes, P * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
     PA_HIP(hipMemsetAsync(d_scalars + 2, 0, 2 * sizeof(uint64_t), c->stream));
-    hipLaunchKernelGGL(iota_or_kernel, dim3(grid), dim3(kThreads), 0, c->stream, keys[0], P, vals[0],
-                       reinterpret_cast<unsigned long long *>(d_scalars + 2));
+    hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(kThreads), 0, c->stream, vals[0], P);
+    hipLaunchKernelGGL(last_or_kernel, dim3(ceil_div_u64(n, kThreads)), dim3(kThreads), 0, c->stream, d_hashes, d_off,
+                       n, reinterpret_cast<unsigned long long *>(d_scalars + 2));
     PA_HIP(hipMemcpyAsync(c->h_pinned, d_scalars + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipStreamSynchronize(c->stream));
     const uint64_t all_or = c->h_pinned[0];

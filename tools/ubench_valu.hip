@@ -1,0 +1,141 @@
+// ubench_valu.hip -- VALU / LDS issue-rate microbenchmarks for gfx950 (MI355X).
+// Measures cycles per wave64 instruction per SIMD for the integer ops the k-mer hash kernel
+// is made of, at full occupancy (8 waves/SIMD), with independent dependency chains.
+// Build: hipcc --offload-arch=gfx950 -O3 -o /tmp/ubench tools/ubench_valu.hip ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+constexpr int ITERS = 4096;
+constexpr int UNROLL = 8;  // independent chains
+
+#define KERNEL(name, DECL, BODY, SINK)                                              \
+  __global__ __launch_bounds__(256) void name(uint32_t *out, uint32_t seed) {       \
+    DECL;                                                                           \
+    for (int it = 0; it < ITERS; ++it) {                                            \
+      BODY;                                                                         \
+    }                                                                               \
+    SINK;                                                                           \
+  }
+
+#define DECL32 uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; uint32_t k = seed | 1
+#define SINK32 out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7
+#define REP8(OP) OP(a0) OP(a1) OP(a2) OP(a3) OP(a4) OP(a5) OP(a6) OP(a7)
+
+#define OP_XOR(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_ADD(x) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_MULHI(x) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_MUL24(x) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x) : "v"(k));
+#define OP_MAD24(x) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(x) : "v"(k));
+#define OP_ALIGN(x) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(x) : "v"(k));
+#define OP_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %0" : "+v"(x) : "v"(k));
+#define OP_ADD3(x) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(x) : "v"(k));
+#define OP_LSHLOR(x) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(x) : "v"(k));
+#define OP_BFE(x) asm volatile("v_bfe_u32 %0, %0, 3, 20" : "+v"(x));
+#define OP_CNDMASK(x) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(k));
+
+KERNEL(k_xor, DECL32, REP8(OP_XOR), SINK32)
+KERNEL(k_add, DECL32, REP8(OP_ADD), SINK32)
+KERNEL(k_mullo, DECL32, REP8(OP_MULLO), SINK32)
+KERNEL(k_mulhi, DECL32, REP8(OP_MULHI), SINK32)
+KERNEL(k_mul24, DECL32, REP8(OP_MUL24), SINK32)
+KERNEL(k_mad24, DECL32, REP8(OP_MAD24), SINK32)
+KERNEL(k_align, DECL32, REP8(OP_ALIGN), SINK32)
+KERNEL(k_perm, DECL32, REP8(OP_PERM), SINK32)
+KERNEL(k_add3, DECL32, REP8(OP_ADD3), SINK32)
+KERNEL(k_lshlor, DECL32, REP8(OP_LSHLOR), SINK32)
+KERNEL(k_bfe, DECL32, REP8(OP_BFE), SINK32)
+KERNEL(k_cndmask, DECL32, REP8(OP_CNDMASK), SINK32)
+
+#define DECL64 uint64_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; uint32_t k = seed | 1; uint64_t k64 = ((uint64_t)k << 32) | k; uint64_t cc
+#define SINK64 out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^ (uint32_t)((a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) >> 32)
+#define OP_MAD64(x) asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(x), "=s"(cc) : "v"((uint32_t)x), "v"(k));
+#define OP_SHL64(x) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(x));
+#define OP_SHR64(x) asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(x));
+#define OP_LSHLADD64(x) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(x) : "v"(k64));
+#define OP_CMP64(x) asm volatile("v_cmp_gt_u64 vcc, %0, %1" : : "v"(x), "v"(k64) : "vcc");
+#define OP_ADDCO(x) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(*(uint32_t*)&x) : "v"(k) : "vcc");
+
+KERNEL(k_mad64, DECL64, REP8(OP_MAD64), SINK64)
+KERNEL(k_shl64, DECL64, REP8(OP_SHL64), SINK64)
+KERNEL(k_shr64, DECL64, REP8(OP_SHR64), SINK64)
+KERNEL(k_lshladd64, DECL64, REP8(OP_LSHLADD64), SINK64)
+KERNEL(k_cmp64, DECL64, REP8(OP_CMP64), SINK64)
+KERNEL(k_addco_pair, DECL64, REP8(OP_ADDCO), SINK64)
+
+// LDS random reads: 256-entry tables, index from a cheap LCG per lane
+__global__ __launch_bounds__(256) void k_lds_b64(uint32_t *out, uint32_t seed) {
+  __shared__ uint64_t tab[4][256];
+  for (int j = 0; j < 4; ++j) tab[j][threadIdx.x] = threadIdx.x * 0x9e3779b97f4a7c15ULL + j;
+  __syncthreads();
+  uint32_t x = threadIdx.x * 2654435761u + seed;
+  uint64_t acc = 0;
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc += tab[j & 3][(x >> (j * 3)) & 255];
+    }
+    x = x * 1664525u + 1013904223u;
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)acc ^ (uint32_t)(acc >> 32);
+}
+__global__ __launch_bounds__(256) void k_lds_b32(uint32_t *out, uint32_t seed) {
+  __shared__ uint32_t tab[4][256];
+  for (int j = 0; j < 4; ++j) tab[j][threadIdx.x] = threadIdx.x * 0x9e3779b9u + j;
+  __syncthreads();
+  uint32_t x = threadIdx.x * 2654435761u + seed;
+  uint32_t acc = 0;
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc += tab[j & 3][(x >> (j * 3)) & 255];
+    }
+    x = x * 1664525u + 1013904223u;
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+typedef void (*kern_t)(uint32_t *, uint32_t);
+struct Entry { const char *name; kern_t fn; int ops_per_iter; };
+
+int main() {
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  const int blocks = cus * 8;  // 8 blocks x 4 waves = 32 waves/CU = 8 waves/SIMD
+  uint32_t *d_out;
+  CHECK(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
+  std::vector<Entry> es = {
+      {"v_xor_b32", k_xor, 8}, {"v_add_u32", k_add, 8}, {"v_mul_lo_u32", k_mullo, 8}, {"v_mul_hi_u32", k_mulhi, 8},
+      {"v_mul_u32_u24", k_mul24, 8}, {"v_mad_u32_u24", k_mad24, 8}, {"v_alignbit_b32", k_align, 8},
+      {"v_perm_b32", k_perm, 8}, {"v_add3_u32", k_add3, 8}, {"v_lshl_or_b32", k_lshlor, 8}, {"v_bfe_u32", k_bfe, 8},
+      {"v_cndmask_b32", k_cndmask, 8}, {"v_mad_u64_u32", k_mad64, 8}, {"v_lshlrev_b64", k_shl64, 8},
+      {"v_lshrrev_b64", k_shr64, 8}, {"v_lshl_add_u64", k_lshladd64, 8}, {"v_cmp_gt_u64", k_cmp64, 8},
+      {"v_add_co+v_addc pair", k_addco_pair, 8}, {"ds_read_b64 random(+add64)", k_lds_b64, 8},
+      {"ds_read_b32 random(+add)", k_lds_b32, 8},
+  };
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  printf("device %s, %d CUs, clock %d kHz\n", prop.gcnArchName, cus, prop.clockRate);
+  for (auto &e : es) {
+    hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, d_out, 12345u);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, d_out, 12345u + r);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double per_launch_s = ms * 1e-3 / 5;
+    // wave-instructions per SIMD: 8 waves x ITERS x ops
+    const double winstr_per_simd = 8.0 * ITERS * e.ops_per_iter;
+    const double cyc = per_launch_s * 2.4e9 / winstr_per_simd;
+    printf("%-28s %8.3f ms/launch  -> %6.2f cycles per wave-instr per SIMD (at 2.4 GHz)\n", e.name, per_launch_s * 1e3, cyc);
+  }
+  return 0;
+}
