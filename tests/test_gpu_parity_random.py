@@ -1,0 +1,189 @@
+"""GPU parity on seeded random inputs and the reference-tested edge cases (through the C ABI).
+
+Integer work (hashes, sketches, intersection counts) must be bit-exact against the oracle;
+the device ANI transform is f64 within 1 ulp (rtol 2.3e-16) of host libm, which itself
+reproduces the reference fixtures bit for bit (tests/test_gpu_parity_fixtures.py).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle
+from pyani_plus_amd.synth import arena_to_ascii, synth_arena_numpy
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from pyani_plus_amd.engine import HipEngine
+
+    eng = HipEngine(0)
+    yield eng
+    eng.close()
+
+
+def _random_fasta(rng, n_records, max_len, *, lower=False, n_runs=0) -> bytes:
+    out = []
+    for r in range(n_records):
+        length = int(rng.integers(0, max_len))
+        seq = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=length)
+        for _ in range(n_runs):
+            if length > 50:
+                p = int(rng.integers(0, length - 5))
+                seq[p : p + int(rng.integers(1, 40))] = ord("N")
+        if lower:
+            mask = rng.random(length) < 0.3
+            seq[mask] = seq[mask] + 32
+        body = seq.tobytes()
+        lines = [body[i : i + 70] for i in range(0, len(body), 70)]
+        out.append(b">rec%d some description\n" % r + b"\n".join(lines) + b"\n")
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("k", [15, 16, 21, 31, 32])
+@pytest.mark.parametrize("scaled", [1, 7, 1000])
+def test_sketch_random_fasta_matches_oracle(engine, k, scaled):
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(1000 * k + scaled)
+    texts = [
+        _random_fasta(rng, 1, 30000),
+        _random_fasta(rng, 3, 8000, n_runs=4),
+        _random_fasta(rng, 2, 5000, lower=True, n_runs=2),
+        b"",  # empty file
+        b">short\nACGTACGTAC\n",  # shorter than k
+        b">exact\n" + rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=64 * 50).tobytes() + b"\n",  # multiple of 64
+        b">allN\n" + b"N" * 500 + b"\n",
+        b"no header at all\nACGTACGT\n",
+    ]
+    arena = pack_genomes(texts)
+    got = engine.sketch(engine.upload(arena), k, scaled).to_host()
+    for g, text in enumerate(texts):
+        want, total = oracle.sketch_fasta_text(text, k, scaled)
+        assert arena.residues[g] == total
+        assert np.array_equal(got[g], want), f"genome {g}: {len(got[g])} vs {len(want)} (k={k}, scaled={scaled})"
+
+
+def test_sketch_staging_overflow_and_capacity_retry(engine):
+    """scaled=1 floods the LDS staging buffer; a low-complexity genome overruns the candidate estimate."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(7)
+    k = 31
+    # find a 31-mer whose canonical hash passes scaled=1000
+    thresh = oracle.max_hash(1000)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    while True:
+        kmer = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=k).tobytes()
+        canon = min(kmer, kmer.translate(comp)[::-1])
+        if oracle.murmur3_h1(canon, 42) <= thresh:
+            break
+    repeat = kmer * (4_200_000 // k)  # every 31st window is that k-mer: ~135 000 candidates, estimate ~70 000
+    rand = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=300_000).tobytes()
+    arena = pack_genomes([repeat, rand], fasta=False)
+    got = engine.sketch(engine.upload(arena), k, 1000).to_host()
+    assert np.array_equal(got[0], oracle.sketch_seq(repeat, k, 1000)) and got[0].size >= 1
+    assert np.array_equal(got[1], oracle.sketch_seq(rand, k, 1000))
+    # scaled=1: every window survives -> staging overflow path, duplicates collapse
+    small = pack_genomes([rand[:50_000], (b"ACGT" * 3000)], fasta=False)
+    got = engine.sketch(engine.upload(small), k, 1).to_host()
+    assert np.array_equal(got[0], oracle.sketch_seq(rand[:50_000], k, 1))
+    assert np.array_equal(got[1], oracle.sketch_seq(b"ACGT" * 3000, k, 1)) and got[1].size <= 4
+
+
+def test_sketch_synthetic_arena_and_idempotence(engine):
+    arena = synth_arena_numpy(12, [200_000, 64, 0 + 100, 150_000, 64 * 1000, 99_999, 31, 30, 250_000, 5, 128, 77_777], n_species=3)
+    dev = engine.upload(arena)
+    a = engine.sketch(dev, 31, 100).to_host()
+    b = engine.sketch(dev, 31, 100).to_host()
+    for g in range(arena.n_genomes):
+        want = oracle.sketch_seq(arena_to_ascii(arena, g), 31, 100)
+        assert np.array_equal(a[g], want) and np.array_equal(a[g], b[g])
+
+
+def _random_sketches(rng, sizes, universe):
+    pool = np.unique(rng.integers(0, 2**63, size=universe, dtype=np.uint64))
+    return [np.sort(rng.choice(pool, size=min(s, pool.size), replace=False)) for s in sizes]
+
+
+@pytest.mark.parametrize(
+    "sizes,universe",
+    [
+        ([0, 1, 5, 64, 65, 300, 0, 1000], 1500),  # empty sketches, tiny, dense overlap
+        (list(range(0, 140)), 400),  # 140 subjects -> two-thread rows
+        ([50] * 300, 2000),  # 300 subjects -> four-thread rows
+        ([8] * 2100, 3000),  # > 2048 subjects -> two subject tiles
+        ([70_000, 500, 66_000], 90_000),  # > 255 rows per lane -> vertical-counter flush
+    ],
+)
+def test_pair_counts_match_oracle(engine, sizes, universe):
+    rng = np.random.default_rng(len(sizes) + universe)
+    sketches = _random_sketches(rng, sizes, universe)
+    sk = engine.sketches_from_host(sketches)
+    want = oracle.pair_counts(sketches, threads=8)
+    for algo in (1, 2):
+        got = engine.pair_counts(sk, algo=algo).cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, want), f"algo {algo}"
+    n = len(sketches)
+    # rectangular tiles (a subject column, a query band)
+    for q_range, s_range in (((0, n), (n - 1, n)), ((1, min(n, 5)), (0, n)), ((2, 3), (1, 2))):
+        for algo in (1, 2):
+            got = engine.pair_counts(sk, q_range, s_range, algo=algo).cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, want[q_range[0] : q_range[1], s_range[0] : s_range[1]])
+
+
+def test_device_ani_within_one_ulp_of_libm(engine):
+    from pyani_plus_amd.engine import ani_host
+
+    rng = np.random.default_rng(11)
+    sketches = _random_sketches(rng, rng.integers(1, 3000, size=200).tolist(), 6000)
+    sk = engine.sketches_from_host(sketches)
+    counts_t = engine.pair_counts(sk)
+    counts = counts_t.cpu().numpy().view(np.uint32)
+    sizes = [len(s) for s in sketches]
+    for k in (21, 31):
+        ident, cov, null = ani_host(counts, sizes, sizes, k)
+        d_ident, d_cov = (x.cpu().numpy() for x in engine.ani(counts_t, sk, k))
+        assert np.array_equal(np.isnan(d_ident), null) and np.array_equal(np.isnan(d_cov), null)
+        for got, want in ((d_ident, ident), (d_cov, cov)):
+            rel = np.abs(got[~null] - want[~null]) / want[~null]
+            assert rel.max() <= 2.3e-16, rel.max()
+        assert np.all(np.diag(d_ident) == 1.0) and np.all(np.diag(d_cov) == 1.0)
+        assert np.array_equal(d_ident, d_ident.T, equal_nan=True)  # max-containment is symmetric
+
+
+def test_full_size_properties_baseline_config(engine):
+    """BASELINE configs[1] at full size: 1000 x 5 Mb, k=31, scaled=1000 (size-independent properties)."""
+    from pyani_plus_amd.synth import device_arena_to_host, synth_arena_torch
+
+    n, length, k, scaled = 1000, 5_000_000, 31, 1000
+    arena = synth_arena_torch(engine, n, length)
+    sk = engine.sketch(arena, k, scaled)
+    sk2 = engine.sketch(arena, k, scaled)
+    t = engine.torch
+    assert sk.total == sk2.total and t.equal(sk.hashes[: sk.total], sk2.hashes[: sk2.total]) and t.equal(sk.off, sk2.off)
+    off = sk.off.cpu().numpy()
+    sizes = np.diff(off)
+    assert sizes.min() > 4500 and sizes.max() < 5500  # ~L/scaled
+    flat = sk.hashes[: sk.total].cpu().numpy().view(np.uint64)
+    assert flat.max() <= oracle.max_hash(scaled)
+    for g in range(0, n, 97):  # ascending and duplicate-free inside every sampled sketch
+        assert np.all(np.diff(flat[off[g] : off[g + 1]].astype(np.float64)) > 0)
+    counts = engine.pair_counts(sk)
+    c = counts.cpu().numpy().view(np.uint32)
+    assert np.array_equal(c, c.T) and np.array_equal(np.diag(c), sizes.astype(np.uint32))
+    merged = engine.pair_counts(sk, algo=2).cpu().numpy().view(np.uint32)  # independent second kernel, full 10^6 pairs
+    assert np.array_equal(c, merged)
+    # genomes of the same species overlap, different species do not
+    assert c[0, 40] > 3000 and c[0, 1] == 0
+    # oracle spot checks at full genome size
+    sample = [0, 41, 999]
+    host = device_arena_to_host(arena, sample, length)
+    for i, g in enumerate(sample):
+        want = oracle.sketch_seq(arena_to_ascii(host, i), k, scaled)
+        assert np.array_equal(flat[off[g] : off[g + 1]], want)
+    block = [flat[off[g] : off[g + 1]] for g in range(0, 1000, 25)]
+    assert np.array_equal(c[0:1000:25, 0:1000:25], oracle.pair_counts(block, threads=8))
