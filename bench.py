@@ -54,10 +54,22 @@ def cpu_baseline(engine, arena, sk, args, n_total: int) -> dict:
     from pyani_plus_amd.synth import arena_to_ascii, device_arena_to_host
 
     cores = len(os.sched_getaffinity(0))
-    n_samp = args.cpu_sample_genomes or max(2, min(arena.n_genomes, 2 * cores, 64))
+    # enough genomes to keep every thread busy twice over, bounded (<= 512 genomes = 2.5 GB of text)
+    n_samp = args.cpu_sample_genomes or max(2, min(arena.n_genomes, max(2 * cores, 16), 512))
     sample = list(range(n_samp))
-    host = device_arena_to_host(arena, sample, args.length)
-    seqs = [arena_to_ascii(host, i) for i in range(n_samp)]
+    # unpack the sampled genomes to ASCII on the GPU (plumbing), then hand the text to the oracle
+    t = engine.torch
+    lut = t.tensor(list(b"ACGT"), dtype=t.uint8, device=engine.device)
+    shifts = (t.arange(16, device=engine.device, dtype=t.int32) * 2)[None, :]
+    seqs = []
+    for g in sample:
+        s0, s1 = int(arena.genome_start[g]), int(arena.genome_start[g + 1])
+        words = arena.packed[s0 // 16 : s1 // 16]
+        codes = ((words[:, None] >> shifts) & 3).reshape(-1)[: args.length].to(t.int64)
+        seqs.append(lut[codes].cpu().numpy())
+    if n_samp <= 4:  # tiny runs: also exercise the host-side unpacker
+        host = device_arena_to_host(arena, sample, args.length)
+        assert all(arena_to_ascii(host, i) == seqs[i].tobytes() for i in range(n_samp))
     oracle.sketch_many(seqs[:1], args.kmer, args.scaled, threads=1, fast=True)  # warm (table init, page-in)
     t0 = time.perf_counter()
     cpu_sk = oracle.sketch_many(seqs, args.kmer, args.scaled, threads=cores, fast=True)
@@ -108,10 +120,17 @@ def main():
     from pyani_plus_amd.engine import DeviceSketches, HipEngine
     from pyani_plus_amd.synth import synth_arena_torch
 
+    # PA_BENCH_BACKEND=gloo is a plumbing check for boxes with fewer GPUs than ranks: ranks share
+    # GPUs and the collectives run on host tensors.  The measured configuration is always nccl (RCCL).
+    backend = os.environ.get("PA_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            dist.init_process_group(backend, rank=rank, world_size=world)
     engine = HipEngine(local_rank)
 
     n_total = args.genomes or (1000 if world == 1 else 1250 * world)
@@ -124,7 +143,11 @@ def main():
         sk_local = engine.sketch(arena, args.kmer, args.scaled)
         if world > 1:
             sizes = sk_local.off[1:] - sk_local.off[:-1]
-            hashes, off = allgather_sketches(torch, dist, sk_local.hashes, sizes, shard_sizes)
+            if backend == "nccl":
+                hashes, off = allgather_sketches(torch, dist, sk_local.hashes, sizes, shard_sizes)
+            else:
+                hashes, off = allgather_sketches(torch, dist, sk_local.hashes[: max(1, sk_local.total)].cpu(), sizes.cpu(), shard_sizes)
+                hashes, off = hashes.to(engine.device), off.to(engine.device)
             sk = DeviceSketches(hashes, off, n_total, int(off[-1].item()))
         else:
             sk = sk_local
@@ -149,9 +172,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=engine.device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=engine.device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        # every rank cross-checks a block of its column tile with the independent merge kernel
+        nq_chk, ns_chk = min(n_total, 256), min(g1 - g0, 64)
+        chk = engine.pair_counts(out[1], (0, nq_chk), (g0, g0 + ns_chk), algo=_capi.PA_PAIRS_MERGE)
+        if not torch.equal(chk, out[2][:nq_chk, :ns_chk]):
+            raise SystemExit(f"PARITY FAILURE on rank {rank}: bit-row and merge counts differ")
     prof = engine.prof_get()
     engine.prof_enable(False)
     sk_local, sk, counts, ident, cov = out
@@ -196,7 +224,7 @@ def main():
                 "scaled": args.scaled,
                 "species": args.species,
                 "mean_sketch_size": local_hashes / max(1, n_local),
-                "parallelism": f"genome shards + RCCL sketch all-gather + subject-column tiles x{world}" if world > 1 else "single GPU",
+                "parallelism": f"genome shards + {'RCCL' if backend == 'nccl' else backend} sketch all-gather + subject-column tiles x{world}" if world > 1 else "single GPU",
             },
             "roofline": {
                 "kernel": "kmer_hash_kernel<31>",

@@ -34,7 +34,15 @@ __device__ __forceinline__ uint32_t ascii4(uint32_t b8) {
   return __builtin_amdgcn_perm(0u, 0x54474341u, v);
 }
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// 64-bit rotate as two funnel shifts (v_alignbit_b32); r is a compile-time constant in 1..63
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) {
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  if (r == 32) return u64_of(hi, lo);
+  if (r < 32) return u64_of(alignbit(lo, hi, 32 - r), alignbit(hi, lo, 32 - r));
+  return u64_of(alignbit(hi, lo, 64 - r), alignbit(lo, hi, 64 - r));
+}
 
 __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
   k ^= k >> 33;
@@ -44,8 +52,6 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
   k ^= k >> 33;
   return k;
 }
-
-__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // ---- MurmurHash3_x64_128(seed 42).h1, split at the first multiply -----------------
 // The K ASCII bytes form up to four little-endian 64-bit words; word j is a "k1" word
@@ -212,8 +218,7 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
           }
           (void)kMaskHi;
           const uint64_t h = murmur3_from_products<K>(P);
-          const bool ok = (h <= max_hash) && !((badw >> i) & 1u);
-          if (ok) {
+          if (h <= max_hash && !((badw >> i) & 1u)) {
             const uint32_t slot = atomicAdd(&s_n, 1u);
             if (slot < kStageCap) {
               s_hash[slot] = h;
