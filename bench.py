@@ -123,8 +123,12 @@ def main():
     # PA_BENCH_BACKEND=gloo is a plumbing check for boxes with fewer GPUs than ranks: ranks share
     # GPUs and the collectives run on host tensors.  The measured configuration is always nccl (RCCL).
     backend = os.environ.get("PA_BENCH_BACKEND", "nccl")
-    if world > 1:
+    # PA_BENCH_FORCE_DIST=1 runs the distributed code path (process group, all-gather, column tile)
+    # even with one rank, so the RCCL calls can be exercised on a single-GPU box.
+    dist_path = world > 1 or os.environ.get("PA_BENCH_FORCE_DIST") == "1"
+    if dist_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -141,7 +145,7 @@ def main():
 
     def step():
         sk_local = engine.sketch(arena, args.kmer, args.scaled)
-        if world > 1:
+        if dist_path:
             sizes = sk_local.off[1:] - sk_local.off[:-1]
             if backend == "nccl":
                 hashes, off = allgather_sketches(torch, dist, sk_local.hashes, sizes, shard_sizes)
@@ -157,7 +161,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_path:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -171,7 +175,7 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_path:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=engine.device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -253,7 +257,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_path:
         dist.barrier()
         dist.destroy_process_group()
     engine.close()

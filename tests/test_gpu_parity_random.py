@@ -187,3 +187,34 @@ def test_full_size_properties_baseline_config(engine):
         assert np.array_equal(flat[off[g] : off[g + 1]], want)
     block = [flat[off[g] : off[g + 1]] for g in range(0, 1000, 25)]
     assert np.array_equal(c[0:1000:25, 0:1000:25], oracle.pair_counts(block, threads=8))
+
+
+def test_mixed_length_set_config5_style(engine):
+    """BASELINE configs[4] shape at reduced count: log-uniform lengths 100 kb - 10 Mb, cost-balanced shards."""
+    from pyani_plus_amd.distributed import shard_bounds_by_cost
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(2026)
+    n = 40
+    lengths = np.exp(rng.uniform(np.log(1e5), np.log(1e7), size=n)).astype(int)
+    roots = [rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=int(lengths.max())) for _ in range(3)]
+    seqs = []
+    for g, length in enumerate(lengths):
+        seq = roots[g % 3][:length].copy()
+        hit = rng.random(length) < (0.002, 0.02, 0.08)[(g // 3) % 3]
+        seq[hit] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=int(hit.sum()))]
+        seqs.append(seq.tobytes())
+    arena = pack_genomes(seqs, fasta=False)
+    sk = engine.sketch(engine.upload(arena), 31, 1000)
+    got = sk.to_host()
+    want = oracle.sketch_many(seqs, 31, 1000, threads=8, fast=True)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    sizes = np.array([len(s) for s in got])
+    assert sizes.min() >= 60 and sizes.max() > 20 * sizes.min()  # ragged sketches
+    counts = engine.pair_counts(sk).cpu().numpy().view(np.uint32)
+    assert np.array_equal(counts, oracle.pair_counts(want, threads=8))
+    # cost-balanced contiguous column tiles reproduce the full matrix when stitched
+    bounds = shard_bounds_by_cost(sizes, 4)
+    stitched = np.concatenate([engine.pair_counts(sk, (0, n), b).cpu().numpy().view(np.uint32) for b in bounds if b[1] > b[0]], axis=1)
+    assert np.array_equal(stitched, counts)
