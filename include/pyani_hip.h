@@ -110,6 +110,24 @@ PA_API int pa_pack_fasta(const uint8_t *h_text, uint64_t n_text, uint32_t *h_pac
 PA_API int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_packed, uint32_t *h_mask,
                 uint64_t cap_bases, uint64_t *n_bases, uint64_t *n_invalid);
 
+/* ---- host side: files -> md5 + length + title + arena, on a pool of host threads ----
+ * One pass per file does what the reference does in three (md5 of the decompressed bytes,
+ * pyani_plus/utils.py:142-196; length and description, pyani_plus/db_orm.py:832-866; the
+ * sketcher's own read, pyani_plus/methods/sourmash.py:67-83): read, gunzip, md5, parse, pack.
+ * pa_fasta_batch_info returns the file's own status (PA_OK or a negative code with `message`,
+ * e.g. "Has .gz ending, but x.fa.gz is NOT gzip compressed", db_orm.py:846-854); strings are
+ * owned by the batch.  pa_fasta_batch_copy_arena concatenates the successfully loaded genomes
+ * (failed files occupy no space) and writes genome_start[n+1]. */
+typedef struct pa_fasta_batch pa_fasta_batch;
+PA_API int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fasta_batch **out);
+PA_API int pa_fasta_batch_info(const pa_fasta_batch *batch, uint32_t i, char md5hex33[33], uint64_t *n_residues,
+                        uint64_t *n_records, uint64_t *n_invalid, uint64_t *n_bases, uint64_t *n_text,
+                        const char **description, const char **message, int *was_gzip);
+PA_API uint64_t pa_fasta_batch_arena_bases(const pa_fasta_batch *batch);
+PA_API int pa_fasta_batch_copy_arena(const pa_fasta_batch *batch, uint32_t *h_packed, uint32_t *h_mask,
+                              uint64_t *h_genome_start);
+PA_API void pa_fasta_batch_free(pa_fasta_batch *batch);
+
 /* FracMinHash threshold for `scaled` (sourmash max_hash; fixtures pin
  * 61489146912365176 @300 and 18446744073709552 @1000). */
 PA_API uint64_t pa_max_hash(uint64_t scaled);
@@ -149,6 +167,14 @@ PA_API int pa_ani(pa_ctx *ctx, const uint32_t *d_counts, const uint64_t *d_off, 
 PA_API int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, const uint64_t *h_s_sizes,
                 uint32_t nq, uint32_t ns, uint32_t k, double *h_identity, double *h_cov_query,
                 uint8_t *h_is_null);
+
+/* ---- bulk writer of the reference's JSON column file (pyani_plus/private_cli.py:454-504) ----
+ * Writes prefix + rows + suffix, rows byte-identical to json.dumps of
+ * {"query_hash", "subject_hash", "identity", "cov_query"} dicts (", " separated, `null` where
+ * is_null, floats in Python repr form), query-major over the nq x ns matrices. */
+PA_API int pa_write_comparisons_json(const char *path, const char *prefix, const char *suffix,
+                              const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
+                              const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null);
 
 /* ---- in-library HIP-event timing of the kernels (bench.py roofline) ----
  * Phases are timed with hipEvents on the context's stream when enabled. */

@@ -47,6 +47,14 @@ SIGNATURES: dict[str, tuple] = {
     "pa_pack_fasta": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _u64p, _u64p, _u64p, _u64p]),
     "pa_pack_seq": (C.c_int, [_vp, C.c_uint64, _vp, _vp, C.c_uint64, _u64p, _u64p]),
     "pa_max_hash": (C.c_uint64, [C.c_uint64]),
+    "pa_fasta_batch_load": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_int, C.POINTER(_vp)]),
+    "pa_fasta_batch_info": (
+        C.c_int,
+        [_vp, C.c_uint32, C.c_char_p, _u64p, _u64p, _u64p, _u64p, _u64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int)],
+    ),
+    "pa_fasta_batch_arena_bases": (C.c_uint64, [_vp]),
+    "pa_fasta_batch_copy_arena": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pa_fasta_batch_free": (None, [_vp]),
     "pa_sketch": (
         C.c_int,
         [_vp, _vp, _vp, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp, _u64p],
@@ -57,6 +65,10 @@ SIGNATURES: dict[str, tuple] = {
     ),
     "pa_ani": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
     "pa_ani_host": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "pa_write_comparisons_json": (
+        C.c_int,
+        [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp],
+    ),
     "pa_prof_enable": (C.c_int, [_vp, C.c_int]),
     "pa_prof_reset": (C.c_int, [_vp]),
     "pa_prof_get": (C.c_int, [_vp, C.c_int, _f64p, _u64p]),

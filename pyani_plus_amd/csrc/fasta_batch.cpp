@@ -1,0 +1,306 @@
+// fasta_batch.cpp -- multi-threaded host front-end: files -> (md5, length, title, 2-bit arena).
+//
+// "Next" row 2 of SURVEY.md section 8(f).  The reference reads every genome twice, serially,
+// in Python: once for the md5 of the decompressed bytes (pyani_plus/utils.py:142-196), once
+// for length/description (pyani_plus/db_orm.py:832-866), and a third time inside
+// `sourmash scripts singlesketch` (pyani_plus/methods/sourmash.py:67-83).  Here one pass per
+// file on a pool of host threads does all of it: read, gunzip (zlib), md5, parse, pack.
+//
+// Error conventions follow the reference: a `.gz` suffix that disagrees with the content
+// (db_orm.py:846-854), a file without any FASTA record (db_orm.py:839-843) and unreadable
+// files are reported per file through `status`/`message`, never by aborting the batch.
+#include <zlib.h>
+
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/pyani_hip.h"
+
+void pa_set_error(const char *fmt, ...);
+
+namespace {
+
+// ---- MD5 (RFC 1321) ---------------------------------------------------------
+struct Md5 {
+  uint32_t a = 0x67452301u, b = 0xefcdab89u, c = 0x98badcfeu, d = 0x10325476u;
+  uint64_t total = 0;
+  uint8_t buf[64];
+  size_t fill = 0;
+
+  static inline uint32_t rol(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+
+  void block(const uint8_t *p) {
+    static const uint32_t K[64] = {
+        0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501,
+        0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821,
+        0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8,
+        0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a,
+        0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70,
+        0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665,
+        0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1,
+        0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+    static const int S[64] = {7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9,  14, 20, 5, 9,
+                              14, 20, 5, 9,  14, 20, 5, 9,  14, 20, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23,
+                              4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21};
+    uint32_t m[16];
+    for (int i = 0; i < 16; ++i)
+      m[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) |
+             ((uint32_t)p[4 * i + 3] << 24);
+    uint32_t A = a, B = b, C = c, D = d;
+    for (int i = 0; i < 64; ++i) {
+      uint32_t f;
+      int g;
+      if (i < 16) { f = (B & C) | (~B & D); g = i; }
+      else if (i < 32) { f = (D & B) | (~D & C); g = (5 * i + 1) & 15; }
+      else if (i < 48) { f = B ^ C ^ D; g = (3 * i + 5) & 15; }
+      else { f = C ^ (B | ~D); g = (7 * i) & 15; }
+      const uint32_t t = D;
+      D = C;
+      C = B;
+      B = B + rol(A + f + K[i] + m[g], S[i]);
+      A = t;
+    }
+    a += A; b += B; c += C; d += D;
+  }
+
+  void update(const uint8_t *p, size_t n) {
+    total += n;
+    if (fill) {
+      const size_t take = n < 64 - fill ? n : 64 - fill;
+      memcpy(buf + fill, p, take);
+      fill += take; p += take; n -= take;
+      if (fill == 64) { block(buf); fill = 0; }
+    }
+    while (n >= 64) { block(p); p += 64; n -= 64; }
+    if (n) { memcpy(buf, p, n); fill = n; }
+  }
+
+  void hex(char out[33]) {
+    const uint64_t bits = total * 8;
+    uint8_t pad[72] = {0x80};
+    const size_t padlen = (fill < 56) ? 56 - fill : 120 - fill;
+    uint8_t len[8];
+    for (int i = 0; i < 8; ++i) len[i] = (uint8_t)(bits >> (8 * i));
+    const uint64_t keep = total;
+    update(pad, padlen);
+    update(len, 8);
+    total = keep;
+    const uint32_t w[4] = {a, b, c, d};
+    for (int i = 0; i < 16; ++i) snprintf(out + 2 * i, 3, "%02x", (w[i / 4] >> (8 * (i % 4))) & 0xffu);
+    out[32] = 0;
+  }
+};
+
+struct FileResult {
+  int status = PA_OK;
+  std::string message, description;
+  char md5[33] = {0};
+  bool gz = false;
+  uint64_t n_text = 0, n_bases = 0, n_residues = 0, n_records = 0, n_invalid = 0;
+  std::vector<uint32_t> packed, mask;
+};
+
+bool read_file(const std::string &path, std::vector<uint8_t> &raw, std::string &err) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) { err = "Input " + path + " not found"; return false; }
+  fseek(f, 0, SEEK_END);
+  const long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  raw.resize(sz > 0 ? (size_t)sz : 0);
+  const size_t got = raw.empty() ? 0 : fread(raw.data(), 1, raw.size(), f);
+  fclose(f);
+  if (got != raw.size()) { err = "Short read on " + path; return false; }
+  return true;
+}
+
+// multi-member gzip inflate
+bool gunzip(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out, std::string &err) {
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "inflateInit2 failed"; return false; }
+  // the gzip trailer holds the size of the last member mod 2^32: a good first guess
+  size_t guess = raw.size() * 4 + 65536;
+  if (raw.size() >= 18) {
+    const uint8_t *t = raw.data() + raw.size() - 4;
+    const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+    if (isize > raw.size() / 2 && isize < raw.size() * 1100) guess = isize + 64;
+  }
+  if (out.size() < guess) out.resize(guess);
+  zs.next_in = const_cast<Bytef *>(raw.data());
+  zs.avail_in = (uInt)raw.size();
+  size_t have = 0;
+  for (;;) {
+    if (have == out.size()) out.resize(out.size() * 2);
+    zs.next_out = out.data() + have;
+    zs.avail_out = (uInt)std::min<size_t>(out.size() - have, 1u << 30);
+    const int rc = inflate(&zs, Z_NO_FLUSH);
+    have = (size_t)(zs.next_out - out.data());
+    if (rc == Z_STREAM_END) {
+      if (zs.avail_in == 0) break;
+      if (inflateReset(&zs) != Z_OK) { err = "inflateReset failed"; inflateEnd(&zs); return false; }  // next member
+      continue;
+    }
+    if (rc != Z_OK) { err = "corrupt gzip stream"; inflateEnd(&zs); return false; }
+    if (zs.avail_in == 0 && zs.avail_out != 0) { err = "truncated gzip stream"; inflateEnd(&zs); return false; }
+  }
+  inflateEnd(&zs);
+  out.resize(have);
+  return true;
+}
+
+bool ends_with(const std::string &s, const char *suf) {
+  const size_t n = strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+std::string basename_of(const std::string &p) {
+  const size_t k = p.find_last_of('/');
+  return k == std::string::npos ? p : p.substr(k + 1);
+}
+
+// raw/text are the calling worker's scratch buffers, reused from file to file: repeated
+// multi-megabyte allocations from many threads serialise in the kernel's address-space lock.
+void process(const std::string &path, FileResult &r, std::vector<uint8_t> &raw, std::vector<uint8_t> &text) {
+  if (!read_file(path, raw, r.message)) { r.status = PA_E_INVALID; return; }
+  r.gz = raw.size() >= 2 && raw[0] == 0x1f && raw[1] == 0x8b;
+  const std::string name = basename_of(path);
+  if (r.gz && !ends_with(path, ".gz")) {
+    r.status = PA_E_INVALID;
+    r.message = "No .gz ending, but " + name + " is gzip compressed";
+    return;
+  }
+  if (!r.gz && ends_with(path, ".gz")) {
+    r.status = PA_E_INVALID;
+    r.message = "Has .gz ending, but " + name + " is NOT gzip compressed";
+    return;
+  }
+  if (r.gz) {
+    if (!gunzip(raw, text, r.message)) { r.status = PA_E_INVALID; r.message = name + ": " + r.message; return; }
+  } else {
+    text.swap(raw);
+  }
+  r.n_text = text.size();
+  Md5 md5;
+  md5.update(text.data(), text.size());
+  md5.hex(r.md5);
+  // first title = description (db_orm.py:836-838): first line starting with '>'
+  {
+    size_t i = 0;
+    while (i < text.size()) {
+      size_t e = i;
+      while (e < text.size() && text[e] != '\n') ++e;
+      if (text[i] == '>') {
+        size_t b = i + 1, t = e;
+        while (t > b && (text[t - 1] == ' ' || text[t - 1] == '\t' || text[t - 1] == '\r' || text[t - 1] == '\n' ||
+                         text[t - 1] == '\v' || text[t - 1] == '\f'))
+          --t;
+        r.description.assign(reinterpret_cast<const char *>(text.data()) + b, t - b);
+        break;
+      }
+      i = e + 1;
+    }
+  }
+  const uint64_t cap = pa_pack_bound(text.size());
+  r.packed.resize(cap / 16);
+  r.mask.resize(cap / 32);
+  const int st = pa_pack_fasta(text.data(), text.size(), r.packed.data(), r.mask.data(), cap, &r.n_bases, &r.n_residues,
+                               &r.n_records, &r.n_invalid);
+  if (st != PA_OK) { r.status = st; r.message = name + ": packing failed"; return; }
+  r.packed.resize(r.n_bases / 16);
+  r.mask.resize(r.n_bases / 32);
+  if (r.n_records == 0) {
+    r.status = PA_E_INVALID;
+    r.message = "File " + name + " is not recognised as a FASTA record";
+  }
+}
+
+}  // namespace
+
+struct pa_fasta_batch {
+  std::vector<FileResult> files;
+};
+
+extern "C" {
+
+int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fasta_batch **out) {
+  if (!out || (n && !paths)) { pa_set_error("pa_fasta_batch_load: null argument"); return PA_E_INVALID; }
+  *out = nullptr;
+  pa_fasta_batch *b = new (std::nothrow) pa_fasta_batch();
+  if (!b) { pa_set_error("out of host memory"); return PA_E_NOMEM; }
+  b->files.resize(n);
+  std::vector<std::string> p(n);
+  for (uint32_t i = 0; i < n; ++i) p[i] = paths[i] ? paths[i] : "";
+  std::atomic<uint32_t> next{0};
+  auto work = [&]() {
+    std::vector<uint8_t> raw, text;
+    for (;;) {
+      const uint32_t i = next.fetch_add(1);
+      if (i >= n) break;
+      try {
+        process(p[i], b->files[i], raw, text);
+      } catch (const std::exception &e) {
+        b->files[i].status = PA_E_NOMEM;
+        b->files[i].message = std::string("exception while loading ") + p[i] + ": " + e.what();
+      }
+    }
+  };
+  int nt = threads > 0 ? threads : 1;
+  if ((uint32_t)nt > n) nt = (int)(n ? n : 1);
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto &t : pool) t.join();
+  *out = b;
+  return PA_OK;
+}
+
+int pa_fasta_batch_info(const pa_fasta_batch *b, uint32_t i, char md5hex33[33], uint64_t *n_residues,
+                        uint64_t *n_records, uint64_t *n_invalid, uint64_t *n_bases, uint64_t *n_text,
+                        const char **description, const char **message, int *was_gzip) {
+  if (!b || i >= b->files.size()) { pa_set_error("pa_fasta_batch_info: index out of range"); return PA_E_INVALID; }
+  const FileResult &r = b->files[i];
+  if (md5hex33) memcpy(md5hex33, r.md5, 33);
+  if (n_residues) *n_residues = r.n_residues;
+  if (n_records) *n_records = r.n_records;
+  if (n_invalid) *n_invalid = r.n_invalid;
+  if (n_bases) *n_bases = r.n_bases;
+  if (n_text) *n_text = r.n_text;
+  if (description) *description = r.description.c_str();
+  if (message) *message = r.message.c_str();
+  if (was_gzip) *was_gzip = r.gz ? 1 : 0;
+  return r.status;
+}
+
+uint64_t pa_fasta_batch_arena_bases(const pa_fasta_batch *b) {
+  uint64_t total = 0;
+  if (b)
+    for (const FileResult &r : b->files)
+      if (r.status == PA_OK) total += r.n_bases;
+  return total;
+}
+
+int pa_fasta_batch_copy_arena(const pa_fasta_batch *b, uint32_t *h_packed, uint32_t *h_mask, uint64_t *h_genome_start) {
+  if (!b || !h_genome_start) { pa_set_error("pa_fasta_batch_copy_arena: null argument"); return PA_E_INVALID; }
+  uint64_t pos = 0;
+  for (size_t i = 0; i < b->files.size(); ++i) {
+    const FileResult &r = b->files[i];
+    h_genome_start[i] = pos;
+    if (r.status != PA_OK) continue;  // failed files occupy no space
+    if (r.n_bases) {
+      memcpy(h_packed + pos / 16, r.packed.data(), r.n_bases / 4);
+      memcpy(h_mask + pos / 32, r.mask.data(), r.n_bases / 8);
+    }
+    pos += r.n_bases;
+  }
+  h_genome_start[b->files.size()] = pos;
+  return PA_OK;
+}
+
+void pa_fasta_batch_free(pa_fasta_batch *b) { delete b; }
+
+}  // extern "C"

@@ -1,0 +1,119 @@
+// json_writer.cpp -- bulk writer of the reference's JSON column file.
+//
+// "Next" row 1 of SURVEY.md section 8(f).  The reference builds one Python dict per
+// comparison and re-serialises the whole list after every 100 000 rows
+// (pyani_plus/private_cli.py:1863-1888).  For N^2 = 10^6 rows that is tens of seconds of
+// interpreter time against milliseconds of GPU time, so the rows are formatted here,
+// byte-identical to json.dumps of the same dicts (pyani_plus/private_cli.py:454-504):
+//   {"query_hash": "Q", "subject_hash": "S", "identity": 0.99, "cov_query": 0.98}
+// with ", " between rows, `null` for NULL, and floats in Python's repr() form (shortest
+// round-trip digits; fixed notation for 1e-4 <= |x| < 1e16, otherwise d.ddde-XX).
+#include <charconv>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pyani_hip.h"
+
+void pa_set_error(const char *fmt, ...);
+
+namespace {
+
+// Python float.__repr__ for finite doubles
+inline char *put_double(char *p, char *end, double v) {
+  if (v == 0.0) {
+    if (std::signbit(v)) *p++ = '-';
+    memcpy(p, "0.0", 3);
+    return p + 3;
+  }
+  const double a = std::fabs(v);
+  // shortest round-trip digits in scientific form (Ryu inside libstdc++), then place the point
+  char sci[40];
+  auto r = std::to_chars(sci, sci + sizeof(sci), v, std::chars_format::scientific);
+  if (!(a >= 1e-4 && a < 1e16)) {  // Python repr keeps d[.ddd]e[+-]XX outside this range
+    const size_t n = (size_t)(r.ptr - sci);
+    memcpy(p, sci, n);
+    return p + n;
+  }
+  const char *q = sci;
+  if (*q == '-') *p++ = *q++;
+  char digits[24];
+  int nd = 0;
+  digits[nd++] = *q++;
+  if (*q == '.') {
+    ++q;
+    while (*q != 'e') digits[nd++] = *q++;
+  }
+  ++q;  // 'e'
+  const bool neg = (*q == '-');
+  ++q;  // sign
+  int ex = 0;
+  while (q < r.ptr) ex = ex * 10 + (*q++ - '0');
+  if (neg) ex = -ex;
+  if (ex >= 0) {  // ddd[.ddd] with ex+1 integer digits
+    for (int i = 0; i <= ex; ++i) *p++ = i < nd ? digits[i] : '0';
+    *p++ = '.';
+    if (nd > ex + 1) for (int i = ex + 1; i < nd; ++i) *p++ = digits[i];
+    else *p++ = '0';
+  } else {  // 0.000ddd
+    *p++ = '0';
+    *p++ = '.';
+    for (int i = 0; i < -ex - 1; ++i) *p++ = '0';
+    for (int i = 0; i < nd; ++i) *p++ = digits[i];
+  }
+  (void)end;
+  return p;
+}
+
+}  // namespace
+
+extern "C" int pa_write_comparisons_json(const char *path, const char *prefix, const char *suffix,
+                                         const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
+                                         uint32_t ns, const double *identity, const double *cov_query,
+                                         const uint8_t *is_null) {
+  if (!path || !prefix || !suffix || (nq && !q_hashes) || (ns && !s_hashes) || !identity || !cov_query || !is_null) {
+    pa_set_error("pa_write_comparisons_json: null argument");
+    return PA_E_INVALID;
+  }
+  FILE *f = fopen(path, "wb");
+  if (!f) { pa_set_error("cannot open %s for writing", path); return PA_E_INVALID; }
+  std::vector<char> buf(1 << 22);
+  size_t fill = 0;
+  auto flush = [&]() -> bool {
+    const bool ok = fwrite(buf.data(), 1, fill, f) == fill;
+    fill = 0;
+    return ok;
+  };
+  bool ok = fwrite(prefix, 1, strlen(prefix), f) == strlen(prefix);
+  std::vector<size_t> qlen(nq), slen(ns);
+  for (uint32_t q = 0; q < nq; ++q) qlen[q] = strlen(q_hashes[q]);
+  for (uint32_t s = 0; s < ns; ++s) slen[s] = strlen(s_hashes[s]);
+  bool first = true;
+  for (uint32_t q = 0; q < nq && ok; ++q) {
+    for (uint32_t s = 0; s < ns; ++s) {
+      if (fill + qlen[q] + slen[s] + 256 > buf.size()) { if (!flush()) { ok = false; break; } }
+      char *p = buf.data() + fill;
+      char *const end = buf.data() + buf.size();
+      if (!first) { memcpy(p, ", ", 2); p += 2; }
+      first = false;
+      memcpy(p, "{\"query_hash\": \"", 16); p += 16;
+      memcpy(p, q_hashes[q], qlen[q]); p += qlen[q];
+      memcpy(p, "\", \"subject_hash\": \"", 20); p += 20;
+      memcpy(p, s_hashes[s], slen[s]); p += slen[s];
+      memcpy(p, "\", \"identity\": ", 15); p += 15;
+      const uint64_t idx = (uint64_t)q * ns + s;
+      if (is_null[idx]) { memcpy(p, "null", 4); p += 4; } else p = put_double(p, end, identity[idx]);
+      memcpy(p, ", \"cov_query\": ", 15); p += 15;
+      if (is_null[idx]) { memcpy(p, "null", 4); p += 4; } else p = put_double(p, end, cov_query[idx]);
+      *p++ = '}';
+      fill = (size_t)(p - buf.data());
+    }
+  }
+  ok = ok && flush() && fwrite(suffix, 1, strlen(suffix), f) == strlen(suffix);
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { pa_set_error("short write to %s", path); return PA_E_INVALID; }
+  return PA_OK;
+}

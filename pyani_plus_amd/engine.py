@@ -76,6 +76,65 @@ def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
     return HostArena(packed[: pos // 16].copy(), mask[: pos // 32].copy(), starts, residues, records, invalid)
 
 
+@dataclass
+class LoadedFasta:
+    """Per-file result of the threaded host front-end (``pa_fasta_batch_load``)."""
+
+    path: str
+    status: int
+    message: str
+    md5: str
+    length: int  # sum of residues = Genome.length
+    records: int
+    invalid: int
+    description: str
+    gzip: bool
+
+
+def load_fasta_files(paths, threads: int = 0) -> tuple[list[LoadedFasta], HostArena]:
+    """Read, gunzip, md5, parse and pack FASTA files on host threads.
+
+    Returns per-file metadata (failed files carry ``status != 0`` and the reference's error
+    text in ``message``) and the arena of the files that loaded, in order."""
+    import os
+
+    lib = _capi.load_library()
+    paths = [str(p) for p in paths]
+    n = len(paths)
+    if threads <= 0:
+        threads = len(os.sched_getaffinity(0))
+    arr = (C.c_char_p * max(n, 1))(*[p.encode() for p in paths])
+    batch = C.c_void_p()
+    check(lib.pa_fasta_batch_load(arr, n, threads, C.byref(batch)), "pa_fasta_batch_load")
+    try:
+        infos: list[LoadedFasta] = []
+        ok_residues, ok_records, ok_invalid = [], [], []
+        for i, path in enumerate(paths):
+            md5 = C.create_string_buffer(33)
+            nres, nrec, ninv, nb, nt = (C.c_uint64(0) for _ in range(5))
+            desc, msg = C.c_char_p(), C.c_char_p()
+            gz = C.c_int(0)
+            st = lib.pa_fasta_batch_info(batch, i, md5, C.byref(nres), C.byref(nrec), C.byref(ninv), C.byref(nb), C.byref(nt), C.byref(desc), C.byref(msg), C.byref(gz))
+            infos.append(
+                LoadedFasta(path, st, (msg.value or b"").decode(errors="replace"), md5.value.decode(), int(nres.value), int(nrec.value),
+                            int(ninv.value), (desc.value or b"").decode(errors="replace"), bool(gz.value))
+            )  # fmt: skip
+            if st == 0:
+                ok_residues.append(int(nres.value))
+                ok_records.append(int(nrec.value))
+                ok_invalid.append(int(ninv.value))
+        total = int(lib.pa_fasta_batch_arena_bases(batch))
+        packed = np.zeros(max(total // 16, 1), dtype=np.uint32)
+        mask = np.zeros(max(total // 32, 1), dtype=np.uint32)
+        starts_all = np.zeros(n + 1, dtype=np.uint64)
+        check(lib.pa_fasta_batch_copy_arena(batch, packed.ctypes.data, mask.ctypes.data, starts_all.ctypes.data), "pa_fasta_batch_copy_arena")
+        keep = [i for i, info in enumerate(infos) if info.status == 0]
+        starts = np.array([starts_all[i] for i in keep] + [total], dtype=np.uint64)
+        return infos, HostArena(packed[: total // 16], mask[: total // 32], starts, ok_residues, ok_records, ok_invalid)
+    finally:
+        lib.pa_fasta_batch_free(batch)
+
+
 # --------------------------------------------------------------------------- device objects
 @dataclass
 class DeviceArena:

@@ -23,9 +23,7 @@ CSV columns -> ``ani_host`` (host libm ``pow``: bit-identical to the reference f
 
 from __future__ import annotations
 
-import gzip
 import logging
-import platform
 import sys
 from collections.abc import Iterator
 from dataclasses import dataclass
@@ -94,14 +92,6 @@ def sig_cache_dir(cache: Path, kmersize: int, extra: str) -> Path:
     return Path(cache) / f"sourmash_k={kmersize}_{extra}"
 
 
-def read_fasta_file(path: Path) -> bytes:
-    """Decompressed file content; gzip detected by content like utils.file_md5sum (utils.py:178-190)."""
-    raw = Path(path).read_bytes()
-    if raw[:2] == b"\x1f\x8b":
-        return gzip.decompress(raw)
-    return raw
-
-
 _ENGINE = None
 
 
@@ -138,19 +128,22 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None) ->
     sig_dir.mkdir(exist_ok=True)
     fasta_dir = Path(run.fasta_directory)
 
-    from ..engine import max_hash_for_scaled, pack_genomes
+    from ..engine import load_fasta_files, max_hash_for_scaled
 
     max_hash = max_hash_for_scaled(scaled)
     batch: list = []
-    batch_texts: list[bytes] = []
-    batch_bases = 0
+    batch_bytes = 0
 
     def flush() -> None:
-        nonlocal batch, batch_texts, batch_bases
+        nonlocal batch, batch_bytes
         if not batch:
             return
+        # threaded host front-end: read + gunzip + parse + 2-bit pack, then ONE batched sketch launch
+        infos, arena = load_fasta_files([fasta_dir / entry.fasta_filename for entry in batch])
+        for info in infos:
+            if info.status != 0:
+                log_sys_exit(logger, info.message)
         eng = engine or get_engine()
-        arena = pack_genomes(batch_texts)
         sketches = eng.sketch(eng.upload(arena), config.kmersize, scaled, max_hash=max_hash).to_host()
         for entry, mins in zip(batch, sketches):
             sig.write_sig(
@@ -161,22 +154,78 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None) ->
                 max_hash=max_hash,
                 mins=mins,
             )
-        batch, batch_texts, batch_bases = [], [], 0
+        batch, batch_bytes = [], 0
 
     pending: list = []
     for entry in run.fasta_hashes:
         if not (sig_dir / f"{entry.genome_hash}.sig").is_file():
-            text = read_fasta_file(fasta_dir / entry.fasta_filename)
             batch.append(entry)
-            batch_texts.append(text)
-            batch_bases += len(text)
+            fasta_file = fasta_dir / entry.fasta_filename
+            batch_bytes += 4 * fasta_file.stat().st_size if fasta_file.is_file() else 0  # gz expands ~4x
         pending.append(entry)
-        if batch_bases >= PREPARE_BATCH_BASES:
+        if batch_bytes >= PREPARE_BATCH_BASES:
             flush()
             yield from pending
             pending = []
     flush()
     yield from pending
+
+
+def compute_sourmash_matrices(
+    logger: logging.Logger,
+    subject_hashes,
+    query_hashes,
+    cache: Path,
+    *,
+    kmersize: int,
+    scaled: int,
+    engine=None,
+    algo: int = _capi.PA_PAIRS_AUTO,
+):
+    """``(queries, subjects, query_containment_ani, max_containment_ani, is_null)`` for the sorted
+    query x subject block: the array form of what ``compute_sourmash_tile`` yields row by row."""
+    cache = Path(cache)
+    if not cache.is_dir():
+        msg = f"Given cache directory '{cache}' does not exist"
+        raise ValueError(msg)
+    from ..engine import ani_host, max_hash_for_scaled
+
+    queries = sorted(query_hashes)
+    subjects = sorted(subject_hashes)
+    extra_subjects = sorted(set(subjects) - set(queries))
+    order = queries + extra_subjects  # CSR order: queries first, then subjects not among them
+    index = {h: i for i, h in enumerate(order)}
+    max_hash = max_hash_for_scaled(scaled)
+    sketches = []
+    for genome_hash in order:
+        sig_file = cache / f"{genome_hash}.sig"
+        if not sig_file.is_file():
+            log_sys_exit(logger, f"Missing sourmash signature file '{sig_file}'")
+        mins, _ = sig.read_sig(sig_file, ksize=kmersize, max_hash=max_hash)
+        sketches.append(mins)
+    nq = len(queries)
+    sizes = np.array([len(s) for s in sketches], dtype=np.uint64)
+    if not queries or not subjects:
+        empty = np.zeros((nq, len(subjects)))
+        return queries, subjects, empty, empty.copy(), np.zeros((nq, len(subjects)), dtype=bool)
+    eng = engine or get_engine()
+    dsk = eng.sketches_from_host(sketches)
+    sub_idx = np.array([index[s] for s in subjects])
+    # contiguous subject range if possible (all-vs-all, or a single subject column)
+    lo, hi = int(sub_idx.min()), int(sub_idx.max()) + 1
+    if hi - lo != len(sub_idx):
+        lo, hi = 0, len(order)  # scattered subjects: compute the covering block, pick columns below
+    counts = eng.pair_counts(dsk, (0, nq), (lo, hi), algo=algo).cpu().numpy().view(np.uint32)
+    counts = np.ascontiguousarray(counts[:, sub_idx - lo])
+    ident, cov, null = ani_host(counts, sizes[:nq], sizes[sub_idx], kmersize)
+    # the reference refuses a self-comparison that is not exactly one (sourmash.py:119-127)
+    sub_pos = {s: i for i, s in enumerate(subjects)}
+    for qi, q in enumerate(queries):
+        si = sub_pos.get(q)
+        if si is not None and not null[qi, si] and ident[qi, si] != 1.0:
+            msg = f"Expected {METHOD} {q} vs self to be one, not {ident[qi, si]!r}"
+            raise ValueError(msg)
+    return queries, subjects, cov, ident, null
 
 
 def compute_sourmash_tile(
@@ -194,48 +243,15 @@ def compute_sourmash_tile(
     query x subject pair, ``None, None`` where the sketches share no hash -- what
     ``compute_sourmash_tile`` + ``parse_sourmash_manysearch_csv`` yield in the reference
     (pyani_plus/methods/sourmash.py:87-206).  Row order is deterministic here (query-major)."""
-    cache = Path(cache)
-    if not cache.is_dir():
-        msg = f"Given cache directory '{cache}' does not exist"
-        raise ValueError(msg)
-    from ..engine import ani_host, max_hash_for_scaled
-
-    queries = sorted(query_hashes)
-    extra_subjects = sorted(set(subject_hashes) - set(queries))
-    order = queries + extra_subjects  # CSR order: queries first, then subjects not among them
-    index = {h: i for i, h in enumerate(order)}
-    max_hash = max_hash_for_scaled(scaled)
-    sketches = []
-    for genome_hash in order:
-        sig_file = cache / f"{genome_hash}.sig"
-        if not sig_file.is_file():
-            log_sys_exit(logger, f"Missing sourmash signature file '{sig_file}'")
-        mins, _ = sig.read_sig(sig_file, ksize=kmersize, max_hash=max_hash)
-        sketches.append(mins)
-    eng = engine or get_engine()
-    dsk = eng.sketches_from_host(sketches)
-    subjects = sorted(subject_hashes)
-    sub_idx = [index[s] for s in subjects]
-    nq = len(queries)
-    # contiguous subject range if possible (all-vs-all, or a single subject column)
-    lo, hi = min(sub_idx), max(sub_idx) + 1
-    if hi - lo != len(sub_idx):
-        lo, hi = 0, len(order)  # scattered subjects: compute the covering block, pick columns below
-    counts = eng.pair_counts(dsk, (0, nq), (lo, hi), algo=algo).cpu().numpy().view(np.uint32)
-    sizes = np.array([len(s) for s in sketches], dtype=np.uint64)
-    cols = np.array(sub_idx) - lo
-    counts = np.ascontiguousarray(counts[:, cols])
-    ident, cov, null = ani_host(counts, sizes[:nq], sizes[np.array(sub_idx)], kmersize)
+    queries, subjects, cov, ident, null = compute_sourmash_matrices(
+        logger, subject_hashes, query_hashes, cache, kmersize=kmersize, scaled=scaled, engine=engine, algo=algo
+    )
     for qi, q in enumerate(queries):
         for si, s in enumerate(subjects):
             if null[qi, si]:
                 yield q, s, None, None
-                continue
-            if q == s and ident[qi, si] != 1.0:
-                # the reference refuses a self-comparison that is not exactly one (sourmash.py:119-127)
-                msg = f"Expected {METHOD} {q} vs self to be one, not {ident[qi, si]!r}"
-                raise ValueError(msg)
-            yield q, s, float(cov[qi, si]), float(ident[qi, si])
+            else:
+                yield q, s, float(cov[qi, si]), float(ident[qi, si])
 
 
 def compute_sourmash_hip(  # noqa: PLR0913
@@ -258,11 +274,9 @@ def compute_sourmash_hip(  # noqa: PLR0913
     Field mapping as private_cli.py:1875-1887: ``identity`` <- max-containment ANI,
     ``cov_query`` <- query-containment ANI; ``aln_length``/``sim_errors``/``cov_subject`` unset.
     """
-    uname = platform.uname()
     configuration = run.configuration
     tool = get_sourmash_hip()
     _check_tool_version(logger, tool, configuration)
-    config_id = getattr(configuration, "configuration_id", None)
 
     sig_cache = sig_cache_dir(cache, configuration.kmersize, configuration.extra)
     if not sig_cache.is_dir():
@@ -271,9 +285,9 @@ def compute_sourmash_hip(  # noqa: PLR0913
             f"Missing sourmash signatures directory '{sig_cache}' - check cache setting '{cache}'.",
         )
     scaled = parse_scaled(configuration.extra)
-    db_entries: list[dict] = []
+    result = None
     try:
-        for q, s, q_containment, max_containment in compute_sourmash_tile(
+        result = compute_sourmash_matrices(
             logger,
             {subject_hash} if subject_hash else set(query_hashes),
             set(query_hashes),
@@ -281,26 +295,19 @@ def compute_sourmash_hip(  # noqa: PLR0913
             kmersize=configuration.kmersize,
             scaled=scaled,
             engine=engine,
-        ):
-            db_entries.append(
-                {
-                    "query_hash": q,
-                    "subject_hash": s,
-                    "identity": max_containment,
-                    "cov_query": q_containment,
-                    "configuration_id": config_id,
-                    "uname_system": uname.system,
-                    "uname_release": uname.release,
-                    "uname_machine": uname.machine,
-                }
-            )
+        )
     except KeyboardInterrupt:  # pragma: no cover
-        # abort gracefully without wasting the work done (private_cli.py:1889-1894)
-        logger.error("Interrupted with %d completed %s comparisons", len(db_entries), METHOD)  # noqa: TRY400
+        # abort gracefully (private_cli.py:1889-1894); the device step is all-or-nothing
+        logger.error("Interrupted with 0 completed %s comparisons", METHOD)  # noqa: TRY400
         run.status = "Worker interrupted"
         session.commit()
     try:
-        wire.export_json_db_entries(logger, json_filename, configuration, db_entries)
+        if result is None:
+            wire.export_json_db_entries(logger, json_filename, configuration, [])
+        else:
+            queries, subjects, cov, ident, null = result
+            # identity <- max-containment ANI, cov_query <- query-containment ANI (private_cli.py:1879-1880)
+            wire.export_json_matrices(logger, json_filename, configuration, queries, subjects, ident, cov, null)
     except Exception:  # pragma: no cover
         logger.exception("Unexpected exception saving JSON:")
         return RECORDING_FAILED

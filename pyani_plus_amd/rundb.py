@@ -20,9 +20,6 @@ Databases written here can be opened by the reference and vice versa.
 from __future__ import annotations
 
 import datetime
-import gzip
-import hashlib
-import json
 import logging
 import sqlite3
 import sys
@@ -135,23 +132,6 @@ def check_fasta(logger: logging.Logger, fasta: Path) -> list[Path]:
             logger, f"No FASTA input genomes under {fasta} with extensions {', '.join(sorted(FASTA_EXTENSIONS))}"
         )
     return sorted(names)
-
-
-def read_genome(logger: logging.Logger, path: Path) -> tuple[bytes, str]:
-    """(decompressed bytes, md5).  A ``.gz`` suffix that disagrees with the content is an error
-    (pyani_plus/db_orm.py:846-854)."""
-    path = Path(path)
-    if not path.is_file():
-        msg = f"Input {path} is a broken symlink" if path.is_symlink() else f"Input {path} not found"
-        raise ValueError(msg)
-    raw = path.read_bytes()
-    is_gz = raw[:2] == b"\x1f\x8b"
-    if is_gz and not str(path).endswith(".gz"):
-        sourmash_hip.log_sys_exit(logger, f"No .gz ending, but {path.name} is gzip compressed")
-    if not is_gz and str(path).endswith(".gz"):
-        sourmash_hip.log_sys_exit(logger, f"Has .gz ending, but {path.name} is NOT gzip compressed")
-    data = gzip.decompress(raw) if is_gz else raw
-    return data, hashlib.md5(data).hexdigest()  # noqa: S324 - content fingerprint
 
 
 def fasta_length_and_description(text: bytes) -> tuple[int, str | None]:
@@ -293,15 +273,18 @@ def cache_comparisons(conn, run: Run) -> dict[str, str]:
     index = {h: i for i, h in enumerate(hashes)}
     n = len(hashes)
     mats = {k: np.full((n, n), np.nan, float) for k in ("identity", "cov_query", "aln_length", "sim_errors")}
-    for q, s, ident, cov, aln, sim in conn.execute(
+    rows = conn.execute(
         "SELECT c.query_hash, c.subject_hash, c.identity, c.cov_query, c.aln_length, c.sim_errors FROM comparisons c "
         "JOIN runs_genomes rq ON c.query_hash = rq.genome_hash AND rq.run_id = ? "
         "JOIN runs_genomes rs ON c.subject_hash = rs.genome_hash AND rs.run_id = ? WHERE c.configuration_id = ?",
         (run.run_id, run.run_id, run.configuration_id),
-    ):
-        r, c = index[q], index[s]
-        for key, val in (("identity", ident), ("cov_query", cov), ("aln_length", aln), ("sim_errors", sim)):
-            mats[key][r, c] = np.nan if val is None else val
+    ).fetchall()
+    if rows:
+        # one dictionary lookup per row (the reference does a list.index per row: O(N^3) overall)
+        r_idx = np.fromiter((index[r[0]] for r in rows), dtype=np.int64, count=len(rows))
+        c_idx = np.fromiter((index[r[1]] for r in rows), dtype=np.int64, count=len(rows))
+        for col, key in enumerate(("identity", "cov_query", "aln_length", "sim_errors"), start=2):
+            mats[key][r_idx, c_idx] = np.array([r[col] for r in rows], dtype=float)  # None -> NaN
     mats["hadamard"] = mats["identity"] * mats["cov_query"]
     out = {
         f"df_{key}": pd.DataFrame(data=mat, index=hashes, columns=hashes, dtype=float).to_json(orient="split")
@@ -343,20 +326,21 @@ def run_sourmash_hip(  # noqa: PLR0913
     )
     filename_to_md5: dict[Path, str] = {}
     seen: set[str] = set()
-    for filename in fasta_names:
-        try:
-            text, md5 = read_genome(logger, filename)
-        except ValueError as err:
-            sourmash_hip.log_sys_exit(logger, str(err))
+    from .engine import load_fasta_files
+
+    # one threaded pass per file: md5 of the decompressed bytes, length, first title
+    infos, _arena = load_fasta_files(fasta_names)
+    del _arena
+    for filename, info in zip(fasta_names, infos):
+        if info.status != 0:
+            sourmash_hip.log_sys_exit(logger, info.message)
+        md5 = info.md5
         if md5 in seen:
             dups = "\n" + "\n".join(sorted({str(k) for k, v in filename_to_md5.items() if v == md5} | {str(filename)}))
             sourmash_hip.log_sys_exit(logger, f"Multiple genomes with same MD5 checksum {md5}:{dups}")
         seen.add(md5)
         filename_to_md5[filename] = md5
-        length, description = fasta_length_and_description(text)
-        if description is None:
-            sourmash_hip.log_sys_exit(logger, f"File {filename.name} is not recognised as a FASTA record")
-        db_genome(conn, filename, md5, length, description)
+        db_genome(conn, filename, md5, info.length, info.description)
     run = add_run(
         conn, config, " ".join(sys.argv), fasta, "Initialising",
         f"{len(filename_to_md5)} genomes using {sourmash_hip.METHOD}" if name is None else name, filename_to_md5,

@@ -53,9 +53,37 @@ def write_sig(path: Path, *, name: str, filename: str, ksize: int, max_hash: int
     tmp.replace(path)
 
 
+def _read_single_sketch_fast(text: str, ksize: int | None, max_hash: int | None):
+    """Files with exactly one sketch (what singlesketch and this backend write): parse the long
+    ``mins`` list with numpy instead of the JSON decoder; anything unusual falls back to json."""
+    if text.count('"mins":[') != 1 or text.count('"signatures":[') != 1:
+        return None
+    a = text.index('"mins":[') + len('"mins":[')
+    b = text.index("]", a)
+    body = text[a:b]
+    try:
+        head = json.loads(text[: a - len('"mins":[')] + '"mins":[]' + text[b + 1 :])
+        sketch = head[0]["signatures"][0]
+        if sketch.get("molecule", "DNA") != "DNA" or sketch.get("num", 0) != 0:
+            return None
+        if (ksize is not None and sketch.get("ksize") != ksize) or (max_hash is not None and sketch.get("max_hash") != max_hash):
+            return None
+        mins = np.array(body.split(","), dtype=np.uint64) if body else np.empty(0, dtype=np.uint64)
+    except (ValueError, KeyError, IndexError, TypeError):
+        return None
+    if mins.size > 1 and not bool(np.all(mins[1:] > mins[:-1])):
+        mins = np.unique(mins)
+    sketch["mins"] = mins.tolist() if mins.size <= 16 else None  # large lists are returned only as the array
+    return mins, sketch
+
+
 def read_sig(path: Path, *, ksize: int | None = None, max_hash: int | None = None) -> tuple[np.ndarray, dict]:
     """Return (ascending uint64 hashes, sketch dict) of the DNA sketch with the wanted k."""
-    data = json.loads(Path(path).read_text())
+    text = Path(path).read_text()
+    fast = _read_single_sketch_fast(text, ksize, max_hash)
+    if fast is not None:
+        return fast
+    data = json.loads(text)
     if not isinstance(data, list) or not data:
         msg = f"{path} is not a sourmash signature file"
         raise ValueError(msg)

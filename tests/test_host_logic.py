@@ -281,3 +281,79 @@ def test_synthetic_generator_roundtrip():
     assert same > 900
     again = synth_arena_numpy(5, [1000, 64, 777, 1000, 1000], n_species=2)
     assert np.array_equal(again.packed, arena.packed) and np.array_equal(again.mask, arena.mask)
+
+
+def test_bulk_json_writer_is_byte_identical_to_json_dumps(tmp_path):
+    """pa_write_comparisons_json must produce exactly what the reference's json.dumps produces."""
+    import platform
+
+    rng = np.random.default_rng(3)
+    nq, ns = 7, 5
+    ident = rng.random((nq, ns))
+    cov = rng.random((nq, ns)) ** 8
+    special = [1.0, 0.0, 1e-4, 9.999e-5, 1e-5, 1.5e-7, 5e-324, 1e15, 1e16, 1.2345e22, 0.1, 1 / 3, 0.9997081124294064, 2.0**-31]
+    ident.ravel()[: len(special)] = special
+    cov.ravel()[-len(special) :] = special
+    null = rng.random((nq, ns)) < 0.2
+    queries = [f"{i:032x}" for i in range(nq)]
+    subjects = [f"{i + 100:032x}" for i in range(ns)]
+    cfg = rundb.Configuration(3, "sourmash-hip", "libpyani_hip", "0.1.0", kmersize=31, extra="scaled=1000")
+    out = tmp_path / "bulk.json"
+    wire.export_json_matrices(LOGGER, out, cfg, queries, subjects, ident, cov, null)
+    uname = platform.uname()
+    want = json.dumps(
+        {
+            "configuration": wire.configuration_dict(cfg),
+            "uname": {"system": uname.system, "release": uname.release, "machine": uname.machine},
+            "comparisons": [
+                {
+                    "query_hash": q,
+                    "subject_hash": s,
+                    "identity": None if null[i, j] else float(ident[i, j]),
+                    "cov_query": None if null[i, j] else float(cov[i, j]),
+                }
+                for i, q in enumerate(queries)
+                for j, s in enumerate(subjects)
+            ],
+        }
+    )
+    assert out.read_text() == want
+    via_dicts = tmp_path / "dicts.json"
+    wire.export_json_db_entries(LOGGER, via_dicts, cfg, json.loads(want)["comparisons"])
+    assert via_dicts.read_text() == want
+    wire.export_json_matrices(LOGGER, out, cfg, [], [], np.zeros((0, 0)), np.zeros((0, 0)), np.zeros((0, 0), bool))
+    assert json.loads(out.read_text())["comparisons"] == []
+
+
+def test_threaded_fasta_loader_matches_python_reader(tmp_path):
+    from pyani_plus_amd.engine import load_fasta_files
+    from tests.helpers import md5_hex
+
+    paths = [GOLDEN / "bacterial_example" / "NC_002696.fasta.gz", GOLDEN / "viral_example" / "OP073605.fasta", GOLDEN / "MIBY01000005.fasta"]
+    bad_gz = tmp_path / "plain.fa.gz"
+    bad_gz.write_bytes(b">x\nACGT\n")
+    import gzip as _gzip
+
+    hidden_gz = tmp_path / "zipped.fasta"
+    hidden_gz.write_bytes(_gzip.compress(b">x\nACGT\n"))
+    empty = tmp_path / "empty.fna"
+    empty.write_bytes(b"\n\n")
+    two_members = tmp_path / "two.fa.gz"
+    two_members.write_bytes(_gzip.compress(b">a desc one  \nACGTNN\n") + _gzip.compress(b">b\nGGCC\n"))
+    infos, arena = load_fasta_files([*paths, bad_gz, hidden_gz, empty, tmp_path / "missing.fa", two_members], threads=3)
+    for info, path in zip(infos[:3], paths):
+        text = read_fasta_bytes(path)
+        assert info.status == 0 and info.md5 == md5_hex(text)
+        assert (info.length, info.description) == rundb.fasta_length_and_description(text)
+    assert infos[0].records == 2 and infos[0].gzip and not infos[1].gzip and infos[2].invalid == 28
+    assert infos[3].status != 0 and infos[3].message == "Has .gz ending, but plain.fa.gz is NOT gzip compressed"
+    assert infos[4].status != 0 and infos[4].message == "No .gz ending, but zipped.fasta is gzip compressed"
+    assert infos[5].status != 0 and infos[5].message == "File empty.fna is not recognised as a FASTA record"
+    assert infos[6].status != 0 and "not found" in infos[6].message
+    assert infos[7].status == 0 and infos[7].length == 10 and infos[7].records == 2 and infos[7].description == "a desc one"
+    assert infos[7].md5 == md5_hex(b">a desc one  \nACGTNN\n>b\nGGCC\n")
+    # the arena holds exactly the files that loaded, identical to packing their text one by one
+    ok_texts = [read_fasta_bytes(p) for p in paths] + [b">a desc one  \nACGTNN\n>b\nGGCC\n"]
+    ref = pack_genomes(ok_texts)
+    assert np.array_equal(arena.packed, ref.packed) and np.array_equal(arena.mask, ref.mask)
+    assert np.array_equal(arena.genome_start, ref.genome_start) and arena.residues == ref.residues
