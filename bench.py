@@ -43,12 +43,13 @@ def parse_args():
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--scaled", type=int, default=1000)
     ap.add_argument("--species", type=int, default=40)
+    ap.add_argument("--mixed-lengths", action="store_true", help="log-uniform 100 kb - 10 Mb genomes (BASELINE configs[4])")
     ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="genomes sketched by the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(engine, arena, sk, args, n_total: int) -> dict:
+def cpu_baseline(engine, arena, sk, args, n_total: int, lengths: list[int]) -> dict:
     """Time the oracle's tuned scalar form on a bounded sample and check GPU == CPU on it."""
     import oracle
     from pyani_plus_amd.synth import arena_to_ascii, device_arena_to_host
@@ -65,15 +66,17 @@ def cpu_baseline(engine, arena, sk, args, n_total: int) -> dict:
     for g in sample:
         s0, s1 = int(arena.genome_start[g]), int(arena.genome_start[g + 1])
         words = arena.packed[s0 // 16 : s1 // 16]
-        codes = ((words[:, None] >> shifts) & 3).reshape(-1)[: args.length].to(t.int64)
+        codes = ((words[:, None] >> shifts) & 3).reshape(-1)[: lengths[g]].to(t.int64)
         seqs.append(lut[codes].cpu().numpy())
     if n_samp <= 4:  # tiny runs: also exercise the host-side unpacker
-        host = device_arena_to_host(arena, sample, args.length)
+        host = device_arena_to_host(arena, sample, lengths[: n_samp])
         assert all(arena_to_ascii(host, i) == seqs[i].tobytes() for i in range(n_samp))
     oracle.sketch_many(seqs[:1], args.kmer, args.scaled, threads=1, fast=True)  # warm (table init, page-in)
     t0 = time.perf_counter()
     cpu_sk = oracle.sketch_many(seqs, args.kmer, args.scaled, threads=cores, fast=True)
-    t_sketch = (time.perf_counter() - t0) / n_samp  # wall seconds per genome with `cores` threads
+    sample_bases = sum(lengths[g] for g in sample)
+    t_base = (time.perf_counter() - t0) / sample_bases  # wall seconds per base with `cores` threads
+    t_sketch = t_base * sum(lengths) / n_total  # per average genome
     gpu_sk = sk.to_host()
     for i in sample:
         if not np.array_equal(cpu_sk[i], gpu_sk[i]):
@@ -93,7 +96,7 @@ def cpu_baseline(engine, arena, sk, args, n_total: int) -> dict:
         "unit": "pairs/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{n_samp} genomes x {args.length} bp sketched + {n_pair}x{n_pair} sketch pairs+ANI with {cores} OpenMP threads "
+        "sample": f"{n_samp} genomes ({sample_bases / 1e6:.0f} Mb) sketched + {n_pair}x{n_pair} sketch pairs+ANI with {cores} OpenMP threads "
         f"(oracle tuned scalar form); extrapolated to N={n_total}: N*{t_sketch:.4f}s + N^2*{t_pair * 1e6:.3f}us",
         "sketch_s_per_genome": t_sketch,
         "pair_us": t_pair * 1e6,
@@ -116,9 +119,9 @@ def main():
     import torch.distributed as dist
 
     from pyani_plus_amd import _capi
-    from pyani_plus_amd.distributed import allgather_sketches, shard_bounds
+    from pyani_plus_amd.distributed import allgather_sketches, shard_bounds, shard_bounds_by_cost
     from pyani_plus_amd.engine import DeviceSketches, HipEngine
-    from pyani_plus_amd.synth import synth_arena_torch
+    from pyani_plus_amd.synth import mixed_lengths, synth_arena_torch
 
     # PA_BENCH_BACKEND=gloo is a plumbing check for boxes with fewer GPUs than ranks: ranks share
     # GPUs and the collectives run on host tensors.  The measured configuration is always nccl (RCCL).
@@ -138,10 +141,14 @@ def main():
     engine = HipEngine(local_rank)
 
     n_total = args.genomes or (1000 if world == 1 else 1250 * world)
-    bounds = shard_bounds(n_total, world)
+    # sketch shards: contiguous genome ranges balanced by length; pair tiles: subject columns balanced
+    # by count (the row-gather cost of a column tile depends on its width, not on its sketch sizes)
+    lengths = mixed_lengths(n_total) if args.mixed_lengths else [args.length] * n_total
+    bounds = shard_bounds_by_cost(lengths, world) if args.mixed_lengths else shard_bounds(n_total, world)
     g0, g1 = bounds[rank]
     shard_sizes = [b - a for a, b in bounds]
-    arena = synth_arena_torch(engine, g1 - g0, args.length, n_species=args.species, genome_offset=g0)
+    c0, c1 = shard_bounds(n_total, world)[rank]
+    arena = synth_arena_torch(engine, g1 - g0, lengths[g0:g1], n_species=args.species, genome_offset=g0)
 
     def step():
         sk_local = engine.sketch(arena, args.kmer, args.scaled)
@@ -155,8 +162,8 @@ def main():
             sk = DeviceSketches(hashes, off, n_total, int(off[-1].item()))
         else:
             sk = sk_local
-        counts = engine.pair_counts(sk, (0, n_total), (g0, g1))
-        ident, cov = engine.ani(counts, sk, args.kmer, (0, n_total), (g0, g1))
+        counts = engine.pair_counts(sk, (0, n_total), (c0, c1))
+        ident, cov = engine.ani(counts, sk, args.kmer, (0, n_total), (c0, c1))
         return sk_local, sk, counts, ident, cov
 
     def fence():
@@ -180,8 +187,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         # every rank cross-checks a block of its column tile with the independent merge kernel
-        nq_chk, ns_chk = min(n_total, 256), min(g1 - g0, 64)
-        chk = engine.pair_counts(out[1], (0, nq_chk), (g0, g0 + ns_chk), algo=_capi.PA_PAIRS_MERGE)
+        nq_chk, ns_chk = min(n_total, 256), min(c1 - c0, 64)
+        chk = engine.pair_counts(out[1], (0, nq_chk), (c0, c0 + ns_chk), algo=_capi.PA_PAIRS_MERGE)
         if not torch.equal(chk, out[2][:nq_chk, :ns_chk]):
             raise SystemExit(f"PARITY FAILURE on rank {rank}: bit-row and merge counts differ")
     prof = engine.prof_get()
@@ -193,7 +200,7 @@ def main():
     n_local = g1 - g0
     local_hashes = int(sk_local.total)
     # per genome read ceil(L/4) B of 2-bit input + write 8*|S| B of sketch
-    alg_bytes = n_local * ((args.length + 3) // 4) + 8 * local_hashes
+    alg_bytes = sum((x + 3) // 4 for x in lengths[g0:g1]) + 8 * local_hashes
     per_launch_s = (hash_ms / max(1, hash_launches)) * 1e-3
     achieved = alg_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
     traffic = None
@@ -220,7 +227,9 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": f"{n_total} synthetic {args.length / 1e6:g} Mb genomes, k={args.kmer} scaled={args.scaled} sketch + NxN containment ANI",
+                "workload": f"{n_total} synthetic "
+                + ("100 kb-10 Mb (log-uniform)" if args.mixed_lengths else f"{args.length / 1e6:g} Mb")
+                + f" genomes, k={args.kmer} scaled={args.scaled} FracMinHash sketch + NxN containment ANI",
                 "genomes": n_total,
                 "genomes_per_gpu": n_local,
                 "length": args.length,
@@ -246,7 +255,7 @@ def main():
             "device": engine.device_info()["name"],
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(engine, arena, sk, args, n_total)
+            cb = cpu_baseline(engine, arena, sk, args, n_total, lengths)
             n_pair = cb.pop("_n_pair")
             cpu_counts = cb.pop("_cpu_counts")
             gpu_counts = counts[:n_pair, :n_pair].cpu().numpy().view(np.uint32)

@@ -70,43 +70,56 @@ def arena_to_ascii(arena: HostArena, g: int) -> bytes:
     return out[:length].tobytes()
 
 
-def synth_arena_torch(engine, n_genomes: int, length: int, n_species: int = 40, seed: int = SEED, *, rank: int = 0,
-                      genome_offset: int = 0) -> DeviceArena:
-    """Generate the arena on the GPU (torch RNG).  ``genome_offset`` numbers this shard's
-    genomes globally so that every rank of a multi-GPU run draws its own slice of one set."""
+def mixed_lengths(n_genomes: int, lo: int = 100_000, hi: int = 10_000_000, seed: int = SEED) -> list[int]:
+    """Log-uniform genome lengths (BASELINE configs[4]: 100 kb - 10 Mb)."""
+    rng = np.random.Generator(np.random.Philox(key=seed + 1))
+    return [int(x) for x in np.exp(rng.uniform(np.log(lo), np.log(hi), size=n_genomes))]
+
+
+def synth_arena_torch(engine, n_genomes: int, length, n_species: int = 40, seed: int = SEED, *, genome_offset: int = 0) -> DeviceArena:
+    """Generate the arena on the GPU (torch RNG).  ``length`` is one length or a list with one
+    entry per genome of THIS shard; ``genome_offset`` numbers the shard's genomes globally so
+    that every rank of a multi-GPU run draws its own slice of one set."""
     t = engine.torch
     dev = engine.device
-    padded = _padded(length)
-    wpg = padded // 16  # words per genome
+    lengths = [int(length)] * n_genomes if np.isscalar(length) else [int(x) for x in length]
+    assert len(lengths) == n_genomes
+    max_pad = _padded(max(lengths)) if lengths else 64
     gen = t.Generator(device=dev)
     shifts = (t.arange(16, device=dev, dtype=t.int64) * 2)[None, :]
+    mshifts = t.arange(32, device=dev, dtype=t.int64)[None, :]
     # roots depend only on (seed, species) so every rank builds identical roots
-    roots = []
-    for sp in range(n_species):
-        gen.manual_seed(seed * 1000003 + sp)
-        roots.append(t.randint(0, 4, (padded,), generator=gen, device=dev, dtype=t.int64))
-    packed = t.empty(n_genomes * wpg, dtype=t.int32, device=dev)
-    mask = t.zeros(n_genomes * (padded // 32), dtype=t.int32, device=dev)
-    valid = t.arange(padded, device=dev) < length
-    inv_words = ((~valid).to(t.int64).view(-1, 32) << t.arange(32, device=dev, dtype=t.int64)[None, :]).sum(1)
-    inv_words = t.where(inv_words >= 2**31, inv_words - 2**32, inv_words).to(t.int32)
+    roots = {}
+    pads = [_padded(x) for x in lengths]
+    starts = np.zeros(n_genomes + 1, dtype=np.uint64)
+    np.cumsum(pads, out=starts[1:])
+    total = int(starts[-1])
+    packed = t.empty(max(total // 16, 1), dtype=t.int32, device=dev)
+    mask = t.empty(max(total // 32, 1), dtype=t.int32, device=dev)
+    position = t.arange(max_pad, device=dev)
     for i in range(n_genomes):
         g = genome_offset + i
         sp, rate = species_and_rate(g, n_species)
+        if sp not in roots:
+            gen.manual_seed(seed * 1000003 + sp)
+            roots[sp] = t.randint(0, 4, (max_pad,), generator=gen, device=dev, dtype=t.int64)
+        padded = pads[i]
+        valid = position[:padded] < lengths[i]
         gen.manual_seed(seed * 7919 + 104729 * (g + 1))
         hit = t.rand(padded, generator=gen, device=dev) < rate
         delta = t.randint(1, 4, (padded,), generator=gen, device=dev, dtype=t.int64) * hit
-        codes = ((roots[sp] + delta) & 3) * valid
+        codes = ((roots[sp][:padded] + delta) & 3) * valid
         words = (codes.view(-1, 16) << shifts).sum(1)
         words = t.where(words >= 2**31, words - 2**32, words).to(t.int32)
-        packed[i * wpg : (i + 1) * wpg] = words
-        mask[i * (padded // 32) : (i + 1) * (padded // 32)] = inv_words
-    starts = (np.arange(n_genomes + 1, dtype=np.uint64) * np.uint64(padded)).astype(np.uint64)
+        s0 = int(starts[i])
+        packed[s0 // 16 : s0 // 16 + padded // 16] = words
+        inv = ((~valid).to(t.int64).view(-1, 32) << mshifts).sum(1)
+        mask[s0 // 32 : s0 // 32 + padded // 32] = t.where(inv >= 2**31, inv - 2**32, inv).to(t.int32)
     t.cuda.synchronize(dev)
     return DeviceArena(packed, mask, starts)
 
 
-def device_arena_to_host(arena: DeviceArena, genomes: list[int], length: int) -> HostArena:
+def device_arena_to_host(arena: DeviceArena, genomes: list[int], length) -> HostArena:
     """Copy a few genomes of a device arena back to the host (oracle sample)."""
     starts = np.zeros(len(genomes) + 1, dtype=np.uint64)
     packed, mask = [], []
@@ -115,5 +128,6 @@ def device_arena_to_host(arena: DeviceArena, genomes: list[int], length: int) ->
         packed.append(arena.packed[s // 16 : e // 16].cpu().numpy().view(np.uint32))
         mask.append(arena.mask[s // 32 : e // 32].cpu().numpy().view(np.uint32))
         starts[i + 1] = starts[i] + np.uint64(e - s)
-    return HostArena(np.concatenate(packed), np.concatenate(mask), starts, residues=[length] * len(genomes),
+    residues = [int(length)] * len(genomes) if np.isscalar(length) else [int(x) for x in length]
+    return HostArena(np.concatenate(packed), np.concatenate(mask), starts, residues=residues,
                      records=[1] * len(genomes), invalid=[0] * len(genomes))
