@@ -9,6 +9,13 @@ that pin it).
 from .pyoracle import (  # noqa: F401
     ani,
     build,
+    fragani_identity,
+    fragani_kmer_hash,
+    fragani_map,
+    fragani_minimizers,
+    fragani_pair,
+    fragani_tables,
+    fragani_window_size,
     intersect,
     max_hash,
     murmur3_h1,

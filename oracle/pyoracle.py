@@ -21,8 +21,8 @@ _f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> Path:
     """Compile the C restatement with gcc (a few hundred ms)."""
-    src = _HERE / "sourmash_oracle.c"
-    if force or not _LIB_PATH.is_file() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+    newest = max((_HERE / name).stat().st_mtime for name in ("sourmash_oracle.c", "fragani_oracle.c"))
+    if force or not _LIB_PATH.is_file() or _LIB_PATH.stat().st_mtime < newest:
         subprocess.run(["make", "-C", str(_HERE), "-s", "-B"], check=True)
     return _LIB_PATH
 
@@ -152,3 +152,97 @@ def ani(counts: np.ndarray, q_sizes, s_sizes, k: int) -> tuple[np.ndarray, np.nd
     null = np.empty((nq, ns), dtype=np.uint8)
     _load().orc_ani(_p(counts, _u32p), _p(q_sizes, _u64p), _p(s_sizes, _u64p), nq, ns, k, _p(ident, _f64p), _p(cov, _f64p), _p(null, _u8p))
     return ident, cov, null.astype(bool)
+
+
+# ---------------------------------------------------------------- fastANI-style fragment ANI
+_frag_typed = False
+
+
+def _load_frag() -> C.CDLL:
+    global _frag_typed
+    lib = _load()
+    if not _frag_typed:
+        i32p = C.POINTER(C.c_int32)
+        lib.orc_fragani_window_size.restype = C.c_int
+        lib.orc_fragani_window_size.argtypes = [C.c_int, C.c_int]
+        lib.orc_fragani_min_hits.restype = C.c_int
+        lib.orc_fragani_min_hits.argtypes = [C.c_int, C.c_int]
+        lib.orc_fragani_min_shared.restype = C.c_int
+        lib.orc_fragani_min_shared.argtypes = [C.c_int, C.c_int]
+        lib.orc_fragani_identity.restype = C.c_double
+        lib.orc_fragani_identity.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.orc_fragani_kmer_hash.restype = C.c_uint32
+        lib.orc_fragani_kmer_hash.argtypes = [C.c_char_p, C.c_int]
+        lib.orc_fragani_minimizers.restype = C.c_int64
+        lib.orc_fragani_minimizers.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.c_int, _u32p, i32p, C.c_uint64]
+        lib.orc_fragani_map.restype = C.c_int
+        lib.orc_fragani_map.argtypes = [C.c_char_p, _u64p, C.c_uint32, C.c_char_p, _u64p, C.c_uint32, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i32p, C.POINTER(C.c_int)]
+        lib.orc_fragani_pair.restype = C.c_int
+        lib.orc_fragani_pair.argtypes = [C.c_char_p, _u64p, C.c_uint32, C.c_char_p, _u64p, C.c_uint32, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _frag_typed = True
+    return lib
+
+
+def fragani_window_size(k: int, frag_len: int) -> int:
+    return int(_load_frag().orc_fragani_window_size(k, frag_len))
+
+
+def fragani_tables(k: int, s_max: int) -> tuple[np.ndarray, np.ndarray]:
+    """(min_hits[s], min_shared[s]) for s = 0..s_max (entry 0 unused)."""
+    lib = _load_frag()
+    mh = np.array([0] + [lib.orc_fragani_min_hits(s, k) for s in range(1, s_max + 1)], dtype=np.int32)
+    ms = np.array([0] + [lib.orc_fragani_min_shared(s, k) for s in range(1, s_max + 1)], dtype=np.int32)
+    return mh, ms
+
+
+def fragani_identity(shared: int, s: int, k: int) -> float:
+    return float(_load_frag().orc_fragani_identity(shared, s, k))
+
+
+def fragani_kmer_hash(kmer: bytes) -> int:
+    return int(_load_frag().orc_fragani_kmer_hash(kmer, len(kmer)))
+
+
+def fragani_minimizers(seq: bytes, k: int, w: int) -> tuple[np.ndarray, np.ndarray]:
+    lib = _load_frag()
+    cap = max(16, len(seq))
+    h = np.empty(cap, dtype=np.uint32)
+    p = np.empty(cap, dtype=np.int32)
+    n = lib.orc_fragani_minimizers(seq, len(seq), k, w, _p(h, _u32p), p.ctypes.data_as(C.POINTER(C.c_int32)), cap)
+    if n < 0:
+        raise MemoryError("oracle allocation failed")
+    return h[:n].copy(), p[:n].copy()
+
+
+def _contig_blob(contigs: list[bytes]) -> tuple[bytes, np.ndarray]:
+    off = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    np.cumsum([len(c) for c in contigs], out=off[1:])
+    return b"".join(contigs), off
+
+
+def fragani_map(query: list[bytes], ref: list[bytes], k: int = 16, frag_len: int = 3000, window: int = 0):
+    """Per-fragment mappings of a genome pair: dict of int32 arrays (frag, ref_seq, ref_pos, shared, s) and total."""
+    lib = _load_frag()
+    qs, qo = _contig_blob(query)
+    rs, ro = _contig_blob(ref)
+    total_cap = int(sum(len(c) // frag_len for c in query)) + 1
+    arrs = [np.zeros(total_cap, dtype=np.int32) for _ in range(5)]
+    total = C.c_int(0)
+    i32p = C.POINTER(C.c_int32)
+    n = lib.orc_fragani_map(qs, _p(qo, _u64p), len(query), rs, _p(ro, _u64p), len(ref), k, frag_len, window, *[a.ctypes.data_as(i32p) for a in arrs], C.byref(total))
+    if n < 0:
+        raise MemoryError("oracle allocation failed")
+    names = ("frag", "ref_seq", "ref_pos", "shared", "s")
+    return {name: a[:n].copy() for name, a in zip(names, arrs)}, int(total.value)
+
+
+def fragani_pair(query: list[bytes], ref: list[bytes], k: int = 16, frag_len: int = 3000, min_fraction: float = 0.2, window: int = 0):
+    """(ANI percent or NaN, kept fragments, total fragments) of one ordered genome pair."""
+    lib = _load_frag()
+    qs, qo = _contig_blob(query)
+    rs, ro = _contig_blob(ref)
+    ani_v, m, t = C.c_double(0), C.c_int(0), C.c_int(0)
+    rc = lib.orc_fragani_pair(qs, _p(qo, _u64p), len(query), rs, _p(ro, _u64p), len(ref), k, frag_len, min_fraction, window, C.byref(ani_v), C.byref(m), C.byref(t))
+    if rc:
+        raise MemoryError("oracle allocation failed")
+    return float(ani_v.value), int(m.value), int(t.value)
