@@ -123,6 +123,9 @@ PA_API int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads
 PA_API int pa_fasta_batch_info(const pa_fasta_batch *batch, uint32_t i, char md5hex33[33], uint64_t *n_residues,
                         uint64_t *n_records, uint64_t *n_invalid, uint64_t *n_bases, uint64_t *n_text,
                         const char **description, const char **message, int *was_gzip);
+/* FASTA records of file i (start relative to the genome's first position, residues); batch-owned */
+PA_API int pa_fasta_batch_records(const pa_fasta_batch *batch, uint32_t i, const uint64_t **rec_start,
+                           const uint64_t **rec_len, uint64_t *n_records);
 PA_API uint64_t pa_fasta_batch_arena_bases(const pa_fasta_batch *batch);
 PA_API int pa_fasta_batch_copy_arena(const pa_fasta_batch *batch, uint32_t *h_packed, uint32_t *h_mask,
                               uint64_t *h_genome_start);
@@ -167,6 +170,35 @@ PA_API int pa_ani(pa_ctx *ctx, const uint32_t *d_counts, const uint64_t *d_off, 
 PA_API int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, const uint64_t *h_s_sizes,
                 uint32_t nq, uint32_t ns, uint32_t k, double *h_identity, double *h_cov_query,
                 uint8_t *h_is_null);
+
+/* ---- fastANI-style fragment-mapping ANI (BASELINE configs[3]) ----
+ * Replaces one `fastANI --ql queries -r subject --fragLen F -k K --minFraction M` process per subject
+ * column (pyani_plus/private_cli.py:1044-1063): all ordered pairs of the arena's genomes in one call.
+ * Contigs (FASTA records): h_contig_start[i] = first arena position, h_contig_len[i] = residues,
+ * h_contig_genome[i] = owning genome, in arena order (pa_fasta_records / the packers' layout).
+ * Outputs (host): h_total_frags[g] = sum over g's contigs of floor(len/fragLen) (the last column of a
+ * fastANI line); h_matched[q*n+r] = kept (orthologous) fragments, h_ident_sum[q*n+r] = sum of their
+ * identities in percent, so ANI(q,r) = sum/matched, reported by fastANI when matched/total >= minFraction
+ * (pyani_plus/methods/fastani.py:98-120 parses exactly these three numbers).
+ * Algorithm and its tolerance-only parity: oracle/fragani_oracle.c.  k in {12,14,15,16}. */
+PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+               const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
+               uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t *h_total_frags,
+               uint32_t *h_matched, double *h_ident_sum);
+/* stage 1 alone (testing): the winnowed minimizers of every contig, in arena order */
+PA_API int pa_fragani_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                      const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
+                      uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t window, uint32_t *h_hash,
+                      uint32_t *h_wpos, uint32_t *h_contig, uint64_t cap, uint64_t *n_out);
+/* parameters derived from (k, fragLen): winnowing window; per sketch size s the L1 seed threshold and
+ * the smallest accepted number of shared minimizers; identity (percent) of shared/s */
+PA_API int pa_fragani_window(uint32_t k, uint32_t frag_len);
+PA_API int pa_fragani_tables(uint32_t k, uint32_t s_max, uint32_t *h_min_hits, uint32_t *h_min_shared);
+PA_API double pa_fragani_identity(uint32_t shared, uint32_t s, uint32_t k);
+/* record table of a FASTA text as pa_pack_fasta lays it out: start (relative to the genome's first
+ * position) and length of each record; returns the number of records (may exceed cap) */
+PA_API int64_t pa_fasta_records(const uint8_t *h_text, uint64_t n_text, uint64_t *h_rec_start, uint64_t *h_rec_len,
+                         uint64_t cap);
 
 /* ---- bulk writer of the reference's JSON column file (pyani_plus/private_cli.py:454-504) ----
  * Writes prefix + rows + suffix, rows byte-identical to json.dumps of

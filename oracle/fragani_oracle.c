@@ -21,7 +21,7 @@
  *
  * PARITY STATUS: tolerance only.  The reference holds 25 output rows for 7 small inputs
  * (tests/fixtures/{viral,bacterial}_example/intermediates/fastANI/, files all_vs_X.fastani) and
- * nothing pins the internals.  Four choices below are this restatement's own (each marked
+ * nothing pins the internals.  Five choices below are this restatement's own (each marked
  * RESTATEMENT) -- they are what the HIP path implements bit for bit -- and
  * tests/test_fragani_oracle.py records the distance to the fastANI fixtures they leave:
  * |dANI| <= 0.3 percentage points, kept fragments within 5 %, total fragments exact.
@@ -278,11 +278,30 @@ static int map_fragments(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q
   uint32_t *winh = NULL; size_t win_cap = 0;
   const int64_t count_windows = (int64_t)frag_len - (w - 1) - (k - 1);
 
+  /* RESTATEMENT: a fragment is not re-sketched.  Its sketch is the slice of its genome's minimizers
+   * whose window ids lie in the fragment, plus the one recorded last before it unless a new one is
+   * recorded exactly at the fragment's first window -- on sequence without skipped k-mers this is
+   * exactly what sketching the fragment alone gives (tests/test_fragani_oracle.py checks that). */
+  MiniVec qall = {0, 0, 0};
+  for (uint32_t c = 0; c < q_contigs; ++c)
+    if (add_minimizers(&qall, q_seq + q_off[c], (int64_t)(q_off[c + 1] - q_off[c]), k, w, (int32_t)c)) return -1;
   for (uint32_t c = 0; c < q_contigs; ++c) {
     const int64_t clen = (int64_t)(q_off[c + 1] - q_off[c]);
     for (int64_t f = 0; f < clen / frag_len; ++f, ++frag_id) {
       qm.n = 0;
-      if (add_minimizers(&qm, q_seq + q_off[c] + f * frag_len, frag_len, k, w, 0)) return -1;
+      {
+        const int64_t p = f * frag_len;
+        const size_t b = lower_bound_pos(qall.v, qall.n, (int32_t)c, p);
+        const size_t e = lower_bound_pos(qall.v, qall.n, (int32_t)c, p + count_windows);
+        const int fresh = b < qall.n && qall.v[b].seq == (int32_t)c && (int64_t)qall.v[b].wpos == p;
+        const size_t b0 = (!fresh && b > 0 && qall.v[b - 1].seq == (int32_t)c) ? b - 1 : b;
+        for (size_t t = b0; t < e; ++t) {
+          Mini m = qall.v[t];
+          m.seq = 0;
+          m.wpos = (int64_t)m.wpos > p ? (int32_t)(m.wpos - p) : 0;
+          if (mv_push(&qm, m)) return -1;
+        }
+      }
       uint32_t *qh = (uint32_t *)malloc(sizeof(uint32_t) * (qm.n ? qm.n : 1));
       for (size_t i = 0; i < qm.n; ++i) qh[i] = qm.v[i].hash;
       qsort(qh, qm.n, sizeof(uint32_t), cmp_u32);
@@ -351,7 +370,7 @@ static int map_fragments(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q
       }
     }
   }
-  free(qm.v); free(hits); free(winh); free(rpos.v); free(rhash);
+  free(qm.v); free(qall.v); free(hits); free(winh); free(rpos.v); free(rhash);
   *maps_out = maps; *n_maps_out = n_maps; *total_out = total;
   return 0;
 }

@@ -52,6 +52,7 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [_vp, C.c_uint32, C.c_char_p, _u64p, _u64p, _u64p, _u64p, _u64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_int)],
     ),
+    "pa_fasta_batch_records": (C.c_int, [_vp, C.c_uint32, C.POINTER(_u64p), C.POINTER(_u64p), _u64p]),
     "pa_fasta_batch_arena_bases": (C.c_uint64, [_vp]),
     "pa_fasta_batch_copy_arena": (C.c_int, [_vp, _vp, _vp, _vp]),
     "pa_fasta_batch_free": (None, [_vp]),
@@ -65,6 +66,15 @@ SIGNATURES: dict[str, tuple] = {
     ),
     "pa_ani": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
     "pa_ani_host": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "pa_fragani": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "pa_fragani_sketch": (
+        C.c_int,
+        [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_uint64, _u64p],
+    ),
+    "pa_fragani_window": (C.c_int, [C.c_uint32, C.c_uint32]),
+    "pa_fragani_tables": (C.c_int, [C.c_uint32, C.c_uint32, _vp, _vp]),
+    "pa_fragani_identity": (C.c_double, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "pa_fasta_records": (C.c_int64, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
     "pa_write_comparisons_json": (
         C.c_int,
         [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp],

@@ -103,6 +103,7 @@ struct FileResult {
   bool gz = false;
   uint64_t n_text = 0, n_bases = 0, n_residues = 0, n_records = 0, n_invalid = 0;
   std::vector<uint32_t> packed, mask;
+  std::vector<uint64_t> rec_start, rec_len;  // FASTA records, positions relative to the genome start
 };
 
 bool read_file(const std::string &path, std::vector<uint8_t> &raw, std::string &err) {
@@ -213,6 +214,9 @@ void process(const std::string &path, FileResult &r, std::vector<uint8_t> &raw, 
   if (st != PA_OK) { r.status = st; r.message = name + ": packing failed"; return; }
   r.packed.resize(r.n_bases / 16);
   r.mask.resize(r.n_bases / 32);
+  r.rec_start.resize(r.n_records);
+  r.rec_len.resize(r.n_records);
+  if (r.n_records) pa_fasta_records(text.data(), text.size(), r.rec_start.data(), r.rec_len.data(), r.n_records);
   if (r.n_records == 0) {
     r.status = PA_E_INVALID;
     r.message = "File " + name + " is not recognised as a FASTA record";
@@ -273,6 +277,19 @@ int pa_fasta_batch_info(const pa_fasta_batch *b, uint32_t i, char md5hex33[33], 
   if (description) *description = r.description.c_str();
   if (message) *message = r.message.c_str();
   if (was_gzip) *was_gzip = r.gz ? 1 : 0;
+  return r.status;
+}
+
+int pa_fasta_batch_records(const pa_fasta_batch *b, uint32_t i, const uint64_t **rec_start, const uint64_t **rec_len,
+                           uint64_t *n_records) {
+  if (!b || i >= b->files.size() || !rec_start || !rec_len || !n_records) {
+    pa_set_error("pa_fasta_batch_records: bad argument");
+    return PA_E_INVALID;
+  }
+  const FileResult &r = b->files[i];
+  *rec_start = r.rec_start.data();
+  *rec_len = r.rec_len.data();
+  *n_records = r.rec_start.size();
   return r.status;
 }
 

@@ -1,0 +1,930 @@
+// fragani.hip -- fastANI-style fragment-mapping ANI on gfx950 (BASELINE configs[3]).
+//
+// Replaces one `fastANI --ql queries -r subject --fragLen F -k K --minFraction M` process per
+// subject column (pyani_plus/private_cli.py:1044-1063) by an all-vs-all device pipeline.  The
+// algorithm is the restatement pinned in oracle/fragani_oracle.c (published fastANI / Mashmap
+// method; tolerance-only parity with the reference's 25 fixture rows); every integer this file
+// produces (minimizers, per-fragment shared counts, kept fragments) equals the oracle's.
+//
+//   1. minimizer_kernel   both-strand 32-bit murmur of every K-mer (first multiply by LDS table,
+//                         as in kmer_hash.hip), winnowing minimum over w positions from an LDS tile,
+//                         ordered compaction -> minimizers (hash, window id, contig) per contig
+//   2. radix sort by hash -> dense hash ids, postings, "same hash earlier in this contig" links
+//   3. query_sketch_kernel a fragment's sketch is a SLICE of its genome's minimizers (window ids
+//                         inside the fragment + the one still active at its first window): sort,
+//                         de-duplicate in LDS, no re-hashing
+//   4. seed hits           every posting of every sketch hash -> (fragment, ref contig, window id),
+//                         radix sorted; one wave per (fragment, reference genome) segment then
+//                         applies the L1 run test and evaluates the winnowed-MinHash Jaccard at the
+//                         window starts the hits imply (rank histogram in LDS, no per-window sort)
+//   5. one best fragment per reference bin by atomicMax on (J, shared, s); per pair the kept
+//      fragments and the sum of their identities.
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#include "murmur_dev.h"
+#include "pa_internal.h"
+
+namespace {
+
+using namespace pa_dev;
+
+constexpr int kThreads = 256;
+constexpr uint32_t kSkip = 0xffffffffu;
+constexpr int kQMax = 512;       // largest fragment sketch handled
+constexpr int kHitCap = 1024;    // seed hits of one (fragment, reference genome) segment staged in LDS
+constexpr double kPercIdentity = 80.0, kConfLevel = 0.9, kPvalCutoff = 1e-3, kRefSize = 5e6;
+
+// ============================================================== host statistics (Mashmap)
+double md2j(double d, int k) { return 1.0 / (2.0 * std::exp(k * d) - 1.0); }
+double j2md(double j, int k) {
+  if (j == 0) return 1.0;
+  if (j == 1) return 0.0;
+  return (-1.0 / k) * std::log(2.0 * j / (1.0 + j));
+}
+double binom_cdf(int x, int n, double p) {
+  if (x < 0) return 0.0;
+  if (x >= n) return 1.0;
+  double sum = 0.0;
+  const double lp = std::log(p), lq = std::log1p(-p);
+  for (int i = 0; i <= x; ++i)
+    sum += std::exp(std::lgamma(n + 1.0) - std::lgamma(i + 1.0) - std::lgamma(n - i + 1.0) + i * lp + (n - i) * lq);
+  return sum > 1.0 ? 1.0 : sum;
+}
+int binom_quantile_upper(int n, double p, double q) {
+  if (p <= 0.0) return 0;
+  if (p >= 1.0) return n;
+  for (int x = 0; x <= n; ++x)
+    if (1.0 - binom_cdf(x, n, p) <= q) return x;
+  return n;
+}
+double md_lower_bound(double d, int s, int k) {
+  const int x = binom_quantile_upper(s, md2j(d, k), (1.0 - kConfLevel) / 2.0);
+  return j2md((double)x / s, k);
+}
+bool upper_bound_passes(int shared, int s, int k) {
+  const double d = j2md((double)shared / s, k);
+  return 100.0 * (1.0 - md_lower_bound(d, s, k)) >= kPercIdentity;
+}
+int min_shared_for(int s, int k) {
+  for (int x = 0; x <= s; ++x)
+    if (upper_bound_passes(x, s, k)) return x;
+  return s + 1;
+}
+int relaxed_min_hits(int s, int k) {
+  int best = (int)std::ceil(1.0 * s * md2j(1.0 - kPercIdentity / 100.0, k));
+  for (int i = best; i >= 0; --i) {
+    if (upper_bound_passes(i, s, k)) best = i; else break;
+  }
+  return best;
+}
+int window_size_for(int k, int frag_len) {
+  int s;
+  for (s = 10; s < frag_len; s += 50) {
+    const double px = 1.0 / (1.0 + std::pow(4.0, k) / frag_len);
+    const double r = px * px / (px + px - px * px);
+    const int x = relaxed_min_hits(s, k);
+    const double comp = x == 0 ? 1.0 : 1.0 - binom_cdf(x - 1, s, r);
+    if (kRefSize * comp <= kPvalCutoff) break;
+  }
+  int w = (int)(2.0 * frag_len / s);
+  if (w < 1) w = 1;
+  if (w > frag_len) w = frag_len;
+  return w;
+}
+
+// ============================================================== device helpers
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__ v, uint32_t lo, uint32_t hi, uint32_t x) {
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (v[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t contig_of(const uint64_t *__restrict__ start, uint32_t n, uint64_t pos) {
+  uint32_t lo = 0, hi = n;  // largest c with start[c] <= pos (start[0] == 0)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (start[mid] <= pos) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o, 64);
+    if (lane >= (uint32_t)o) inc += t;
+  }
+  return inc - v;
+}
+
+// ============================================================== 1. minimizers
+constexpr int kPPT = 8;                       // positions per thread
+constexpr int kTile = kThreads * kPPT;        // 2048 positions per workgroup, of which
+constexpr int kHalo = 128;                    // the first 128 are look-back (needs w <= 64)
+constexpr int kOwn = kTile - kHalo;
+
+template <int K, bool WRITE>
+__global__ __launch_bounds__(kThreads) void minimizer_kernel(
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
+    const uint64_t *__restrict__ contig_start, const uint32_t *__restrict__ contig_len, uint32_t n_contigs, int w,
+    uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_offsets, uint32_t *__restrict__ out_hash,
+    uint32_t *__restrict__ out_wpos, uint32_t *__restrict__ out_contig) {
+  static_assert(K >= 8 && K <= 16, "both k-mer registers are 32-bit");
+  constexpr int kWords = (K + 7) / 8;
+  __shared__ uint64_t s_lo[kWords][256];
+  __shared__ uint32_t s_hi[kWords][256];
+  __shared__ uint32_t s_h[kTile];
+  __shared__ int32_t s_mp[kTile];
+  __shared__ uint32_t s_scan[kThreads / 64];
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (int j = 0; j < kWords; ++j) {
+    const uint64_t cj = (j & 1) ? kC2 : kC1;
+    s_lo[j][tid] = (uint64_t)ascii_group(tid, K - 8 * j) * cj;
+    s_hi[j][tid] = (uint32_t)((uint64_t)ascii_group(tid, K - 8 * j - 4) * cj);
+  }
+  const int64_t tile0 = (int64_t)blockIdx.x * kOwn - kHalo;
+  const int64_t p0 = tile0 + (int64_t)tid * kPPT;
+  __syncthreads();
+
+  // ---- both-strand hashes of the kPPT k-mers starting at p0 .. p0+kPPT-1
+  {
+    uint64_t bases = 0, bad = ~0ULL;  // bit j of `bad`: position p0+j is not a usable base
+    if (p0 >= 0 && (uint64_t)p0 < arena_bases) {
+      const uint64_t wi = (uint64_t)p0 >> 4, mi = (uint64_t)p0 >> 5;
+      const uint64_t nw = arena_bases >> 4, nm = arena_bases >> 5;
+      const uint64_t w0 = packed[wi], w1 = wi + 1 < nw ? packed[wi + 1] : 0u;
+      bases = ((w1 << 32) | w0) >> (2 * ((uint32_t)p0 & 15u));
+      const uint64_t m0 = mask[mi], m1 = mi + 1 < nm ? mask[mi + 1] : 0xffffffffu;
+      bad = ((m1 << 32) | m0) >> ((uint32_t)p0 & 31u);
+      if ((uint32_t)p0 & 31u) bad |= ~0ULL << (64 - ((uint32_t)p0 & 31u));  // beyond the two mask words: unusable
+    }
+    constexpr uint32_t kMask = (K == 16) ? 0xffffffffu : ((1u << (2 * K)) - 1u);
+    constexpr uint64_t kBadMask = (1ULL << K) - 1;
+    uint32_t fm = 0, fl = 0;
+#pragma unroll
+    for (int j = 0; j < K - 1; ++j) {
+      const uint32_t b = (uint32_t)(bases >> (2 * j)) & 3u;
+      fm = ((fm << 2) | b) & kMask;
+      fl = (fl >> 2) | (b << (2 * (K - 1)));
+    }
+#pragma unroll
+    for (int j = 0; j < kPPT; ++j) {
+      const uint32_t b = (uint32_t)(bases >> (2 * (j + K - 1))) & 3u;
+      fm = ((fm << 2) | b) & kMask;
+      fl = (fl >> 2) | (b << (2 * (K - 1)));
+      uint32_t h = kSkip;
+      if (((bad >> j) & kBadMask) == 0) {
+        const uint32_t strands[2] = {fl, fm ^ kMask};  // LSB-first forward, LSB-first reverse complement
+        uint32_t hs[2];
+#pragma unroll
+        for (int sidx = 0; sidx < 2; ++sidx) {
+          uint64_t P[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < kWords; ++q) {
+            const uint32_t glo = (strands[sidx] >> (16 * q)) & 0xffu, ghi = (strands[sidx] >> (16 * q + 8)) & 0xffu;
+            const uint64_t lo = s_lo[q][glo];
+            P[q] = u64_of((uint32_t)lo, (uint32_t)(lo >> 32) + s_hi[q][ghi]);
+          }
+          hs[sidx] = (uint32_t)murmur3_from_products<K>(P);
+        }
+        if (hs[0] != hs[1]) h = hs[0] < hs[1] ? hs[0] : hs[1];
+      }
+      s_h[tid * kPPT + j] = h;
+    }
+  }
+  __syncthreads();
+
+  // ---- winnowing minimum (rightmost on ties) for every position that can be asked about
+  uint32_t c = 0;
+  bool have_c = false;
+  if (p0 >= 0 && (uint64_t)p0 < arena_bases) { c = contig_of(contig_start, n_contigs, (uint64_t)p0); have_c = true; }
+  uint32_t local[kPPT];
+  uint32_t cidx[kPPT];
+#pragma unroll
+  for (int j = 0; j < kPPT; ++j) {
+    const int x = (int)tid * kPPT + j;
+    int32_t mp = -1;
+    local[j] = 0; cidx[j] = 0;
+    if (have_c && x >= kHalo / 2) {
+      const uint64_t pos = (uint64_t)(p0 + j);
+      while (c + 1 < n_contigs && contig_start[c + 1] <= pos) ++c;
+      const uint64_t loc = pos - contig_start[c];
+      if (loc < contig_len[c] && loc + 1 >= (uint64_t)w && s_h[x] != kSkip) {
+        uint32_t best = s_h[x];
+        mp = x;
+        for (int y = x - 1; y > x - w; --y) {
+          const uint32_t hy = s_h[y];
+          if (hy < best) { best = hy; mp = y; }
+        }
+        local[j] = (uint32_t)loc;
+        cidx[j] = c;
+      }
+    }
+    s_mp[x] = mp;
+  }
+  __syncthreads();
+
+  // ---- a minimizer is recorded when it differs from the previous usable window's
+  uint32_t flags = 0, cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kPPT; ++j) {
+    const int x = (int)tid * kPPT + j;
+    if (x < kHalo) continue;
+    const int32_t mp = s_mp[x];
+    if (mp < 0) continue;
+    int32_t prev = -2;
+    for (int y = x - 1; y > x - w; --y) {
+      const int32_t my = s_mp[y];
+      if (my >= 0) { prev = my; break; }
+    }
+    if (prev != mp) { flags |= 1u << j; ++cnt; }
+  }
+  // block exclusive scan of cnt
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  const uint32_t wex = wave_excl_scan(cnt, lane);
+  if (lane == 63) s_scan[wave] = wex + cnt;
+  __syncthreads();
+  uint32_t pre = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < kThreads / 64; ++q) {
+    if ((uint32_t)q < wave) pre += s_scan[q];
+    total += s_scan[q];
+  }
+  if constexpr (!WRITE) {
+    if (tid == 0) block_counts[blockIdx.x] = total;
+  } else {
+    uint32_t o = block_offsets[blockIdx.x] + pre + wex;
+#pragma unroll
+    for (int j = 0; j < kPPT; ++j) {
+      if (!((flags >> j) & 1u)) continue;
+      const int x = (int)tid * kPPT + j;
+      out_hash[o] = s_h[s_mp[x]];
+      out_wpos[o] = local[j] - (uint32_t)w + 1u;
+      out_contig[o] = cidx[j];
+      ++o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void contig_offsets_kernel(const uint32_t *__restrict__ mini_contig, uint32_t m,
+                                                                   uint32_t n_contigs, uint32_t *__restrict__ off) {
+  const uint32_t c = blockIdx.x * kThreads + threadIdx.x;
+  if (c <= n_contigs) off[c] = lower_bound_u32(mini_contig, 0, m, c);
+}
+
+// ============================================================== 2. dictionary of minimizer hashes
+__global__ __launch_bounds__(kThreads) void mini_keys_kernel(const uint32_t *__restrict__ hash, uint32_t m,
+                                                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < m) { keys[i] = hash[i]; vals[i] = i; }
+}
+__global__ __launch_bounds__(kThreads) void key_heads_kernel(const uint64_t *__restrict__ keys, uint32_t m,
+                                                             uint32_t *__restrict__ flags) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < m) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__restrict__ keys,
+                                                            const uint32_t *__restrict__ sorted_idx,
+                                                            const uint32_t *__restrict__ flags,
+                                                            const uint32_t *__restrict__ pos, uint32_t m, uint32_t n_ids,
+                                                            const uint32_t *__restrict__ mini_contig,
+                                                            uint32_t *__restrict__ mini_id, uint32_t *__restrict__ post_start,
+                                                            int32_t *__restrict__ prev_same) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t id = pos[i] + flags[i] - 1u, me = sorted_idx[i];
+  mini_id[me] = id;
+  if (flags[i]) post_start[id] = i;
+  if (i == m - 1) post_start[n_ids] = m;
+  int32_t ps = -1;
+  if (i > 0 && keys[i] == keys[i - 1]) {
+    const uint32_t other = sorted_idx[i - 1];  // stable sort: other < me
+    if (mini_contig[other] == mini_contig[me]) ps = (int32_t)other;
+  }
+  prev_same[me] = ps;
+}
+
+// ============================================================== 3. fragment sketches
+// one wave per fragment: slice of the contig's minimizers, sorted by (hash, slice index), first of each hash kept
+__global__ __launch_bounds__(kThreads) void query_sketch_kernel(
+    const uint32_t *__restrict__ frag_contig, const uint32_t *__restrict__ frag_no, uint32_t n_frags, uint32_t frag_len,
+    uint32_t count_windows, const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ mini_hash,
+    const uint32_t *__restrict__ mini_wpos, const uint32_t *__restrict__ mini_id, const uint32_t *__restrict__ post_start,
+    uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos, uint32_t *__restrict__ q_id, uint32_t *__restrict__ q_s,
+    uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow) {
+  __shared__ uint64_t s_key[kThreads / 64][kQMax];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t f = blockIdx.x * (kThreads / 64) + wave;
+  const bool active = f < n_frags;  // every wave takes part in the barriers below
+  uint64_t *key = s_key[wave];
+  uint32_t p = 0, b0 = 0, n = 0;
+  if (active) {
+    const uint32_t c = frag_contig[f];
+    p = frag_no[f] * frag_len;
+    const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
+    const uint32_t b = lower_bound_u32(mini_wpos, m0, m1, p), e = lower_bound_u32(mini_wpos, m0, m1, p + count_windows);
+    const bool fresh = b < m1 && mini_wpos[b] == p;
+    b0 = (!fresh && b > m0) ? b - 1 : b;
+    n = e - b0;
+    if (n > (uint32_t)kQMax) { if (lane == 0) atomicAdd(overflow, 1u); n = kQMax; }
+  }
+  for (uint32_t i = lane; i < (uint32_t)kQMax; i += 64)
+    key[i] = i < n ? (((uint64_t)mini_hash[b0 + i] << 16) | i) : ~0ULL;
+  __syncthreads();
+  // bitonic sort of kQMax keys, one wave per fragment
+  for (uint32_t size = 2; size <= (uint32_t)kQMax; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = lane; t < (uint32_t)kQMax / 2; t += 64) {
+        const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
+        const bool up = (i & size) == 0;
+        const uint64_t a = key[i], bb = key[j];
+        if ((a > bb) == up) { key[i] = bb; key[j] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  if (!active) return;
+  // keep the first entry of every hash run (smallest slice index = smallest window id)
+  uint32_t s = 0, hits = 0;
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t i = base + lane;
+    bool keep = false;
+    uint32_t h = 0, idx = 0;
+    if (i < n) {
+      h = (uint32_t)(key[i] >> 16);
+      idx = (uint32_t)(key[i] & 0xffffu);
+      keep = (i == 0) || ((uint32_t)(key[i - 1] >> 16) != h);
+    }
+    const uint64_t bal = __ballot(keep);
+    if (keep) {
+      const uint32_t o = s + __popcll(bal & ((1ULL << lane) - 1ULL));
+      const uint32_t g = b0 + idx, id = mini_id[g];
+      const uint32_t wp = mini_wpos[g];
+      q_hash[(uint64_t)f * kQMax + o] = h;
+      q_pos[(uint64_t)f * kQMax + o] = wp > p ? wp - p : 0u;
+      q_id[(uint64_t)f * kQMax + o] = id;
+      hits += post_start[id + 1] - post_start[id];
+    }
+    s += __popcll(bal);
+  }
+  hits = wave_sum(hits);
+  if (lane == 0) { q_s[f] = s; hit_count[f] = hits; }
+}
+
+// ============================================================== 4. seed hits
+__global__ __launch_bounds__(kThreads) void fill_hits_kernel(
+    uint32_t n_frags, const uint32_t *__restrict__ q_pos, const uint32_t *__restrict__ q_id,
+    const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ hit_off, const uint32_t *__restrict__ post_start,
+    const uint32_t *__restrict__ sorted_idx, const uint32_t *__restrict__ mini_wpos,
+    const uint32_t *__restrict__ mini_contig, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t f = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (f >= n_frags) return;
+  const uint32_t s = q_s[f];
+  uint32_t base = hit_off[f];
+  for (uint32_t i0 = 0; i0 < s; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    uint32_t lo = 0, n = 0, qp = 0;
+    if (i < s) {
+      const uint32_t id = q_id[(uint64_t)f * kQMax + i];
+      lo = post_start[id];
+      n = post_start[id + 1] - lo;
+      qp = q_pos[(uint64_t)f * kQMax + i];
+    }
+    const uint32_t ex = wave_excl_scan(n, lane);
+    for (uint32_t t = 0; t < n; ++t) {
+      const uint32_t g = sorted_idx[lo + t];
+      keys[base + ex + t] = ((uint64_t)f << 44) | ((uint64_t)mini_contig[g] << 24) | mini_wpos[g];
+      vals[base + ex + t] = qp;
+    }
+    base += wave_sum(n);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void segment_heads_kernel(const uint64_t *__restrict__ keys, uint32_t n,
+                                                                 const uint32_t *__restrict__ contig_genome,
+                                                                 uint32_t *__restrict__ flags) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  bool head = i == 0;
+  if (!head) {
+    const uint64_t a = keys[i - 1], b = keys[i];
+    head = (a >> 44) != (b >> 44) || contig_genome[(a >> 24) & 0xfffffu] != contig_genome[(b >> 24) & 0xfffffu];
+  }
+  flags[i] = head ? 1u : 0u;
+}
+__global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t *__restrict__ flags,
+                                                                  const uint32_t *__restrict__ pos, uint32_t n,
+                                                                  uint32_t *__restrict__ seg_start) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  if (flags[i]) seg_start[pos[i]] = i;
+  if (i == n - 1) seg_start[pos[i] + flags[i]] = n;
+}
+
+struct EvalShared {
+  uint32_t qh[kQMax];
+  uint32_t cnt[kQMax + 64];
+  uint32_t matched[kQMax / 32];
+  uint32_t hw[kHitCap];   // window id of each staged hit
+  uint32_t hc[kHitCap];   // contig of each staged hit
+  uint32_t hq[kHitCap];   // query window id of each staged hit
+  uint32_t run[kHitCap];  // inclusive prefix count of valid L1 runs starting at or before this index
+};
+
+// one wave per (fragment, reference genome) segment
+__global__ __launch_bounds__(64) void map_segments_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_start,
+    uint32_t n_segs, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
+    const uint32_t *__restrict__ frag_genome_local, uint32_t frag_len, uint32_t count_windows,
+    const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ tab_min_shared,
+    const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ mini_hash,
+    const uint32_t *__restrict__ mini_wpos, const int32_t *__restrict__ prev_same,
+    const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride, unsigned long long *__restrict__ table,
+    uint32_t *__restrict__ run_g) {
+  __shared__ EvalShared sh;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t seg = blockIdx.x;
+  if (seg >= n_segs) return;
+  const uint32_t a0 = seg_start[seg];
+  uint32_t nh = seg_start[seg + 1] - a0;
+  const uint32_t f = (uint32_t)(keys[a0] >> 44);
+  const uint32_t s = q_s[f];
+  if (s == 0) return;
+  // segments of up to kHitCap hits are staged in LDS; larger ones (repeats: rRNA operons, IS elements)
+  // are read in place from the sorted hit arrays
+  const bool staged = nh <= (uint32_t)kHitCap;
+  auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] : (uint32_t)(keys[a0 + i] & 0xffffffu); };
+  auto HC = [&](uint32_t i) -> uint32_t { return staged ? sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu; };
+  auto HQ = [&](uint32_t i) -> uint32_t { return staged ? sh.hq[i] : vals[a0 + i]; };
+  auto RUN = [&](uint32_t i) -> uint32_t { return staged ? sh.run[i] : run_g[a0 + i]; };
+  for (uint32_t i = lane; i < s; i += 64) sh.qh[i] = q_hash[(uint64_t)f * kQMax + i];
+  if (staged) {
+    for (uint32_t i = lane; i < nh; i += 64) {
+      const uint64_t key = keys[a0 + i];
+      sh.hw[i] = (uint32_t)(key & 0xffffffu);
+      sh.hc[i] = (uint32_t)(key >> 24) & 0xfffffu;
+      sh.hq[i] = vals[a0 + i];
+    }
+  }
+  __syncthreads();
+  // L1: run a is valid when hits a .. a+mh-1 share a contig and span < frag_len window ids
+  const uint32_t mh = tab_min_hits[s];
+  {
+    uint32_t carry = 0;
+    for (uint32_t i0 = 0; i0 < nh; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      uint32_t v = 0;
+      if (i + mh <= nh && HC(i) == HC(i + mh - 1) && HW(i + mh - 1) - HW(i) < frag_len) v = 1;
+      const uint32_t ex = wave_excl_scan(v, lane);
+      if (i < nh) { if (staged) sh.run[i] = carry + ex + v; else run_g[a0 + i] = carry + ex + v; }
+      carry += wave_sum(v);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  uint32_t best_shared = 0, best_c = 0xffffffffu, best_p = 0xffffffffu;
+  bool have_best = false;
+  uint32_t last_p = 0xffffffffu, last_c = 0xffffffffu;
+  for (uint32_t a = 0; a < nh; ++a) {
+    const uint32_t c = HC(a), v = HW(a);
+    // hit a is evaluated iff some valid run [x..y] on its contig has y.w - L + 1 <= v <= x.w + count_windows
+    // <=> a valid run lies inside the hits whose window ids are in [v - count_windows, v + frag_len - 1]
+    bool qualifies;
+    {
+      uint32_t lo = 0, hi = a;  // first index with (contig, wpos) >= (c, v - count_windows)
+      const uint32_t vlo = v > count_windows ? v - count_windows : 0u;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t mc = HC(mid);
+        if (mc < c || (mc == c && HW(mid) < vlo)) lo = mid + 1; else hi = mid;
+      }
+      const uint32_t first = lo;
+      lo = a; hi = nh;  // first index with (contig, wpos) > (c, v + frag_len - 1)
+      const uint32_t vhi = v + frag_len - 1u;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t mc = HC(mid);
+        if (mc < c || (mc == c && HW(mid) <= vhi)) lo = mid + 1; else hi = mid;
+      }
+      const uint32_t end = lo;  // hits [first, end)
+      qualifies = false;
+      if (end >= first + mh) {
+        const uint32_t last_run = end - mh;  // runs starting in [first, last_run]
+        const uint32_t before = first ? RUN(first - 1) : 0u;
+        qualifies = RUN(last_run) > before;
+      }
+    }
+    if (!qualifies) continue;
+    const uint32_t qa = HQ(a);
+    const uint32_t p = v > qa ? v - qa : 0u;
+    if (p == last_p && c == last_c) continue;
+    last_p = p; last_c = c;
+    // ---- winnowed-MinHash Jaccard numerator of the fragment vs the reference window starting at p
+    const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
+    const uint32_t b = lower_bound_u32(mini_wpos, m0, m1, p), e = lower_bound_u32(mini_wpos, m0, m1, p + count_windows);
+    const bool fresh = b < m1 && mini_wpos[b] == p;
+    const uint32_t b0 = (!fresh && b > m0) ? b - 1 : b;
+    for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
+    if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
+    __syncthreads();
+    for (uint32_t t = b0 + lane; t < e; t += 64) {
+      if (prev_same[t] >= (int32_t)b0) continue;  // the same hash already counted inside this window
+      const uint32_t h = mini_hash[t];
+      const uint32_t r = lower_bound_u32(sh.qh, 0, s, h);
+      if (r < s && sh.qh[r] == h) atomicOr(&sh.matched[r >> 5], 1u << (r & 31u));
+      else atomicAdd(&sh.cnt[r], 1u);
+    }
+    __syncthreads();
+    // x = reference-only hashes among the s smallest of the union: bucket r (between query ranks r-1 and r)
+    // contributes min(cnt[r], max(0, s - r - prefix(r)))
+    uint32_t x;
+    {
+      constexpr uint32_t per = (kQMax + 64) / 64;  // buckets per lane
+      uint32_t local_sum = 0;
+      for (uint32_t q = 0; q < per; ++q) {
+        const uint32_t r = lane * per + q;
+        if (r <= s) local_sum += sh.cnt[r];
+      }
+      uint32_t prefix = wave_excl_scan(local_sum, lane), acc = 0;
+      for (uint32_t q = 0; q < per; ++q) {
+        const uint32_t r = lane * per + q;
+        if (r <= s) {
+          const uint32_t cr = sh.cnt[r];
+          const int32_t room = (int32_t)s - (int32_t)r - (int32_t)prefix;
+          if (room > 0) acc += cr < (uint32_t)room ? cr : (uint32_t)room;
+          prefix += cr;
+        }
+      }
+      x = wave_sum(acc);
+    }
+    const uint32_t take = s - x;  // the `take` smallest query hashes are in the bottom-s of the union
+    uint32_t shared = 0;
+    if (lane < (uint32_t)kQMax / 32) {
+      const uint32_t lo_bit = lane * 32u;
+      uint32_t m = sh.matched[lane];
+      if (take <= lo_bit) m = 0;
+      else if (take < lo_bit + 32u) m &= (1u << (take - lo_bit)) - 1u;
+      shared = __popc(m);
+    }
+    shared = wave_sum(shared);
+    if (!have_best || shared > best_shared || (shared == best_shared && (c < best_c || (c == best_c && p < best_p)))) {
+      have_best = true; best_shared = shared; best_c = c; best_p = p;
+    }
+    __syncthreads();
+  }
+  if (have_best && best_shared >= tab_min_shared[s] && lane == 0) {
+    const uint64_t jq = ((uint64_t)best_shared << 30) / s;
+    const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
+    const uint64_t bin = contig_bin_off[best_c] + (best_p + frag_len / 2u) / frag_len;
+    atomicMax(&table[(uint64_t)frag_genome_local[f] * table_stride + bin], packed);
+  }
+}
+
+// ============================================================== 5. per-pair reduction
+// one wave per (query of the batch, reference genome): kept fragments and the sum of their identities
+__global__ __launch_bounds__(64) void reduce_pairs_kernel(const unsigned long long *__restrict__ table,
+                                                          uint64_t table_stride,
+                                                          const uint32_t *__restrict__ genome_bin_off,
+                                                          uint32_t n_genomes, const double *__restrict__ ident_tab,
+                                                          uint32_t *__restrict__ matched, double *__restrict__ ident_sum) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t q = blockIdx.x / n_genomes, r = blockIdx.x % n_genomes;
+  const uint32_t b0 = genome_bin_off[r], b1 = genome_bin_off[r + 1];
+  uint32_t cnt = 0;
+  double sum = 0.0;
+  for (uint32_t bidx = b0 + lane; bidx < b1; bidx += 64) {
+    const unsigned long long v = table[(uint64_t)q * table_stride + bidx];
+    if (v) {
+      const uint32_t shared = (uint32_t)(v >> 16) & 0xffffu, s = (uint32_t)v & 0xffffu;
+      sum += ident_tab[(uint64_t)s * (kQMax + 1) + shared];
+      ++cnt;
+    }
+  }
+  cnt = wave_sum(cnt);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (lane == 0) {
+    matched[(uint64_t)q * n_genomes + r] = cnt;
+    ident_sum[(uint64_t)q * n_genomes + r] = sum;
+  }
+}
+
+// ============================================================== host driver
+template <typename T>
+int upload(pa_ctx *c, DevBuf &buf, const std::vector<T> &v) {
+  PA_TRY(buf.reserve(v.size() * sizeof(T) + 16));
+  if (!v.empty()) PA_HIP(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return PA_OK;
+}
+
+struct FragWork {
+  DevBuf contig_start, contig_len, contig_genome, block_counts, block_offsets, mini_hash, mini_wpos, mini_contig,
+      contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
+      frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
+      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g;
+  ~FragWork() {
+    DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
+                     &mini_contig, &contig_mini_off, &keys[0], &keys[1], &vals[0], &vals[1], &flags, &mini_id,
+                     &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
+                     &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
+                     &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
+                     &ident_sum, &scalars, &run_g};
+    for (DevBuf *b : all) b->release();
+  }
+};
+
+template <int K>
+int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                   uint32_t n_contigs, int w, uint32_t *m_out) {
+  const uint32_t blocks = ceil_div_u64(arena_bases, kOwn);
+  PA_TRY(W.block_counts.reserve((uint64_t)blocks * 4));
+  PA_TRY(W.block_offsets.reserve((uint64_t)blocks * 4));
+  PA_TRY(W.scalars.reserve(64));
+  hipLaunchKernelGGL((minimizer_kernel<K, false>), dim3(blocks), dim3(kThreads), 0, c->stream, d_packed, d_mask,
+                     arena_bases, W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
+                     W.block_counts.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                     (uint32_t *)nullptr);
+  PA_TRY(pa_exclusive_scan_u32(c, W.block_counts.as<uint32_t>(), W.block_offsets.as<uint32_t>(), blocks,
+                               W.scalars.as<uint64_t>()));
+  PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  const uint64_t m = c->h_pinned[0];
+  PA_REQUIRE(m < (1ULL << 31), "fragment ANI: %llu minimizers exceed the 31-bit index space", (unsigned long long)m);
+  PA_TRY(W.mini_hash.reserve(m * 4 + 16));
+  PA_TRY(W.mini_wpos.reserve(m * 4 + 16));
+  PA_TRY(W.mini_contig.reserve(m * 4 + 16));
+  hipLaunchKernelGGL((minimizer_kernel<K, true>), dim3(blocks), dim3(kThreads), 0, c->stream, d_packed, d_mask,
+                     arena_bases, W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
+                     (uint32_t *)nullptr, W.block_offsets.as<uint32_t>(), W.mini_hash.as<uint32_t>(),
+                     W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>());
+  PA_HIP(hipGetLastError());
+  *m_out = (uint32_t)m;
+  return PA_OK;
+}
+
+int dispatch_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                        uint32_t n_contigs, uint32_t k, int w, uint32_t *m_out) {
+  switch (k) {
+    case 12: return run_minimizers<12>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
+    case 14: return run_minimizers<14>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
+    case 15: return run_minimizers<15>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
+    case 16: return run_minimizers<16>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
+    default:
+      pa_set_error("fragment ANI: k=%u is not compiled in (supported: 12, 14, 15, 16)", k);
+      return PA_E_INVALID;
+  }
+}
+
+int stage_contigs(pa_ctx *c, FragWork &W, const uint64_t *h_contig_start, const uint32_t *h_contig_len,
+                  const uint32_t *h_contig_genome, uint32_t n_contigs, uint32_t n_genomes, uint64_t arena_bases) {
+  PA_REQUIRE(n_contigs >= 1 && n_contigs < (1u << 20), "fragment ANI: %u contigs (supported: 1 .. 2^20-1)", n_contigs);
+  std::vector<uint64_t> cs(h_contig_start, h_contig_start + n_contigs);
+  std::vector<uint32_t> cl(h_contig_len, h_contig_len + n_contigs), cg(h_contig_genome, h_contig_genome + n_contigs);
+  for (uint32_t i = 0; i < n_contigs; ++i) {
+    PA_REQUIRE(cs[i] + cl[i] <= arena_bases && (i == 0 || cs[i] >= cs[i - 1] + cl[i - 1]) && cg[i] < n_genomes &&
+                   (i == 0 || cg[i] >= cg[i - 1]) && cl[i] < (1u << 24),
+               "fragment ANI: contig %u is out of order, outside the arena, or longer than 2^24", i);
+  }
+  cs[0] = 0;  // positions before the first contig (none in practice) resolve to contig 0
+  PA_TRY(upload(c, W.contig_start, cs));
+  PA_TRY(upload(c, W.contig_len, cl));
+  PA_TRY(upload(c, W.contig_genome, cg));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  return PA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pa_fragani_window(uint32_t k, uint32_t frag_len) { return window_size_for((int)k, (int)frag_len); }
+
+int pa_fragani_tables(uint32_t k, uint32_t s_max, uint32_t *h_min_hits, uint32_t *h_min_shared) {
+  if (!h_min_hits || !h_min_shared) { pa_set_error("pa_fragani_tables: null argument"); return PA_E_INVALID; }
+  h_min_hits[0] = h_min_shared[0] = 0;
+  for (uint32_t s = 1; s <= s_max; ++s) {
+    const int mh = relaxed_min_hits((int)s, (int)k);
+    h_min_hits[s] = (uint32_t)(mh < 1 ? 1 : mh);
+    h_min_shared[s] = (uint32_t)min_shared_for((int)s, (int)k);
+  }
+  return PA_OK;
+}
+
+double pa_fragani_identity(uint32_t shared, uint32_t s, uint32_t k) {
+  return s ? 100.0 * (1.0 - j2md((double)shared / s, (int)k)) : 0.0;
+}
+
+int pa_fragani_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                      const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
+                      uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t window, uint32_t *h_hash,
+                      uint32_t *h_wpos, uint32_t *h_contig, uint64_t cap, uint64_t *n_out) {
+  PA_REQUIRE(c && d_packed && d_mask && n_out, "pa_fragani_sketch: null argument");
+  PA_REQUIRE(window >= 1 && window <= 64, "pa_fragani_sketch: window %u outside [1,64]", window);
+  PA_HIP(hipSetDevice(c->device));
+  FragWork W;
+  PA_TRY(stage_contigs(c, W, h_contig_start, h_contig_len, h_contig_genome, n_contigs, n_genomes, arena_bases));
+  uint32_t m = 0;
+  PA_TRY(dispatch_minimizers(c, W, d_packed, d_mask, arena_bases, n_contigs, k, (int)window, &m));
+  *n_out = m;
+  if (m > cap) { pa_set_error("pa_fragani_sketch: %u minimizers, room for %llu", m, (unsigned long long)cap); return PA_E_CAPACITY; }
+  if (m) {
+    PA_HIP(hipMemcpyAsync(h_hash, W.mini_hash.p, (uint64_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipMemcpyAsync(h_wpos, W.mini_wpos.p, (uint64_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipMemcpyAsync(h_contig, W.mini_contig.p, (uint64_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  PA_HIP(hipStreamSynchronize(c->stream));
+  return PA_OK;
+}
+
+int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+               const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
+               uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t *h_total_frags,
+               uint32_t *h_matched, double *h_ident_sum) {
+  PA_REQUIRE(c && d_packed && d_mask && h_total_frags && h_matched && h_ident_sum, "pa_fragani: null argument");
+  PA_REQUIRE(frag_len >= 100 && frag_len < (1u << 20), "pa_fragani: fragLen %u outside [100, 2^20)", frag_len);
+  PA_HIP(hipSetDevice(c->device));
+  const int w = window_size_for((int)k, (int)frag_len);
+  PA_REQUIRE(w >= 1 && w <= 64, "pa_fragani: winnowing window %d outside [1,64] for k=%u fragLen=%u", w, k, frag_len);
+  PA_REQUIRE((int)frag_len > w + (int)k, "pa_fragani: fragLen %u too short for window %d", frag_len, w);
+  const uint32_t count_windows = frag_len - (uint32_t)(w - 1) - (k - 1);
+  FragWork W;
+  PA_TRY(stage_contigs(c, W, h_contig_start, h_contig_len, h_contig_genome, n_contigs, n_genomes, arena_bases));
+
+  // ---- 1. minimizers of every contig
+  uint32_t m = 0;
+  PA_TRY(dispatch_minimizers(c, W, d_packed, d_mask, arena_bases, n_contigs, k, w, &m));
+  PA_TRY(W.contig_mini_off.reserve((uint64_t)(n_contigs + 2) * 4));
+  hipLaunchKernelGGL(contig_offsets_kernel, dim3(ceil_div_u64(n_contigs + 1, kThreads)), dim3(kThreads), 0, c->stream,
+                     W.mini_contig.as<uint32_t>(), m, n_contigs, W.contig_mini_off.as<uint32_t>());
+
+  // ---- fragments and reference bins (host bookkeeping)
+  std::vector<uint32_t> frag_contig, frag_no, genome_frag_off(n_genomes + 1, 0), contig_bin_off(n_contigs + 1, 0),
+      genome_bin_off(n_genomes + 1, 0);
+  for (uint32_t g = 0; g < n_genomes; ++g) h_total_frags[g] = 0;
+  for (uint32_t ci = 0; ci < n_contigs; ++ci) {
+    const uint32_t nf = h_contig_len[ci] / frag_len;
+    for (uint32_t f = 0; f < nf; ++f) { frag_contig.push_back(ci); frag_no.push_back(f); }
+    h_total_frags[h_contig_genome[ci]] += nf;
+    contig_bin_off[ci + 1] = contig_bin_off[ci] + h_contig_len[ci] / frag_len + 2;
+  }
+  for (uint32_t g = 0; g < n_genomes; ++g) genome_frag_off[g + 1] = genome_frag_off[g] + h_total_frags[g];
+  {
+    uint32_t ci = 0;
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+      genome_bin_off[g] = contig_bin_off[ci];
+      while (ci < n_contigs && h_contig_genome[ci] == g) ++ci;
+    }
+    genome_bin_off[n_genomes] = contig_bin_off[n_contigs];
+  }
+  const uint64_t total_bins = contig_bin_off[n_contigs];
+  const uint32_t n_frags = (uint32_t)frag_contig.size();
+  for (uint64_t i = 0; i < (uint64_t)n_genomes * n_genomes; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
+  if (m == 0 || n_frags == 0) { PA_HIP(hipStreamSynchronize(c->stream)); return PA_OK; }
+
+  // ---- 2. dictionary of minimizer hashes: ids, postings, same-hash links
+  for (int b = 0; b < 2; ++b) { PA_TRY(W.keys[b].reserve((uint64_t)m * 8)); PA_TRY(W.vals[b].reserve((uint64_t)m * 4)); }
+  PA_TRY(W.flags.reserve((uint64_t)m * 8 + 64));
+  PA_TRY(W.mini_id.reserve((uint64_t)m * 4));
+  PA_TRY(W.prev_same.reserve((uint64_t)m * 4));
+  uint64_t *keys[2] = {W.keys[0].as<uint64_t>(), W.keys[1].as<uint64_t>()};
+  uint32_t *vals[2] = {W.vals[0].as<uint32_t>(), W.vals[1].as<uint32_t>()};
+  const uint32_t gm = ceil_div_u64(m, kThreads);
+  hipLaunchKernelGGL(mini_keys_kernel, dim3(gm), dim3(kThreads), 0, c->stream, W.mini_hash.as<uint32_t>(), m, keys[0], vals[0]);
+  int which = 0;
+  PA_TRY(pa_radix_sort_pairs(c, keys, vals, m, 0, 32, false, &which));
+  uint32_t *d_flags = W.flags.as<uint32_t>(), *d_pos = d_flags + m;
+  hipLaunchKernelGGL(key_heads_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], m, d_flags);
+  PA_TRY(pa_exclusive_scan_u32(c, d_flags, d_pos, m, W.scalars.as<uint64_t>()));
+  PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  const uint32_t n_ids = (uint32_t)c->h_pinned[0];
+  PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
+  hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
+                     n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
+                     W.prev_same.as<int32_t>());
+  const uint32_t *d_sorted_idx = vals[which];
+
+  // ---- tables indexed by sketch size
+  {
+    std::vector<uint32_t> mh(kQMax + 1), ms(kQMax + 1);
+    PA_TRY(pa_fragani_tables(k, kQMax, mh.data(), ms.data()));
+    std::vector<double> ident((uint64_t)(kQMax + 1) * (kQMax + 1), 0.0);
+    for (uint32_t s = 1; s <= (uint32_t)kQMax; ++s)
+      for (uint32_t x = 0; x <= s; ++x) ident[(uint64_t)s * (kQMax + 1) + x] = pa_fragani_identity(x, s, k);
+    PA_TRY(upload(c, W.tab_min_hits, mh));
+    PA_TRY(upload(c, W.tab_min_shared, ms));
+    PA_TRY(upload(c, W.ident_tab, ident));
+    PA_TRY(upload(c, W.contig_bin_off, contig_bin_off));
+    PA_TRY(upload(c, W.genome_bin_off, genome_bin_off));
+    PA_HIP(hipStreamSynchronize(c->stream));
+  }
+
+  // ---- batches of query genomes
+  const uint32_t kMaxBatchFrags = 1u << 16;
+  const uint64_t kMaxTableBytes = 1ULL << 30;
+  PA_TRY(W.scalars.reserve(64));
+  uint32_t *d_overflow = W.scalars.as<uint32_t>() + 8;
+  PA_HIP(hipMemsetAsync(d_overflow, 0, 8, c->stream));
+  for (uint32_t g0 = 0; g0 < n_genomes;) {
+    uint32_t g1 = g0 + 1;
+    while (g1 < n_genomes && genome_frag_off[g1 + 1] - genome_frag_off[g0] <= kMaxBatchFrags &&
+           (uint64_t)(g1 + 1 - g0) * total_bins * 8 <= kMaxTableBytes)
+      ++g1;
+    const uint32_t f0 = genome_frag_off[g0], nf = genome_frag_off[g1] - f0, nq = g1 - g0;
+    PA_REQUIRE(nf < (1u << 20), "pa_fragani: genome %u alone has %u fragments (limit 2^20)", g0, nf);
+    if (nf == 0) { g0 = g1; continue; }
+    std::vector<uint32_t> fc(frag_contig.begin() + f0, frag_contig.begin() + f0 + nf),
+        fn(frag_no.begin() + f0, frag_no.begin() + f0 + nf), fg(nf);
+    for (uint32_t i = 0; i < nf; ++i) fg[i] = h_contig_genome[fc[i]] - g0;
+    PA_TRY(upload(c, W.frag_contig, fc));
+    PA_TRY(upload(c, W.frag_no, fn));
+    PA_TRY(upload(c, W.frag_genome_local, fg));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    PA_TRY(W.q_hash.reserve((uint64_t)nf * kQMax * 4));
+    PA_TRY(W.q_pos.reserve((uint64_t)nf * kQMax * 4));
+    PA_TRY(W.q_id.reserve((uint64_t)nf * kQMax * 4));
+    PA_TRY(W.q_s.reserve((uint64_t)nf * 4));
+    PA_TRY(W.hit_count.reserve((uint64_t)nf * 4));
+    PA_TRY(W.hit_off.reserve((uint64_t)nf * 4));
+    const uint32_t gw = ceil_div_u64(nf, kThreads / 64);
+    hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, W.frag_contig.as<uint32_t>(),
+                       W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
+                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
+                       W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),
+                       W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow);
+    PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
+    PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    const uint64_t n_hits = c->h_pinned[0];
+    PA_REQUIRE(n_hits < (1ULL << 31), "pa_fragani: %llu seed hits in one batch (limit 2^31); highly repetitive input",
+               (unsigned long long)n_hits);
+    PA_TRY(W.table.reserve((uint64_t)nq * total_bins * 8));
+    PA_HIP(hipMemsetAsync(W.table.p, 0, (uint64_t)nq * total_bins * 8, c->stream));
+    if (n_hits) {
+      for (int b = 0; b < 2; ++b) { PA_TRY(W.hkeys[b].reserve(n_hits * 8)); PA_TRY(W.hvals[b].reserve(n_hits * 4)); }
+      uint64_t *hk[2] = {W.hkeys[0].as<uint64_t>(), W.hkeys[1].as<uint64_t>()};
+      uint32_t *hv[2] = {W.hvals[0].as<uint32_t>(), W.hvals[1].as<uint32_t>()};
+      hipLaunchKernelGGL(fill_hits_kernel, dim3(gw), dim3(kThreads), 0, c->stream, nf, W.q_pos.as<uint32_t>(),
+                         W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_off.as<uint32_t>(),
+                         W.post_start.as<uint32_t>(), d_sorted_idx, W.mini_wpos.as<uint32_t>(),
+                         W.mini_contig.as<uint32_t>(), hk[0], hv[0]);
+      int bits = 44;
+      for (uint32_t x = nf; x > 1; x >>= 1) ++bits;
+      bits = (bits + 1 + 7) & ~7;
+      if (bits > 64) bits = 64;
+      int hw = 0;
+      PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
+      PA_TRY(W.flags.reserve(n_hits * 8 + 64));
+      uint32_t *hf = W.flags.as<uint32_t>(), *hp = hf + n_hits;
+      const uint32_t gh = ceil_div_u64(n_hits, kThreads);
+      hipLaunchKernelGGL(segment_heads_kernel, dim3(gh), dim3(kThreads), 0, c->stream, hk[hw], (uint32_t)n_hits,
+                         W.contig_genome.as<uint32_t>(), hf);
+      PA_TRY(pa_exclusive_scan_u32(c, hf, hp, n_hits, W.scalars.as<uint64_t>()));
+      PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+      PA_HIP(hipStreamSynchronize(c->stream));
+      const uint32_t n_segs = (uint32_t)c->h_pinned[0];
+      PA_TRY(W.seg_start.reserve((uint64_t)(n_segs + 2) * 4));
+      PA_TRY(W.run_g.reserve(n_hits * 4 + 16));
+      hipLaunchKernelGGL(segment_starts_kernel, dim3(gh), dim3(kThreads), 0, c->stream, hf, hp, (uint32_t)n_hits,
+                         W.seg_start.as<uint32_t>());
+      hipLaunchKernelGGL(map_segments_kernel, dim3(n_segs), dim3(64), 0, c->stream, hk[hw], hv[hw],
+                         W.seg_start.as<uint32_t>(), n_segs, W.q_hash.as<uint32_t>(), W.q_s.as<uint32_t>(),
+                         W.frag_genome_local.as<uint32_t>(), frag_len, count_windows, W.tab_min_hits.as<uint32_t>(),
+                         W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(), W.mini_hash.as<uint32_t>(),
+                         W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(),
+                         total_bins, W.table.as<unsigned long long>(), W.run_g.as<uint32_t>());
+    }
+    PA_TRY(W.matched.reserve((uint64_t)nq * n_genomes * 4));
+    PA_TRY(W.ident_sum.reserve((uint64_t)nq * n_genomes * 8));
+    hipLaunchKernelGGL(reduce_pairs_kernel, dim3(nq * n_genomes), dim3(64), 0, c->stream,
+                       W.table.as<unsigned long long>(), total_bins, W.genome_bin_off.as<uint32_t>(), n_genomes,
+                       W.ident_tab.as<double>(), W.matched.as<uint32_t>(), W.ident_sum.as<double>());
+    PA_HIP(hipGetLastError());
+    PA_HIP(hipMemcpyAsync(h_matched + (uint64_t)g0 * n_genomes, W.matched.p, (uint64_t)nq * n_genomes * 4,
+                          hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipMemcpyAsync(h_ident_sum + (uint64_t)g0 * n_genomes, W.ident_sum.p, (uint64_t)nq * n_genomes * 8,
+                          hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    g0 = g1;
+  }
+  uint32_t h_over[2] = {0, 0};
+  PA_HIP(hipMemcpy(h_over, d_overflow, 8, hipMemcpyDeviceToHost));
+  if (h_over[0]) {
+    pa_set_error("pa_fragani: %u fragment sketches exceeded %d minimizers (fragLen too long for this window); "
+                 "those sketches were truncated", h_over[0], kQMax);
+    return PA_E_CAPACITY;
+  }
+  return PA_OK;
+}
+
+}  // extern "C"

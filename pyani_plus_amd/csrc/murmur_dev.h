@@ -1,0 +1,93 @@
+// murmur_dev.h -- device helpers shared by the k-mer hashing kernels (gfx950).
+//
+// MurmurHash3_x64_128 (Appleby, public-domain algorithm), seed 42, first 64-bit word: the hash
+// sourmash applies to canonical k-mers (call site pyani_plus/methods/sourmash.py:67-83) and, in its
+// low 32 bits, the one fastANI/Mashmap applies to both strands of every k-mer
+// (call site pyani_plus/private_cli.py:1044-1063).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pa_dev {
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) {
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+}
+
+// 4 bases (8 bits, base j at bits 2j) -> 4 ASCII bytes (base j in byte j).
+// spread the 2-bit codes to one per byte, then use v_perm_b32 as a 4-entry LUT.
+__device__ __forceinline__ uint32_t ascii4(uint32_t b8) {
+  uint32_t u = (b8 | (b8 << 12)) & 0x000F000Fu;
+  uint32_t v = (u | (u << 6)) & 0x03030303u;
+  // selector byte value 0..3 picks that byte of the second source: "ACGT" little-endian
+  return __builtin_amdgcn_perm(0u, 0x54474341u, v);
+}
+
+__device__ __forceinline__ uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// 64-bit rotate as two funnel shifts (v_alignbit_b32); r is a compile-time constant in 1..63
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) {
+  const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+  if (r == 32) return u64_of(hi, lo);
+  if (r < 32) return u64_of(alignbit(lo, hi, 32 - r), alignbit(hi, lo, 32 - r));
+  return u64_of(alignbit(hi, lo, 64 - r), alignbit(lo, hi, 64 - r));
+}
+
+__device__ __forceinline__ uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+
+// ---- MurmurHash3_x64_128(seed 42).h1, split at the first multiply -----------------
+// The K ASCII bytes form up to four little-endian 64-bit words; word j is a "k1" word
+// (j even: k*c1, rotl 31, *c2, xor into h1) or a "k2" word (j odd: k*c2, rotl 33, *c1,
+// xor into h2), in the 16-byte blocks and in the tail alike.  P[j] is the FIRST product
+// (word * c1 or c2); everything after it is computed here.
+constexpr uint64_t kC1 = 0x87c37b91114253d5ULL, kC2 = 0x4cf5ad432745937fULL;
+
+// h*5 + c as shift-and-add.  Left to itself hipcc turns this back into two quarter-rate
+// v_mad_u64_u32; the empty asm keeps the shifted value opaque so it stays three full-rate ops.
+__device__ __forceinline__ uint64_t times5_plus(uint64_t h, uint64_t c) {
+  uint64_t t = h << 2;
+  asm volatile("" : "+v"(t));
+  return t + h + c;
+}
+
+template <int K>
+__device__ __forceinline__ uint64_t murmur3_from_products(const uint64_t (&P)[4]) {
+  uint64_t h1 = 42, h2 = 42;
+  constexpr int nblocks = K / 16;
+  constexpr int tail = K % 16;
+#pragma unroll
+  for (int i = 0; i < nblocks; ++i) {
+    const uint64_t k1 = rotl64(P[2 * i], 31) * kC2;
+    h1 ^= k1;
+    h1 = rotl64(h1, 27) + h2;
+    h1 = times5_plus(h1, 0x52dce729ULL);
+    const uint64_t k2 = rotl64(P[2 * i + 1], 33) * kC1;
+    h2 ^= k2;
+    h2 = rotl64(h2, 31) + h1;
+    h2 = times5_plus(h2, 0x38495ab5ULL);
+  }
+  if constexpr (tail > 8) h2 ^= rotl64(P[2 * nblocks + 1], 33) * kC1;
+  if constexpr (tail > 0) h1 ^= rotl64(P[2 * nblocks], 31) * kC2;
+  h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2;
+  return h1;
+}
+
+// the 4-base group `b8` (base j at bits 2j) as ASCII, keeping only its first `nv` bytes
+__device__ __forceinline__ uint32_t ascii_group(uint32_t b8, int nv) {
+  const uint32_t a = ascii4(b8);
+  return nv >= 4 ? a : (nv <= 0 ? 0u : (a & ((1u << (8 * nv)) - 1u)));
+}
+
+}  // namespace pa_dev

@@ -109,6 +109,40 @@ extern "C" int pa_pack_fasta(const uint8_t *h_text, uint64_t n_text, uint32_t *h
   return PA_OK;
 }
 
+extern "C" int64_t pa_fasta_records(const uint8_t *h_text, uint64_t n_text, uint64_t *h_rec_start,
+                                    uint64_t *h_rec_len, uint64_t cap) {
+  // same line/record rules as pa_pack_fasta; positions count the one-position separators
+  uint64_t pos = 0, i = 0, n_rec = 0, cur_len = 0;
+  bool in_record = false;
+  while (i < n_text) {
+    if (h_text[i] == '>') {
+      if (in_record) {
+        if (n_rec - 1 < cap && h_rec_len) h_rec_len[n_rec - 1] = cur_len;
+        ++pos;  // separator
+      }
+      in_record = true;
+      if (n_rec < cap && h_rec_start) h_rec_start[n_rec] = pos;
+      ++n_rec;
+      cur_len = 0;
+      while (i < n_text && h_text[i] != '\n') ++i;
+      if (i < n_text) ++i;
+      continue;
+    }
+    if (!in_record) {
+      while (i < n_text && h_text[i] != '\n') ++i;
+      if (i < n_text) ++i;
+      continue;
+    }
+    while (i < n_text) {
+      const uint8_t ch = h_text[i++];
+      if (kLut.v[ch] <= 4) { ++pos; ++cur_len; }
+      else if (ch == '\n') break;
+    }
+  }
+  if (in_record && n_rec - 1 < cap && h_rec_len) h_rec_len[n_rec - 1] = cur_len;
+  return (int64_t)n_rec;
+}
+
 extern "C" int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_packed, uint32_t *h_mask,
                            uint64_t cap_bases, uint64_t *n_bases, uint64_t *n_invalid) {
   if ((!h_seq && n_seq) || !h_packed || !h_mask || (cap_bases & 63)) {

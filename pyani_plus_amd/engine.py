@@ -36,6 +36,10 @@ class HostArena:
     residues: list[int] = field(default_factory=list)  # Genome.length per genome
     records: list[int] = field(default_factory=list)
     invalid: list[int] = field(default_factory=list)
+    # FASTA records (contigs) in arena order: first arena position, residues, owning genome
+    contig_start: np.ndarray | None = None
+    contig_len: np.ndarray | None = None
+    contig_genome: np.ndarray | None = None
 
     @property
     def n_genomes(self) -> int:
@@ -55,6 +59,7 @@ def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
     mask = np.zeros(total // 32, dtype=np.uint32)
     starts = np.zeros(len(texts) + 1, dtype=np.uint64)
     residues, records, invalid = [], [], []
+    c_start, c_len, c_genome = [], [], []
     pos = 0
     for g, text in enumerate(texts):
         nb, nr, nrec, ninv = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
@@ -67,13 +72,27 @@ def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
             st = lib.pa_pack_seq(buf, len(text), p_ptr, m_ptr, bounds[g], C.byref(nb), C.byref(ninv))
             nr.value, nrec.value = len(text), 1
         check(st, "pa_pack_fasta" if fasta else "pa_pack_seq")
+        if fasta and nrec.value:
+            rs = np.zeros(int(nrec.value), dtype=np.uint64)
+            rl = np.zeros(int(nrec.value), dtype=np.uint64)
+            lib.pa_fasta_records(buf, len(text), rs.ctypes.data, rl.ctypes.data, int(nrec.value))
+            c_start.extend((rs + np.uint64(pos)).tolist())
+            c_len.extend(rl.tolist())
+            c_genome.extend([g] * int(nrec.value))
+        elif not fasta:
+            c_start.append(pos)
+            c_len.append(len(text))
+            c_genome.append(g)
         starts[g] = pos
         pos += int(nb.value)
         residues.append(int(nr.value))
         records.append(int(nrec.value))
         invalid.append(int(ninv.value))
     starts[len(texts)] = pos
-    return HostArena(packed[: pos // 16].copy(), mask[: pos // 32].copy(), starts, residues, records, invalid)
+    return HostArena(
+        packed[: pos // 16].copy(), mask[: pos // 32].copy(), starts, residues, records, invalid,
+        np.array(c_start, dtype=np.uint64), np.array(c_len, dtype=np.uint32), np.array(c_genome, dtype=np.uint32),
+    )
 
 
 @dataclass
@@ -109,6 +128,7 @@ def load_fasta_files(paths, threads: int = 0) -> tuple[list[LoadedFasta], HostAr
     try:
         infos: list[LoadedFasta] = []
         ok_residues, ok_records, ok_invalid = [], [], []
+        rec_tables = []
         for i, path in enumerate(paths):
             md5 = C.create_string_buffer(33)
             nres, nrec, ninv, nb, nt = (C.c_uint64(0) for _ in range(5))
@@ -123,6 +143,10 @@ def load_fasta_files(paths, threads: int = 0) -> tuple[list[LoadedFasta], HostAr
                 ok_residues.append(int(nres.value))
                 ok_records.append(int(nrec.value))
                 ok_invalid.append(int(ninv.value))
+                rs_p, rl_p, rn = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)(), C.c_uint64(0)
+                lib.pa_fasta_batch_records(batch, i, C.byref(rs_p), C.byref(rl_p), C.byref(rn))
+                k_rec = int(rn.value)
+                rec_tables.append((np.ctypeslib.as_array(rs_p, (k_rec,)).copy(), np.ctypeslib.as_array(rl_p, (k_rec,)).copy()) if k_rec else (np.zeros(0, np.uint64), np.zeros(0, np.uint64)))
         total = int(lib.pa_fasta_batch_arena_bases(batch))
         packed = np.zeros(max(total // 16, 1), dtype=np.uint32)
         mask = np.zeros(max(total // 32, 1), dtype=np.uint32)
@@ -130,7 +154,13 @@ def load_fasta_files(paths, threads: int = 0) -> tuple[list[LoadedFasta], HostAr
         check(lib.pa_fasta_batch_copy_arena(batch, packed.ctypes.data, mask.ctypes.data, starts_all.ctypes.data), "pa_fasta_batch_copy_arena")
         keep = [i for i, info in enumerate(infos) if info.status == 0]
         starts = np.array([starts_all[i] for i in keep] + [total], dtype=np.uint64)
-        return infos, HostArena(packed[: total // 16], mask[: total // 32], starts, ok_residues, ok_records, ok_invalid)
+        c_start = np.concatenate([rs + starts[g] for g, (rs, _rl) in enumerate(rec_tables)]) if rec_tables else np.zeros(0, np.uint64)
+        c_len = np.concatenate([rl for _rs, rl in rec_tables]).astype(np.uint32) if rec_tables else np.zeros(0, np.uint32)
+        c_genome = np.concatenate([np.full(len(rs), g, dtype=np.uint32) for g, (rs, _rl) in enumerate(rec_tables)]) if rec_tables else np.zeros(0, np.uint32)
+        return infos, HostArena(
+            packed[: total // 16], mask[: total // 32], starts, ok_residues, ok_records, ok_invalid,
+            c_start.astype(np.uint64), c_len, c_genome,
+        )
     finally:
         lib.pa_fasta_batch_free(batch)
 
@@ -279,6 +309,46 @@ class HipEngine:
             "pa_ani",
         )
         return ident, cov
+
+    # -- fastANI-style fragment ANI (BASELINE configs[3])
+    def fragani(self, arena: DeviceArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000):
+        """All ordered genome pairs: (total_frags[n], matched[n, n], ident_sum[n, n]) as numpy arrays;
+        ANI(q, r) = ident_sum / matched (percent), rows = query."""
+        n = arena.n_genomes
+        cs = np.ascontiguousarray(contig_start, dtype=np.uint64)
+        cl = np.ascontiguousarray(contig_len, dtype=np.uint32)
+        cg = np.ascontiguousarray(contig_genome, dtype=np.uint32)
+        total = np.zeros(n, dtype=np.uint32)
+        matched = np.zeros((n, n), dtype=np.uint32)
+        ident_sum = np.zeros((n, n), dtype=np.float64)
+        check(
+            self.lib.pa_fragani(
+                self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,
+                cg.ctypes.data, len(cs), n, k, frag_len, total.ctypes.data, matched.ctypes.data, ident_sum.ctypes.data,
+            ),  # fmt: skip
+            "pa_fragani",
+        )
+        return total, matched, ident_sum
+
+    def fragani_sketch(self, arena: DeviceArena, contig_start, contig_len, contig_genome, k: int, window: int):
+        """Stage 1 alone: winnowed minimizers (hash, window id, contig) of every contig."""
+        cs = np.ascontiguousarray(contig_start, dtype=np.uint64)
+        cl = np.ascontiguousarray(contig_len, dtype=np.uint32)
+        cg = np.ascontiguousarray(contig_genome, dtype=np.uint32)
+        cap = max(1024, arena.arena_bases)  # at most one minimizer per position
+        h = np.zeros(cap, dtype=np.uint32)
+        wp = np.zeros(cap, dtype=np.uint32)
+        ct = np.zeros(cap, dtype=np.uint32)
+        n = C.c_uint64(0)
+        check(
+            self.lib.pa_fragani_sketch(
+                self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,
+                cg.ctypes.data, len(cs), arena.n_genomes, k, window, h.ctypes.data, wp.ctypes.data, ct.ctypes.data, cap, C.byref(n),
+            ),  # fmt: skip
+            "pa_fragani_sketch",
+        )
+        m = int(n.value)
+        return h[:m], wp[:m], ct[:m]
 
     # -- profiling
     def prof_enable(self, on: bool = True) -> None:

@@ -1,0 +1,138 @@
+"""GPU: the fastANI-style fragment-ANI path against its oracle (exact integers) and, through the
+oracle, against the reference's fastANI fixtures (stated tolerance, tests/test_fragani_oracle.py)."""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import GOLDEN, read_fasta_bytes
+from tests.test_fragani_oracle import ANI_TOL, contigs_of, fixture_rows
+
+pytestmark = pytest.mark.gpu
+K, FRAG = 16, 3000
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from pyani_plus_amd.engine import HipEngine
+
+    eng = HipEngine(0)
+    yield eng
+    eng.close()
+
+
+def _random_genomes(seed: int):
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    root = rng.choice(acgt, size=40_000)
+    texts, contig_lists = [], []
+    for g, (rate, cuts) in enumerate([(0.0, [40_000]), (0.03, [9_500, 12_345, 18_155]), (0.12, [40_000]), (0.0, [7_000, 3_100, 2_999, 26_901])]):
+        seq = root.copy()
+        hit = rng.random(seq.size) < rate
+        seq[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+        if g == 2:
+            seq[5_000:5_040] = ord("N")  # a run of N inside a fragment
+        contigs, pos = [], 0
+        for n in cuts:
+            contigs.append(seq[pos : pos + n].tobytes())
+            pos += n
+        contig_lists.append(contigs)
+        texts.append(b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs)))
+    unrelated = rng.choice(acgt, size=20_000).tobytes()
+    contig_lists.append([unrelated])
+    texts.append(b">u\n" + unrelated + b"\n")
+    return texts, contig_lists
+
+
+def test_parameters_match_oracle(engine):
+    from pyani_plus_amd import _capi
+
+    lib = _capi.load_library()
+    for k, frag in ((16, 3000), (15, 2000), (16, 1000), (14, 3000)):
+        assert lib.pa_fragani_window(k, frag) == oracle.fragani_window_size(k, frag)
+    mh = np.zeros(513, dtype=np.uint32)
+    ms = np.zeros(513, dtype=np.uint32)
+    assert lib.pa_fragani_tables(16, 512, mh.ctypes.data, ms.ctypes.data) == 0
+    omh, oms = oracle.fragani_tables(16, 512)
+    assert np.array_equal(mh, omh.astype(np.uint32)) and np.array_equal(ms, oms.astype(np.uint32))
+    for shared, s in ((0, 10), (3, 200), (150, 214), (214, 214)):
+        assert lib.pa_fragani_identity(shared, s, 16) == oracle.fragani_identity(shared, s, 16)
+
+
+@pytest.mark.parametrize("k,w", [(16, 23), (15, 19), (16, 5), (12, 64)])
+def test_minimizers_equal_oracle(engine, k, w):
+    from pyani_plus_amd.engine import pack_genomes
+
+    texts, contig_lists = _random_genomes(k * 100 + w)
+    texts.append(read_fasta_bytes(GOLDEN / "viral_example" / "OP073605.fasta"))
+    contig_lists.append(contigs_of(GOLDEN / "viral_example" / "OP073605.fasta"))
+    arena = pack_genomes(texts)
+    h, wp, ct = engine.fragani_sketch(engine.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, k, w)
+    ci = 0
+    for contigs in contig_lists:
+        for contig in contigs:
+            want_h, want_p = oracle.fragani_minimizers(contig, k, w)
+            sel = ct == ci
+            assert np.array_equal(h[sel], want_h), f"contig {ci}: {sel.sum()} vs {len(want_h)} minimizers"
+            assert np.array_equal(wp[sel].astype(np.int32), want_p)
+            ci += 1
+    assert ci == len(arena.contig_start)
+
+
+def _check_against_oracle(engine, texts, contig_lists, frag=FRAG, k=K):
+    from pyani_plus_amd.engine import pack_genomes
+
+    arena = pack_genomes(texts)
+    total, matched, ident_sum = engine.fragani(engine.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, k, frag)
+    n = len(texts)
+    for q in range(n):
+        for r in range(n):
+            ani, m, t = oracle.fragani_pair(contig_lists[q], contig_lists[r], k, frag, 0.0)
+            assert total[q] == t
+            assert matched[q, r] == m, (q, r, matched[q, r], m)
+            if m:
+                assert abs(ident_sum[q, r] / m - ani) <= 1e-9 * ani  # same doubles, summation order differs
+            else:
+                assert math.isnan(ani) and ident_sum[q, r] == 0.0
+    return total, matched, ident_sum
+
+
+def test_pairs_equal_oracle_on_random_genomes(engine):
+    texts, contig_lists = _random_genomes(7)
+    total, matched, _ = _check_against_oracle(engine, texts, contig_lists)
+    assert matched[0, 0] == total[0] and matched[0, 4] == 0 and matched[4, 0] == 0
+    _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
+
+
+def test_viral_fixture_rows(engine):
+    files = sorted((GOLDEN / "viral_example").glob("*.f*"))
+    texts = [read_fasta_bytes(p) for p in files]
+    contig_lists = [contigs_of(p) for p in files]
+    total, matched, ident_sum = _check_against_oracle(engine, texts, contig_lists)
+    names = [p.name for p in files]
+    for q, r, ani, m, t in fixture_rows("viral_example"):
+        qi, ri = names.index(q), names.index(r)
+        assert total[qi] == t and abs(int(matched[qi, ri]) - m) <= 1
+        assert abs(ident_sum[qi, ri] / matched[qi, ri] - ani) <= ANI_TOL
+
+
+def test_bacterial_fixture_rows(engine):
+    """All 16 bacterial fastANI rows on the GPU (the CPU oracle is only asked for two pairs here)."""
+    from pyani_plus_amd.engine import load_fasta_files
+
+    files = sorted((GOLDEN / "bacterial_example").glob("*.gz"))
+    infos, arena = load_fasta_files(files)
+    total, matched, ident_sum = engine.fragani(engine.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    names = [p.name for p in files]
+    for q, r, ani, m, t in fixture_rows("bacterial_example"):
+        qi, ri = names.index(q), names.index(r)
+        assert total[qi] == t
+        assert abs(int(matched[qi, ri]) - m) <= 0.05 * t
+        assert abs(ident_sum[qi, ri] / matched[qi, ri] - ani) <= ANI_TOL, (q, r)
+    for qi, ri in ((1, 0), (0, 2)):
+        ani, m, t = oracle.fragani_pair(contigs_of(files[qi]), contigs_of(files[ri]), K, FRAG, 0.0)
+        assert matched[qi, ri] == m and abs(ident_sum[qi, ri] / m - ani) <= 1e-9 * ani
