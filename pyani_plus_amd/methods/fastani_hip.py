@@ -1,0 +1,133 @@
+"""The ``fastANI-hip`` method: pyani-plus's fastANI column worker on an MI355X.
+
+Drop-in shaped like ``private_cli.compute_fastani`` (pyani_plus/private_cli.py:976-1117) and the
+defaults module ``pyani_plus/methods/fastani.py``:
+
+* constants ``KMER_SIZE`` / ``FRAG_LEN`` / ``MIN_FRACTION`` (fastani.py:27-30);
+* ``compute_fastani_hip(...)`` with the positional signature of the ``compute`` dict entries
+  (private_cli.py:956-968): queries vs one subject column (or all columns when ``subject_hash``
+  is ``""``), JSON column file out, 0 / 2 return codes, interrupt handling.
+
+Where the reference runs ``fastANI --ql <queries> -r <subject> -o out --fragLen F -k K
+--minFraction M`` in batches of 500 queries (private_cli.py:1029-1063) and parses
+``query ref ANI matched total`` lines (fastani.py:98-120), this module makes one
+``pa_fragani`` call for all genomes involved and derives the same five fields
+(private_cli.py:1070-1080):
+
+    identity   = ANI / 100            (None when fastANI would print no line)
+    aln_length = round(fragsize * matched)
+    sim_errors = total - matched
+    cov_query  = matched / total
+
+Parity with fastANI itself is tolerance-only (oracle/fragani_oracle.c): ANI within 0.3 percentage
+points and kept fragments within 5 % on the reference's 25 fixture rows.
+"""
+
+from __future__ import annotations
+
+import logging
+import platform
+from pathlib import Path
+
+import numpy as np
+
+from .. import wire
+from .sourmash_hip import RECORDING_FAILED, ExternalToolData, _check_tool_version, get_engine, get_sourmash_hip, log_sys_exit
+
+METHOD = "fastANI-hip"
+KMER_SIZE = 16  # pyani_plus/methods/fastani.py:27-30
+FRAG_LEN = 3000
+MIN_FRACTION = 0.2
+
+
+def get_fastani_hip() -> ExternalToolData:
+    """Counterpart of ``tools.get_fastani`` (pyani_plus/tools.py:140-164): the HIP library is the tool."""
+    return get_sourmash_hip()
+
+
+def fragment_ani_matrices(fasta_files: list[Path], *, kmersize: int, fragsize: int, engine=None):
+    """(total_frags[n], matched[n, n], ani_percent[n, n]) for the given FASTA files, rows = query."""
+    from ..engine import load_fasta_files
+
+    infos, arena = load_fasta_files(fasta_files)
+    for info in infos:
+        if info.status != 0:
+            raise ValueError(info.message)
+    eng = engine or get_engine()
+    total, matched, ident_sum = eng.fragani(eng.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ani = np.where(matched > 0, ident_sum / np.maximum(matched, 1), np.nan)
+    return total, matched, ani
+
+
+def compute_fastani_hip(  # noqa: PLR0913
+    logger: logging.Logger,
+    tmp_dir: Path,  # noqa: ARG001
+    session,
+    run,
+    json_filename: Path,
+    fasta_dir: Path,
+    hash_to_filename: dict[str, str],
+    filename_to_hash: dict[str, str],  # noqa: ARG001
+    query_hashes: dict[str, int],
+    subject_hash: str,
+    *,
+    cache: Path = Path(),  # noqa: ARG001
+    engine=None,
+) -> int:
+    """Run many-vs-subject (all-vs-all when ``subject_hash == ""``) and log the column(s) to JSON."""
+    uname = platform.uname()
+    configuration = run.configuration
+    tool = get_fastani_hip()
+    _check_tool_version(logger, tool, configuration)
+    config_id = getattr(configuration, "configuration_id", None)
+    fragsize = configuration.fragsize
+    if not fragsize:
+        log_sys_exit(logger, f"{METHOD} run-id {run.run_id} is missing fragsize parameter")
+    kmersize = configuration.kmersize
+    if not kmersize:
+        log_sys_exit(logger, f"{METHOD} run-id {run.run_id} is missing kmersize parameter")
+    minmatch = configuration.minmatch
+    if not minmatch:
+        log_sys_exit(logger, f"{METHOD} run-id {run.run_id} is missing minmatch parameter")
+
+    queries = sorted(query_hashes)
+    subjects = [subject_hash] if subject_hash else queries
+    genomes = sorted(set(queries) | set(subjects))
+    index = {h: i for i, h in enumerate(genomes)}
+    db_entries: list[dict] = []
+    try:
+        total, matched, ani = fragment_ani_matrices(
+            [Path(fasta_dir) / hash_to_filename[h] for h in genomes], kmersize=kmersize, fragsize=fragsize, engine=engine
+        )
+        for q in queries:
+            qi = index[q]
+            for s in subjects:
+                si = index[s]
+                frags, matches = int(total[qi]), int(matched[qi, si])
+                reported = frags > 0 and matches > 0 and matches / frags >= minmatch  # fastANI prints a line
+                db_entries.append(
+                    {
+                        "query_hash": q,
+                        "subject_hash": s,
+                        "identity": float(ani[qi, si]) / 100.0 if reported else None,
+                        # proxy values, private_cli.py:1072-1080
+                        "aln_length": round(fragsize * matches) if reported else None,
+                        "sim_errors": frags - matches if reported else None,
+                        "cov_query": matches / frags if reported else None,
+                        "configuration_id": config_id,
+                        "uname_system": uname.system,
+                        "uname_release": uname.release,
+                        "uname_machine": uname.machine,
+                    }
+                )
+    except KeyboardInterrupt:  # pragma: no cover
+        logger.error("Interrupted with %d completed %s comparisons", len(db_entries), METHOD)  # noqa: TRY400
+        run.status = "Worker interrupted"
+        session.commit()
+    try:
+        wire.export_json_db_entries(logger, json_filename, configuration, db_entries)
+    except Exception:  # pragma: no cover
+        logger.exception("Unexpected exception saving JSON:")
+        return RECORDING_FAILED
+    return 0

@@ -136,3 +136,49 @@ def test_bacterial_fixture_rows(engine):
     for qi, ri in ((1, 0), (0, 2)):
         ani, m, t = oracle.fragani_pair(contigs_of(files[qi]), contigs_of(files[ri]), K, FRAG, 0.0)
         assert matched[qi, ri] == m and abs(ident_sum[qi, ri] / m - ani) <= 1e-9 * ani
+
+
+def test_plugin_column_matches_reference_matrices(engine, tmp_path):
+    """compute_fastani_hip -> JSON column vs the reference's fastANI matrices for the viral set
+    (identity within the ANI tolerance, aln_length / sim_errors / cov_query from kept fragments)."""
+    import json
+    import logging
+
+    from pyani_plus_amd import rundb
+    from pyani_plus_amd.methods import fastani_hip
+    from tests.helpers import load_matrix_tsv, md5_hex
+
+    files = sorted((GOLDEN / "viral_example").glob("*.f*"))
+    hash_to_filename = {md5_hex(read_fasta_bytes(p)): p.name for p in files}
+    tool = fastani_hip.get_fastani_hip()
+    cfg = rundb.Configuration(5, fastani_hip.METHOD, tool.exe_path.stem, tool.version, fragsize=3000, kmersize=16, minmatch=0.2)
+    run = rundb.Run(1, cfg, str(GOLDEN / "viral_example"), [], "Testing")
+
+    class _S:
+        def commit(self):
+            pass
+
+    out = tmp_path / "col.json"
+    lengths = {h: 1 for h in hash_to_filename}
+    assert fastani_hip.compute_fastani_hip(logging.getLogger("t"), tmp_path, _S(), run, out, GOLDEN / "viral_example", hash_to_filename, {}, lengths, "", engine=engine) == 0
+    data = json.loads(out.read_text())
+    assert data["configuration"]["method"] == "fastANI-hip" and data["configuration"]["fragsize"] == 3000
+    rows = {(e["query_hash"], e["subject_hash"]): e for e in data["comparisons"]}
+    assert len(rows) == 9
+    stem_of = {h: name.split(".")[0] for h, name in hash_to_filename.items()}
+    for fname, key, tol in (("fastANI_identity.tsv", "identity", ANI_TOL / 100), ("fastANI_coverage.tsv", "cov_query", 1 / 13 + 1e-9)):
+        labels, want = load_matrix_tsv(GOLDEN / "viral_example" / "matrices" / fname)
+        for (q, s), e in rows.items():
+            w = want[labels.index(stem_of[q]), labels.index(stem_of[s])]
+            assert abs(e[key] - w) <= tol, (key, stem_of[q], stem_of[s], e[key], w)
+    for e in rows.values():
+        assert e["aln_length"] == round(3000 * e["cov_query"] * (e["aln_length"] + 3000 * e["sim_errors"]) / 3000) and e["sim_errors"] >= 0
+    # one subject column and a minFraction nothing reaches
+    subject = sorted(hash_to_filename)[0]
+    assert fastani_hip.compute_fastani_hip(logging.getLogger("t"), tmp_path, _S(), run, out, GOLDEN / "viral_example", hash_to_filename, {}, lengths, subject, engine=engine) == 0
+    col = json.loads(out.read_text())["comparisons"]
+    assert [(e["query_hash"], e["subject_hash"]) for e in col] == [(q, subject) for q in sorted(hash_to_filename)]
+    assert all(abs(e["identity"] - rows[(e["query_hash"], subject)]["identity"]) < 1e-12 for e in col)
+    cfg.minmatch = 1.5
+    assert fastani_hip.compute_fastani_hip(logging.getLogger("t"), tmp_path, _S(), run, out, GOLDEN / "viral_example", hash_to_filename, {}, lengths, subject, engine=engine) == 0
+    assert all(e["identity"] is None and e["cov_query"] is None for e in json.loads(out.read_text())["comparisons"])
