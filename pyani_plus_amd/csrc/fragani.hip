@@ -460,6 +460,8 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   const uint32_t f = (uint32_t)(keys[a0] >> 44);
   const uint32_t s = q_s[f];
   if (s == 0) return;
+  const uint32_t mh = tab_min_hits[s];
+  if (nh < mh) return;  // chance matches with unrelated genomes: fewer seed hits than any L1 run needs
   // segments of up to kHitCap hits are staged in LDS; larger ones (repeats: rRNA operons, IS elements)
   // are read in place from the sorted hit arrays
   const bool staged = nh <= (uint32_t)kHitCap;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   }
   __syncthreads();
   // L1: run a is valid when hits a .. a+mh-1 share a contig and span < frag_len window ids
-  const uint32_t mh = tab_min_hits[s];
+  uint32_t n_runs;
   {
     uint32_t carry = 0;
     for (uint32_t i0 = 0; i0 < nh; i0 += 64) {
@@ -489,44 +491,53 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       if (i < nh) { if (staged) sh.run[i] = carry + ex + v; else run_g[a0 + i] = carry + ex + v; }
       carry += wave_sum(v);
     }
+    n_runs = carry;
   }
+  if (n_runs == 0) return;
   __threadfence_block();
   __syncthreads();
   uint32_t best_shared = 0, best_c = 0xffffffffu, best_p = 0xffffffffu;
   bool have_best = false;
   uint32_t last_p = 0xffffffffu, last_c = 0xffffffffu;
-  for (uint32_t a = 0; a < nh; ++a) {
+  for (uint32_t chunk = 0; chunk < nh; chunk += 64) {
+   // lane-parallel: does hit `chunk + lane` qualify, and which window start does it imply?
+   uint32_t my_c = 0, my_p = 0;
+   bool my_q = false;
+   if (chunk + lane < nh) {
+    const uint32_t a = chunk + lane;
     const uint32_t c = HC(a), v = HW(a);
     // hit a is evaluated iff some valid run [x..y] on its contig has y.w - L + 1 <= v <= x.w + count_windows
     // <=> a valid run lies inside the hits whose window ids are in [v - count_windows, v + frag_len - 1]
-    bool qualifies;
-    {
-      uint32_t lo = 0, hi = a;  // first index with (contig, wpos) >= (c, v - count_windows)
-      const uint32_t vlo = v > count_windows ? v - count_windows : 0u;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t mc = HC(mid);
-        if (mc < c || (mc == c && HW(mid) < vlo)) lo = mid + 1; else hi = mid;
-      }
-      const uint32_t first = lo;
-      lo = a; hi = nh;  // first index with (contig, wpos) > (c, v + frag_len - 1)
-      const uint32_t vhi = v + frag_len - 1u;
-      while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const uint32_t mc = HC(mid);
-        if (mc < c || (mc == c && HW(mid) <= vhi)) lo = mid + 1; else hi = mid;
-      }
-      const uint32_t end = lo;  // hits [first, end)
-      qualifies = false;
-      if (end >= first + mh) {
-        const uint32_t last_run = end - mh;  // runs starting in [first, last_run]
-        const uint32_t before = first ? RUN(first - 1) : 0u;
-        qualifies = RUN(last_run) > before;
-      }
+    uint32_t lo = 0, hi = a;  // first index with (contig, wpos) >= (c, v - count_windows)
+    const uint32_t vlo = v > count_windows ? v - count_windows : 0u;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      const uint32_t mc = HC(mid);
+      if (mc < c || (mc == c && HW(mid) < vlo)) lo = mid + 1; else hi = mid;
     }
-    if (!qualifies) continue;
+    const uint32_t first = lo;
+    lo = a; hi = nh;  // first index with (contig, wpos) > (c, v + frag_len - 1)
+    const uint32_t vhi = v + frag_len - 1u;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      const uint32_t mc = HC(mid);
+      if (mc < c || (mc == c && HW(mid) <= vhi)) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t end = lo;  // hits [first, end)
+    if (end >= first + mh) {
+      const uint32_t last_run = end - mh;  // runs starting in [first, last_run]
+      const uint32_t before = first ? RUN(first - 1) : 0u;
+      my_q = RUN(last_run) > before;
+    }
     const uint32_t qa = HQ(a);
-    const uint32_t p = v > qa ? v - qa : 0u;
+    my_c = c;
+    my_p = v > qa ? v - qa : 0u;
+   }
+   uint64_t todo = __ballot(my_q);
+   while (todo) {
+    const int bit = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const uint32_t c = __shfl(my_c, bit, 64), p = __shfl(my_p, bit, 64);
     if (p == last_p && c == last_c) continue;
     last_p = p; last_c = c;
     // ---- winnowed-MinHash Jaccard numerator of the fragment vs the reference window starting at p
@@ -581,6 +592,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       have_best = true; best_shared = shared; best_c = c; best_p = p;
     }
     __syncthreads();
+   }
   }
   if (have_best && best_shared >= tab_min_shared[s] && lane == 0) {
     const uint64_t jq = ((uint64_t)best_shared << 30) / s;
