@@ -250,6 +250,15 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": per_launch_s * 1e3,
                 "note": "kernel is integer-VALU bound (MurmurHash3 per window), see DESIGN.md",
+                # VALU-issue view of the same launch: static instruction mix of
+                # kmer_hash_kernel<31,true> x measured issue costs (profiles/r01_ubench_valu_gfx950.txt)
+                "valu": {
+                    "instr_per_window": 119.5,
+                    "model_cycles_per_wave_step": 25.25 * 2.7 + 79.75 * 4.4,
+                    "measured_cycles_per_wave_step": per_launch_s * 2.4e9 * 1024 / max(1.0, sum(lengths[g0:g1]) / 64.0),
+                    "clock_ghz_assumed": 2.4,
+                    "simds": 1024,
+                },
             },
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "device": engine.device_info()["name"],
