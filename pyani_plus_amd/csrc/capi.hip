@@ -235,11 +235,14 @@ int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint6
 // ---- pairs ----------------------------------------------------------------------
 int pa_pair_counts(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint32_t q0, uint32_t q1,
                    uint32_t s0, uint32_t s1, uint32_t *d_counts, int algo) {
-  PA_REQUIRE(c && d_off && d_counts, "pa_pair_counts: null argument");
+  PA_REQUIRE(c && d_off, "pa_pair_counts: null argument");
   PA_REQUIRE(q0 <= q1 && q1 <= n && s0 <= s1 && s1 <= n, "pa_pair_counts: ranges [%u,%u) x [%u,%u) outside [0,%u)", q0,
              q1, s0, s1, n);
+  PA_REQUIRE(algo == PA_PAIRS_AUTO || algo == PA_PAIRS_BITROW || algo == PA_PAIRS_MERGE, "pa_pair_counts: unknown algo %d",
+             algo);
   PA_HIP(hipSetDevice(c->device));
-  if (q0 == q1 || s0 == s1) return PA_OK;
+  if (q0 == q1 || s0 == s1) return PA_OK;  // empty tile: nothing to write
+  PA_REQUIRE(d_counts != nullptr, "pa_pair_counts: null counts buffer");
   uint64_t total = 0;
   PA_HIP(hipMemcpyAsync(c->h_pinned, d_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   PA_HIP(hipStreamSynchronize(c->stream));

@@ -218,3 +218,42 @@ def test_mixed_length_set_config5_style(engine):
     bounds = shard_bounds_by_cost(sizes, 4)
     stitched = np.concatenate([engine.pair_counts(sk, (0, n), b).cpu().numpy().view(np.uint32) for b in bounds if b[1] > b[0]], axis=1)
     assert np.array_equal(stitched, counts)
+
+
+def test_degenerate_inputs_and_error_codes(engine):
+    """Empty sets, empty genomes, unsupported k and bad ranges through the C ABI."""
+    import ctypes as C
+
+    from pyani_plus_amd import _capi
+    from pyani_plus_amd.engine import DeviceSketches, pack_genomes
+
+    # no genome has a usable window -> every sketch is empty, all counts 0, all ANI NULL
+    arena = pack_genomes([b"", b"ACGT", b"NNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN"], fasta=False)
+    sk = engine.sketch(engine.upload(arena), 31, 1)
+    assert sk.total == 0 and [len(x) for x in sk.to_host()] == [0, 0, 0]
+    counts = engine.pair_counts(sk)
+    assert int(counts.abs().sum().item()) == 0
+    ident, cov = engine.ani(counts, sk, 31)
+    assert bool(ident.isnan().all()) and bool(cov.isnan().all())
+    # zero genomes
+    t = engine.torch
+    empty = DeviceSketches(t.zeros(1, dtype=t.int64, device=engine.device), t.zeros(1, dtype=t.int64, device=engine.device), 0, 0)
+    assert tuple(engine.pair_counts(empty).shape) == (0, 0)
+    # unsupported k, bad ranges, bad algo -> error codes with messages, no crash
+    one = pack_genomes([b"ACGT" * 100], fasta=False)
+    with pytest.raises(_capi.HipBackendError, match="not compiled in"):
+        engine.sketch(engine.upload(one), 20, 10)
+    with pytest.raises(_capi.HipBackendError, match=r"outside \[1,32\]"):
+        engine.sketch(engine.upload(one), 33, 10)
+    good = engine.sketch(engine.upload(one), 31, 10)
+    with pytest.raises(_capi.HipBackendError, match="ranges"):
+        engine.pair_counts(good, (0, 2), (0, 1))
+    with pytest.raises(_capi.HipBackendError, match="unknown algo"):
+        engine.pair_counts(good, algo=7)
+    lib = _capi.load_library()
+    assert lib.pa_ctx_sync(None) == -1 and b"null context" in lib.pa_last_error()
+    # arena size not a multiple of 64 is rejected before any launch
+    total = C.c_uint64(0)
+    gs = (C.c_uint64 * 2)(0, 100)
+    st = lib.pa_sketch(engine.ctx, one_ptr := engine.upload(one).packed.data_ptr(), one_ptr, 100, gs, 1, 31, 1, None, 0, good.off.data_ptr(), C.byref(total))
+    assert st == -1 and b"multiple of 64" in lib.pa_last_error()
