@@ -33,7 +33,7 @@ using namespace pa_dev;
 constexpr int kThreads = 256;
 constexpr uint32_t kSkip = 0xffffffffu;
 constexpr int kQMax = 512;       // largest fragment sketch handled
-constexpr int kHitCap = 1024;    // seed hits of one (fragment, reference genome) segment staged in LDS
+constexpr int kHitCap = 512;     // seed hits of one (fragment, reference genome) segment staged in LDS
 constexpr double kPercIdentity = 80.0, kConfLevel = 0.9, kPvalCutoff = 1e-3, kRefSize = 5e6;
 
 // ============================================================== host statistics (Mashmap)
@@ -102,6 +102,21 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *__restrict__
   }
   return lo;
 }
+// first minimizer of contig c with window id >= x, through the per-contig bucket index
+// (bucket b of a contig = window ids [b*256, b*256+256); bucket_first holds global minimizer indices and
+// one closing entry per contig): two dependent loads plus a ~20-entry search instead of a 19-step
+// binary search whose every probe misses the caches
+constexpr uint32_t kBucketShift = 8;
+__device__ __forceinline__ uint32_t wpos_lower_bound(const uint32_t *__restrict__ mini_wpos,
+                                                     const uint32_t *__restrict__ bucket_first, uint32_t bucket_base,
+                                                     uint32_t n_buckets, uint32_t x) {
+  uint32_t b = x >> kBucketShift;
+  if (b >= n_buckets) b = n_buckets;  // beyond the contig: the closing entry
+  const uint32_t lo = bucket_first[bucket_base + b];
+  const uint32_t hi = b < n_buckets ? bucket_first[bucket_base + b + 1] : lo;
+  return lower_bound_u32(mini_wpos, lo, hi, x);
+}
+
 __device__ __forceinline__ uint32_t contig_of(const uint64_t *__restrict__ start, uint32_t n, uint64_t pos) {
   uint32_t lo = 0, hi = n;  // largest c with start[c] <= pos (start[0] == 0)
   while (hi - lo > 1) {
@@ -281,6 +296,23 @@ __global__ __launch_bounds__(kThreads) void contig_offsets_kernel(const uint32_t
   if (c <= n_contigs) off[c] = lower_bound_u32(mini_contig, 0, m, c);
 }
 
+// bucket_first[base_c + b] = first minimizer of contig c with window id >= b*256, b = 0 .. n_buckets_c
+__global__ __launch_bounds__(kThreads) void bucket_index_kernel(const uint32_t *__restrict__ mini_wpos,
+                                                                const uint32_t *__restrict__ contig_mini_off,
+                                                                const uint32_t *__restrict__ contig_bucket_off,
+                                                                uint32_t n_contigs, uint32_t total_entries,
+                                                                uint32_t *__restrict__ bucket_first) {
+  const uint32_t e = blockIdx.x * kThreads + threadIdx.x;
+  if (e >= total_entries) return;
+  uint32_t lo = 0, hi = n_contigs;  // contig owning entry e
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (contig_bucket_off[mid] <= e) lo = mid; else hi = mid;
+  }
+  const uint32_t c = lo, b = e - contig_bucket_off[c];
+  bucket_first[e] = lower_bound_u32(mini_wpos, contig_mini_off[c], contig_mini_off[c + 1], b << kBucketShift);
+}
+
 // ============================================================== 2. dictionary of minimizer hashes
 __global__ __launch_bounds__(kThreads) void mini_keys_kernel(const uint32_t *__restrict__ hash, uint32_t m,
                                                              uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
@@ -317,7 +349,8 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
 // one wave per fragment: slice of the contig's minimizers, sorted by (hash, slice index), first of each hash kept
 __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const uint32_t *__restrict__ frag_contig, const uint32_t *__restrict__ frag_no, uint32_t n_frags, uint32_t frag_len,
-    uint32_t count_windows, const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ mini_hash,
+    uint32_t count_windows, const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
+    const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const uint32_t *__restrict__ mini_id, const uint32_t *__restrict__ post_start,
     uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos, uint32_t *__restrict__ q_id, uint32_t *__restrict__ q_s,
     uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow) {
@@ -331,7 +364,9 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const uint32_t c = frag_contig[f];
     p = frag_no[f] * frag_len;
     const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
-    const uint32_t b = lower_bound_u32(mini_wpos, m0, m1, p), e = lower_bound_u32(mini_wpos, m0, m1, p + count_windows);
+    const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
+    const uint32_t b = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p);
+    const uint32_t e = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p + count_windows);
     const bool fresh = b < m1 && mini_wpos[b] == p;
     b0 = (!fresh && b > m0) ? b - 1 : b;
     n = e - b0;
@@ -447,7 +482,8 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     uint32_t n_segs, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
     const uint32_t *__restrict__ frag_genome_local, uint32_t frag_len, uint32_t count_windows,
     const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ tab_min_shared,
-    const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ mini_hash,
+    const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
+    const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const int32_t *__restrict__ prev_same,
     const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride, unsigned long long *__restrict__ table,
     uint32_t *__restrict__ run_g) {
@@ -542,7 +578,9 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     last_p = p; last_c = c;
     // ---- winnowed-MinHash Jaccard numerator of the fragment vs the reference window starting at p
     const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
-    const uint32_t b = lower_bound_u32(mini_wpos, m0, m1, p), e = lower_bound_u32(mini_wpos, m0, m1, p + count_windows);
+    const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
+    const uint32_t b = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p);
+    const uint32_t e = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p + count_windows);
     const bool fresh = b < m1 && mini_wpos[b] == p;
     const uint32_t b0 = (!fresh && b > m0) ? b - 1 : b;
     for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
@@ -643,14 +681,15 @@ struct FragWork {
   DevBuf contig_start, contig_len, contig_genome, block_counts, block_offsets, mini_hash, mini_wpos, mini_contig,
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
-      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g;
+      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g,
+      contig_bucket_off, bucket_first;
   ~FragWork() {
     DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
                      &mini_contig, &contig_mini_off, &keys[0], &keys[1], &vals[0], &vals[1], &flags, &mini_id,
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g};
+                     &ident_sum, &scalars, &run_g, &contig_bucket_off, &bucket_first};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -779,6 +818,19 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   hipLaunchKernelGGL(contig_offsets_kernel, dim3(ceil_div_u64(n_contigs + 1, kThreads)), dim3(kThreads), 0, c->stream,
                      W.mini_contig.as<uint32_t>(), m, n_contigs, W.contig_mini_off.as<uint32_t>());
 
+  // ---- per-contig bucket index over window ids
+  {
+    std::vector<uint32_t> cbo(n_contigs + 1, 0);
+    for (uint32_t ci = 0; ci < n_contigs; ++ci) cbo[ci + 1] = cbo[ci] + (h_contig_len[ci] >> kBucketShift) + 2;
+    PA_REQUIRE((uint64_t)cbo[n_contigs] < (1ULL << 31), "pa_fragani: bucket index too large");
+    PA_TRY(upload(c, W.contig_bucket_off, cbo));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    PA_TRY(W.bucket_first.reserve((uint64_t)cbo[n_contigs] * 4 + 16));
+    hipLaunchKernelGGL(bucket_index_kernel, dim3(ceil_div_u64(cbo[n_contigs], kThreads)), dim3(kThreads), 0, c->stream,
+                       W.mini_wpos.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(), W.contig_bucket_off.as<uint32_t>(),
+                       n_contigs, cbo[n_contigs], W.bucket_first.as<uint32_t>());
+  }
+
   // ---- fragments and reference bins (host bookkeeping)
   std::vector<uint32_t> frag_contig, frag_no, genome_frag_off(n_genomes + 1, 0), contig_bin_off(n_contigs + 1, 0),
       genome_bin_off(n_genomes + 1, 0);
@@ -871,7 +923,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
     const uint32_t gw = ceil_div_u64(nf, kThreads / 64);
     hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, W.frag_contig.as<uint32_t>(),
                        W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
-                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
+                       W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
                        W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),
                        W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow);
     PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
@@ -912,7 +964,8 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
       hipLaunchKernelGGL(map_segments_kernel, dim3(n_segs), dim3(64), 0, c->stream, hk[hw], hv[hw],
                          W.seg_start.as<uint32_t>(), n_segs, W.q_hash.as<uint32_t>(), W.q_s.as<uint32_t>(),
                          W.frag_genome_local.as<uint32_t>(), frag_len, count_windows, W.tab_min_hits.as<uint32_t>(),
-                         W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(), W.mini_hash.as<uint32_t>(),
+                         W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),
+                         W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),
                          W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(),
                          total_bins, W.table.as<unsigned long long>(), W.run_g.as<uint32_t>());
     }
