@@ -56,3 +56,58 @@ def test_run_driver_on_gpu_matches_reference_database(name, tmp_path):
     rows = conn.execute("SELECT query_hash, subject_hash, identity, cov_query FROM comparisons ORDER BY 1, 2").fetchall()
     assert rows == [(c["query_hash"], c["subject_hash"], c["identity"], c["cov_query"]) for c in boundary["comparisons"]]
     conn.close()
+
+
+def test_run_driver_end_to_end_on_synthetic_fasta_files(tmp_path):
+    """FASTA files on disk (plain and gzip, multi-record) -> threaded loader -> GPU -> JSON -> SQLite
+    matrices, checked against the oracle on every pair."""
+    import gzip
+
+    import numpy as np
+
+    import oracle
+    from pyani_plus_amd.synth import arena_to_ascii, synth_arena_numpy
+
+    n, scaled = 24, 200
+    arena = synth_arena_numpy(n, [120_000 + 1000 * g for g in range(n)], n_species=3)
+    indir = tmp_path / "genomes"
+    indir.mkdir()
+    seqs = []
+    for g in range(n):
+        seq = arena_to_ascii(arena, g)
+        seqs.append(seq)
+        half = len(seq) // 2
+        text = b">g%d contig1 desc\n" % g + seq[:half] + b"\n>g%d contig2\n" % g + b"\n".join(seq[half + i : half + i + 80] for i in range(0, len(seq) - half, 80)) + b"\n"
+        path = indir / (f"genome_{g:02d}.fna.gz" if g % 3 == 0 else f"genome_{g:02d}.fasta")
+        path.write_bytes(gzip.compress(text) if g % 3 == 0 else text)
+    db = tmp_path / "run.sqlite"
+    run = rundb.run_sourmash_hip(indir, db, cache=tmp_path / "cache", scaled=scaled, temp=tmp_path)
+    assert run.status == "Done"
+    conn = sqlite3.connect(db)
+    assert conn.execute("SELECT COUNT(*) FROM comparisons").fetchone()[0] == n * n
+    hashes = [r[0] for r in conn.execute("SELECT genome_hash FROM genomes ORDER BY 1")]
+    by_file = dict(conn.execute("SELECT fasta_filename, genome_hash FROM runs_genomes"))
+    order = [by_file[p.name] for p in sorted(indir.iterdir())]
+    # oracle: two records per genome, windows never span them
+    sketches = [np.union1d(oracle.sketch_seq(s[: len(s) // 2], K, scaled), oracle.sketch_seq(s[len(s) // 2 :], K, scaled)) for s in seqs]
+    counts = oracle.pair_counts(sketches)
+    sizes = [len(s) for s in sketches]
+    ident, cov, null = oracle.ani(counts, sizes, sizes, K)
+    got = json.loads(conn.execute("SELECT df_identity FROM runs").fetchone()[0])
+    got_cov = json.loads(conn.execute("SELECT df_cov_query FROM runs").fetchone()[0])
+    assert got["index"] == hashes == sorted(order)
+    for qi, q in enumerate(order):
+        for si, s in enumerate(order):
+            r, c = got["index"].index(q), got["columns"].index(s)
+            if null[qi, si]:
+                assert got["data"][r][c] is None and got_cov["data"][r][c] is None
+            else:  # pandas writes 10 decimals
+                assert abs(got["data"][r][c] - ident[qi, si]) < 6e-11 and abs(got_cov["data"][r][c] - cov[qi, si]) < 6e-11
+    rows = conn.execute("SELECT query_hash, subject_hash, identity, cov_query FROM comparisons").fetchall()
+    pos = {h: i for i, h in enumerate(order)}
+    for q, s, i_val, c_val in rows:
+        qi, si = pos[q], pos[s]
+        assert (i_val is None) == bool(null[qi, si])
+        if i_val is not None:
+            assert i_val == ident[qi, si] and c_val == cov[qi, si]  # full precision in the comparisons table
+    conn.close()
