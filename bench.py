@@ -263,6 +263,28 @@ def main():
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "device": engine.device_info()["name"],
         }
+        if world == 1:
+            # PCIe-inclusive pass, reported beside (never inside) `value`: packed arena in pinned host
+            # memory -> HBM, one step, f64 matrices back to pinned host memory
+            h_packed = arena.packed.cpu().pin_memory()
+            h_mask = arena.mask.cpu().pin_memory()
+            h_ident = torch.empty((n_total, n_total), dtype=torch.float64).pin_memory()
+            h_cov = torch.empty_like(h_ident).pin_memory()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            arena.packed.copy_(h_packed, non_blocking=True)
+            arena.mask.copy_(h_mask, non_blocking=True)
+            o = step()
+            h_ident.copy_(o[3], non_blocking=True)
+            h_cov.copy_(o[4], non_blocking=True)
+            torch.cuda.synchronize()
+            result["pcie_inclusive"] = {
+                "ms_per_step": (time.perf_counter() - t0) * 1e3,
+                "h2d_bytes": int(h_packed.numel() * 4 + h_mask.numel() * 4),
+                "d2h_bytes": int(2 * h_ident.numel() * 8),
+                "note": "pinned host arena -> HBM -> step -> f64 identity/cov_query back to pinned host; not part of value",
+            }
+            del h_packed, h_mask, h_ident, h_cov
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(engine, arena, sk, args, n_total, lengths)
             n_pair = cb.pop("_n_pair")
