@@ -43,6 +43,10 @@ def parse_args():
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--scaled", type=int, default=1000)
     ap.add_argument("--species", type=int, default=40)
+    ap.add_argument("--sketch-mode", choices=["scaled", "bottom"], default="scaled",
+                    help="scaled = the reference's FracMinHash + containment ANI (default, parity-pinned); "
+                    "bottom = bottom-m MinHash + Mash Jaccard ANI as BASELINE configs[1] words it (parity unpinned)")
+    ap.add_argument("--bottom-m", type=int, default=1000)
     ap.add_argument("--mixed-lengths", action="store_true", help="log-uniform 100 kb - 10 Mb genomes (BASELINE configs[4])")
     ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="genomes sketched by the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -150,8 +154,10 @@ def main():
     c0, c1 = shard_bounds(n_total, world)[rank]
     arena = synth_arena_torch(engine, g1 - g0, lengths[g0:g1], n_species=args.species, genome_offset=g0)
 
+    bottom = args.sketch_mode == "bottom"
+
     def step():
-        sk_local = engine.sketch(arena, args.kmer, args.scaled)
+        sk_local = engine.sketch_bottom(arena, args.kmer, args.bottom_m) if bottom else engine.sketch(arena, args.kmer, args.scaled)
         if dist_path:
             sizes = sk_local.off[1:] - sk_local.off[:-1]
             if backend == "nccl":
@@ -162,6 +168,10 @@ def main():
             sk = DeviceSketches(hashes, off, n_total, int(off[-1].item()))
         else:
             sk = sk_local
+        if bottom:
+            counts, denom = engine.pair_mash(sk, args.bottom_m, (0, n_total), (c0, c1))
+            ident = engine.ani_mash(counts, denom, args.kmer)
+            return sk_local, sk, counts, ident, ident
         counts = engine.pair_counts(sk, (0, n_total), (c0, c1))
         ident, cov = engine.ani(counts, sk, args.kmer, (0, n_total), (c0, c1))
         return sk_local, sk, counts, ident, cov
@@ -188,9 +198,10 @@ def main():
         elapsed = float(tmax.item())
         # every rank cross-checks a block of its column tile with the independent merge kernel
         nq_chk, ns_chk = min(n_total, 256), min(c1 - c0, 64)
-        chk = engine.pair_counts(out[1], (0, nq_chk), (c0, c0 + ns_chk), algo=_capi.PA_PAIRS_MERGE)
-        if not torch.equal(chk, out[2][:nq_chk, :ns_chk]):
-            raise SystemExit(f"PARITY FAILURE on rank {rank}: bit-row and merge counts differ")
+        if not bottom:
+            chk = engine.pair_counts(out[1], (0, nq_chk), (c0, c0 + ns_chk), algo=_capi.PA_PAIRS_MERGE)
+            if not torch.equal(chk, out[2][:nq_chk, :ns_chk]):
+                raise SystemExit(f"PARITY FAILURE on rank {rank}: bit-row and merge counts differ")
     prof = engine.prof_get()
     engine.prof_enable(False)
     sk_local, sk, counts, ident, cov = out
@@ -229,7 +240,9 @@ def main():
             "config": {
                 "workload": f"{n_total} synthetic "
                 + ("100 kb-10 Mb (log-uniform)" if args.mixed_lengths else f"{args.length / 1e6:g} Mb")
-                + f" genomes, k={args.kmer} scaled={args.scaled} FracMinHash sketch + NxN containment ANI",
+                + (f" genomes, k={args.kmer} bottom-m={args.bottom_m} MinHash sketch + NxN Mash-Jaccard ANI (parity unpinned)" if bottom
+                   else f" genomes, k={args.kmer} scaled={args.scaled} FracMinHash sketch + NxN containment ANI"),
+                "sketch_mode": args.sketch_mode,
                 "genomes": n_total,
                 "genomes_per_gpu": n_local,
                 "length": args.length,
@@ -285,7 +298,7 @@ def main():
                 "note": "pinned host arena -> HBM -> step -> f64 identity/cov_query back to pinned host; not part of value",
             }
             del h_packed, h_mask, h_ident, h_cov
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bottom:
             cb = cpu_baseline(engine, arena, sk, args, n_total, lengths)
             n_pair = cb.pop("_n_pair")
             cpu_counts = cb.pop("_cpu_counts")

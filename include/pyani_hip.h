@@ -171,6 +171,22 @@ PA_API int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, cons
                 uint32_t nq, uint32_t ns, uint32_t k, double *h_identity, double *h_cov_query,
                 uint8_t *h_is_null);
 
+/* ---- bottom-m MinHash + Mash Jaccard (the mode BASELINE.json configs[1] names) ----
+ * NOT a reference code path: pyani-plus only ever sketches with `scaled=N`
+ * (pyani_plus/methods/sourmash.py:75-76, "num":0 in every fixture), so these three entry points
+ * replace nothing and their parity is unpinned (checked against the oracle's restatement of the
+ * published Mash estimator).  pa_sketch_bottom: the m smallest distinct hashes per genome, CSR as
+ * pa_sketch (cap_hashes >= n*m).  pa_pair_mash: per ordered pair, among the min(m, |A u B|) smallest
+ * hashes of the union (= denom) how many are in both (= common).  pa_ani_mash:
+ * 1 + ln(2j/(1+j))/k with j = common/denom; NaN when common == 0. */
+PA_API int pa_sketch_bottom(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                     const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint32_t m, uint64_t *d_hashes,
+                     uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total);
+PA_API int pa_pair_mash(pa_ctx *ctx, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint32_t q0, uint32_t q1,
+                 uint32_t s0, uint32_t s1, uint32_t m, uint32_t *d_common, uint32_t *d_denom);
+PA_API int pa_ani_mash(pa_ctx *ctx, const uint32_t *d_common, const uint32_t *d_denom, uint64_t n_pairs, uint32_t k,
+                double *d_ani);
+
 /* ---- fastANI-style fragment-mapping ANI (BASELINE configs[3]) ----
  * Replaces one `fastANI --ql queries -r subject --fragLen F -k K --minFraction M` process per subject
  * column (pyani_plus/private_cli.py:1044-1063): all ordered pairs of the arena's genomes in one call.

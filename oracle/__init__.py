@@ -17,10 +17,13 @@ from .pyoracle import (  # noqa: F401
     fragani_tables,
     fragani_window_size,
     intersect,
+    mash_ani,
+    mash_pairs,
     max_hash,
     murmur3_h1,
     pair_counts,
     sketch_fasta_text,
+    sketch_bottom_seq,
     sketch_many,
     sketch_seq,
 )

@@ -246,3 +246,42 @@ def fragani_pair(query: list[bytes], ref: list[bytes], k: int = 16, frag_len: in
     if rc:
         raise MemoryError("oracle allocation failed")
     return float(ani_v.value), int(m.value), int(t.value)
+
+
+# ---------------------------------------------------------------- bottom-m MinHash (parity unpinned)
+def sketch_bottom_seq(seq: bytes, k: int, m: int) -> np.ndarray:
+    lib = _load()
+    lib.orc_sketch_bottom_seq.restype = C.c_int64
+    lib.orc_sketch_bottom_seq.argtypes = [C.c_char_p, C.c_uint64, C.c_uint32, C.c_uint64, _u64p]
+    out = np.empty(max(m, 1), dtype=np.uint64)
+    n = lib.orc_sketch_bottom_seq(seq, len(seq), k, m, _p(out, _u64p))
+    if n < 0:
+        raise MemoryError("oracle allocation failed")
+    return out[:n].copy()
+
+
+def mash_pairs(sketches: list[np.ndarray], m: int) -> tuple[np.ndarray, np.ndarray]:
+    """(common, denom) uint32 matrices of the Mash Jaccard estimator over all ordered pairs."""
+    lib = _load()
+    lib.orc_mash_pair.restype = None
+    lib.orc_mash_pair.argtypes = [_u64p, C.c_uint64, _u64p, C.c_uint64, C.c_uint64, _u32p, _u32p]
+    n = len(sketches)
+    common = np.zeros((n, n), dtype=np.uint32)
+    denom = np.zeros((n, n), dtype=np.uint32)
+    sk = [np.ascontiguousarray(s, dtype=np.uint64) for s in sketches]
+    c, d = C.c_uint32(0), C.c_uint32(0)
+    for q in range(n):
+        for s in range(n):
+            lib.orc_mash_pair(_p(sk[q], _u64p), len(sk[q]), _p(sk[s], _u64p), len(sk[s]), m, C.byref(c), C.byref(d))
+            common[q, s], denom[q, s] = c.value, d.value
+    return common, denom
+
+
+def mash_ani(common: np.ndarray, denom: np.ndarray, k: int) -> np.ndarray:
+    lib = _load()
+    lib.orc_mash_ani.restype = C.c_double
+    lib.orc_mash_ani.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    out = np.empty(common.shape, dtype=np.float64)
+    for idx in np.ndindex(common.shape):
+        out[idx] = lib.orc_mash_ani(int(common[idx]), int(denom[idx]), k)
+    return out

@@ -314,3 +314,43 @@ ORC_API void orc_ani(const uint32_t *counts, const uint64_t *q_sizes, const uint
       is_null[idx] = 0;
     }
 }
+
+/* ---- bottom-m MinHash (BASELINE.json configs[1] names it; the REFERENCE NEVER USES IT: every fixture
+ * has "num":0 and the only sketch parameter is scaled=N, pyani_plus/methods/sourmash.py:75-76).
+ * PARITY UNPINNED: these three functions restate the published Mash estimator (Ondov et al. 2016) and
+ * are checked only against each other and the HIP path. ---- */
+
+/* the m smallest distinct canonical k-mer hashes of one bare sequence */
+ORC_API int64_t orc_sketch_bottom_seq(const uint8_t *seq, uint64_t len, uint32_t k, uint64_t m, uint64_t *out) {
+  u64vec hashes = {0, 0, 0};
+  if (hash_record(seq, len, k, UINT64_MAX, &hashes)) { free(hashes.v); return -1; }
+  uint64_t n = sort_unique(hashes.v, hashes.n);
+  if (n > m) n = m;
+  for (uint64_t i = 0; i < n; ++i) out[i] = hashes.v[i];
+  free(hashes.v);
+  return (int64_t)n;
+}
+
+/* Mash Jaccard of two bottom-m sketches: among the (up to) m smallest elements of A u B, how many
+ * are in both.  *denom = elements of the union examined = min(m, |A u B|). */
+ORC_API void orc_mash_pair(const uint64_t *a, uint64_t na, const uint64_t *b, uint64_t nb, uint64_t m,
+                           uint32_t *common, uint32_t *denom) {
+  uint64_t i = 0, j = 0, taken = 0;
+  uint32_t c = 0;
+  while (taken < m && (i < na || j < nb)) {
+    if (j >= nb || (i < na && a[i] < b[j])) ++i;
+    else if (i >= na || b[j] < a[i]) ++j;
+    else { ++c; ++i; ++j; }
+    ++taken;
+  }
+  *common = c;
+  *denom = (uint32_t)taken;
+}
+
+/* Mash distance -> ANI: j = common/denom, d = -ln(2j/(1+j))/k, ANI = 1 - d; common == 0 -> NaN (NULL) */
+ORC_API double orc_mash_ani(uint32_t common, uint32_t denom, uint32_t k) {
+  if (common == 0 || denom == 0) return NAN;
+  if (common == denom) return 1.0;
+  const double j = (double)common / (double)denom;
+  return 1.0 + log(2.0 * j / (1.0 + j)) / (double)k;
+}

@@ -310,6 +310,42 @@ class HipEngine:
         )
         return ident, cov
 
+    # -- bottom-m MinHash + Mash Jaccard (named by BASELINE configs[1]; not a reference code path)
+    def sketch_bottom(self, arena: DeviceArena, k: int, m: int) -> DeviceSketches:
+        t = self.torch
+        n = arena.n_genomes
+        hashes = t.empty(max(n * m, 1), dtype=t.int64, device=self.device)
+        off = t.empty(n + 1, dtype=t.int64, device=self.device)
+        gs = np.ascontiguousarray(arena.genome_start, dtype=np.uint64)
+        total = C.c_uint64(0)
+        check(
+            self.lib.pa_sketch_bottom(
+                self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases,
+                gs.ctypes.data_as(C.POINTER(C.c_uint64)), n, k, m, hashes.data_ptr(), n * m, off.data_ptr(), C.byref(total),
+            ),  # fmt: skip
+            "pa_sketch_bottom",
+        )
+        return DeviceSketches(hashes, off, n, int(total.value))
+
+    def pair_mash(self, sk: DeviceSketches, m: int, q_range=None, s_range=None):
+        """(common, denom) int32 tensors [nq, ns] of the Mash Jaccard estimator."""
+        t = self.torch
+        q0, q1 = q_range or (0, sk.n)
+        s0, s1 = s_range or (0, sk.n)
+        common = t.empty((q1 - q0, s1 - s0), dtype=t.int32, device=self.device)
+        denom = t.empty_like(common)
+        check(
+            self.lib.pa_pair_mash(self.ctx, sk.hashes.data_ptr(), sk.off.data_ptr(), sk.n, q0, q1, s0, s1, m, common.data_ptr(), denom.data_ptr()),
+            "pa_pair_mash",
+        )
+        return common, denom
+
+    def ani_mash(self, common, denom, k: int):
+        t = self.torch
+        out = t.empty(common.shape, dtype=t.float64, device=self.device)
+        check(self.lib.pa_ani_mash(self.ctx, common.data_ptr(), denom.data_ptr(), common.numel(), k, out.data_ptr()), "pa_ani_mash")
+        return out
+
     # -- fastANI-style fragment ANI (BASELINE configs[3])
     def fragani(self, arena: DeviceArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000):
         """All ordered genome pairs: (total_frags[n], matched[n, n], ident_sum[n, n]) as numpy arrays;
