@@ -153,9 +153,10 @@ PA_API int pa_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_ma
  * d_hashes/d_off describe n sketches (any source: pa_sketch, a `.sig` cache,
  * an all-gather).  Computes d_counts[(q-q0)*(s1-s0) + (s-s0)] = |S_q n S_s| for
  * q in [q0,q1), s in [s0,s1).  algo: PA_PAIRS_AUTO, or force one kernel. */
-#define PA_PAIRS_AUTO 0
-#define PA_PAIRS_BITROW 1 /* dictionary + bit-row column sums (default) */
-#define PA_PAIRS_MERGE 2  /* per-pair LDS merge-path intersection */
+#define PA_PAIRS_AUTO 0        /* = PA_PAIRS_BITROW_HASH */
+#define PA_PAIRS_BITROW 1      /* dictionary by radix sort + bit-row column sums */
+#define PA_PAIRS_MERGE 2       /* per-pair merge-path intersection */
+#define PA_PAIRS_BITROW_HASH 3 /* dictionary by hash table (subjects of the tile only) + bit-row column sums */
 PA_API int pa_pair_counts(pa_ctx *ctx, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n,
                    uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts, int algo);
 

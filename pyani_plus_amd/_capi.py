@@ -17,7 +17,7 @@ LIB_PATH = _PKG / "_lib" / "libpyani_hip.so"
 
 PA_OK = 0
 PA_E_CAPACITY = -4
-PA_PAIRS_AUTO, PA_PAIRS_BITROW, PA_PAIRS_MERGE = 0, 1, 2
+PA_PAIRS_AUTO, PA_PAIRS_BITROW, PA_PAIRS_MERGE, PA_PAIRS_BITROW_HASH = 0, 1, 2, 3
 PA_ALIGN_BASES = 64
 PROF_PHASES = {"kmer_hash": 0, "sketch_sort": 1, "pair_dict": 2, "pair_count": 3, "ani": 4}
 

@@ -238,8 +238,8 @@ int pa_pair_counts(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, u
   PA_REQUIRE(c && d_off, "pa_pair_counts: null argument");
   PA_REQUIRE(q0 <= q1 && q1 <= n && s0 <= s1 && s1 <= n, "pa_pair_counts: ranges [%u,%u) x [%u,%u) outside [0,%u)", q0,
              q1, s0, s1, n);
-  PA_REQUIRE(algo == PA_PAIRS_AUTO || algo == PA_PAIRS_BITROW || algo == PA_PAIRS_MERGE, "pa_pair_counts: unknown algo %d",
-             algo);
+  PA_REQUIRE(algo == PA_PAIRS_AUTO || algo == PA_PAIRS_BITROW || algo == PA_PAIRS_MERGE || algo == PA_PAIRS_BITROW_HASH,
+             "pa_pair_counts: unknown algo %d", algo);
   PA_HIP(hipSetDevice(c->device));
   if (q0 == q1 || s0 == s1) return PA_OK;  // empty tile: nothing to write
   PA_REQUIRE(d_counts != nullptr, "pa_pair_counts: null counts buffer");
@@ -250,6 +250,8 @@ int pa_pair_counts(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, u
   PA_REQUIRE(total == 0 || d_hashes, "pa_pair_counts: null hashes");
   switch (algo) {
     case PA_PAIRS_AUTO:
+    case PA_PAIRS_BITROW_HASH:
+      return pa_pairs_bitrow_hash(c, d_hashes, d_off, n, total, q0, q1, s0, s1, d_counts);
     case PA_PAIRS_BITROW:
       return pa_pairs_bitrow(c, d_hashes, d_off, n, total, q0, q1, s0, s1, d_counts);
     case PA_PAIRS_MERGE:

@@ -17,6 +17,8 @@
 //
 // The per-ordered-pair cost drops from O(|Q|+|S|) merge steps to
 // O(|Q|/32) word operations; the result is the exact integer |Q n S|.
+#include <vector>
+
 #include "pa_internal.h"
 
 namespace {
@@ -24,6 +26,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kPlanes = 8;                       // vertical counter planes -> flush every 255 rows
 constexpr uint32_t kMaxTileSubjects = 2048;      // widest bit row: 64 words = 256 bytes
+constexpr uint32_t kNone = 0xffffffffu;          // "no id": the hash occurs in no subject of the tile
+constexpr uint64_t kEmptyKey = ~0ULL;            // empty slot of the hash dictionary
 
 __global__ __launch_bounds__(kThreads) void iota_kernel(uint32_t *__restrict__ vals, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(kThreads) void row_sum_kernel(const uint32_t *__res
 
   for (uint64_t j = slot; j < len; j += kRowsPerIter) {
     const uint32_t id = ids[j];
+    if (id == kNone) continue;  // hash absent from every subject of the tile (hash-dictionary variant)
     const uint4 r = *reinterpret_cast<const uint4 *>(rows + (uint64_t)id * kW32 + quad * 4);
     uint32_t carry[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -150,6 +155,84 @@ __global__ __launch_bounds__(kThreads) void row_sum_kernel(const uint32_t *__res
   __syncthreads();
   uint32_t *__restrict__ out = counts + (uint64_t)blockIdx.x * ns + col0;
   for (uint32_t x = tid; x < tile_cols; x += kThreads) out[x] = s_cnt[x];
+}
+
+// ---- hash dictionary (PA_PAIRS_BITROW_HASH): dense ids without sorting -------------------------
+// Open addressing, linear probing, load <= 1/2.  Only the hashes of the tile's SUBJECTS are inserted;
+// the winner of a slot draws the dense id.  Lookups run in a later launch, so every id is visible.
+// The legal key ~0 doubles as the empty marker and is therefore kept in `special[0]` instead.
+__device__ __forceinline__ uint32_t slot_of(uint64_t h, uint32_t mask) { return (uint32_t)(h ^ (h >> 32)) & mask; }
+
+constexpr int kInsertPerThread = 4;
+__global__ __launch_bounds__(kThreads) void table_insert_kernel(const uint64_t *__restrict__ hashes, uint64_t p0,
+                                                                uint64_t p1, unsigned long long *__restrict__ keys,
+                                                                uint32_t *__restrict__ slot_ids, uint32_t mask,
+                                                                uint32_t *__restrict__ counter,
+                                                                uint32_t *__restrict__ special) {
+  __shared__ uint32_t s_won, s_base;
+  if (threadIdx.x == 0) s_won = 0;
+  __syncthreads();
+  uint32_t won_slot[kInsertPerThread];
+  int won = 0;
+  bool won_special = false;
+  const uint64_t base = p0 + (uint64_t)blockIdx.x * (kThreads * kInsertPerThread) + threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < kInsertPerThread; ++i) {
+    const uint64_t p = base + (uint64_t)i * kThreads;
+    if (p >= p1) break;
+    const uint64_t h = hashes[p];
+    if (h == kEmptyKey) {
+      won_special = atomicCAS(&special[0], kNone, kNone - 1u) == kNone;
+      continue;
+    }
+    uint32_t slot = slot_of(h, mask);
+    for (;;) {
+      // most postings repeat a key that is already there: look before paying for the atomic
+      unsigned long long k = __builtin_nontemporal_load(&keys[slot]);
+      if (k == kEmptyKey) k = atomicCAS(&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)h);
+      if (k == kEmptyKey) { won_slot[won++] = slot; break; }
+      if (k == h) break;
+      slot = (slot + 1u) & mask;
+    }
+  }
+  // dense ids: one global atomic per workgroup instead of one per new key
+  const uint32_t mine = (uint32_t)won + (won_special ? 1u : 0u);
+  uint32_t local = mine ? atomicAdd(&s_won, mine) : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = s_won ? atomicAdd(counter, s_won) : 0u;
+  __syncthreads();
+  local += s_base;
+  for (int i = 0; i < won; ++i) slot_ids[won_slot[i]] = local++;
+  if (won_special) special[0] = local;
+}
+
+// ids of the postings [p0, p1); postings of tile subjects (SET_BITS) also set their bit in the row
+template <bool SET_BITS>
+__global__ __launch_bounds__(kThreads) void table_lookup_kernel(
+    const uint64_t *__restrict__ hashes, uint64_t p0, uint64_t p1, const unsigned long long *__restrict__ keys,
+    const uint32_t *__restrict__ slot_ids, uint32_t mask, const uint32_t *__restrict__ special,
+    uint32_t *__restrict__ ids_csr, const uint64_t *__restrict__ off, uint32_t n, uint32_t t0, uint32_t w32,
+    uint32_t *__restrict__ rows) {
+  const uint64_t p = p0 + (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (p >= p1) return;
+  const uint64_t h = hashes[p];
+  uint32_t id = kNone;
+  if (h == kEmptyKey) {
+    id = special[0];
+  } else {
+    uint32_t slot = slot_of(h, mask);
+    for (;;) {
+      const unsigned long long k = keys[slot];
+      if (k == h) { id = slot_ids[slot]; break; }
+      if (k == kEmptyKey) break;
+      slot = (slot + 1u) & mask;
+    }
+  }
+  ids_csr[p] = id;
+  if constexpr (SET_BITS) {
+    const uint32_t col = owner_of(off, n, p) - t0;
+    atomicOr(&rows[(uint64_t)id * w32 + (col >> 5)], 1u << (col & 31u));
+  }
 }
 
 template <int TPR>
@@ -226,6 +309,89 @@ int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, 
       PA_HIP(hipMemsetAsync(c->bitrows.p, 0, row_bytes, c->stream));
       hipLaunchKernelGGL(build_rows_kernel, dim3(ceil_div_u64(P, kThreads)), dim3(kThreads), 0, c->stream,
                          d_id_sorted, d_genome_sorted, P, t0, t1, w32, c->bitrows.as<uint32_t>());
+    }
+    {
+      ProfScope prof(c, PA_PROF_PAIR_COUNT);
+      const uint32_t *rows = c->bitrows.as<uint32_t>();
+      switch (tpr) {
+        case 1: launch_row_sum<1>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
+        case 2: launch_row_sum<2>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
+        case 4: launch_row_sum<4>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
+        case 8: launch_row_sum<8>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
+        default: launch_row_sum<16>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
+      }
+    }
+    PA_HIP(hipGetLastError());
+  }
+  return PA_OK;
+}
+
+
+int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t total,
+                         uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts) {
+  const uint32_t nq = q1 - q0, ns = s1 - s0;
+  if (nq == 0 || ns == 0) return PA_OK;
+  if (total == 0) {
+    PA_HIP(hipMemsetAsync(d_counts, 0, (uint64_t)nq * ns * sizeof(uint32_t), c->stream));
+    return PA_OK;
+  }
+  PA_REQUIRE(total < (1ULL << 32), "pair phase: %llu postings exceed the 32-bit index space", (unsigned long long)total);
+  // CSR offsets of the genome ranges involved (host copy of four entries per tile would need a sync each;
+  // one copy of the whole offset array is cheaper than that for any n)
+  std::vector<uint64_t> h_off(n + 1);
+  PA_HIP(hipMemcpyAsync(h_off.data(), d_off, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  PA_TRY(c->ids.reserve(total * sizeof(uint32_t)));
+  uint32_t *d_ids = c->ids.as<uint32_t>();
+  uint32_t *d_counter = reinterpret_cast<uint32_t *>(c->counters.as<uint64_t>() + 4);  // [0] counter, [1] special id
+  for (uint32_t t0 = s0; t0 < s1; t0 += kMaxTileSubjects) {
+    const uint32_t t1 = (s1 - t0 > kMaxTileSubjects) ? t0 + kMaxTileSubjects : s1;
+    const uint32_t cols = t1 - t0;
+    int tpr = 1;
+    while ((uint32_t)tpr * 128u < cols) tpr *= 2;
+    const uint32_t w32 = (uint32_t)tpr * 4u;
+    const uint64_t pt0 = h_off[t0], pt1 = h_off[t1], pq0 = h_off[q0], pq1 = h_off[q1];
+    uint64_t U = 0;
+    uint32_t mask = 0;
+    {
+      ProfScope prof(c, PA_PROF_PAIR_DICT);
+      uint64_t cap = 1024;
+      while (cap < 2 * (pt1 - pt0)) cap <<= 1;
+      PA_REQUIRE(cap <= (1ULL << 31), "pair phase: tile with %llu subject postings is too large for the hash dictionary",
+                 (unsigned long long)(pt1 - pt0));
+      mask = (uint32_t)(cap - 1);
+      PA_TRY(c->dict_keys[0].reserve(cap * 8));
+      PA_TRY(c->dict_vals[0].reserve(cap * 4));
+      PA_HIP(hipMemsetAsync(c->dict_keys[0].p, 0xff, cap * 8, c->stream));
+      PA_HIP(hipMemsetAsync(d_counter, 0, 4, c->stream));
+      PA_HIP(hipMemsetAsync(d_counter + 1, 0xff, 4, c->stream));
+      if (pt1 > pt0)
+        hipLaunchKernelGGL(table_insert_kernel, dim3(ceil_div_u64(pt1 - pt0, kThreads * kInsertPerThread)), dim3(kThreads), 0, c->stream,
+                           d_hashes, pt0, pt1, c->dict_keys[0].as<unsigned long long>(), c->dict_vals[0].as<uint32_t>(),
+                           mask, d_counter, d_counter + 1);
+      PA_HIP(hipMemcpyAsync(c->h_pinned, d_counter, 4, hipMemcpyDeviceToHost, c->stream));
+      PA_HIP(hipStreamSynchronize(c->stream));
+      U = *reinterpret_cast<uint32_t *>(c->h_pinned);
+      const uint64_t row_bytes = (U ? U : 1) * w32 * sizeof(uint32_t);
+      PA_TRY(c->bitrows.reserve(row_bytes));
+      PA_HIP(hipMemsetAsync(c->bitrows.p, 0, row_bytes, c->stream));
+      const unsigned long long *keys = c->dict_keys[0].as<unsigned long long>();
+      const uint32_t *sids = c->dict_vals[0].as<uint32_t>();
+      if (pt1 > pt0)
+        hipLaunchKernelGGL(table_lookup_kernel<true>, dim3(ceil_div_u64(pt1 - pt0, kThreads)), dim3(kThreads), 0,
+                           c->stream, d_hashes, pt0, pt1, keys, sids, mask, d_counter + 1, d_ids, d_off, n, t0, w32,
+                           c->bitrows.as<uint32_t>());
+      // query postings outside the tile's own range
+      const uint64_t a0 = pq0, a1 = pq1 < pt0 ? pq1 : pt0;  // part before the tile
+      const uint64_t b0 = pq0 > pt1 ? pq0 : pt1, b1 = pq1;  // part after the tile
+      if (a1 > a0)
+        hipLaunchKernelGGL(table_lookup_kernel<false>, dim3(ceil_div_u64(a1 - a0, kThreads)), dim3(kThreads), 0,
+                           c->stream, d_hashes, a0, a1, keys, sids, mask, d_counter + 1, d_ids, d_off, n, t0, w32,
+                           (uint32_t *)nullptr);
+      if (b1 > b0)
+        hipLaunchKernelGGL(table_lookup_kernel<false>, dim3(ceil_div_u64(b1 - b0, kThreads)), dim3(kThreads), 0,
+                           c->stream, d_hashes, b0, b1, keys, sids, mask, d_counter + 1, d_ids, d_off, n, t0, w32,
+                           (uint32_t *)nullptr);
     }
     {
       ProfScope prof(c, PA_PROF_PAIR_COUNT);

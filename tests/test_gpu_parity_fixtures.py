@@ -37,7 +37,7 @@ def test_sketch_equals_sig_fixtures(engine, name):
         assert np.array_equal(mins, want), f"{name}/{m}: {len(mins)} vs {len(want)} hashes"
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 @pytest.mark.parametrize("name", list(FIXTURE_SETS))
 def test_pairs_equal_manysearch(engine, name, algo):
     from pyani_plus_amd.engine import ani_host

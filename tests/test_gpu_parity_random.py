@@ -124,13 +124,13 @@ def test_pair_counts_match_oracle(engine, sizes, universe):
     sketches = _random_sketches(rng, sizes, universe)
     sk = engine.sketches_from_host(sketches)
     want = oracle.pair_counts(sketches, threads=8)
-    for algo in (1, 2):
+    for algo in (1, 2, 3):
         got = engine.pair_counts(sk, algo=algo).cpu().numpy().view(np.uint32)
         assert np.array_equal(got, want), f"algo {algo}"
     n = len(sketches)
     # rectangular tiles (a subject column, a query band)
     for q_range, s_range in (((0, n), (n - 1, n)), ((1, min(n, 5)), (0, n)), ((2, 3), (1, 2))):
-        for algo in (1, 2):
+        for algo in (1, 2, 3):
             got = engine.pair_counts(sk, q_range, s_range, algo=algo).cpu().numpy().view(np.uint32)
             assert np.array_equal(got, want[q_range[0] : q_range[1], s_range[0] : s_range[1]])
 
