@@ -222,6 +222,22 @@ def main():
         except Exception:
             traffic = None
 
+    # a device copy on the same box, so fractions can be read against the nominal
+    # 8 TB/s and against what this GPU actually streams (1 GiB read + 1 GiB written per copy)
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=engine.device)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     result = None
     if rank == 0:
         result = {
@@ -260,6 +276,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "measured_copy_gbs": copy_gbs,
+                "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": per_launch_s * 1e3,
                 "note": "kernel is integer-VALU bound (MurmurHash3 per window), see DESIGN.md",

@@ -11,9 +11,13 @@
 //   pa_sketch_bottom : the scaled pipeline with a threshold sized for ~4m survivors of the shortest
 //                      genome, then truncation of every sketch to its m smallest hashes (threshold
 //                      raised and the call repeated if a genome came up short)
-//   pa_pair_mash     : one wavefront per ordered pair; merge path over the two sketches, per-lane
-//                      (union, common) counts, a wave scan finds the lane where the union reaches m
+//   pa_pair_mash     : hashes -> dense ids in hash order (one sort of all postings), then one THREAD per
+//                      ordered pair of a (TQ x TS) tile whose TQ+TS id lists sit in LDS (4 bytes per hash,
+//                      up to 156 KB of the CU's 160 KB): a two-pointer merge that stops at the m-th union
+//                      element.  Lists too long for LDS fall back to one wavefront per pair with a merge
+//                      path over the 64-bit lists in HBM.
 //   pa_ani_mash      : 1 + ln(2j/(1+j))/k, j = common/denom; common == 0 -> NaN
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -124,6 +128,47 @@ __global__ __launch_bounds__(kThreads) void mash_pair_kernel(const uint64_t *__r
   }
 }
 
+constexpr uint32_t kSentinel = 0xffffffffu;
+constexpr uint32_t kLdsBudget = 156u * 1024u;  // of the 160 KB a gfx950 CU has
+constexpr uint32_t kMaxTileThreads = 1024;
+
+// Tile kernel.  lds = (tq + ts) lists of `stride` ids: the first min(len, m) ids of the sketch, then a sentinel.
+__global__ __launch_bounds__(kMaxTileThreads) void mash_tile_kernel(
+    const uint32_t *__restrict__ ids, const uint64_t *__restrict__ off, uint32_t q0, uint32_t nq, uint32_t s0,
+    uint32_t ns, uint32_t m, uint32_t tq, uint32_t ts, uint32_t stride, uint32_t tiles_s,
+    uint32_t *__restrict__ common, uint32_t *__restrict__ denom) {
+  extern __shared__ uint32_t lds[];
+  const uint32_t qb = (blockIdx.x / tiles_s) * tq, sb = (blockIdx.x % tiles_s) * ts;
+  const uint32_t nqt = min(tq, nq - qb), nst = min(ts, ns - sb);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  for (uint32_t l = wave; l < nqt + nst; l += n_waves) {
+    const uint32_t g = l < nqt ? q0 + qb + l : s0 + sb + (l - nqt);
+    const uint64_t beg = off[g];
+    const uint32_t len = (uint32_t)min((uint64_t)m, off[g + 1] - beg);
+    uint32_t *dst = lds + (l < nqt ? l : tq + (l - nqt)) * stride;
+    for (uint32_t x = lane; x < len; x += 64) dst[x] = ids[beg + x];
+    if (lane == 0) dst[len] = kSentinel;
+  }
+  __syncthreads();
+  const uint32_t qi = threadIdx.x / ts, si = threadIdx.x % ts;
+  if (qi >= nqt || si >= nst) return;
+  const uint32_t *A = lds + qi * stride, *B = lds + (tq + si) * stride;
+  uint32_t i = 0, j = 0, uni = 0, com = 0;
+  uint32_t x = A[0], y = B[0];
+  while (uni < m && (x & y) != kSentinel) {  // ids are < sentinel, so x & y is all ones only when both lists are spent
+    const uint32_t adv_a = x <= y ? 1u : 0u, adv_b = y <= x ? 1u : 0u;
+    com += adv_a & adv_b;
+    ++uni;
+    i += adv_a;
+    j += adv_b;
+    x = A[i];
+    y = B[j];
+  }
+  const uint64_t pair = (uint64_t)(qb + qi) * ns + (sb + si);
+  common[pair] = com;
+  denom[pair] = uni;
+}
+
 __global__ __launch_bounds__(kThreads) void mash_ani_kernel(const uint32_t *__restrict__ common,
                                                             const uint32_t *__restrict__ denom, uint64_t n,
                                                             double inv_k, double *__restrict__ ani) {
@@ -208,6 +253,35 @@ int pa_pair_mash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uin
   PA_REQUIRE(d_hashes && d_common && d_denom, "pa_pair_mash: null buffer");
   PA_REQUIRE(pairs / kWavesPerBlock < (1ULL << 31), "pa_pair_mash: tile of %llu pairs is too large for one launch",
              (unsigned long long)pairs);
+  // lengths on the host: the longest staged list decides whether a tile of lists fits in LDS
+  std::vector<uint64_t> h_off(n + 1);
+  PA_HIP(hipMemcpyAsync(h_off.data(), d_off, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  uint64_t longest = 0;
+  for (uint32_t g = q0; g < q1; ++g) longest = std::max(longest, std::min<uint64_t>(m, h_off[g + 1] - h_off[g]));
+  for (uint32_t g = s0; g < s1; ++g) longest = std::max(longest, std::min<uint64_t>(m, h_off[g + 1] - h_off[g]));
+  const uint64_t P = h_off[n];
+  const uint32_t stride = (uint32_t)longest + 1u;
+  const uint32_t lists = kLdsBudget / (4u * stride);
+  if (lists >= 2 && P < (1ULL << 32) && P > 0) {
+    uint64_t n_distinct = 0;
+    PA_TRY(pa_dense_ids_sorted(c, d_hashes, d_off, n, P, &n_distinct));
+    ProfScope prof(c, PA_PROF_PAIR_COUNT);
+    const uint32_t nq = q1 - q0, ns = s1 - s0;
+    uint32_t tq = std::min({lists / 2u, nq, 32u});
+    uint32_t ts = std::min({lists - tq, ns, kMaxTileThreads / tq});
+    const uint32_t tiles_q = (nq + tq - 1) / tq, tiles_s = (ns + ts - 1) / ts;
+    PA_REQUIRE((uint64_t)tiles_q * tiles_s < (1ULL << 31), "pa_pair_mash: %llu tiles are too many for one launch",
+               (unsigned long long)tiles_q * tiles_s);
+    const uint32_t threads = ((tq * ts + 63u) / 64u) * 64u;
+    const uint32_t lds_bytes = (tq + ts) * stride * 4u;
+    PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(mash_tile_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(mash_tile_kernel, dim3(tiles_q * tiles_s), dim3(threads), lds_bytes, c->stream,
+                       c->ids.as<uint32_t>(), d_off, q0, nq, s0, ns, m, tq, ts, stride, tiles_s, d_common, d_denom);
+    PA_HIP(hipGetLastError());
+    return PA_OK;
+  }
   ProfScope prof(c, PA_PROF_PAIR_COUNT);
   hipLaunchKernelGGL(mash_pair_kernel, dim3(ceil_div_u64(pairs, kWavesPerBlock)), dim3(kThreads), 0, c->stream, d_hashes,
                      d_off, q0, q1 - q0, s0, s1 - s0, m, d_common, d_denom);

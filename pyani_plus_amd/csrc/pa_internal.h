@@ -130,6 +130,8 @@ int pa_build_sketch_csr(pa_ctx *c, const uint64_t *d_sorted_hash, const uint32_t
 // pairs_bitrow.hip / pairs_merge.hip
 int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t total,
                     uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts);
+int pa_dense_ids_sorted(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t P,
+                        uint64_t *n_distinct);
 int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t total,
                          uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts);
 int pa_pairs_merge(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint32_t q0,

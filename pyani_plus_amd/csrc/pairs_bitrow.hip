@@ -244,6 +244,50 @@ void launch_row_sum(pa_ctx *c, uint32_t nq, const uint32_t *ids, const uint64_t 
 
 }  // namespace
 
+// Dense ids in ascending hash order for all P postings (id order == hash order): sort (hash, posting),
+// flag the first posting of every distinct hash, scan.  Leaves ids in CSR order in c->ids and the
+// (id, genome) pairs in sorted order in c->post_genome[0..P) / [P..2P).
+int pa_dense_ids_sorted(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t P,
+                        uint64_t *n_distinct) {
+  ProfScope prof(c, PA_PROF_PAIR_DICT);
+  for (int b = 0; b < 2; ++b) {
+    PA_TRY(c->dict_keys[b].reserve(P * sizeof(uint64_t)));
+    PA_TRY(c->dict_vals[b].reserve(P * sizeof(uint32_t)));
+  }
+  PA_TRY(c->ids.reserve(P * sizeof(uint32_t)));
+  PA_TRY(c->post_genome.reserve(2 * P * sizeof(uint32_t)));
+  PA_TRY(c->flags.reserve(2 * P * sizeof(uint32_t)));
+  uint64_t *keys[2] = {c->dict_keys[0].as<uint64_t>(), c->dict_keys[1].as<uint64_t>()};
+  uint32_t *vals[2] = {c->dict_vals[0].as<uint32_t>(), c->dict_vals[1].as<uint32_t>()};
+  uint32_t *d_ids = c->ids.as<uint32_t>();
+  uint32_t *d_id_sorted = c->post_genome.as<uint32_t>();
+  uint32_t *d_genome_sorted = d_id_sorted + P;
+  uint32_t *d_flags = c->flags.as<uint32_t>(), *d_pos = d_flags + P;
+  uint64_t *d_scalars = c->counters.as<uint64_t>();  // [2] = OR of keys, [3] = U
+
+  const uint32_t grid = ceil_div_u64(P, kThreads);
+  PA_HIP(hipMemcpyAsync(keys[0], d_hashes, P * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
+  PA_HIP(hipMemsetAsync(d_scalars + 2, 0, 2 * sizeof(uint64_t), c->stream));
+  hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(kThreads), 0, c->stream, vals[0], P);
+  hipLaunchKernelGGL(last_or_kernel, dim3(ceil_div_u64(n, kThreads)), dim3(kThreads), 0, c->stream, d_hashes, d_off,
+                     n, reinterpret_cast<unsigned long long *>(d_scalars + 2));
+  PA_HIP(hipMemcpyAsync(c->h_pinned, d_scalars + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  const uint64_t all_or = c->h_pinned[0];
+  int bit_hi = all_or ? 64 - __builtin_clzll(all_or) : 0;
+  bit_hi = (bit_hi + 7) & ~7;
+  int which = 0;
+  PA_TRY(pa_radix_sort_pairs(c, keys, vals, P, 0, bit_hi, false, &which));
+  hipLaunchKernelGGL(key_heads_kernel, dim3(grid), dim3(kThreads), 0, c->stream, keys[which], P, d_flags);
+  PA_TRY(pa_exclusive_scan_u32(c, d_flags, d_pos, P, d_scalars + 3));
+  hipLaunchKernelGGL(assign_ids_kernel, dim3(grid), dim3(kThreads), 0, c->stream, vals[which], d_flags, d_pos, P,
+                     d_off, n, d_ids, d_id_sorted, d_genome_sorted);
+  PA_HIP(hipMemcpyAsync(c->h_pinned, d_scalars + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  *n_distinct = c->h_pinned[0];
+  return PA_OK;
+}
+
 int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t total,
                     uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts) {
   const uint32_t nq = q1 - q0, ns = s1 - s0;
@@ -255,46 +299,11 @@ int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, 
   PA_REQUIRE(total < (1ULL << 32), "pair phase: %llu postings exceed the 32-bit index space",
              (unsigned long long)total);
   const uint64_t P = total;
-  uint32_t *d_ids, *d_id_sorted, *d_genome_sorted;
   uint64_t U = 0;
-  {
-    ProfScope prof(c, PA_PROF_PAIR_DICT);
-    for (int b = 0; b < 2; ++b) {
-      PA_TRY(c->dict_keys[b].reserve(P * sizeof(uint64_t)));
-      PA_TRY(c->dict_vals[b].reserve(P * sizeof(uint32_t)));
-    }
-    PA_TRY(c->ids.reserve(P * sizeof(uint32_t)));
-    PA_TRY(c->post_genome.reserve(2 * P * sizeof(uint32_t)));
-    PA_TRY(c->flags.reserve(2 * P * sizeof(uint32_t)));
-    uint64_t *keys[2] = {c->dict_keys[0].as<uint64_t>(), c->dict_keys[1].as<uint64_t>()};
-    uint32_t *vals[2] = {c->dict_vals[0].as<uint32_t>(), c->dict_vals[1].as<uint32_t>()};
-    d_ids = c->ids.as<uint32_t>();
-    d_id_sorted = c->post_genome.as<uint32_t>();
-    d_genome_sorted = d_id_sorted + P;
-    uint32_t *d_flags = c->flags.as<uint32_t>(), *d_pos = d_flags + P;
-    uint64_t *d_scalars = c->counters.as<uint64_t>();  // [2] = OR of keys, [3] = U
-
-    const uint32_t grid = ceil_div_u64(P, kThreads);
-    PA_HIP(hipMemcpyAsync(keys[0], d_hashes, P * sizeof(uint64_t), hipMemcpyDeviceToDevice, c->stream));
-    PA_HIP(hipMemsetAsync(d_scalars + 2, 0, 2 * sizeof(uint64_t), c->stream));
-    hipLaunchKernelGGL(iota_kernel, dim3(grid), dim3(kThreads), 0, c->stream, vals[0], P);
-    hipLaunchKernelGGL(last_or_kernel, dim3(ceil_div_u64(n, kThreads)), dim3(kThreads), 0, c->stream, d_hashes, d_off,
-                       n, reinterpret_cast<unsigned long long *>(d_scalars + 2));
-    PA_HIP(hipMemcpyAsync(c->h_pinned, d_scalars + 2, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    PA_HIP(hipStreamSynchronize(c->stream));
-    const uint64_t all_or = c->h_pinned[0];
-    int bit_hi = all_or ? 64 - __builtin_clzll(all_or) : 0;
-    bit_hi = (bit_hi + 7) & ~7;
-    int which = 0;
-    PA_TRY(pa_radix_sort_pairs(c, keys, vals, P, 0, bit_hi, false, &which));
-    hipLaunchKernelGGL(key_heads_kernel, dim3(grid), dim3(kThreads), 0, c->stream, keys[which], P, d_flags);
-    PA_TRY(pa_exclusive_scan_u32(c, d_flags, d_pos, P, d_scalars + 3));
-    hipLaunchKernelGGL(assign_ids_kernel, dim3(grid), dim3(kThreads), 0, c->stream, vals[which], d_flags, d_pos, P,
-                       d_off, n, d_ids, d_id_sorted, d_genome_sorted);
-    PA_HIP(hipMemcpyAsync(c->h_pinned, d_scalars + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-    PA_HIP(hipStreamSynchronize(c->stream));
-    U = c->h_pinned[0];
-  }
+  PA_TRY(pa_dense_ids_sorted(c, d_hashes, d_off, n, P, &U));
+  uint32_t *d_ids = c->ids.as<uint32_t>();
+  uint32_t *d_id_sorted = c->post_genome.as<uint32_t>();
+  uint32_t *d_genome_sorted = d_id_sorted + P;
   // subject tiles of up to kMaxTileSubjects columns
   for (uint32_t t0 = s0; t0 < s1; t0 += kMaxTileSubjects) {
     const uint32_t t1 = (s1 - t0 > kMaxTileSubjects) ? t0 + kMaxTileSubjects : s1;

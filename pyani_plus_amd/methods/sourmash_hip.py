@@ -105,12 +105,16 @@ def get_engine(device: int = 0):
     return _ENGINE
 
 
-def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None) -> Iterator:
+def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, preloaded=None) -> Iterator:
     """Build the sketch signatures in ``cache/sourmash_k={kmersize}_scaled={N}``.
 
     Yields the run's FASTA entries as their signatures are completed (progress bar),
     skipping genomes whose ``.sig`` already exists -- the contract of
     pyani_plus/methods/sourmash.py:34-84.
+
+    ``preloaded`` = ``(paths, arena)`` from an earlier ``load_fasta_files(paths)`` lets a caller that has
+    just read the files for their checksums (``rundb.run_sourmash_hip``) hand the packed genomes over
+    instead of having them read a second time; it is used when every genome still needs its signature.
     """
     config = run.configuration
     if config.method != METHOD:
@@ -139,10 +143,14 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None) ->
         if not batch:
             return
         # threaded host front-end: read + gunzip + parse + 2-bit pack, then ONE batched sketch launch
-        infos, arena = load_fasta_files([fasta_dir / entry.fasta_filename for entry in batch])
-        for info in infos:
-            if info.status != 0:
-                log_sys_exit(logger, info.message)
+        paths = [fasta_dir / entry.fasta_filename for entry in batch]
+        if preloaded is not None and [Path(p) for p in preloaded[0]] == paths:
+            arena = preloaded[1]
+        else:
+            infos, arena = load_fasta_files(paths)
+            for info in infos:
+                if info.status != 0:
+                    log_sys_exit(logger, info.message)
         eng = engine or get_engine()
         sketches = eng.sketch(eng.upload(arena), config.kmersize, scaled, max_hash=max_hash).to_host()
         for entry, mins in zip(batch, sketches):
@@ -163,7 +171,7 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None) ->
             fasta_file = fasta_dir / entry.fasta_filename
             batch_bytes += 4 * fasta_file.stat().st_size if fasta_file.is_file() else 0  # gz expands ~4x
         pending.append(entry)
-        if batch_bytes >= PREPARE_BATCH_BASES:
+        if batch_bytes >= PREPARE_BATCH_BASES and preloaded is None:
             flush()
             yield from pending
             pending = []

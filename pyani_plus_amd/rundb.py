@@ -329,8 +329,7 @@ def run_sourmash_hip(  # noqa: PLR0913
     from .engine import load_fasta_files
 
     # one threaded pass per file: md5 of the decompressed bytes, length, first title
-    infos, _arena = load_fasta_files(fasta_names)
-    del _arena
+    infos, arena = load_fasta_files(fasta_names)
     for filename, info in zip(fasta_names, infos):
         if info.status != 0:
             sourmash_hip.log_sys_exit(logger, info.message)
@@ -355,8 +354,12 @@ def run_sourmash_hip(  # noqa: PLR0913
         own_cache = cache is None
         cache_dir = Path(tempfile.mkdtemp(prefix="pyani_hip_cache_")) if own_cache else Path(cache)
         cache_dir.mkdir(parents=True, exist_ok=True)
-        for _ in sourmash_hip.prepare_genomes(logger, run, cache_dir, engine=engine):
+        # the genomes were packed while their checksums were taken: sketch them from memory
+        ordered = [fasta / a.fasta_filename for a in run.fasta_hashes]
+        preloaded = (fasta_names, arena) if ordered == list(fasta_names) else None
+        for _ in sourmash_hip.prepare_genomes(logger, run, cache_dir, engine=engine, preloaded=preloaded):
             pass
+        del arena, preloaded
         tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
         json_file = tmp_dir / f"{sourmash_hip.METHOD}.run_{run.run_id}.column_0.json"
         hash_to_filename = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}

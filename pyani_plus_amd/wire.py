@@ -88,3 +88,79 @@ def load_json_comparisons(json_filename: Path) -> dict:
                 msg = f"JSON file {json_filename} has a comparison without {key!r}"
                 raise ValueError(msg)
     return data
+
+
+MANYSEARCH_COLUMNS = (
+    "query_name,query_md5,match_name,containment,intersect_hashes,ksize,scaled,moltype,match_md5,jaccard,"
+    "max_containment,query_containment_ani,match_containment_ani,average_containment_ani,max_containment_ani"
+)
+
+
+def _rust_float(x: float) -> str:
+    """Shortest round-trip decimal the way Rust's ``Display`` prints an f64 (never an exponent)."""
+    text = repr(float(x))
+    if "e" not in text:
+        return text
+    from decimal import Decimal
+
+    fixed = format(Decimal(text), "f")
+    return fixed if "." in fixed else fixed + ".0"
+
+
+def export_manysearch_csv(  # noqa: PLR0913
+    csv_filename: Path,
+    query_names: list[str],
+    query_sig_md5: list[str],
+    subject_names: list[str],
+    subject_sig_md5: list[str],
+    counts,
+    query_sizes,
+    subject_sizes,
+    kmersize: int,
+    scaled: int,
+) -> int:
+    """Write a tile's intersection counts as the CSV ``sourmash scripts manysearch`` would write.
+
+    Same 15 columns and header as the reference's intermediate file (column list pinned by
+    tests/fixtures/viral_example/intermediates/sourmash/manysearch.csv:1, read by name in
+    pyani_plus/methods/sourmash.py:107-110); pairs without a shared hash get no row, exactly as
+    upstream.  Row order is query-major (upstream's is thread-dependent,
+    tests/test_public_cli.py:1055-1057).  Returns the number of rows written.  This is an export for
+    people who post-process that file; the method itself never parses it back.
+    """
+    import numpy as np
+
+    from pyani_plus_amd.engine import ani_host
+
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    q_sizes = np.asarray(query_sizes, dtype=np.uint64)
+    s_sizes = np.asarray(subject_sizes, dtype=np.uint64)
+    _ident, q_ani, _null = ani_host(counts, q_sizes, s_sizes, kmersize)
+    _ident_t, m_ani_t, _null_t = ani_host(np.ascontiguousarray(counts.T), s_sizes, q_sizes, kmersize)
+    rows = 0
+    with Path(csv_filename).open("w") as handle:
+        handle.write(MANYSEARCH_COLUMNS + "\n")
+        for q, s in zip(*np.nonzero(counts)):
+            shared = int(counts[q, s])
+            nq, ns = int(q_sizes[q]), int(s_sizes[s])
+            qa, ma = float(q_ani[q, s]), float(m_ani_t[s, q])
+            fields = (
+                query_names[q],
+                query_sig_md5[q],
+                subject_names[s],
+                _rust_float(shared / nq),
+                str(shared),
+                str(kmersize),
+                str(scaled),
+                "DNA",
+                subject_sig_md5[s],
+                _rust_float(shared / (nq + ns - shared)),
+                _rust_float(shared / min(nq, ns)),
+                _rust_float(qa),
+                _rust_float(ma),
+                _rust_float((qa + ma) / 2.0),
+                _rust_float(max(qa, ma)),
+            )
+            handle.write(",".join(fields) + "\n")
+            rows += 1
+    return rows

@@ -21,7 +21,7 @@ def engine():
     eng.close()
 
 
-@pytest.mark.parametrize("m,k", [(1000, 31), (64, 21), (5000, 31)])
+@pytest.mark.parametrize("m,k", [(1000, 31), (64, 21), (5000, 31), (30000, 21)])
 def test_bottom_sketch_pairs_and_ani_match_oracle(engine, m, k):
     lengths = [300_000, 120_000, 40, 300_000, 2_500, 300_000, 90_000, 31, 0, 150_000]
     arena = synth_arena_numpy(len(lengths), lengths, n_species=3)

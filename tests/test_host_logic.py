@@ -358,3 +358,27 @@ def test_threaded_fasta_loader_matches_python_reader(tmp_path):
     ref = pack_genomes(ok_texts)
     assert np.array_equal(arena.packed, ref.packed) and np.array_equal(arena.mask, ref.mask)
     assert np.array_equal(arena.genome_start, ref.genome_start) and arena.residues == ref.residues
+
+
+@pytest.mark.parametrize("name", list(FIXTURE_SETS))
+def test_manysearch_csv_export_equals_fixture_text(name, tmp_path):
+    """All 15 columns of the reference's intermediate manysearch.csv, as text, from counts + sizes."""
+    from pyani_plus_amd.sig import signature_md5
+    from pyani_plus_amd.wire import _rust_float, export_manysearch_csv
+
+    scaled, genomes = FIXTURE_SETS[name]
+    md5s = sorted(genomes)
+    sketches = [np.array(load_sig(GOLDEN / name / "sourmash" / f"{m}.sig")["signatures"][0]["mins"], dtype=np.uint64) for m in md5s]
+    sig_md5 = [signature_md5(31, s) for s in sketches]
+    for m, got in zip(md5s, sig_md5):
+        assert got == load_sig(GOLDEN / name / "sourmash" / f"{m}.sig")["signatures"][0]["md5sum"]
+    counts = oracle.pair_counts(sketches)
+    sizes = [len(s) for s in sketches]
+    out = tmp_path / "manysearch.csv"
+    n_rows = export_manysearch_csv(out, md5s, sig_md5, md5s, sig_md5, counts, sizes, sizes, 31, scaled)
+    got_lines = out.read_text().splitlines()
+    want_lines = (GOLDEN / name / "sourmash" / "manysearch.csv").read_text().splitlines()
+    assert got_lines[0] == want_lines[0]
+    assert sorted(got_lines[1:]) == sorted(line for line in want_lines[1:] if line)  # upstream row order is thread-dependent
+    assert n_rows == len(got_lines) - 1 == int((counts > 0).sum())
+    assert _rust_float(5e-05) == "0.00005" and _rust_float(1.0) == "1.0" and _rust_float(1e-7) == "0.0000001"
