@@ -59,8 +59,11 @@ __device__ __forceinline__ uint64_t times5_plus(uint64_t h, uint64_t c) {
   return t + h + c;
 }
 
+// Everything up to, but not including, the last `k ^= k >> 33` of the two fmix64 calls: the hash is
+// (X ^ X>>33) + (Y ^ Y>>33).  That last step only touches the low 31 bits, so the high words of X and Y
+// already decide -- up to one carry -- whether the hash can be <= max_hash (see kmer_hash.hip).
 template <int K>
-__device__ __forceinline__ uint64_t murmur3_from_products(const uint64_t (&P)[4]) {
+__device__ __forceinline__ void murmur3_pre_final(const uint64_t (&P)[4], uint64_t &X, uint64_t &Y) {
   uint64_t h1 = 42, h2 = 42;
   constexpr int nblocks = K / 16;
   constexpr int tail = K % 16;
@@ -79,9 +82,17 @@ __device__ __forceinline__ uint64_t murmur3_from_products(const uint64_t (&P)[4]
   if constexpr (tail > 0) h1 ^= rotl64(P[2 * nblocks], 31) * kC2;
   h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
   h1 += h2; h2 += h1;
-  h1 = fmix64(h1); h2 = fmix64(h2);
-  h1 += h2;
-  return h1;
+  h1 ^= h1 >> 33; h1 *= 0xff51afd7ed558ccdULL; h1 ^= h1 >> 33; h1 *= 0xc4ceb9fe1a85ec53ULL;
+  h2 ^= h2 >> 33; h2 *= 0xff51afd7ed558ccdULL; h2 ^= h2 >> 33; h2 *= 0xc4ceb9fe1a85ec53ULL;
+  X = h1;
+  Y = h2;
+}
+
+template <int K>
+__device__ __forceinline__ uint64_t murmur3_from_products(const uint64_t (&P)[4]) {
+  uint64_t X, Y;
+  murmur3_pre_final<K>(P, X, Y);
+  return (X ^ (X >> 33)) + (Y ^ (Y >> 33));
 }
 
 // the 4-base group `b8` (base j at bits 2j) as ASCII, keeping only its first `nv` bytes
