@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kThreads) void row_sum_kernel(const uint32_t *__res
     pending = 0;
   };
 
-  for (uint64_t j = slot; j < len; j += kRowsPerIter) {
+  // TPR need not divide the workgroup: the threads past the last whole row sit the loop out
+  for (uint64_t j = slot < (uint32_t)kRowsPerIter ? slot : len; j < len; j += kRowsPerIter) {
     const uint32_t id = ids[j];
     if (id == kNone) continue;  // hash absent from every subject of the tile (hash-dictionary variant)
     const uint4 r = *reinterpret_cast<const uint4 *>(rows + (uint64_t)id * kW32 + quad * 4);
@@ -158,16 +159,27 @@ __global__ __launch_bounds__(kThreads) void row_sum_kernel(const uint32_t *__res
 }
 
 // ---- hash dictionary (PA_PAIRS_BITROW_HASH): dense ids without sorting -------------------------
-// Open addressing, linear probing, load <= 1/2.  Only the hashes of the tile's SUBJECTS are inserted;
-// the winner of a slot draws the dense id.  Lookups run in a later launch, so every id is visible.
-// The legal key ~0 doubles as the empty marker and is therefore kept in `special[0]` instead.
-__device__ __forceinline__ uint32_t slot_of(uint64_t h, uint32_t mask) { return (uint32_t)(h ^ (h >> 32)) & mask; }
+// Open addressing, linear probing, load 2/3.  Only the hashes of the tile's SUBJECTS are inserted; the
+// winner of a slot draws the dense id.  Key and id share one 16-byte entry, so a probe costs one HBM
+// line, which is what bounds both kernels (the table is far larger than L2).  Lookups run in a later
+// launch, so every id is visible.  The legal key ~0 doubles as the empty marker and is therefore kept
+// in `special[0]` instead.
+struct DictEntry {
+  unsigned long long key;
+  uint32_t id;
+  uint32_t pad;
+};
+static_assert(sizeof(DictEntry) == 16, "one probe = one 16-byte entry");
+
+__device__ __forceinline__ uint32_t slot_of(uint64_t h, uint32_t cap) {
+  const uint32_t x = ((uint32_t)h * 0x9E3779B1u) ^ (uint32_t)(h >> 32);
+  return (uint32_t)(((uint64_t)x * cap) >> 32);
+}
 
 constexpr int kInsertPerThread = 4;
 __global__ __launch_bounds__(kThreads) void table_insert_kernel(const uint64_t *__restrict__ hashes, uint64_t p0,
-                                                                uint64_t p1, unsigned long long *__restrict__ keys,
-                                                                uint32_t *__restrict__ slot_ids, uint32_t mask,
-                                                                uint32_t *__restrict__ counter,
+                                                                uint64_t p1, DictEntry *__restrict__ table,
+                                                                uint32_t cap, uint32_t *__restrict__ counter,
                                                                 uint32_t *__restrict__ special) {
   __shared__ uint32_t s_won, s_base;
   if (threadIdx.x == 0) s_won = 0;
@@ -185,14 +197,14 @@ __global__ __launch_bounds__(kThreads) void table_insert_kernel(const uint64_t *
       won_special = atomicCAS(&special[0], kNone, kNone - 1u) == kNone;
       continue;
     }
-    uint32_t slot = slot_of(h, mask);
+    uint32_t slot = slot_of(h, cap);
     for (;;) {
       // most postings repeat a key that is already there: look before paying for the atomic
-      unsigned long long k = __builtin_nontemporal_load(&keys[slot]);
-      if (k == kEmptyKey) k = atomicCAS(&keys[slot], (unsigned long long)kEmptyKey, (unsigned long long)h);
+      unsigned long long k = __builtin_nontemporal_load(&table[slot].key);
+      if (k == kEmptyKey) k = atomicCAS(&table[slot].key, (unsigned long long)kEmptyKey, (unsigned long long)h);
       if (k == kEmptyKey) { won_slot[won++] = slot; break; }
       if (k == h) break;
-      slot = (slot + 1u) & mask;
+      if (++slot == cap) slot = 0;
     }
   }
   // dense ids: one global atomic per workgroup instead of one per new key
@@ -202,17 +214,16 @@ __global__ __launch_bounds__(kThreads) void table_insert_kernel(const uint64_t *
   if (threadIdx.x == 0) s_base = s_won ? atomicAdd(counter, s_won) : 0u;
   __syncthreads();
   local += s_base;
-  for (int i = 0; i < won; ++i) slot_ids[won_slot[i]] = local++;
+  for (int i = 0; i < won; ++i) table[won_slot[i]].id = local++;
   if (won_special) special[0] = local;
 }
 
 // ids of the postings [p0, p1); postings of tile subjects (SET_BITS) also set their bit in the row
 template <bool SET_BITS>
 __global__ __launch_bounds__(kThreads) void table_lookup_kernel(
-    const uint64_t *__restrict__ hashes, uint64_t p0, uint64_t p1, const unsigned long long *__restrict__ keys,
-    const uint32_t *__restrict__ slot_ids, uint32_t mask, const uint32_t *__restrict__ special,
-    uint32_t *__restrict__ ids_csr, const uint64_t *__restrict__ off, uint32_t n, uint32_t t0, uint32_t w32,
-    uint32_t *__restrict__ rows) {
+    const uint64_t *__restrict__ hashes, uint64_t p0, uint64_t p1, const DictEntry *__restrict__ table, uint32_t cap,
+    const uint32_t *__restrict__ special, uint32_t *__restrict__ ids_csr, const uint64_t *__restrict__ off, uint32_t n,
+    uint32_t t0, uint32_t w32, uint32_t *__restrict__ rows) {
   const uint64_t p = p0 + (uint64_t)blockIdx.x * kThreads + threadIdx.x;
   if (p >= p1) return;
   const uint64_t h = hashes[p];
@@ -220,12 +231,13 @@ __global__ __launch_bounds__(kThreads) void table_lookup_kernel(
   if (h == kEmptyKey) {
     id = special[0];
   } else {
-    uint32_t slot = slot_of(h, mask);
+    uint32_t slot = slot_of(h, cap);
     for (;;) {
-      const unsigned long long k = keys[slot];
-      if (k == h) { id = slot_ids[slot]; break; }
+      const uint4 e = *reinterpret_cast<const uint4 *>(&table[slot]);  // key and id in one load
+      const uint64_t k = ((uint64_t)e.y << 32) | e.x;
+      if (k == h) { id = e.z; break; }
       if (k == kEmptyKey) break;
-      slot = (slot + 1u) & mask;
+      if (++slot == cap) slot = 0;
     }
   }
   ids_csr[p] = id;
@@ -240,6 +252,21 @@ void launch_row_sum(pa_ctx *c, uint32_t nq, const uint32_t *ids, const uint64_t 
                     const uint32_t *rows, uint32_t tile_cols, uint32_t *counts, uint32_t ns, uint32_t col0) {
   hipLaunchKernelGGL(row_sum_kernel<TPR>, dim3(nq), dim3(kThreads), 0, c->stream, ids, off, q0, rows, tile_cols,
                      counts, ns, col0);
+}
+
+int dispatch_row_sum(pa_ctx *c, int tpr, uint32_t nq, const uint32_t *ids, const uint64_t *off, uint32_t q0,
+                     const uint32_t *rows, uint32_t tile_cols, uint32_t *counts, uint32_t ns, uint32_t col0) {
+#define PA_ROW_CASE(T) \
+  case T: launch_row_sum<T>(c, nq, ids, off, q0, rows, tile_cols, counts, ns, col0); return PA_OK;
+  switch (tpr) {
+    PA_ROW_CASE(1) PA_ROW_CASE(2) PA_ROW_CASE(3) PA_ROW_CASE(4) PA_ROW_CASE(5) PA_ROW_CASE(6) PA_ROW_CASE(7)
+    PA_ROW_CASE(8) PA_ROW_CASE(9) PA_ROW_CASE(10) PA_ROW_CASE(11) PA_ROW_CASE(12) PA_ROW_CASE(13) PA_ROW_CASE(14)
+    PA_ROW_CASE(15) PA_ROW_CASE(16)
+    default:
+      pa_set_error("pair phase: %d threads per bit row (tile wider than %u subjects)", tpr, kMaxTileSubjects);
+      return PA_E_INVALID;
+  }
+#undef PA_ROW_CASE
 }
 
 }  // namespace
@@ -308,8 +335,7 @@ int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, 
   for (uint32_t t0 = s0; t0 < s1; t0 += kMaxTileSubjects) {
     const uint32_t t1 = (s1 - t0 > kMaxTileSubjects) ? t0 + kMaxTileSubjects : s1;
     const uint32_t cols = t1 - t0;
-    int tpr = 1;  // threads per row: row width = tpr*128 columns
-    while ((uint32_t)tpr * 128u < cols) tpr *= 2;
+    const int tpr = (int)((cols + 127u) / 128u);  // threads per row: row width = tpr*128 columns
     const uint32_t w32 = (uint32_t)tpr * 4u;
     const uint64_t row_bytes = U * w32 * sizeof(uint32_t);
     {
@@ -322,13 +348,7 @@ int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, 
     {
       ProfScope prof(c, PA_PROF_PAIR_COUNT);
       const uint32_t *rows = c->bitrows.as<uint32_t>();
-      switch (tpr) {
-        case 1: launch_row_sum<1>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-        case 2: launch_row_sum<2>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-        case 4: launch_row_sum<4>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-        case 8: launch_row_sum<8>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-        default: launch_row_sum<16>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-      }
+      PA_TRY(dispatch_row_sum(c, tpr, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0));
     }
     PA_HIP(hipGetLastError());
   }
@@ -356,62 +376,52 @@ int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_
   for (uint32_t t0 = s0; t0 < s1; t0 += kMaxTileSubjects) {
     const uint32_t t1 = (s1 - t0 > kMaxTileSubjects) ? t0 + kMaxTileSubjects : s1;
     const uint32_t cols = t1 - t0;
-    int tpr = 1;
-    while ((uint32_t)tpr * 128u < cols) tpr *= 2;
+    const int tpr = (int)((cols + 127u) / 128u);  // threads per row: row width = tpr*128 columns
     const uint32_t w32 = (uint32_t)tpr * 4u;
     const uint64_t pt0 = h_off[t0], pt1 = h_off[t1], pq0 = h_off[q0], pq1 = h_off[q1];
     uint64_t U = 0;
-    uint32_t mask = 0;
+    uint32_t cap = 0;
     {
       ProfScope prof(c, PA_PROF_PAIR_DICT);
-      uint64_t cap = 1024;
-      while (cap < 2 * (pt1 - pt0)) cap <<= 1;
-      PA_REQUIRE(cap <= (1ULL << 31), "pair phase: tile with %llu subject postings is too large for the hash dictionary",
+      const uint64_t cap64 = (pt1 - pt0) + (pt1 - pt0) / 2 + 1024;  // load <= 2/3
+      PA_REQUIRE(cap64 < (1ULL << 32), "pair phase: tile with %llu subject postings is too large for the hash dictionary",
                  (unsigned long long)(pt1 - pt0));
-      mask = (uint32_t)(cap - 1);
-      PA_TRY(c->dict_keys[0].reserve(cap * 8));
-      PA_TRY(c->dict_vals[0].reserve(cap * 4));
-      PA_HIP(hipMemsetAsync(c->dict_keys[0].p, 0xff, cap * 8, c->stream));
+      cap = (uint32_t)cap64;
+      PA_TRY(c->dict_keys[0].reserve(cap64 * sizeof(DictEntry)));
+      PA_HIP(hipMemsetAsync(c->dict_keys[0].p, 0xff, cap64 * sizeof(DictEntry), c->stream));
       PA_HIP(hipMemsetAsync(d_counter, 0, 4, c->stream));
       PA_HIP(hipMemsetAsync(d_counter + 1, 0xff, 4, c->stream));
       if (pt1 > pt0)
-        hipLaunchKernelGGL(table_insert_kernel, dim3(ceil_div_u64(pt1 - pt0, kThreads * kInsertPerThread)), dim3(kThreads), 0, c->stream,
-                           d_hashes, pt0, pt1, c->dict_keys[0].as<unsigned long long>(), c->dict_vals[0].as<uint32_t>(),
-                           mask, d_counter, d_counter + 1);
+        hipLaunchKernelGGL(table_insert_kernel, dim3(ceil_div_u64(pt1 - pt0, kThreads * kInsertPerThread)),
+                           dim3(kThreads), 0, c->stream, d_hashes, pt0, pt1, c->dict_keys[0].as<DictEntry>(), cap,
+                           d_counter, d_counter + 1);
       PA_HIP(hipMemcpyAsync(c->h_pinned, d_counter, 4, hipMemcpyDeviceToHost, c->stream));
       PA_HIP(hipStreamSynchronize(c->stream));
       U = *reinterpret_cast<uint32_t *>(c->h_pinned);
       const uint64_t row_bytes = (U ? U : 1) * w32 * sizeof(uint32_t);
       PA_TRY(c->bitrows.reserve(row_bytes));
       PA_HIP(hipMemsetAsync(c->bitrows.p, 0, row_bytes, c->stream));
-      const unsigned long long *keys = c->dict_keys[0].as<unsigned long long>();
-      const uint32_t *sids = c->dict_vals[0].as<uint32_t>();
+      const DictEntry *table = c->dict_keys[0].as<DictEntry>();
       if (pt1 > pt0)
         hipLaunchKernelGGL(table_lookup_kernel<true>, dim3(ceil_div_u64(pt1 - pt0, kThreads)), dim3(kThreads), 0,
-                           c->stream, d_hashes, pt0, pt1, keys, sids, mask, d_counter + 1, d_ids, d_off, n, t0, w32,
+                           c->stream, d_hashes, pt0, pt1, table, cap, d_counter + 1, d_ids, d_off, n, t0, w32,
                            c->bitrows.as<uint32_t>());
       // query postings outside the tile's own range
       const uint64_t a0 = pq0, a1 = pq1 < pt0 ? pq1 : pt0;  // part before the tile
       const uint64_t b0 = pq0 > pt1 ? pq0 : pt1, b1 = pq1;  // part after the tile
       if (a1 > a0)
         hipLaunchKernelGGL(table_lookup_kernel<false>, dim3(ceil_div_u64(a1 - a0, kThreads)), dim3(kThreads), 0,
-                           c->stream, d_hashes, a0, a1, keys, sids, mask, d_counter + 1, d_ids, d_off, n, t0, w32,
+                           c->stream, d_hashes, a0, a1, table, cap, d_counter + 1, d_ids, d_off, n, t0, w32,
                            (uint32_t *)nullptr);
       if (b1 > b0)
         hipLaunchKernelGGL(table_lookup_kernel<false>, dim3(ceil_div_u64(b1 - b0, kThreads)), dim3(kThreads), 0,
-                           c->stream, d_hashes, b0, b1, keys, sids, mask, d_counter + 1, d_ids, d_off, n, t0, w32,
+                           c->stream, d_hashes, b0, b1, table, cap, d_counter + 1, d_ids, d_off, n, t0, w32,
                            (uint32_t *)nullptr);
     }
     {
       ProfScope prof(c, PA_PROF_PAIR_COUNT);
       const uint32_t *rows = c->bitrows.as<uint32_t>();
-      switch (tpr) {
-        case 1: launch_row_sum<1>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-        case 2: launch_row_sum<2>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-        case 4: launch_row_sum<4>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-        case 8: launch_row_sum<8>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-        default: launch_row_sum<16>(c, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0); break;
-      }
+      PA_TRY(dispatch_row_sum(c, tpr, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0));
     }
     PA_HIP(hipGetLastError());
   }

@@ -114,7 +114,9 @@ def _random_sketches(rng, sizes, universe):
     [
         ([0, 1, 5, 64, 65, 300, 0, 1000], 1500),  # empty sketches, tiny, dense overlap
         (list(range(0, 140)), 400),  # 140 subjects -> two-thread rows
-        ([50] * 300, 2000),  # 300 subjects -> four-thread rows
+        ([50] * 300, 2000),  # 300 subjects -> three-thread rows (384 columns)
+        ([20] * 1250, 3000),  # 1250 subjects -> ten-thread rows: the per-rank tile of the 8-GPU configuration
+        ([12] * 1700, 2500),  # 14-thread rows, 18 whole rows per iteration and 4 idle threads
         ([8] * 2100, 3000),  # > 2048 subjects -> two subject tiles
         ([70_000, 500, 66_000], 90_000),  # > 255 rows per lane -> vertical-counter flush
     ],
