@@ -1,4 +1,5 @@
 // capi.hip -- extern "C" entry points of libpyani_hip.so (see include/pyani_hip.h).
+#include <algorithm>
 #include <cstdarg>
 #include <cstring>
 
@@ -86,7 +87,7 @@ void pa_ctx_destroy(pa_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->cand_keys[0], &c->cand_keys[1], &c->cand_vals[0], &c->cand_vals[1], &c->genome_blk,
-                    &c->counters, &c->hist, &c->flags, &c->scan_tmp, &c->dict_keys[0], &c->dict_keys[1],
+                    &c->counters, &c->hist, &c->flags, &c->scan_tmp, &c->region_off, &c->region_cursor, &c->dict_keys[0], &c->dict_keys[1],
                     &c->dict_vals[0], &c->dict_vals[1], &c->ids, &c->post_genome, &c->bitrows};
   for (DevBuf *b : bufs) b->release();
   for (auto &ph : c->prof)
@@ -187,10 +188,52 @@ int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint6
   PA_TRY(c->genome_blk.reserve((uint64_t)(n_genomes + 1) * sizeof(uint32_t)));
   PA_HIP(hipMemcpyAsync(c->genome_blk.p, blk.data(), (uint64_t)(n_genomes + 1) * sizeof(uint32_t),
                         hipMemcpyHostToDevice, c->stream));
-  PA_HIP(hipStreamSynchronize(c->stream));  // blk is a stack-owned vector
-
   // expected survivors: one window in 2^64/(max_hash+1)
   const double frac = (max_hash == UINT64_MAX) ? 1.0 : ((double)max_hash + 1.0) / 18446744073709551616.0;
+  // Per-genome candidate regions (expectation + 25 % + 128 slots).  When the longest fits an LDS sort the
+  // sketches are finished by sketch_lds.hip; otherwise, or if a region overflows, by the global sort below.
+  static const bool force_global = [] {
+    const char *v = getenv("PA_SKETCH_SORT");
+    return v && v[0] == 'g';
+  }();
+  std::vector<uint64_t> region_off(n_genomes + 1, 0);
+  uint64_t longest_region = 0;
+  for (uint32_t g = 0; g < n_genomes; ++g) {
+    const uint64_t room = (uint64_t)((double)(h_genome_start[g + 1] - h_genome_start[g]) * frac * 1.25) + 128;
+    longest_region = std::max(longest_region, room);
+    region_off[g + 1] = region_off[g] + room;
+  }
+  const bool use_regions = !force_global && n_genomes > 0 && longest_region <= kLdsSortMax;
+  if (use_regions) {
+    PA_TRY(c->region_off.reserve((uint64_t)(n_genomes + 1) * sizeof(uint64_t)));
+    PA_TRY(c->region_cursor.reserve((uint64_t)n_genomes * sizeof(uint32_t)));
+    PA_HIP(hipMemcpyAsync(c->region_off.p, region_off.data(), (uint64_t)(n_genomes + 1) * sizeof(uint64_t),
+                          hipMemcpyHostToDevice, c->stream));
+  }
+  PA_HIP(hipStreamSynchronize(c->stream));  // blk and region_off are stack-owned vectors
+
+  if (use_regions) {
+    uint32_t *d_overflow = c->counters.as<uint32_t>() + 12;
+    PA_TRY(c->cand_keys[0].reserve(region_off[n_genomes] * sizeof(uint64_t)));
+    PA_HIP(hipMemsetAsync(c->region_cursor.p, 0, (uint64_t)n_genomes * sizeof(uint32_t), c->stream));
+    PA_HIP(hipMemsetAsync(d_overflow, 0, sizeof(uint32_t), c->stream));
+    {
+      ProfScope prof(c, PA_PROF_KMER_HASH);
+      PA_TRY(pa_launch_kmer_hash(c, d_packed, d_mask, n_blocks, c->genome_blk.as<uint32_t>(), n_genomes, k, max_hash,
+                                 c->cand_keys[0].as<uint64_t>(), nullptr, 0, nullptr, c->region_off.as<uint64_t>(),
+                                 c->region_cursor.as<uint32_t>(), d_overflow));
+    }
+    bool overflow = false;
+    {
+      ProfScope prof(c, PA_PROF_SKETCH_SORT);
+      const int st = pa_sketch_from_regions(c, c->cand_keys[0].as<uint64_t>(), c->region_off.as<uint64_t>(),
+                                            c->region_cursor.as<uint32_t>(), d_overflow, n_genomes,
+                                            (uint32_t)longest_region, d_hashes, cap_hashes, d_off, h_total, &overflow);
+      if (st != PA_OK) return st;
+    }
+    if (!overflow) return PA_OK;
+    *h_total = 0;  // a region was too small (repeats, low-complexity sequence): take the general path
+  }
   uint64_t cap = (uint64_t)((double)arena_bases * frac * 1.25) + 65536;
   if (cap > arena_bases) cap = arena_bases;
   uint64_t *d_count = c->counters.as<uint64_t>();

@@ -34,6 +34,14 @@ __device__ __forceinline__ uint32_t find_genome(const uint32_t *__restrict__ gen
   return lo;
 }
 
+// one candidate into the region of genome g (slow path: one atomic per candidate)
+__device__ __forceinline__ void region_append(uint64_t *__restrict__ regions, const uint64_t *__restrict__ region_off,
+                                              uint32_t *__restrict__ cursor, uint32_t *__restrict__ overflow,
+                                              uint32_t g, uint64_t h) {
+  const uint64_t slot = atomicAdd(&cursor[g], 1u);
+  if (slot < region_off[g + 1] - region_off[g]) regions[region_off[g] + slot] = h; else *overflow = 1u;
+}
+
 // LUT = true (default): the first multiply of every murmur word is looked up.  A word is
 // two 4-base groups (lo, hi); word*c = (ascii(lo) + ascii(hi)*2^32)*c
 //                                    = s_lo[j][lo] + (s_hi[j][hi] << 32)   (mod 2^64)
@@ -45,7 +53,8 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
     const uint4 *__restrict__ packed, const uint2 *__restrict__ mask, uint32_t n_blocks64,
     const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash,
     uint64_t *__restrict__ cand_hash, uint32_t *__restrict__ cand_genome, uint64_t cap,
-    unsigned long long *__restrict__ count) {
+    unsigned long long *__restrict__ count, const uint64_t *__restrict__ region_off, uint32_t *__restrict__ cursor,
+    uint32_t *__restrict__ overflow) {
   static_assert(K >= 4 && K <= 32, "k-mer state is one 64-bit register pair");
   __shared__ uint64_t s_hash[kStageCap];
   __shared__ uint32_t s_blk[kStageCap];
@@ -157,7 +166,9 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
             if (slot < kStageCap) {
               s_hash[slot] = h;
               s_blk[slot] = t;
-            } else {  // staging full (tiny `scaled`): append straight to global
+            } else if (region_off) {  // staging full (tiny `scaled`): append straight to the genome's region
+              region_append(cand_hash, region_off, cursor, overflow, find_genome(genome_blk, n_genomes, t), h);
+            } else {  // ... or to the global candidate list
               const unsigned long long g = atomicAdd(count, 1ULL);
               if (g < cap) {
                 cand_hash[g] = h;
@@ -172,6 +183,27 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
   __syncthreads();
   const uint32_t n = min(s_n, kStageCap);
   if (n == 0) return;
+  if (region_off) {
+    // per-genome regions (see sketch_lds.hip): a workgroup that lies inside one genome -- all but the
+    // few that straddle a boundary -- reserves its slots with one atomic on that genome's cursor
+    const uint32_t b0 = blockIdx.x * kThreads;
+    const uint32_t b1 = min(b0 + (uint32_t)kThreads, n_blocks64) - 1u;
+    const uint32_t g0 = find_genome(genome_blk, n_genomes, b0);
+    if (genome_blk[g0 + 1] > b1) {
+      if (tid == 0) s_base = atomicAdd(&cursor[g0], n);
+      __syncthreads();
+      const uint64_t room = region_off[g0 + 1] - region_off[g0];
+      uint64_t *__restrict__ dst = cand_hash + region_off[g0];
+      for (uint32_t i = tid; i < n; i += kThreads) {
+        const uint64_t slot = s_base + i;
+        if (slot < room) dst[slot] = s_hash[i]; else *overflow = 1u;
+      }
+    } else {
+      for (uint32_t i = tid; i < n; i += kThreads)
+        region_append(cand_hash, region_off, cursor, overflow, find_genome(genome_blk, n_genomes, s_blk[i]), s_hash[i]);
+    }
+    return;
+  }
   if (tid == 0) s_base = atomicAdd(count, (unsigned long long)n);
   __syncthreads();
   const unsigned long long base = s_base;
@@ -187,12 +219,13 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
 template <int K, bool LUT>
 int launch_variant(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
            const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
-           uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count) {
+           uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count, const uint64_t *d_region_off, uint32_t *d_cursor,
+           uint32_t *d_overflow) {
   const uint32_t grid = ceil_div_u64(n_blocks64, kThreads);
   hipLaunchKernelGGL((kmer_hash_kernel<K, LUT>), dim3(grid), dim3(kThreads), 0, c->stream,
                      reinterpret_cast<const uint4 *>(d_packed), reinterpret_cast<const uint2 *>(d_mask),
                      (uint32_t)n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap,
-                     reinterpret_cast<unsigned long long *>(d_count));
+                     reinterpret_cast<unsigned long long *>(d_count), d_region_off, d_cursor, d_overflow);
   PA_HIP(hipGetLastError());
   return PA_OK;
 }
@@ -200,27 +233,29 @@ int launch_variant(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, 
 template <int K>
 int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
            const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
-           uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count) {
+           uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count, const uint64_t *d_region_off, uint32_t *d_cursor,
+           uint32_t *d_overflow) {
   static const bool arithmetic = [] {
     const char *v = getenv("PA_KMER_VARIANT");
     return v && v[0] == '0';
   }();
   if (arithmetic)
     return launch_variant<K, false>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
-                                    d_cand_genome, cap, d_count);
+                                    d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow);
   return launch_variant<K, true>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
-                                 d_cand_genome, cap, d_count);
+                                 d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow);
 }
 
 }  // namespace
 
 int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
                         const uint32_t *d_genome_blk, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
-                        uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count) {
+                        uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count,
+                        const uint64_t *d_region_off, uint32_t *d_cursor, uint32_t *d_overflow) {
   PA_REQUIRE(n_blocks64 < (1ULL << 32), "arena too large: %llu blocks of 64 bases", (unsigned long long)n_blocks64);
   if (n_blocks64 == 0) return PA_OK;
 #define PA_K_CASE(KK) \
-  case KK: return launch<KK>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap, d_count);
+  case KK: return launch<KK>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow);
   switch (k) {
     PA_K_CASE(15) PA_K_CASE(16) PA_K_CASE(17) PA_K_CASE(19) PA_K_CASE(21) PA_K_CASE(23) PA_K_CASE(25)
     PA_K_CASE(27) PA_K_CASE(29) PA_K_CASE(31) PA_K_CASE(32)

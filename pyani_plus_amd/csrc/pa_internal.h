@@ -83,6 +83,7 @@ struct pa_ctx {
   DevBuf counters;                    // small device scalars
   DevBuf hist;                        // radix histograms / scan scratch
   DevBuf flags, scan_tmp;             // compaction
+  DevBuf region_off, region_cursor;   // per-genome candidate regions (LDS-sort path)
   // workspaces (pair phase)
   DevBuf dict_keys[2], dict_vals[2];
   DevBuf ids, post_genome, bitrows;
@@ -120,7 +121,17 @@ int pa_exclusive_scan_u32(pa_ctx *c, const uint32_t *d_in, uint32_t *d_out, uint
 // kmer_hash.hip
 int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
                         const uint32_t *d_genome_blk, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
-                        uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count);
+                        uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count,
+                        const uint64_t *d_region_off = nullptr, uint32_t *d_cursor = nullptr,
+                        uint32_t *d_overflow = nullptr);
+// With d_region_off != nullptr the survivors of genome g go, unordered, to d_cand_hash[region_off[g] + i),
+// i < cursor[g] (zeroed by the caller); *d_overflow is set if a region was too small.
+
+// sketch_lds.hip: per-genome regions -> sorted unique CSR sketches, one workgroup and one LDS sort per genome
+constexpr uint32_t kLdsSortMax = 16384;  // longest region the LDS sort takes
+int pa_sketch_from_regions(pa_ctx *c, uint64_t *d_regions, const uint64_t *d_region_off, const uint32_t *d_cursor,
+                           const uint32_t *d_overflow, uint32_t n_genomes, uint32_t longest_region, uint64_t *d_hashes,
+                           uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total, bool *h_overflow);
 
 // sketch_build.hip
 int pa_build_sketch_csr(pa_ctx *c, const uint64_t *d_sorted_hash, const uint32_t *d_sorted_genome,
