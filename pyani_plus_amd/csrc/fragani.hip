@@ -466,6 +466,7 @@ __global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t
   if (i == n - 1) seg_start[pos[i] + flags[i]] = n;
 }
 
+constexpr int kSeenCap = 128;
 struct EvalShared {
   uint32_t qh[kQMax];
   uint32_t cnt[kQMax + 64];
@@ -474,6 +475,7 @@ struct EvalShared {
   uint32_t hc[kHitCap];   // contig of each staged hit
   uint32_t hq[kHitCap];   // query window id of each staged hit
   uint32_t run[kHitCap];  // inclusive prefix count of valid L1 runs starting at or before this index
+  uint32_t seen_c[kSeenCap], seen_p[kSeenCap];  // window starts already evaluated for this segment
 };
 
 // one wave per (fragment, reference genome) segment
@@ -534,7 +536,10 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   __syncthreads();
   uint32_t best_shared = 0, best_c = 0xffffffffu, best_p = 0xffffffffu;
   bool have_best = false;
-  uint32_t last_p = 0xffffffffu, last_c = 0xffffffffu;
+  // Substitutions shift the window a minimizer is first seen in, so the hits of one true location imply a
+  // handful of distinct starts over and over (~20 candidates, few distinct): remember the evaluated ones.
+  // The result of a start does not depend on when it is evaluated, so skipping repeats changes nothing.
+  uint32_t n_seen = 0;
   for (uint32_t chunk = 0; chunk < nh; chunk += 64) {
    // lane-parallel: does hit `chunk + lane` qualify, and which window start does it imply?
    uint32_t my_c = 0, my_p = 0;
@@ -574,8 +579,18 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     const int bit = __builtin_ctzll(todo);
     todo &= todo - 1;
     const uint32_t c = __shfl(my_c, bit, 64), p = __shfl(my_p, bit, 64);
-    if (p == last_p && c == last_c) continue;
-    last_p = p; last_c = c;
+    {
+      bool seen = false;
+      for (uint32_t base = 0; base < n_seen && !seen; base += 64) {
+        const uint32_t x = base + lane;
+        seen = __any(x < n_seen && sh.seen_p[x] == p && sh.seen_c[x] == c);
+      }
+      if (seen) continue;
+      if (n_seen < (uint32_t)kSeenCap) {
+        if (lane == 0) { sh.seen_c[n_seen] = c; sh.seen_p[n_seen] = p; }
+        ++n_seen;
+      }
+    }
     // ---- winnowed-MinHash Jaccard numerator of the fragment vs the reference window starting at p
     const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
