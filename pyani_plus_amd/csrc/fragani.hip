@@ -25,6 +25,7 @@
 
 #include "murmur_dev.h"
 #include "pa_internal.h"
+#include "wave_dev.h"
 
 namespace {
 
@@ -33,7 +34,7 @@ using namespace pa_dev;
 constexpr int kThreads = 256;
 constexpr uint32_t kSkip = 0xffffffffu;
 constexpr int kQMax = 512;       // largest fragment sketch handled
-constexpr int kHitCap = 512;     // seed hits of one (fragment, reference genome) segment staged in LDS
+constexpr int kHitCap = 256;     // seed hits of one (fragment, reference genome) segment staged in LDS
 constexpr double kPercIdentity = 80.0, kConfLevel = 0.9, kPvalCutoff = 1e-3, kRefSize = 5e6;
 
 // ============================================================== host statistics (Mashmap)
@@ -125,19 +126,10 @@ __device__ __forceinline__ uint32_t contig_of(const uint64_t *__restrict__ start
   }
   return lo;
 }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return pa_dev::wave_sum_dpp(v); }
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane) {
-  uint32_t inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = __shfl_up(inc, o, 64);
-    if (lane >= (uint32_t)o) inc += t;
-  }
-  return inc - v;
+  (void)lane;
+  return pa_dev::wave_incl_scan_dpp(v) - v;
 }
 
 // ============================================================== 1. minimizers
@@ -353,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const uint32_t *__restrict__ mini_id, const uint32_t *__restrict__ post_start,
     uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos, uint32_t *__restrict__ q_id, uint32_t *__restrict__ q_s,
-    uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow) {
+    uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow, uint32_t *__restrict__ max_hits) {
   __shared__ uint64_t s_key[kThreads / 64][kQMax];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * (kThreads / 64) + wave;
@@ -412,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     s += __popcll(bal);
   }
   hits = wave_sum(hits);
-  if (lane == 0) { q_s[f] = s; hit_count[f] = hits; }
+  if (lane == 0) { q_s[f] = s; hit_count[f] = hits; atomicMax(max_hits, hits); atomicMax(max_hits + 1, s); }
 }
 
 // ============================================================== 4. seed hits
@@ -466,33 +458,143 @@ __global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t
   if (i == n - 1) seg_start[pos[i] + flags[i]] = n;
 }
 
-constexpr int kSeenCap = 128;
+// ---- hits of one fragment, sorted by (contig, window) in LDS --------------------------------------
+// fill_hits_kernel leaves the hits of fragment f contiguous at hit_off[f]; they only need ordering
+// inside the fragment (the fragment number is the top of the key), so one workgroup sorts one fragment
+// in LDS (bitonic on the 64-bit key with its 32-bit payload) instead of 8 radix passes over the
+// whole batch.  Used when the busiest fragment has <= kFragSortMax hits.
+constexpr uint32_t kFragSortMax = 8192;
+constexpr int kFragSortThreads = 256;
+
+__global__ __launch_bounds__(kFragSortThreads) void frag_sort_kernel(uint64_t *__restrict__ keys,
+                                                                     uint32_t *__restrict__ vals,
+                                                                     const uint32_t *__restrict__ hit_off,
+                                                                     const uint32_t *__restrict__ hit_count,
+                                                                     uint32_t np2_max) {
+  extern __shared__ uint64_t fs_key[];
+  uint32_t *fs_val = reinterpret_cast<uint32_t *>(fs_key + np2_max);
+  const uint32_t f = blockIdx.x, tid = threadIdx.x;
+  const uint32_t n = hit_count[f];
+  if (n < 2) return;
+  const uint32_t a0 = hit_off[f];
+  uint32_t np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  for (uint32_t i = tid; i < np2; i += kFragSortThreads) {
+    fs_key[i] = i < n ? keys[a0 + i] : ~0ULL;
+    fs_val[i] = i < n ? vals[a0 + i] : 0u;
+  }
+  __syncthreads();
+  for (uint32_t k = 2; k <= np2; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = tid; t < (np2 >> 1); t += kFragSortThreads) {
+        const uint32_t i = 2u * t - (t & (j - 1u));
+        const uint32_t l = i + j;
+        const uint64_t a = fs_key[i], b = fs_key[l];
+        const bool up = (i & k) == 0u;
+        if ((a > b) == up && a != b) {
+          fs_key[i] = b;
+          fs_key[l] = a;
+          const uint32_t va = fs_val[i];
+          fs_val[i] = fs_val[l];
+          fs_val[l] = va;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = tid; i < n; i += kFragSortThreads) {
+    keys[a0 + i] = fs_key[i];
+    vals[a0 + i] = fs_val[i];
+  }
+}
+
+// keep the segments that can hold an L1 run at all: at least min_hits(s) seed hits
+__global__ __launch_bounds__(kThreads) void segment_keep_kernel(const uint64_t *__restrict__ keys,
+                                                                const uint32_t *__restrict__ seg_start, uint32_t n_segs,
+                                                                const uint32_t *__restrict__ q_s,
+                                                                const uint32_t *__restrict__ tab_min_hits,
+                                                                uint32_t *__restrict__ keep) {
+  const uint32_t seg = blockIdx.x * kThreads + threadIdx.x;
+  if (seg >= n_segs) return;
+  const uint32_t a0 = seg_start[seg], nh = seg_start[seg + 1] - a0;
+  const uint32_t s = q_s[(uint32_t)(keys[a0] >> 44)];
+  keep[seg] = (s != 0 && nh >= tab_min_hits[s]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(kThreads) void segment_list_kernel(const uint32_t *__restrict__ keep,
+                                                                const uint32_t *__restrict__ pos, uint32_t n_segs,
+                                                                uint32_t *__restrict__ seg_list) {
+  const uint32_t seg = blockIdx.x * kThreads + threadIdx.x;
+  if (seg < n_segs && keep[seg]) seg_list[pos[seg]] = seg;
+}
+
+constexpr int kSeenCap = 64;
+constexpr uint32_t kRefCap = 512;    // reference minimizers whose query rank is cached per segment
+constexpr uint32_t kRefSlack = 96;   // entries cached before the first window that asks for them
+// LDS of one segment's wave, carved from dynamic shared memory so that the query-hash arrays are only as
+// long as the longest fragment sketch of the batch (s_cap): ~7 KB per wave instead of 17 KB, which is what
+// sets how many of these latency-bound waves a CU keeps in flight.
 struct EvalShared {
-  uint32_t qh[kQMax];
-  uint32_t cnt[kQMax + 64];
-  uint32_t matched[kQMax / 32];
-  uint32_t hw[kHitCap];   // window id of each staged hit
-  uint32_t hc[kHitCap];   // contig of each staged hit
-  uint32_t hq[kHitCap];   // query window id of each staged hit
-  uint32_t run[kHitCap];  // inclusive prefix count of valid L1 runs starting at or before this index
-  uint32_t seen_c[kSeenCap], seen_p[kSeenCap];  // window starts already evaluated for this segment
+  uint32_t *qh;        // [s_cap] the fragment's sketch, ascending
+  uint32_t *cnt;       // [s_cap + 64] reference-only hashes per query-rank gap
+  uint32_t *matched;   // [kQMax / 32] bitset over query ranks
+  uint32_t *hw;        // [kHitCap] window id of each staged hit
+  uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
+  uint16_t *hq;        // [kHitCap] query window id of each staged hit
+  uint16_t *run;       // [kHitCap] inclusive prefix count of valid L1 runs starting at or before this index
+  uint32_t *seen_c, *seen_p;  // [kSeenCap] window starts already evaluated for this segment
+  uint16_t *ref_rank;  // [kRefCap] bit 15: the hash is one of the query's; bits 0-14: its rank among them
+  int16_t *ref_prev;   // [kRefCap] previous occurrence of the same hash, relative to the cache start (-1: before)
+  uint16_t *ref_w;     // [kRefCap] window id relative to the first cached minimizer's
 };
+__host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap) {
+  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + (uint32_t)kHitCap * 10u + (uint32_t)kSeenCap * 8u +
+         kRefCap * 6u;
+}
+__device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap) {
+  EvalShared sh;
+  sh.qh = base;
+  sh.cnt = sh.qh + s_cap;
+  sh.matched = sh.cnt + s_cap + 64u;
+  sh.hw = sh.matched + kQMax / 32;
+  sh.seen_c = sh.hw + kHitCap;
+  sh.seen_p = sh.seen_c + kSeenCap;
+  sh.hc = reinterpret_cast<uint16_t *>(sh.seen_p + kSeenCap);
+  sh.hq = sh.hc + kHitCap;
+  sh.run = sh.hq + kHitCap;
+  sh.ref_rank = sh.run + kHitCap;
+  sh.ref_prev = reinterpret_cast<int16_t *>(sh.ref_rank + kRefCap);
+  sh.ref_w = reinterpret_cast<uint16_t *>(sh.ref_prev + kRefCap);
+  return sh;
+}
+
+// Number of the first n (<= 512) ascending entries of w that are < target: two rounds of a 64-way search,
+// every lane looks at one entry per round (uniform arguments, uniform result).
+__device__ __forceinline__ uint32_t lds_count_below(const uint16_t *w, uint32_t n, uint32_t target, uint32_t lane) {
+  const uint32_t i1 = lane * 8u;
+  const uint32_t c1 = (uint32_t)__popcll(__ballot(i1 < n && (uint32_t)w[i1] < target));
+  if (c1 == 0) return 0;
+  const uint32_t i2 = (c1 - 1u) * 8u + 1u + lane;
+  const uint32_t c2 = (uint32_t)__popcll(__ballot(lane < 7u && i2 < n && (uint32_t)w[i2] < target));
+  return (c1 - 1u) * 8u + 1u + c2;
+}
 
 // one wave per (fragment, reference genome) segment
 __global__ __launch_bounds__(64) void map_segments_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_start,
-    uint32_t n_segs, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
+    const uint32_t *__restrict__ seg_list, uint32_t n_segs, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
     const uint32_t *__restrict__ frag_genome_local, uint32_t frag_len, uint32_t count_windows,
     const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ tab_min_shared,
     const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const int32_t *__restrict__ prev_same,
     const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride, unsigned long long *__restrict__ table,
-    uint32_t *__restrict__ run_g) {
-  __shared__ EvalShared sh;
+    uint32_t *__restrict__ run_g, uint32_t s_cap) {
+  extern __shared__ uint32_t eval_lds[];
+  const EvalShared sh = eval_carve(eval_lds, s_cap);
   const uint32_t lane = threadIdx.x;
-  const uint32_t seg = blockIdx.x;
-  if (seg >= n_segs) return;
+  if (blockIdx.x >= n_segs) return;
+  const uint32_t seg = seg_list[blockIdx.x];
   const uint32_t a0 = seg_start[seg];
   uint32_t nh = seg_start[seg + 1] - a0;
   const uint32_t f = (uint32_t)(keys[a0] >> 44);
@@ -502,9 +604,13 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   if (nh < mh) return;  // chance matches with unrelated genomes: fewer seed hits than any L1 run needs
   // segments of up to kHitCap hits are staged in LDS; larger ones (repeats: rRNA operons, IS elements)
   // are read in place from the sorted hit arrays
-  const bool staged = nh <= (uint32_t)kHitCap;
+  const uint32_t hc_base = (uint32_t)(keys[a0] >> 24) & 0xfffffu;
+  const bool staged = nh <= (uint32_t)kHitCap && count_windows <= 0xffffu &&
+                      ((uint32_t)(keys[a0 + nh - 1u] >> 24) & 0xfffffu) - hc_base <= 0xffffu;
   auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] : (uint32_t)(keys[a0 + i] & 0xffffffu); };
-  auto HC = [&](uint32_t i) -> uint32_t { return staged ? sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu; };
+  auto HC = [&](uint32_t i) -> uint32_t {
+    return staged ? hc_base + sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu;
+  };
   auto HQ = [&](uint32_t i) -> uint32_t { return staged ? sh.hq[i] : vals[a0 + i]; };
   auto RUN = [&](uint32_t i) -> uint32_t { return staged ? sh.run[i] : run_g[a0 + i]; };
   for (uint32_t i = lane; i < s; i += 64) sh.qh[i] = q_hash[(uint64_t)f * kQMax + i];
@@ -512,8 +618,8 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     for (uint32_t i = lane; i < nh; i += 64) {
       const uint64_t key = keys[a0 + i];
       sh.hw[i] = (uint32_t)(key & 0xffffffu);
-      sh.hc[i] = (uint32_t)(key >> 24) & 0xfffffu;
-      sh.hq[i] = vals[a0 + i];
+      sh.hc[i] = (uint16_t)(((uint32_t)(key >> 24) & 0xfffffu) - hc_base);
+      sh.hq[i] = (uint16_t)vals[a0 + i];
     }
   }
   __syncthreads();
@@ -526,7 +632,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       uint32_t v = 0;
       if (i + mh <= nh && HC(i) == HC(i + mh - 1) && HW(i + mh - 1) - HW(i) < frag_len) v = 1;
       const uint32_t ex = wave_excl_scan(v, lane);
-      if (i < nh) { if (staged) sh.run[i] = carry + ex + v; else run_g[a0 + i] = carry + ex + v; }
+      if (i < nh) { if (staged) sh.run[i] = (uint16_t)(carry + ex + v); else run_g[a0 + i] = carry + ex + v; }
       carry += wave_sum(v);
     }
     n_runs = carry;
@@ -540,6 +646,12 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   // handful of distinct starts over and over (~20 candidates, few distinct): remember the evaluated ones.
   // The result of a start does not depend on when it is evaluated, so skipping repeats changes nothing.
   uint32_t n_seen = 0;
+  // The windows a segment asks about start within a few minimizers of each other, so the rank of every
+  // reference minimizer among the query hashes (a 9-step search) and its duplicate link are worked out
+  // once per stretch of kRefCap minimizers and reused by all of them.
+  // The cache also keeps the window ids, so where a window begins and ends among the reference minimizers
+  // is a two-round LDS search; only the first window of a stretch walks the bucket index in HBM.
+  uint32_t cache_c = 0xffffffffu, cache_lo = 0, cache_hi = 0, cache_wbase = 0, cache_pmin = 1, cache_wmax = 0;
   for (uint32_t chunk = 0; chunk < nh; chunk += 64) {
    // lane-parallel: does hit `chunk + lane` qualify, and which window start does it imply?
    uint32_t my_c = 0, my_p = 0;
@@ -592,21 +704,85 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       }
     }
     // ---- winnowed-MinHash Jaccard numerator of the fragment vs the reference window starting at p
-    const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
-    const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
-    const uint32_t b = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p);
-    const uint32_t e = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p + count_windows);
-    const bool fresh = b < m1 && mini_wpos[b] == p;
-    const uint32_t b0 = (!fresh && b > m0) ? b - 1 : b;
+    uint32_t b0, e;
+    if (c == cache_c && p >= cache_pmin && p + count_windows <= cache_wmax) {
+      const uint32_t n = cache_hi - cache_lo;
+      const uint32_t tb = p > cache_wbase ? p - cache_wbase : 0u;
+      const uint32_t b = cache_lo + lds_count_below(sh.ref_w, n, tb, lane);
+      const uint32_t te = p + count_windows > cache_wbase ? p + count_windows - cache_wbase : 0u;
+      e = cache_lo + lds_count_below(sh.ref_w, n, te, lane);
+      const bool fresh = b < cache_hi && p >= cache_wbase && (uint32_t)sh.ref_w[b - cache_lo] == p - cache_wbase;
+      b0 = (!fresh && b > cache_lo) ? b - 1 : b;  // cache_lo is the contig's first minimizer whenever b can equal it
+    } else {
+      const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
+      const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
+      const uint32_t b = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p);
+      e = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p + count_windows);
+      const bool fresh = b < m1 && mini_wpos[b] == p;
+      b0 = (!fresh && b > m0) ? b - 1 : b;
+      if (e - b0 <= kRefCap) {  // cache the stretch around this window: all loads first, then the rank searches
+        uint32_t lo = b0 > m0 + kRefSlack ? b0 - kRefSlack : m0;
+        if (e > lo + kRefCap) lo = e - kRefCap;
+        uint32_t hi = min(m1, lo + kRefCap);
+        constexpr int kPer = (int)(kRefCap / 64u);
+        uint32_t hh[kPer], ww[kPer];
+        int32_t pp[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint32_t t = lo + (uint32_t)q * 64u + lane;
+          const bool in = t < hi;
+          hh[q] = in ? mini_hash[t] : 0u;
+          ww[q] = in ? mini_wpos[t] : 0xffffffffu;
+          pp[q] = in ? prev_same[t] : -1;
+        }
+        const uint32_t wbase = __shfl(ww[0], 0, 64);
+        // window ids are kept as 16-bit offsets: stop the stretch where they no longer fit
+        uint32_t fit = hi - lo;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint64_t far = __ballot(lo + (uint32_t)q * 64u + lane < hi && ww[q] - wbase > 0xfffeu);
+          if (far && fit == hi - lo) fit = (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(far);
+        }
+        hi = lo + fit;
+        if (e <= hi) {
+          __syncthreads();
+#pragma unroll
+          for (int q = 0; q < kPer; ++q) {
+            const uint32_t x = (uint32_t)q * 64u + lane;
+            if (lo + x < hi) {
+              const uint32_t r = lower_bound_u32(sh.qh, 0, s, hh[q]);
+              sh.ref_rank[x] = (uint16_t)(r | ((r < s && sh.qh[r] == hh[q]) ? 0x8000u : 0u));
+              sh.ref_prev[x] = (int16_t)(pp[q] >= (int32_t)lo ? pp[q] - (int32_t)lo : -1);
+              sh.ref_w[x] = (uint16_t)(ww[q] - wbase);
+            }
+          }
+          cache_c = c; cache_lo = lo; cache_hi = hi; cache_wbase = wbase;
+          cache_pmin = lo == m0 ? 0u : wbase + 1u;
+          __syncthreads();
+          cache_wmax = hi == m1 ? 0xffffffffu : wbase + (uint32_t)sh.ref_w[hi - lo - 1u];
+        }
+      }
+    }
     for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
     if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
     __syncthreads();
-    for (uint32_t t = b0 + lane; t < e; t += 64) {
-      if (prev_same[t] >= (int32_t)b0) continue;  // the same hash already counted inside this window
-      const uint32_t h = mini_hash[t];
-      const uint32_t r = lower_bound_u32(sh.qh, 0, s, h);
-      if (r < s && sh.qh[r] == h) atomicOr(&sh.matched[r >> 5], 1u << (r & 31u));
-      else atomicAdd(&sh.cnt[r], 1u);
+    if (c == cache_c && b0 >= cache_lo && e <= cache_hi) {
+      const int32_t rel0 = (int32_t)(b0 - cache_lo);
+      for (uint32_t t = b0 + lane; t < e; t += 64) {
+        const uint32_t x = t - cache_lo;
+        if ((int32_t)sh.ref_prev[x] >= rel0) continue;  // the same hash already counted inside this window
+        const uint32_t rr = sh.ref_rank[x], r = rr & 0x7fffu;
+        if (rr & 0x8000u) atomicOr(&sh.matched[r >> 5], 1u << (r & 31u));
+        else atomicAdd(&sh.cnt[r], 1u);
+      }
+    } else {  // a window of more than kRefCap minimizers: straight from HBM
+      for (uint32_t t = b0 + lane; t < e; t += 64) {
+        if (prev_same[t] >= (int32_t)b0) continue;
+        const uint32_t h = mini_hash[t];
+        const uint32_t r = lower_bound_u32(sh.qh, 0, s, h);
+        if (r < s && sh.qh[r] == h) atomicOr(&sh.matched[r >> 5], 1u << (r & 31u));
+        else atomicAdd(&sh.cnt[r], 1u);
+      }
     }
     __syncthreads();
     // x = reference-only hashes among the s smallest of the union: bucket r (between query ranks r-1 and r)
@@ -696,7 +872,7 @@ struct FragWork {
   DevBuf contig_start, contig_len, contig_genome, block_counts, block_offsets, mini_hash, mini_wpos, mini_contig,
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
-      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g,
+      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list,
       contig_bucket_off, bucket_first;
   ~FragWork() {
     DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
@@ -704,7 +880,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &contig_bucket_off, &bucket_first};
+                     &ident_sum, &scalars, &run_g, &seg_list, &contig_bucket_off, &bucket_first};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -913,6 +1089,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   const uint64_t kMaxTableBytes = 1ULL << 30;
   PA_TRY(W.scalars.reserve(64));
   uint32_t *d_overflow = W.scalars.as<uint32_t>() + 8;
+  uint32_t *d_max_hits = W.scalars.as<uint32_t>() + 12;  // most seed hits of one fragment in the batch
   PA_HIP(hipMemsetAsync(d_overflow, 0, 8, c->stream));
   for (uint32_t g0 = 0; g0 < n_genomes;) {
     uint32_t g1 = g0 + 1;
@@ -936,15 +1113,19 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
     PA_TRY(W.hit_count.reserve((uint64_t)nf * 4));
     PA_TRY(W.hit_off.reserve((uint64_t)nf * 4));
     const uint32_t gw = ceil_div_u64(nf, kThreads / 64);
+    PA_HIP(hipMemsetAsync(d_max_hits, 0, 8, c->stream));  // [0] most hits, [1] longest sketch of a fragment
     hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, W.frag_contig.as<uint32_t>(),
                        W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
                        W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),
-                       W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow);
+                       W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits);
     PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipMemcpyAsync(c->h_pinned + 1, d_max_hits, 8, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipStreamSynchronize(c->stream));
     const uint64_t n_hits = c->h_pinned[0];
+    const uint32_t max_hits = (uint32_t)c->h_pinned[1];
+    const uint32_t s_cap = std::min<uint32_t>(kQMax, (((uint32_t)(c->h_pinned[1] >> 32) + 63u) / 64u) * 64u);
     PA_REQUIRE(n_hits < (1ULL << 31), "pa_fragani: %llu seed hits in one batch (limit 2^31); highly repetitive input",
                (unsigned long long)n_hits);
     PA_TRY(W.table.reserve((uint64_t)nq * total_bins * 8));
@@ -962,7 +1143,17 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
       bits = (bits + 1 + 7) & ~7;
       if (bits > 64) bits = 64;
       int hw = 0;
-      PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
+      if (max_hits <= kFragSortMax) {  // every fragment's hits fit one LDS sort
+        uint32_t np2_max = 2;
+        while (np2_max < max_hits) np2_max <<= 1;
+        const uint32_t lds_bytes = np2_max * 12u;
+        PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(frag_sort_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(frag_sort_kernel, dim3(nf), dim3(kFragSortThreads), lds_bytes, c->stream, hk[0], hv[0],
+                           W.hit_off.as<uint32_t>(), W.hit_count.as<uint32_t>(), np2_max);
+      } else {
+        PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
+      }
       PA_TRY(W.flags.reserve(n_hits * 8 + 64));
       uint32_t *hf = W.flags.as<uint32_t>(), *hp = hf + n_hits;
       const uint32_t gh = ceil_div_u64(n_hits, kThreads);
@@ -976,13 +1167,26 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
       PA_TRY(W.run_g.reserve(n_hits * 4 + 16));
       hipLaunchKernelGGL(segment_starts_kernel, dim3(gh), dim3(kThreads), 0, c->stream, hf, hp, (uint32_t)n_hits,
                          W.seg_start.as<uint32_t>());
-      hipLaunchKernelGGL(map_segments_kernel, dim3(n_segs), dim3(64), 0, c->stream, hk[hw], hv[hw],
-                         W.seg_start.as<uint32_t>(), n_segs, W.q_hash.as<uint32_t>(), W.q_s.as<uint32_t>(),
+      // most segments are chance hits of unrelated genomes (fewer hits than any L1 run needs): drop them
+      // here, one thread each, instead of spending a workgroup launch on each in the mapping kernel
+      const uint32_t gs = ceil_div_u64(n_segs, kThreads);
+      hipLaunchKernelGGL(segment_keep_kernel, dim3(gs), dim3(kThreads), 0, c->stream, hk[hw],
+                         W.seg_start.as<uint32_t>(), n_segs, W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(), hf);
+      PA_TRY(pa_exclusive_scan_u32(c, hf, hp, n_segs, W.scalars.as<uint64_t>()));
+      PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+      PA_HIP(hipStreamSynchronize(c->stream));
+      const uint32_t n_keep = (uint32_t)c->h_pinned[0];
+      PA_TRY(W.seg_list.reserve((uint64_t)(n_keep + 1) * 4));
+      hipLaunchKernelGGL(segment_list_kernel, dim3(gs), dim3(kThreads), 0, c->stream, hf, hp, n_segs,
+                         W.seg_list.as<uint32_t>());
+      if (n_keep)
+      hipLaunchKernelGGL(map_segments_kernel, dim3(n_keep), dim3(64), eval_lds_bytes(s_cap), c->stream, hk[hw], hv[hw],
+                         W.seg_start.as<uint32_t>(), W.seg_list.as<uint32_t>(), n_keep, W.q_hash.as<uint32_t>(), W.q_s.as<uint32_t>(),
                          W.frag_genome_local.as<uint32_t>(), frag_len, count_windows, W.tab_min_hits.as<uint32_t>(),
                          W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),
                          W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),
                          W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(),
-                         total_bins, W.table.as<unsigned long long>(), W.run_g.as<uint32_t>());
+                         total_bins, W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap);
     }
     PA_TRY(W.matched.reserve((uint64_t)nq * n_genomes * 4));
     PA_TRY(W.ident_sum.reserve((uint64_t)nq * n_genomes * 8));
