@@ -34,7 +34,7 @@ using namespace pa_dev;
 constexpr int kThreads = 256;
 constexpr uint32_t kSkip = 0xffffffffu;
 constexpr int kQMax = 512;       // largest fragment sketch handled
-constexpr int kHitCap = 256;     // seed hits of one (fragment, reference genome) segment staged in LDS
+constexpr int kHitCap = 512;     // seed hits of one (fragment, reference genome) segment staged in LDS
 constexpr double kPercIdentity = 80.0, kConfLevel = 0.9, kPvalCutoff = 1e-3, kRefSize = 5e6;
 
 // ============================================================== host statistics (Mashmap)
@@ -322,11 +322,14 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
                                                             const uint32_t *__restrict__ pos, uint32_t m, uint32_t n_ids,
                                                             const uint32_t *__restrict__ mini_contig,
                                                             uint32_t *__restrict__ mini_id, uint32_t *__restrict__ post_start,
-                                                            int32_t *__restrict__ prev_same) {
+                                                            int32_t *__restrict__ prev_same,
+                                                            const uint32_t *__restrict__ mini_wpos,
+                                                            uint64_t *__restrict__ post_cw) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= m) return;
   const uint32_t id = pos[i] + flags[i] - 1u, me = sorted_idx[i];
   mini_id[me] = id;
+  post_cw[i] = ((uint64_t)mini_contig[me] << 24) | mini_wpos[me];  // the posting as the low 44 bits of a hit key
   if (flags[i]) post_start[id] = i;
   if (i == m - 1) post_start[n_ids] = m;
   int32_t ps = -1;
@@ -458,6 +461,94 @@ __global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t
   if (i == n - 1) seg_start[pos[i] + flags[i]] = n;
 }
 
+// ---- hits of one fragment, bucketed by reference genome --------------------------------------------
+// One wave per fragment and an LDS counter per reference genome: count the postings of the fragment's
+// minimizers per genome, scan, then write every hit into its genome's slice of the fragment's hit range.
+// The (fragment, genome) segments fall out of the scan, so the ones that can hold an L1 run (>= min_hits
+// seed hits) are listed right here; nothing is sorted -- the mapping kernel orders the <= kHitCap hits of a
+// segment in LDS, longer segments (repeats) are listed for segment_sort.  Eight lanes walk one posting
+// list, so a wave reads 8 lists at a time in 64-byte pieces.
+constexpr int kBucketWaves = 4;
+__global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
+    uint32_t n_frags, const uint32_t *__restrict__ q_pos, const uint32_t *__restrict__ q_id,
+    const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ hit_off, const uint32_t *__restrict__ post_start,
+    const uint64_t *__restrict__ post_cw, const uint32_t *__restrict__ contig_genome, uint32_t n_genomes,
+    const uint32_t *__restrict__ tab_min_hits, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+    uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t seg_cap, uint32_t *__restrict__ counters) {
+  extern __shared__ uint32_t bk_lds[];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t f = blockIdx.x * kBucketWaves + wave;
+  if (f >= n_frags) return;  // no workgroup barriers below
+  uint32_t *hist = bk_lds + (uint64_t)wave * n_genomes;
+  const uint32_t s = q_s[f];
+  const uint32_t base = hit_off[f];
+  const uint32_t sub = lane & 7u, grp = lane >> 3;
+  for (uint32_t g = lane; g < n_genomes; g += 64) hist[g] = 0;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i0 = 0; i0 < s; i0 += 8) {
+    const uint32_t i = i0 + grp;
+    if (i < s) {
+      const uint32_t id = q_id[(uint64_t)f * kQMax + i];
+      const uint32_t lo = post_start[id], n = post_start[id + 1] - lo;
+      for (uint32_t t = sub; t < n; t += 8)
+        atomicAdd(&hist[contig_genome[(uint32_t)(post_cw[lo + t] >> 24)]], 1u);
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // exclusive scan over the genomes; list the segments worth mapping
+  const uint32_t mh = s ? tab_min_hits[s] : 0xffffffffu;
+  uint32_t carry = 0;
+  for (uint32_t g0 = 0; g0 < n_genomes; g0 += 64) {
+    const uint32_t g = g0 + lane;
+    const uint32_t cnt = g < n_genomes ? hist[g] : 0u;
+    const uint32_t off = carry + wave_excl_scan(cnt, lane);
+    if (g < n_genomes) hist[g] = off;
+    const bool keep = cnt >= mh;
+    const uint64_t km = __ballot(keep);
+    if (km) {
+      uint32_t slot0 = 0;
+      if (lane == 0) slot0 = atomicAdd(&counters[0], (uint32_t)__popcll(km));
+      slot0 = __shfl(slot0, 0, 64);
+      if (keep) {
+        const uint32_t slot = slot0 + (uint32_t)__popcll(km & ((1ULL << lane) - 1ULL));
+        if (slot < seg_cap) { seg_a0[slot] = base + off; seg_nh[slot] = cnt; }
+      }
+      const uint64_t bm = __ballot(keep && cnt > (uint32_t)kHitCap);
+      if (bm && lane == 0) atomicAdd(&counters[1], (uint32_t)__popcll(bm));
+      if (keep && cnt > (uint32_t)kHitCap) atomicMax(&counters[2], cnt);
+    }
+    carry += wave_sum(cnt);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i0 = 0; i0 < s; i0 += 8) {
+    const uint32_t i = i0 + grp;
+    if (i < s) {
+      const uint32_t id = q_id[(uint64_t)f * kQMax + i];
+      const uint32_t lo = post_start[id], n = post_start[id + 1] - lo;
+      const uint32_t qp = q_pos[(uint64_t)f * kQMax + i];
+      for (uint32_t t = sub; t < n; t += 8) {
+        const uint64_t cw = post_cw[lo + t];
+        const uint32_t slot = base + atomicAdd(&hist[contig_genome[(uint32_t)(cw >> 24)]], 1u);
+        keys[slot] = ((uint64_t)f << 44) | cw;
+        vals[slot] = qp;
+      }
+    }
+  }
+}
+
+// the listed segments longer than kHitCap, as (start, length) pairs for frag_sort_kernel
+__global__ __launch_bounds__(kThreads) void big_segments_kernel(const uint32_t *__restrict__ seg_a0,
+                                                                const uint32_t *__restrict__ seg_nh, uint32_t n_segs,
+                                                                uint32_t *__restrict__ big_a0,
+                                                                uint32_t *__restrict__ big_nh,
+                                                                uint32_t *__restrict__ counter) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_segs || seg_nh[i] <= (uint32_t)kHitCap) return;
+  const uint32_t slot = atomicAdd(counter, 1u);
+  big_a0[slot] = seg_a0[i];
+  big_nh[slot] = seg_nh[i];
+}
+
 // ---- hits of one fragment, sorted by (contig, window) in LDS --------------------------------------
 // fill_hits_kernel leaves the hits of fragment f contiguous at hit_off[f]; they only need ordering
 // inside the fragment (the fragment number is the top of the key), so one workgroup sorts one fragment
@@ -528,6 +619,18 @@ __global__ __launch_bounds__(kThreads) void segment_list_kernel(const uint32_t *
   if (seg < n_segs && keep[seg]) seg_list[pos[seg]] = seg;
 }
 
+// old path: the kept segments of the fully sorted hit list as (start, length) pairs
+__global__ __launch_bounds__(kThreads) void segments_from_list_kernel(const uint32_t *__restrict__ seg_start,
+                                                                      const uint32_t *__restrict__ seg_list,
+                                                                      uint32_t n, uint32_t *__restrict__ seg_a0,
+                                                                      uint32_t *__restrict__ seg_nh) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t seg = seg_list[i];
+  seg_a0[i] = seg_start[seg];
+  seg_nh[i] = seg_start[seg + 1] - seg_start[seg];
+}
+
 constexpr int kSeenCap = 64;
 constexpr uint32_t kRefCap = 512;    // reference minimizers whose query rank is cached per segment
 constexpr uint32_t kRefSlack = 96;   // entries cached before the first window that asks for them
@@ -581,8 +684,9 @@ __device__ __forceinline__ uint32_t lds_count_below(const uint16_t *w, uint32_t 
 
 // one wave per (fragment, reference genome) segment
 __global__ __launch_bounds__(64) void map_segments_kernel(
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_start,
-    const uint32_t *__restrict__ seg_list, uint32_t n_segs, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
+    uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_a0,
+    const uint32_t *__restrict__ seg_nh, uint32_t n_segs, bool presorted, const uint32_t *__restrict__ contig_genome,
+    const uint32_t *__restrict__ genome_first_contig, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
     const uint32_t *__restrict__ frag_genome_local, uint32_t frag_len, uint32_t count_windows,
     const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ tab_min_shared,
     const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
@@ -594,9 +698,8 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   const EvalShared sh = eval_carve(eval_lds, s_cap);
   const uint32_t lane = threadIdx.x;
   if (blockIdx.x >= n_segs) return;
-  const uint32_t seg = seg_list[blockIdx.x];
-  const uint32_t a0 = seg_start[seg];
-  uint32_t nh = seg_start[seg + 1] - a0;
+  const uint32_t a0 = seg_a0[blockIdx.x];
+  uint32_t nh = seg_nh[blockIdx.x];
   const uint32_t f = (uint32_t)(keys[a0] >> 44);
   const uint32_t s = q_s[f];
   if (s == 0) return;
@@ -604,9 +707,10 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   if (nh < mh) return;  // chance matches with unrelated genomes: fewer seed hits than any L1 run needs
   // segments of up to kHitCap hits are staged in LDS; larger ones (repeats: rRNA operons, IS elements)
   // are read in place from the sorted hit arrays
-  const uint32_t hc_base = (uint32_t)(keys[a0] >> 24) & 0xfffffu;
-  const bool staged = nh <= (uint32_t)kHitCap && count_windows <= 0xffffu &&
-                      ((uint32_t)(keys[a0 + nh - 1u] >> 24) & 0xfffffu) - hc_base <= 0xffffu;
+  // contigs are kept relative to the reference genome's first one, window ids of the query as 16 bits: the
+  // host takes this kernel only when both fit
+  const uint32_t hc_base = genome_first_contig[contig_genome[(uint32_t)(keys[a0] >> 24) & 0xfffffu]];
+  const bool staged = nh <= (uint32_t)kHitCap;
   auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] : (uint32_t)(keys[a0 + i] & 0xffffffu); };
   auto HC = [&](uint32_t i) -> uint32_t {
     return staged ? hc_base + sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu;
@@ -620,6 +724,31 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       sh.hw[i] = (uint32_t)(key & 0xffffffu);
       sh.hc[i] = (uint16_t)(((uint32_t)(key >> 24) & 0xfffffu) - hc_base);
       sh.hq[i] = (uint16_t)vals[a0 + i];
+    }
+    if (!presorted) {
+      // the bucketing pass leaves a segment's hits in no particular order: bitonic sort by (contig, window)
+      // in LDS, padded to a power of two with keys above any real one
+      uint32_t np2 = 2;
+      while (np2 < nh) np2 <<= 1;
+      for (uint32_t i = nh + lane; i < np2; i += 64) { sh.hw[i] = 0xffffffffu; sh.hc[i] = 0xffffu; sh.hq[i] = 0; }
+      __syncthreads();
+      for (uint32_t k = 2; k <= np2; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          for (uint32_t t = lane; t < (np2 >> 1); t += 64) {
+            const uint32_t i = 2u * t - (t & (j - 1u)), l = i + j;
+            const uint64_t ka = ((uint64_t)sh.hc[i] << 32) | sh.hw[i], kb = ((uint64_t)sh.hc[l] << 32) | sh.hw[l];
+            const bool up = (i & k) == 0u;
+            if ((ka > kb) == up && ka != kb) {
+              sh.hw[i] = (uint32_t)kb; sh.hc[i] = (uint16_t)(kb >> 32);
+              sh.hw[l] = (uint32_t)ka; sh.hc[l] = (uint16_t)(ka >> 32);
+              const uint16_t qa = sh.hq[i];
+              sh.hq[i] = sh.hq[l];
+              sh.hq[l] = qa;
+            }
+          }
+          __syncthreads();
+        }
+      }
     }
   }
   __syncthreads();
@@ -872,7 +1001,7 @@ struct FragWork {
   DevBuf contig_start, contig_len, contig_genome, block_counts, block_offsets, mini_hash, mini_wpos, mini_contig,
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
-      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list,
+      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, post_cw, seg_a0, seg_nh, genome_first_contig,
       contig_bucket_off, bucket_first;
   ~FragWork() {
     DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
@@ -880,7 +1009,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &contig_bucket_off, &bucket_first};
+                     &ident_sum, &scalars, &run_g, &seg_list, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -1051,6 +1180,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   PA_TRY(W.flags.reserve((uint64_t)m * 8 + 64));
   PA_TRY(W.mini_id.reserve((uint64_t)m * 4));
   PA_TRY(W.prev_same.reserve((uint64_t)m * 4));
+  PA_TRY(W.post_cw.reserve((uint64_t)m * 8));
   uint64_t *keys[2] = {W.keys[0].as<uint64_t>(), W.keys[1].as<uint64_t>()};
   uint32_t *vals[2] = {W.vals[0].as<uint32_t>(), W.vals[1].as<uint32_t>()};
   const uint32_t gm = ceil_div_u64(m, kThreads);
@@ -1066,7 +1196,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
   hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
                      n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
-                     W.prev_same.as<int32_t>());
+                     W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.post_cw.as<uint64_t>());
   const uint32_t *d_sorted_idx = vals[which];
 
   // ---- tables indexed by sketch size
@@ -1090,6 +1220,29 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   PA_TRY(W.scalars.reserve(64));
   uint32_t *d_overflow = W.scalars.as<uint32_t>() + 8;
   uint32_t *d_max_hits = W.scalars.as<uint32_t>() + 12;  // most seed hits of one fragment in the batch
+  uint32_t *d_seg_counters = W.scalars.as<uint32_t>() + 4;  // [0] listed segments, [1] long ones, [2] longest, [3] cursor
+  // The bucketed pipeline needs an LDS counter per reference genome for each of a workgroup's waves and
+  // 16-bit fields for query window ids and for contigs within a genome; otherwise the sorted pipeline runs.
+  std::vector<uint32_t> gfc(n_genomes + 1, n_contigs);
+  uint32_t most_contigs = 0;
+  {
+    for (uint32_t ci = n_contigs; ci-- > 0;) gfc[h_contig_genome[ci]] = ci;
+    for (uint32_t g = n_genomes; g-- > 0;) if (gfc[g] == n_contigs) gfc[g] = gfc[g + 1];  // genome without contigs
+    for (uint32_t g = 0; g < n_genomes; ++g) most_contigs = std::max(most_contigs, gfc[g + 1] - gfc[g]);
+    bool genome_major = true;
+    for (uint32_t ci = 1; ci < n_contigs; ++ci) genome_major = genome_major && h_contig_genome[ci] >= h_contig_genome[ci - 1];
+    PA_REQUIRE(genome_major, "pa_fragani: contigs must be listed genome by genome");
+  }
+  PA_TRY(upload(c, W.genome_first_contig, gfc));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  static const bool force_sorted = [] {
+    const char *v = getenv("PA_FRAGANI_HITS");
+    return v && v[0] == 's';
+  }();
+  const bool fields_fit = count_windows <= 0xffffu && most_contigs <= 0xffffu;
+  PA_REQUIRE(fields_fit, "pa_fragani: fragment length %u or %u contigs in one genome exceed the 16-bit fields of the "
+                         "mapping kernel", frag_len, most_contigs);
+  const bool use_buckets = !force_sorted && (uint64_t)kBucketWaves * n_genomes * 4u <= 128u * 1024u;
   PA_HIP(hipMemsetAsync(d_overflow, 0, 8, c->stream));
   for (uint32_t g0 = 0; g0 < n_genomes;) {
     uint32_t g1 = g0 + 1;
@@ -1134,59 +1287,114 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
       for (int b = 0; b < 2; ++b) { PA_TRY(W.hkeys[b].reserve(n_hits * 8)); PA_TRY(W.hvals[b].reserve(n_hits * 4)); }
       uint64_t *hk[2] = {W.hkeys[0].as<uint64_t>(), W.hkeys[1].as<uint64_t>()};
       uint32_t *hv[2] = {W.hvals[0].as<uint32_t>(), W.hvals[1].as<uint32_t>()};
-      hipLaunchKernelGGL(fill_hits_kernel, dim3(gw), dim3(kThreads), 0, c->stream, nf, W.q_pos.as<uint32_t>(),
-                         W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_off.as<uint32_t>(),
-                         W.post_start.as<uint32_t>(), d_sorted_idx, W.mini_wpos.as<uint32_t>(),
-                         W.mini_contig.as<uint32_t>(), hk[0], hv[0]);
+      PA_TRY(W.run_g.reserve(n_hits * 4 + 16));
       int bits = 44;
       for (uint32_t x = nf; x > 1; x >>= 1) ++bits;
       bits = (bits + 1 + 7) & ~7;
       if (bits > 64) bits = 64;
       int hw = 0;
-      if (max_hits <= kFragSortMax) {  // every fragment's hits fit one LDS sort
-        uint32_t np2_max = 2;
-        while (np2_max < max_hits) np2_max <<= 1;
-        const uint32_t lds_bytes = np2_max * 12u;
-        PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(frag_sort_kernel),
+      uint32_t n_keep = 0;
+      bool presorted = true;
+      if (use_buckets) {
+        // hits bucketed by (fragment, reference genome); segments listed by the same kernel
+        const uint64_t seg_cap64 = std::min<uint64_t>(n_hits, (uint64_t)nf * n_genomes);
+        const uint32_t seg_cap = (uint32_t)std::min<uint64_t>(seg_cap64, 0xfffffff0ull);
+        PA_TRY(W.seg_a0.reserve((uint64_t)seg_cap * 4 + 16));
+        PA_TRY(W.seg_nh.reserve((uint64_t)seg_cap * 4 + 16));
+        PA_HIP(hipMemsetAsync(d_seg_counters, 0, 16, c->stream));
+        const uint32_t lds_bytes = (uint32_t)kBucketWaves * n_genomes * 4u;
+        PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_hits_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(frag_sort_kernel, dim3(nf), dim3(kFragSortThreads), lds_bytes, c->stream, hk[0], hv[0],
-                           W.hit_off.as<uint32_t>(), W.hit_count.as<uint32_t>(), np2_max);
+        hipLaunchKernelGGL(bucket_hits_kernel, dim3(ceil_div_u64(nf, kBucketWaves)), dim3(kBucketWaves * 64), lds_bytes,
+                           c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
+                           W.hit_off.as<uint32_t>(), W.post_start.as<uint32_t>(), W.post_cw.as<uint64_t>(),
+                           W.contig_genome.as<uint32_t>(), n_genomes, W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
+                           W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters);
+        PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters, 16, hipMemcpyDeviceToHost, c->stream));
+        PA_HIP(hipStreamSynchronize(c->stream));
+        const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(c->h_pinned);
+        n_keep = hc32[0];
+        const uint32_t n_big = hc32[1], max_big = hc32[2];
+        PA_REQUIRE(n_keep <= seg_cap, "pa_fragani: %u segments exceed the list capacity %u", n_keep, seg_cap);
+        presorted = false;
+        if (n_big && max_big > kFragSortMax) {
+          // a repeat family with more hits than one LDS sort takes: order the whole batch by key; the
+          // (fragment, genome) slices keep their places because contigs are numbered genome by genome
+          PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
+          presorted = true;
+        } else if (n_big) {
+          PA_TRY(W.seg_list.reserve((uint64_t)n_big * 8 + 16));
+          uint32_t *big_a0 = W.seg_list.as<uint32_t>(), *big_nh = big_a0 + n_big;
+          PA_HIP(hipMemsetAsync(d_seg_counters + 3, 0, 4, c->stream));
+          hipLaunchKernelGGL(big_segments_kernel, dim3(ceil_div_u64(n_keep, kThreads)), dim3(kThreads), 0, c->stream,
+                             W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, big_a0, big_nh,
+                             d_seg_counters + 3);
+          uint32_t np2_max = 2;
+          while (np2_max < max_big) np2_max <<= 1;
+          const uint32_t sort_lds = np2_max * 12u;
+          PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(frag_sort_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
+          hipLaunchKernelGGL(frag_sort_kernel, dim3(n_big), dim3(kFragSortThreads), sort_lds, c->stream, hk[0], hv[0],
+                             big_a0, big_nh, np2_max);
+        }
       } else {
-        PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
+        // general path: all hits sorted by key, segments from head flags
+        hipLaunchKernelGGL(fill_hits_kernel, dim3(gw), dim3(kThreads), 0, c->stream, nf, W.q_pos.as<uint32_t>(),
+                           W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_off.as<uint32_t>(),
+                           W.post_start.as<uint32_t>(), d_sorted_idx, W.mini_wpos.as<uint32_t>(),
+                           W.mini_contig.as<uint32_t>(), hk[0], hv[0]);
+        if (max_hits <= kFragSortMax) {  // every fragment's hits fit one LDS sort
+          uint32_t np2_max = 2;
+          while (np2_max < max_hits) np2_max <<= 1;
+          const uint32_t lds_bytes = np2_max * 12u;
+          PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(frag_sort_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          hipLaunchKernelGGL(frag_sort_kernel, dim3(nf), dim3(kFragSortThreads), lds_bytes, c->stream, hk[0], hv[0],
+                             W.hit_off.as<uint32_t>(), W.hit_count.as<uint32_t>(), np2_max);
+        } else {
+          PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
+        }
+        PA_TRY(W.flags.reserve(n_hits * 8 + 64));
+        uint32_t *hf = W.flags.as<uint32_t>(), *hp = hf + n_hits;
+        const uint32_t gh = ceil_div_u64(n_hits, kThreads);
+        hipLaunchKernelGGL(segment_heads_kernel, dim3(gh), dim3(kThreads), 0, c->stream, hk[hw], (uint32_t)n_hits,
+                           W.contig_genome.as<uint32_t>(), hf);
+        PA_TRY(pa_exclusive_scan_u32(c, hf, hp, n_hits, W.scalars.as<uint64_t>()));
+        PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+        PA_HIP(hipStreamSynchronize(c->stream));
+        const uint32_t n_segs = (uint32_t)c->h_pinned[0];
+        PA_TRY(W.seg_start.reserve((uint64_t)(n_segs + 2) * 4));
+        hipLaunchKernelGGL(segment_starts_kernel, dim3(gh), dim3(kThreads), 0, c->stream, hf, hp, (uint32_t)n_hits,
+                           W.seg_start.as<uint32_t>());
+        // most segments are chance hits of unrelated genomes (fewer hits than any L1 run needs): drop them
+        // here, one thread each, instead of spending a workgroup launch on each in the mapping kernel
+        const uint32_t gs = ceil_div_u64(n_segs, kThreads);
+        hipLaunchKernelGGL(segment_keep_kernel, dim3(gs), dim3(kThreads), 0, c->stream, hk[hw],
+                           W.seg_start.as<uint32_t>(), n_segs, W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(), hf);
+        PA_TRY(pa_exclusive_scan_u32(c, hf, hp, n_segs, W.scalars.as<uint64_t>()));
+        PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+        PA_HIP(hipStreamSynchronize(c->stream));
+        n_keep = (uint32_t)c->h_pinned[0];
+        PA_TRY(W.seg_list.reserve((uint64_t)(n_keep + 1) * 4));
+        PA_TRY(W.seg_a0.reserve((uint64_t)n_keep * 4 + 16));
+        PA_TRY(W.seg_nh.reserve((uint64_t)n_keep * 4 + 16));
+        hipLaunchKernelGGL(segment_list_kernel, dim3(gs), dim3(kThreads), 0, c->stream, hf, hp, n_segs,
+                           W.seg_list.as<uint32_t>());
+        if (n_keep)
+          hipLaunchKernelGGL(segments_from_list_kernel, dim3(ceil_div_u64(n_keep, kThreads)), dim3(kThreads), 0, c->stream,
+                             W.seg_start.as<uint32_t>(), W.seg_list.as<uint32_t>(), n_keep, W.seg_a0.as<uint32_t>(),
+                             W.seg_nh.as<uint32_t>());
       }
-      PA_TRY(W.flags.reserve(n_hits * 8 + 64));
-      uint32_t *hf = W.flags.as<uint32_t>(), *hp = hf + n_hits;
-      const uint32_t gh = ceil_div_u64(n_hits, kThreads);
-      hipLaunchKernelGGL(segment_heads_kernel, dim3(gh), dim3(kThreads), 0, c->stream, hk[hw], (uint32_t)n_hits,
-                         W.contig_genome.as<uint32_t>(), hf);
-      PA_TRY(pa_exclusive_scan_u32(c, hf, hp, n_hits, W.scalars.as<uint64_t>()));
-      PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
-      PA_HIP(hipStreamSynchronize(c->stream));
-      const uint32_t n_segs = (uint32_t)c->h_pinned[0];
-      PA_TRY(W.seg_start.reserve((uint64_t)(n_segs + 2) * 4));
-      PA_TRY(W.run_g.reserve(n_hits * 4 + 16));
-      hipLaunchKernelGGL(segment_starts_kernel, dim3(gh), dim3(kThreads), 0, c->stream, hf, hp, (uint32_t)n_hits,
-                         W.seg_start.as<uint32_t>());
-      // most segments are chance hits of unrelated genomes (fewer hits than any L1 run needs): drop them
-      // here, one thread each, instead of spending a workgroup launch on each in the mapping kernel
-      const uint32_t gs = ceil_div_u64(n_segs, kThreads);
-      hipLaunchKernelGGL(segment_keep_kernel, dim3(gs), dim3(kThreads), 0, c->stream, hk[hw],
-                         W.seg_start.as<uint32_t>(), n_segs, W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(), hf);
-      PA_TRY(pa_exclusive_scan_u32(c, hf, hp, n_segs, W.scalars.as<uint64_t>()));
-      PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
-      PA_HIP(hipStreamSynchronize(c->stream));
-      const uint32_t n_keep = (uint32_t)c->h_pinned[0];
-      PA_TRY(W.seg_list.reserve((uint64_t)(n_keep + 1) * 4));
-      hipLaunchKernelGGL(segment_list_kernel, dim3(gs), dim3(kThreads), 0, c->stream, hf, hp, n_segs,
-                         W.seg_list.as<uint32_t>());
       if (n_keep)
-      hipLaunchKernelGGL(map_segments_kernel, dim3(n_keep), dim3(64), eval_lds_bytes(s_cap), c->stream, hk[hw], hv[hw],
-                         W.seg_start.as<uint32_t>(), W.seg_list.as<uint32_t>(), n_keep, W.q_hash.as<uint32_t>(), W.q_s.as<uint32_t>(),
-                         W.frag_genome_local.as<uint32_t>(), frag_len, count_windows, W.tab_min_hits.as<uint32_t>(),
-                         W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),
-                         W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),
-                         W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(),
-                         total_bins, W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap);
+        hipLaunchKernelGGL(map_segments_kernel, dim3(n_keep), dim3(64), eval_lds_bytes(s_cap), c->stream, hk[hw], hv[hw],
+                           W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, presorted,
+                           W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(), W.q_hash.as<uint32_t>(),
+                           W.q_s.as<uint32_t>(), W.frag_genome_local.as<uint32_t>(), frag_len, count_windows,
+                           W.tab_min_hits.as<uint32_t>(), W.tab_min_shared.as<uint32_t>(),
+                           W.contig_mini_off.as<uint32_t>(), W.contig_bucket_off.as<uint32_t>(),
+                           W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(),
+                           W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), total_bins,
+                           W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap);
     }
     PA_TRY(W.matched.reserve((uint64_t)nq * n_genomes * 4));
     PA_TRY(W.ident_sum.reserve((uint64_t)nq * n_genomes * 8));
