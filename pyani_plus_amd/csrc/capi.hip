@@ -90,6 +90,7 @@ void pa_ctx_destroy(pa_ctx *c) {
                     &c->counters, &c->hist, &c->flags, &c->scan_tmp, &c->region_off, &c->region_cursor, &c->dict_keys[0], &c->dict_keys[1],
                     &c->dict_vals[0], &c->dict_vals[1], &c->ids, &c->post_genome, &c->bitrows};
   for (DevBuf *b : bufs) b->release();
+  pa_fragani_release(c);
   for (auto &ph : c->prof)
     for (auto &pr : ph.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);

@@ -407,7 +407,13 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     s += __popcll(bal);
   }
   hits = wave_sum(hits);
-  if (lane == 0) { q_s[f] = s; hit_count[f] = hits; atomicMax(max_hits, hits); atomicMax(max_hits + 1, s); }
+  if (lane == 0) {
+    q_s[f] = s;
+    hit_count[f] = hits;
+    // running maxima of the batch; look first, most fragments do not raise them
+    if (hits > __builtin_nontemporal_load(max_hits)) atomicMax(max_hits, hits);
+    if (s > __builtin_nontemporal_load(max_hits + 1)) atomicMax(max_hits + 1, s);
+  }
 }
 
 // ============================================================== 4. seed hits
@@ -775,6 +781,10 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   // handful of distinct starts over and over (~20 candidates, few distinct): remember the evaluated ones.
   // The result of a start does not depend on when it is evaluated, so skipping repeats changes nothing.
   uint32_t n_seen = 0;
+  // cnt / matched start clean and every evaluation clears what it read
+  for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
+  if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
+  __syncthreads();
   // The windows a segment asks about start within a few minimizers of each other, so the rank of every
   // reference minimizer among the query hashes (a 9-step search) and its duplicate link are worked out
   // once per stretch of kRefCap minimizers and reused by all of them.
@@ -892,9 +902,6 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         }
       }
     }
-    for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
-    if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
-    __syncthreads();
     if (c == cache_c && b0 >= cache_lo && e <= cache_hi) {
       const int32_t rel0 = (int32_t)(b0 - cache_lo);
       for (uint32_t t = b0 + lane; t < e; t += 64) {
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     // contributes min(cnt[r], max(0, s - r - prefix(r)))
     uint32_t x;
     {
-      constexpr uint32_t per = (kQMax + 64) / 64;  // buckets per lane
+      const uint32_t per = s / 64u + 1u;  // buckets per lane: s + 1 of them
       uint32_t local_sum = 0;
       for (uint32_t q = 0; q < per; ++q) {
         const uint32_t r = lane * per + q;
@@ -929,6 +936,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         const uint32_t r = lane * per + q;
         if (r <= s) {
           const uint32_t cr = sh.cnt[r];
+          sh.cnt[r] = 0;  // ready for the next window
           const int32_t room = (int32_t)s - (int32_t)r - (int32_t)prefix;
           if (room > 0) acc += cr < (uint32_t)room ? cr : (uint32_t)room;
           prefix += cr;
@@ -941,6 +949,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     if (lane < (uint32_t)kQMax / 32) {
       const uint32_t lo_bit = lane * 32u;
       uint32_t m = sh.matched[lane];
+      sh.matched[lane] = 0;
       if (take <= lo_bit) m = 0;
       else if (take < lo_bit + 32u) m &= (1u << (take - lo_bit)) - 1u;
       shared = __popc(m);
@@ -1014,6 +1023,13 @@ struct FragWork {
   }
 };
 
+// The workspace lives in the context like the sketch and pair workspaces do: buffers only grow, and a
+// second call does not pay for returning tens of GB to the driver and asking for them again.
+FragWork &frag_work(pa_ctx *c) {
+  if (!c->frag_work) c->frag_work = new FragWork();
+  return *static_cast<FragWork *>(c->frag_work);
+}
+
 template <int K>
 int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                    uint32_t n_contigs, int w, uint32_t *m_out) {
@@ -1076,6 +1092,11 @@ int stage_contigs(pa_ctx *c, FragWork &W, const uint64_t *h_contig_start, const 
 
 }  // namespace
 
+void pa_fragani_release(pa_ctx *c) {
+  delete static_cast<FragWork *>(c->frag_work);
+  c->frag_work = nullptr;
+}
+
 extern "C" {
 
 int pa_fragani_window(uint32_t k, uint32_t frag_len) { return window_size_for((int)k, (int)frag_len); }
@@ -1102,7 +1123,7 @@ int pa_fragani_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mas
   PA_REQUIRE(c && d_packed && d_mask && n_out, "pa_fragani_sketch: null argument");
   PA_REQUIRE(window >= 1 && window <= 64, "pa_fragani_sketch: window %u outside [1,64]", window);
   PA_HIP(hipSetDevice(c->device));
-  FragWork W;
+  FragWork &W = frag_work(c);
   PA_TRY(stage_contigs(c, W, h_contig_start, h_contig_len, h_contig_genome, n_contigs, n_genomes, arena_bases));
   uint32_t m = 0;
   PA_TRY(dispatch_minimizers(c, W, d_packed, d_mask, arena_bases, n_contigs, k, (int)window, &m));
@@ -1128,7 +1149,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   PA_REQUIRE(w >= 1 && w <= 64, "pa_fragani: winnowing window %d outside [1,64] for k=%u fragLen=%u", w, k, frag_len);
   PA_REQUIRE((int)frag_len > w + (int)k, "pa_fragani: fragLen %u too short for window %d", frag_len, w);
   const uint32_t count_windows = frag_len - (uint32_t)(w - 1) - (k - 1);
-  FragWork W;
+  FragWork &W = frag_work(c);
   PA_TRY(stage_contigs(c, W, h_contig_start, h_contig_len, h_contig_genome, n_contigs, n_genomes, arena_bases));
 
   // ---- 1. minimizers of every contig
@@ -1284,9 +1305,17 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
     PA_TRY(W.table.reserve((uint64_t)nq * total_bins * 8));
     PA_HIP(hipMemsetAsync(W.table.p, 0, (uint64_t)nq * total_bins * 8, c->stream));
     if (n_hits) {
-      for (int b = 0; b < 2; ++b) { PA_TRY(W.hkeys[b].reserve(n_hits * 8)); PA_TRY(W.hvals[b].reserve(n_hits * 4)); }
-      uint64_t *hk[2] = {W.hkeys[0].as<uint64_t>(), W.hkeys[1].as<uint64_t>()};
-      uint32_t *hv[2] = {W.hvals[0].as<uint32_t>(), W.hvals[1].as<uint32_t>()};
+      PA_TRY(W.hkeys[0].reserve(n_hits * 8));
+      PA_TRY(W.hvals[0].reserve(n_hits * 4));
+      uint64_t *hk[2] = {W.hkeys[0].as<uint64_t>(), nullptr};
+      uint32_t *hv[2] = {W.hvals[0].as<uint32_t>(), nullptr};
+      auto second_buffers = [&]() -> int {  // only the radix sort needs the ping-pong copies
+        PA_TRY(W.hkeys[1].reserve(n_hits * 8));
+        PA_TRY(W.hvals[1].reserve(n_hits * 4));
+        hk[1] = W.hkeys[1].as<uint64_t>();
+        hv[1] = W.hvals[1].as<uint32_t>();
+        return PA_OK;
+      };
       PA_TRY(W.run_g.reserve(n_hits * 4 + 16));
       int bits = 44;
       for (uint32_t x = nf; x > 1; x >>= 1) ++bits;
@@ -1320,6 +1349,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
         if (n_big && max_big > kFragSortMax) {
           // a repeat family with more hits than one LDS sort takes: order the whole batch by key; the
           // (fragment, genome) slices keep their places because contigs are numbered genome by genome
+          PA_TRY(second_buffers());
           PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
           presorted = true;
         } else if (n_big) {
@@ -1352,6 +1382,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
           hipLaunchKernelGGL(frag_sort_kernel, dim3(nf), dim3(kFragSortThreads), lds_bytes, c->stream, hk[0], hv[0],
                              W.hit_off.as<uint32_t>(), W.hit_count.as<uint32_t>(), np2_max);
         } else {
+          PA_TRY(second_buffers());
           PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
         }
         PA_TRY(W.flags.reserve(n_hits * 8 + 64));

@@ -87,6 +87,7 @@ struct pa_ctx {
   // workspaces (pair phase)
   DevBuf dict_keys[2], dict_vals[2];
   DevBuf ids, post_genome, bitrows;
+  void *frag_work = nullptr;  // fragment-ANI workspace (fragani.hip), created on first use
   // pinned host scalars
   uint64_t *h_pinned = nullptr;
   // profiling
@@ -117,6 +118,9 @@ int pa_radix_sort_pairs(pa_ctx *c, uint64_t *keys[2], uint32_t *vals[2], uint64_
 // Exclusive prefix sum of u32 -> u32 (n up to 2^32-1 elements, total must fit u32... u64 total out).
 int pa_exclusive_scan_u32(pa_ctx *c, const uint32_t *d_in, uint32_t *d_out, uint64_t n,
                           uint64_t *d_total_u64 /*nullable device ptr*/);
+
+// fragani.hip
+void pa_fragani_release(pa_ctx *c);
 
 // kmer_hash.hip
 int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
