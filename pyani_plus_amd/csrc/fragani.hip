@@ -34,6 +34,7 @@ using namespace pa_dev;
 constexpr int kThreads = 256;
 constexpr uint32_t kSkip = 0xffffffffu;
 constexpr int kQMax = 512;       // largest fragment sketch handled
+constexpr int kHitCapSmall = 256;  // segments up to this many hits run with the smaller LDS footprint
 constexpr int kHitCap = 512;     // seed hits of one (fragment, reference genome) segment staged in LDS
 constexpr double kPercIdentity = 80.0, kConfLevel = 0.9, kPvalCutoff = 1e-3, kRefSize = 5e6;
 
@@ -512,11 +513,20 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     const bool keep = cnt >= mh;
     const uint64_t km = __ballot(keep);
     if (km) {
-      uint32_t slot0 = 0;
-      if (lane == 0) slot0 = atomicAdd(&counters[0], (uint32_t)__popcll(km));
-      slot0 = __shfl(slot0, 0, 64);
+      // short segments fill the list from the front, the ones over kHitCapSmall hits from the back: the two
+      // classes are mapped by launches with different LDS footprints
+      const bool small = keep && cnt <= (uint32_t)kHitCapSmall, large = keep && !small;
+      const uint64_t sm = __ballot(small), lm = __ballot(large);
+      uint32_t s0 = 0, l0 = 0;
+      if (lane == 0) {
+        if (sm) s0 = atomicAdd(&counters[0], (uint32_t)__popcll(sm));
+        if (lm) l0 = atomicAdd(&counters[3], (uint32_t)__popcll(lm));
+      }
+      s0 = __shfl(s0, 0, 64);
+      l0 = __shfl(l0, 0, 64);
       if (keep) {
-        const uint32_t slot = slot0 + (uint32_t)__popcll(km & ((1ULL << lane) - 1ULL));
+        const uint64_t below = (1ULL << lane) - 1ULL;
+        const uint32_t slot = small ? s0 + (uint32_t)__popcll(sm & below) : seg_cap - 1u - (l0 + (uint32_t)__popcll(lm & below));
         if (slot < seg_cap) { seg_a0[slot] = base + off; seg_nh[slot] = cnt; }
       }
       const uint64_t bm = __ballot(keep && cnt > (uint32_t)kHitCap);
@@ -656,22 +666,21 @@ struct EvalShared {
   int16_t *ref_prev;   // [kRefCap] previous occurrence of the same hash, relative to the cache start (-1: before)
   uint16_t *ref_w;     // [kRefCap] window id relative to the first cached minimizer's
 };
-__host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap) {
-  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + (uint32_t)kHitCap * 10u + (uint32_t)kSeenCap * 8u +
-         kRefCap * 6u;
+__host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap) {
+  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 10u + (uint32_t)kSeenCap * 8u + kRefCap * 6u;
 }
-__device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap) {
+__device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap) {
   EvalShared sh;
   sh.qh = base;
   sh.cnt = sh.qh + s_cap;
   sh.matched = sh.cnt + s_cap + 64u;
   sh.hw = sh.matched + kQMax / 32;
-  sh.seen_c = sh.hw + kHitCap;
+  sh.seen_c = sh.hw + hit_cap;
   sh.seen_p = sh.seen_c + kSeenCap;
   sh.hc = reinterpret_cast<uint16_t *>(sh.seen_p + kSeenCap);
-  sh.hq = sh.hc + kHitCap;
-  sh.run = sh.hq + kHitCap;
-  sh.ref_rank = sh.run + kHitCap;
+  sh.hq = sh.hc + hit_cap;
+  sh.run = sh.hq + hit_cap;
+  sh.ref_rank = sh.run + hit_cap;
   sh.ref_prev = reinterpret_cast<int16_t *>(sh.ref_rank + kRefCap);
   sh.ref_w = reinterpret_cast<uint16_t *>(sh.ref_prev + kRefCap);
   return sh;
@@ -699,9 +708,9 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const int32_t *__restrict__ prev_same,
     const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride, unsigned long long *__restrict__ table,
-    uint32_t *__restrict__ run_g, uint32_t s_cap) {
+    uint32_t *__restrict__ run_g, uint32_t s_cap, uint32_t hit_cap) {
   extern __shared__ uint32_t eval_lds[];
-  const EvalShared sh = eval_carve(eval_lds, s_cap);
+  const EvalShared sh = eval_carve(eval_lds, s_cap, hit_cap);
   const uint32_t lane = threadIdx.x;
   if (blockIdx.x >= n_segs) return;
   const uint32_t a0 = seg_a0[blockIdx.x];
@@ -716,7 +725,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   // contigs are kept relative to the reference genome's first one, window ids of the query as 16 bits: the
   // host takes this kernel only when both fit
   const uint32_t hc_base = genome_first_contig[contig_genome[(uint32_t)(keys[a0] >> 24) & 0xfffffu]];
-  const bool staged = nh <= (uint32_t)kHitCap;
+  const bool staged = nh <= hit_cap;  // hit_cap is kHitCapSmall or kHitCap, a power of two
   auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] : (uint32_t)(keys[a0 + i] & 0xffffffu); };
   auto HC = [&](uint32_t i) -> uint32_t {
     return staged ? hc_base + sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu;
@@ -1241,7 +1250,9 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   PA_TRY(W.scalars.reserve(64));
   uint32_t *d_overflow = W.scalars.as<uint32_t>() + 8;
   uint32_t *d_max_hits = W.scalars.as<uint32_t>() + 12;  // most seed hits of one fragment in the batch
-  uint32_t *d_seg_counters = W.scalars.as<uint32_t>() + 4;  // [0] listed segments, [1] long ones, [2] longest, [3] cursor
+  // [0] segments of <= kHitCapSmall hits, [1] of > kHitCap hits, [2] the longest of those, [3] of > kHitCapSmall hits;
+  // [6] cursor of big_segments_kernel
+  uint32_t *d_seg_counters = W.scalars.as<uint32_t>() + 4;
   // The bucketed pipeline needs an LDS counter per reference genome for each of a workgroup's waves and
   // 16-bit fields for query window ids and for contigs within a genome; otherwise the sorted pipeline runs.
   std::vector<uint32_t> gfc(n_genomes + 1, n_contigs);
@@ -1322,7 +1333,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
       bits = (bits + 1 + 7) & ~7;
       if (bits > 64) bits = 64;
       int hw = 0;
-      uint32_t n_keep = 0;
+      uint32_t n_keep = 0, n_large = 0, large_at = 0;  // bucketed path: long segments sit at the end of the lists
       bool presorted = true;
       if (use_buckets) {
         // hits bucketed by (fragment, reference genome); segments listed by the same kernel
@@ -1343,8 +1354,11 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
         PA_HIP(hipStreamSynchronize(c->stream));
         const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(c->h_pinned);
         n_keep = hc32[0];
+        n_large = hc32[3];
+        large_at = seg_cap - n_large;
         const uint32_t n_big = hc32[1], max_big = hc32[2];
-        PA_REQUIRE(n_keep <= seg_cap, "pa_fragani: %u segments exceed the list capacity %u", n_keep, seg_cap);
+        PA_REQUIRE((uint64_t)n_keep + n_large <= seg_cap, "pa_fragani: %u + %u segments exceed the list capacity %u",
+                   n_keep, n_large, seg_cap);
         presorted = false;
         if (n_big && max_big > kFragSortMax) {
           // a repeat family with more hits than one LDS sort takes: order the whole batch by key; the
@@ -1355,10 +1369,10 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
         } else if (n_big) {
           PA_TRY(W.seg_list.reserve((uint64_t)n_big * 8 + 16));
           uint32_t *big_a0 = W.seg_list.as<uint32_t>(), *big_nh = big_a0 + n_big;
-          PA_HIP(hipMemsetAsync(d_seg_counters + 3, 0, 4, c->stream));
-          hipLaunchKernelGGL(big_segments_kernel, dim3(ceil_div_u64(n_keep, kThreads)), dim3(kThreads), 0, c->stream,
-                             W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, big_a0, big_nh,
-                             d_seg_counters + 3);
+          PA_HIP(hipMemsetAsync(d_seg_counters + 6, 0, 4, c->stream));
+          hipLaunchKernelGGL(big_segments_kernel, dim3(ceil_div_u64(n_large, kThreads)), dim3(kThreads), 0, c->stream,
+                             W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, n_large, big_a0,
+                             big_nh, d_seg_counters + 6);
           uint32_t np2_max = 2;
           while (np2_max < max_big) np2_max <<= 1;
           const uint32_t sort_lds = np2_max * 12u;
@@ -1416,16 +1430,24 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                              W.seg_start.as<uint32_t>(), W.seg_list.as<uint32_t>(), n_keep, W.seg_a0.as<uint32_t>(),
                              W.seg_nh.as<uint32_t>());
       }
-      if (n_keep)
-        hipLaunchKernelGGL(map_segments_kernel, dim3(n_keep), dim3(64), eval_lds_bytes(s_cap), c->stream, hk[hw], hv[hw],
-                           W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, presorted,
+      auto launch_map = [&](uint32_t first, uint32_t count, uint32_t hit_cap) {
+        if (count == 0) return;
+        hipLaunchKernelGGL(map_segments_kernel, dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap), c->stream, hk[hw],
+                           hv[hw], W.seg_a0.as<uint32_t>() + first, W.seg_nh.as<uint32_t>() + first, count, presorted,
                            W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(), W.q_hash.as<uint32_t>(),
                            W.q_s.as<uint32_t>(), W.frag_genome_local.as<uint32_t>(), frag_len, count_windows,
                            W.tab_min_hits.as<uint32_t>(), W.tab_min_shared.as<uint32_t>(),
                            W.contig_mini_off.as<uint32_t>(), W.contig_bucket_off.as<uint32_t>(),
                            W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(),
                            W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), total_bins,
-                           W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap);
+                           W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap);
+      };
+      if (use_buckets) {
+        launch_map(0, n_keep, (uint32_t)kHitCapSmall);
+        launch_map(large_at, n_large, (uint32_t)kHitCap);
+      } else {
+        launch_map(0, n_keep, (uint32_t)kHitCap);
+      }
     }
     PA_TRY(W.matched.reserve((uint64_t)nq * n_genomes * 4));
     PA_TRY(W.ident_sum.reserve((uint64_t)nq * n_genomes * 8));
