@@ -205,6 +205,15 @@ def main():
     prof = engine.prof_get()
     engine.prof_enable(False)
     sk_local, sk, counts, ident, cov = out
+    # BASELINE configs[4] / SURVEY.md 8(d): how evenly the shards load the GPUs -- device-busy time of each
+    # rank's own kernels per step (HIP events around the phases; waits for other ranks are not in it)
+    busy = sum(v[0] for v in prof.values()) / max(1, args.steps)
+    rank_busy = [busy]
+    if dist_path:
+        tb = torch.tensor([busy], dtype=torch.float64, device=engine.device if backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(tb) for _ in range(world)]
+        dist.all_gather(gathered, tb)
+        rank_busy = [float(x.item()) for x in gathered]
 
     # roofline of the dominant kernel (k-mer hash + filter), this rank's launches
     hash_ms, hash_launches = prof["kmer_hash"]
@@ -292,6 +301,10 @@ def main():
                 },
             },
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "shard_balance": {
+                "busy_ms_per_step_by_rank": rank_busy,
+                "max_over_mean": max(rank_busy) / (sum(rank_busy) / len(rank_busy)) if sum(rank_busy) > 0 else None,
+            },
             "device": engine.device_info()["name"],
         }
         if world == 1:
@@ -327,11 +340,17 @@ def main():
             result["parity_checked"] = f"sketches of sampled genomes and a {n_pair}x{n_pair} count block equal the oracle"
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
     if dist_path:
         dist.barrier()
         dist.destroy_process_group()
     engine.close()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio, which a pipe buffers until exit: push that out first
+        # so that the JSON line is the last line of the output
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
