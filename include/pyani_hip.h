@@ -149,6 +149,25 @@ PA_API int pa_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_ma
               const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
               uint64_t *d_hashes, uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total);
 
+/* ---- sketch straight from a host arena, upload hidden behind the hash kernel ----
+ * The reference's tools read their FASTA input from disk (pyani_plus/methods/sourmash.py:67-83); here the
+ * packed genomes start in host memory.  pa_mask_runs (host) lists the runs of invalid positions of a mask
+ * (returns their number; writes at most `cap`), so that the mask -- a third of the arena's bytes, almost all
+ * zero -- crosses the bus as a few integers; pa_mask_from_runs rebuilds it in d_mask (arena_bases/8 bytes).
+ * pa_sketch_streamed = pa_mask_from_runs + chunked upload of h_packed (page-locked for a truly asynchronous
+ * copy) into d_packed (arena_bases/4 bytes) on a second stream while the hash kernel works on the chunks
+ * that have arrived + the rest of pa_sketch.  Same outputs and error behaviour as pa_sketch; d_packed and
+ * d_mask hold the complete arena afterwards. */
+PA_API int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, uint64_t *h_run_start, uint64_t *h_run_len,
+                            uint64_t cap);
+PA_API int pa_mask_from_runs(pa_ctx *ctx, const uint64_t *h_run_start, const uint64_t *h_run_len, uint32_t n_runs,
+                             uint32_t *d_mask, uint64_t arena_bases);
+PA_API int pa_sketch_streamed(pa_ctx *ctx, const uint32_t *h_packed, const uint64_t *h_run_start,
+                              const uint64_t *h_run_len, uint32_t n_runs, uint64_t arena_bases,
+                              const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
+                              uint32_t *d_packed, uint32_t *d_mask, uint64_t *d_hashes, uint64_t cap_hashes,
+                              uint64_t *d_off, uint64_t *h_total);
+
 /* ---- pairs: CSR sketches -> intersection counts ----
  * d_hashes/d_off describe n sketches (any source: pa_sketch, a `.sig` cache,
  * an all-gather).  Computes d_counts[(q-q0)*(s1-s0) + (s-s0)] = |S_q n S_s| for

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
     const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash,
     uint64_t *__restrict__ cand_hash, uint32_t *__restrict__ cand_genome, uint64_t cap,
     unsigned long long *__restrict__ count, const uint64_t *__restrict__ region_off, uint32_t *__restrict__ cursor,
-    uint32_t *__restrict__ overflow) {
+    uint32_t *__restrict__ overflow, uint32_t blk0) {
   static_assert(K >= 4 && K <= 32, "k-mer state is one 64-bit register pair");
   __shared__ uint64_t s_hash[kStageCap];
   __shared__ uint32_t s_blk[kStageCap];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
   }
   __syncthreads();
 
-  const uint32_t t = blockIdx.x * kThreads + tid;
+  const uint32_t t = blk0 + blockIdx.x * kThreads + tid;  // blk0: first arena block of this launch (streamed uploads)
   if (t < n_blocks64) {
     const uint4 cur = packed[t];
     const uint2 m = mask[t];
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
   if (region_off) {
     // per-genome regions (see sketch_lds.hip): a workgroup that lies inside one genome -- all but the
     // few that straddle a boundary -- reserves its slots with one atomic on that genome's cursor
-    const uint32_t b0 = blockIdx.x * kThreads;
+    const uint32_t b0 = blk0 + blockIdx.x * kThreads;
     const uint32_t b1 = min(b0 + (uint32_t)kThreads, n_blocks64) - 1u;
     const uint32_t g0 = find_genome(genome_blk, n_genomes, b0);
     if (genome_blk[g0 + 1] > b1) {
@@ -220,12 +220,12 @@ template <int K, bool LUT>
 int launch_variant(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
            const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
            uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count, const uint64_t *d_region_off, uint32_t *d_cursor,
-           uint32_t *d_overflow) {
-  const uint32_t grid = ceil_div_u64(n_blocks64, kThreads);
-  hipLaunchKernelGGL((kmer_hash_kernel<K, LUT>), dim3(grid), dim3(kThreads), 0, c->stream,
+           uint32_t *d_overflow, uint64_t blk0, hipStream_t stream) {
+  const uint32_t grid = ceil_div_u64(n_blocks64 - blk0, kThreads);
+  hipLaunchKernelGGL((kmer_hash_kernel<K, LUT>), dim3(grid), dim3(kThreads), 0, stream ? stream : c->stream,
                      reinterpret_cast<const uint4 *>(d_packed), reinterpret_cast<const uint2 *>(d_mask),
                      (uint32_t)n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap,
-                     reinterpret_cast<unsigned long long *>(d_count), d_region_off, d_cursor, d_overflow);
+                     reinterpret_cast<unsigned long long *>(d_count), d_region_off, d_cursor, d_overflow, (uint32_t)blk0);
   PA_HIP(hipGetLastError());
   return PA_OK;
 }
@@ -234,16 +234,16 @@ template <int K>
 int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
            const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
            uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count, const uint64_t *d_region_off, uint32_t *d_cursor,
-           uint32_t *d_overflow) {
+           uint32_t *d_overflow, uint64_t blk0, hipStream_t stream) {
   static const bool arithmetic = [] {
     const char *v = getenv("PA_KMER_VARIANT");
     return v && v[0] == '0';
   }();
   if (arithmetic)
     return launch_variant<K, false>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
-                                    d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow);
+                                    d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
   return launch_variant<K, true>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
-                                 d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow);
+                                 d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
 }
 
 }  // namespace
@@ -251,11 +251,12 @@ int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t
 int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
                         const uint32_t *d_genome_blk, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
                         uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count,
-                        const uint64_t *d_region_off, uint32_t *d_cursor, uint32_t *d_overflow) {
+                        const uint64_t *d_region_off, uint32_t *d_cursor, uint32_t *d_overflow, uint64_t blk0,
+                        hipStream_t stream) {
   PA_REQUIRE(n_blocks64 < (1ULL << 32), "arena too large: %llu blocks of 64 bases", (unsigned long long)n_blocks64);
-  if (n_blocks64 == 0) return PA_OK;
+  if (n_blocks64 <= blk0) return PA_OK;
 #define PA_K_CASE(KK) \
-  case KK: return launch<KK>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow);
+  case KK: return launch<KK>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
   switch (k) {
     PA_K_CASE(15) PA_K_CASE(16) PA_K_CASE(17) PA_K_CASE(19) PA_K_CASE(21) PA_K_CASE(23) PA_K_CASE(25)
     PA_K_CASE(27) PA_K_CASE(29) PA_K_CASE(31) PA_K_CASE(32)

@@ -87,6 +87,7 @@ struct pa_ctx {
   // workspaces (pair phase)
   DevBuf dict_keys[2], dict_vals[2];
   DevBuf ids, post_genome, bitrows;
+  hipStream_t copy_stream = nullptr;  // uploads of pa_sketch_streamed, created on first use
   void *frag_work = nullptr;  // fragment-ANI workspace (fragani.hip), created on first use
   // pinned host scalars
   uint64_t *h_pinned = nullptr;
@@ -127,7 +128,8 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
                         const uint32_t *d_genome_blk, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
                         uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count,
                         const uint64_t *d_region_off = nullptr, uint32_t *d_cursor = nullptr,
-                        uint32_t *d_overflow = nullptr);
+                        uint32_t *d_overflow = nullptr, uint64_t blk0 = 0, hipStream_t stream = nullptr);
+// The launch covers arena blocks [blk0, n_blocks64) on `stream` (default: the context's).
 // With d_region_off != nullptr the survivors of genome g go, unordered, to d_cand_hash[region_off[g] + i),
 // i < cursor[g] (zeroed by the caller); *d_overflow is set if a region was too small.
 

@@ -55,6 +55,34 @@ constexpr Lut kLut;
 
 extern "C" uint64_t pa_pack_bound(uint64_t n_text_bytes) { return (n_text_bytes / 64 + 1) * 64 + 64; }
 
+// Runs of set bits of an invalid-position mask, ascending (word scan: zero words cost one compare).
+extern "C" int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, uint64_t *h_run_start,
+                                uint64_t *h_run_len, uint64_t cap) {
+  if (!h_mask && arena_bases) return -1;
+  const uint64_t n_words = arena_bases / 32;
+  uint64_t n = 0, start = 0;
+  bool in_run = false;
+  for (uint64_t w = 0; w < n_words; ++w) {
+    uint32_t x = h_mask[w];
+    if (!in_run && x == 0) continue;
+    if (in_run && x == 0xffffffffu) continue;
+    for (uint32_t b = 0; b < 32; ++b) {
+      const bool bit = (x >> b) & 1u;
+      if (bit && !in_run) { in_run = true; start = w * 32 + b; }
+      else if (!bit && in_run) {
+        in_run = false;
+        if (n < cap && h_run_start && h_run_len) { h_run_start[n] = start; h_run_len[n] = w * 32 + b - start; }
+        ++n;
+      }
+    }
+  }
+  if (in_run) {
+    if (n < cap && h_run_start && h_run_len) { h_run_start[n] = start; h_run_len[n] = n_words * 32 - start; }
+    ++n;
+  }
+  return (int64_t)n;
+}
+
 extern "C" uint64_t pa_max_hash(uint64_t scaled) {
   if (scaled == 0) return 0;
   if (scaled == 1) return UINT64_MAX;

@@ -182,6 +182,40 @@ class DeviceArena:
 
 
 @dataclass
+class PinnedArena:
+    """A host arena ready for ``HipEngine.sketch_streamed``: packed bases in page-locked memory and the
+    invalid-position mask as runs (start, length) instead of a bitmap."""
+
+    packed: "object"  # pinned torch.int32 tensor
+    run_start: np.ndarray  # uint64
+    run_len: np.ndarray  # uint64
+    genome_start: np.ndarray  # host uint64 [n+1]
+
+    @property
+    def n_genomes(self) -> int:
+        return len(self.genome_start) - 1
+
+    @property
+    def arena_bases(self) -> int:
+        return int(self.genome_start[-1])
+
+
+def mask_runs(mask: np.ndarray, arena_bases: int) -> tuple[np.ndarray, np.ndarray]:
+    """Runs of invalid positions of a mask bitmap (host helper ``pa_mask_runs``)."""
+    lib = _capi.load_library()
+    mask = np.ascontiguousarray(mask, dtype=np.uint32)
+    n = int(lib.pa_mask_runs(mask.ctypes.data, arena_bases, None, None, 0))
+    if n < 0:
+        raise HipBackendError("pa_mask_runs: null mask")
+    start = np.empty(max(n, 1), dtype=np.uint64)
+    length = np.empty(max(n, 1), dtype=np.uint64)
+    got = int(lib.pa_mask_runs(mask.ctypes.data, arena_bases, start.ctypes.data, length.ctypes.data, n))
+    if got != n:
+        raise HipBackendError("pa_mask_runs: run count changed between calls")
+    return start[:n], length[:n]
+
+
+@dataclass
 class DeviceSketches:
     """CSR of ascending duplicate-free u64 hashes, resident in HBM."""
 
@@ -284,6 +318,43 @@ class HipEngine:
             check(st, "pa_sketch")
             return DeviceSketches(hashes, off, n, int(total.value))
         raise HipBackendError("pa_sketch: capacity retry failed")
+
+    def pin_arena(self, arena: HostArena) -> PinnedArena:
+        """Page-lock the packed bases and reduce the mask to runs (done once, outside any timed region)."""
+        t = self.torch
+        packed = t.from_numpy(np.ascontiguousarray(arena.packed).view(np.int32)).pin_memory()
+        start, length = mask_runs(arena.mask, int(arena.genome_start[-1]))
+        return PinnedArena(packed, start, length, np.ascontiguousarray(arena.genome_start, dtype=np.uint64).copy())
+
+    def sketch_streamed(self, host: PinnedArena, k: int, scaled: int, *, max_hash: int | None = None, arena: DeviceArena | None = None):
+        """Host arena -> (device arena, sketches); the upload runs behind the hash kernel (``pa_sketch_streamed``)."""
+        t = self.torch
+        mh = int(max_hash) if max_hash is not None else max_hash_for_scaled(scaled)
+        n, bases = host.n_genomes, host.arena_bases
+        if arena is None:
+            arena = DeviceArena(
+                t.empty(max(bases // 16, 1), dtype=t.int32, device=self.device),
+                t.empty(max(bases // 32, 1), dtype=t.int32, device=self.device),
+                host.genome_start.copy(),
+            )
+        frac = 1.0 if mh >= 2**64 - 1 else (mh + 1) / 2.0**64
+        cap = int(bases * frac * 1.25) + 4096
+        off = t.empty(n + 1, dtype=t.int64, device=self.device)
+        gs = np.ascontiguousarray(host.genome_start, dtype=np.uint64)
+        total = C.c_uint64(0)
+        for _attempt in range(2):
+            hashes = t.empty(max(cap, 1), dtype=t.int64, device=self.device)
+            st = self.lib.pa_sketch_streamed(
+                self.ctx, host.packed.data_ptr(), host.run_start.ctypes.data, host.run_len.ctypes.data, len(host.run_start),
+                bases, gs.ctypes.data_as(C.POINTER(C.c_uint64)), n, k, mh, arena.packed.data_ptr(), arena.mask.data_ptr(),
+                hashes.data_ptr(), cap, off.data_ptr(), C.byref(total),
+            )  # fmt: skip
+            if st == _capi.PA_E_CAPACITY:
+                cap = int(total.value)
+                continue
+            check(st, "pa_sketch_streamed")
+            return arena, DeviceSketches(hashes, off, n, int(total.value))
+        raise HipBackendError("pa_sketch_streamed: capacity retry failed")
 
     def pair_counts(self, sk: DeviceSketches, q_range=None, s_range=None, algo: int = _capi.PA_PAIRS_AUTO):
         """uint32 |S_q n S_s| for q in q_range, s in s_range -> torch.int32 [nq, ns] on the GPU."""

@@ -259,3 +259,32 @@ def test_degenerate_inputs_and_error_codes(engine):
     gs = (C.c_uint64 * 2)(0, 100)
     st = lib.pa_sketch(engine.ctx, one_ptr := engine.upload(one).packed.data_ptr(), one_ptr, 100, gs, 1, 31, 1, None, 0, good.off.data_ptr(), C.byref(total))
     assert st == -1 and b"multiple of 64" in lib.pa_last_error()
+
+
+def test_streamed_sketch_equals_resident_sketch(engine):
+    """pa_sketch_streamed: run-length mask + chunked upload behind the hash kernel give the same device arena
+    and the same sketches as upload + pa_sketch, on the LDS-sort path and on the fallbacks."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    texts = []
+    for g in range(9):
+        seq = bytearray(rng.choice(acgt, size=int(rng.integers(1000, 400_000))).tobytes())
+        for _ in range(int(rng.integers(0, 4))):  # N runs of various lengths, some crossing word boundaries
+            a, n_len = int(rng.integers(0, len(seq) - 500)), int(rng.integers(1, 400))
+            seq[a : a + n_len] = b"N" * n_len
+        texts.append(b">g%d\n" % g + bytes(seq[: len(seq) // 2]) + b"\n>second record\n" + bytes(seq[len(seq) // 2 :]) + b"\n")
+    texts.append(b">empty\n")
+    ladder = synth_arena_numpy(40, [5_000 + 37_000 * i for i in range(40)], n_species=5)
+    # FASTA with N runs on the LDS-sort path; a length ladder; scaled=1 (regions too long for LDS: plain upload)
+    for arena, scaled in ((pack_genomes(texts), 200), (ladder, 1000), (pack_genomes(texts), 1)):
+        dev = engine.upload(arena)
+        want = engine.sketch(dev, 31, scaled)
+        pinned = engine.pin_arena(arena)
+        dev2, got = engine.sketch_streamed(pinned, 31, scaled)
+        assert got.total == want.total
+        assert engine.torch.equal(got.off, want.off)
+        assert engine.torch.equal(got.hashes[: got.total], want.hashes[: want.total])
+        assert engine.torch.equal(dev2.mask[: arena.mask.size], dev.mask)
+        assert engine.torch.equal(dev2.packed[: arena.packed.size], dev.packed)

@@ -382,3 +382,24 @@ def test_manysearch_csv_export_equals_fixture_text(name, tmp_path):
     assert sorted(got_lines[1:]) == sorted(line for line in want_lines[1:] if line)  # upstream row order is thread-dependent
     assert n_rows == len(got_lines) - 1 == int((counts > 0).sum())
     assert _rust_float(5e-05) == "0.00005" and _rust_float(1.0) == "1.0" and _rust_float(1e-7) == "0.0000001"
+
+
+def test_mask_runs_round_trip():
+    from pyani_plus_amd.engine import mask_runs
+
+    rng = np.random.default_rng(3)
+    bits = np.zeros(64 * 200, dtype=np.uint8)
+    for _ in range(60):
+        a = int(rng.integers(0, bits.size))
+        bits[a : a + int(rng.integers(1, 130))] = 1
+    bits[:3] = 1
+    bits[-70:] = 1
+    mask = (bits.reshape(-1, 32).astype(np.uint64) << np.arange(32, dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint32)
+    start, length = mask_runs(mask, bits.size)
+    rebuilt = np.zeros_like(bits)
+    for s, n in zip(start, length):
+        assert n > 0 and not rebuilt[int(s) : int(s + n)].any()
+        rebuilt[int(s) : int(s + n)] = 1
+    assert np.array_equal(rebuilt, bits)
+    assert np.all(start[1:] > start[:-1] + length[:-1])  # maximal runs: never adjacent
+    assert mask_runs(np.zeros(4, dtype=np.uint32), 128)[0].size == 0
