@@ -216,7 +216,9 @@ PA_API int pa_ani_mash(pa_ctx *ctx, const uint32_t *d_common, const uint32_t *d_
  * fastANI line); h_matched[q*n+r] = kept (orthologous) fragments, h_ident_sum[q*n+r] = sum of their
  * identities in percent, so ANI(q,r) = sum/matched, reported by fastANI when matched/total >= minFraction
  * (pyani_plus/methods/fastani.py:98-120 parses exactly these three numbers).
- * Algorithm and its tolerance-only parity: oracle/fragani_oracle.c.  k in {12,14,15,16}. */
+ * Algorithm and its tolerance-only parity: oracle/fragani_oracle.c.  k in {12,14,15,16}; fragLen in
+ * [100, 65535]; contigs listed genome by genome, at most 65535 per genome and 2^20-1 in all; at most 2^20-1
+ * fragments per genome.  The workspace (about 12 GB for 1000 x 5 Mb genomes) stays in the context. */
 PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
                uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t *h_total_frags,

@@ -1152,7 +1152,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t *h_total_frags,
                uint32_t *h_matched, double *h_ident_sum) {
   PA_REQUIRE(c && d_packed && d_mask && h_total_frags && h_matched && h_ident_sum, "pa_fragani: null argument");
-  PA_REQUIRE(frag_len >= 100 && frag_len < (1u << 20), "pa_fragani: fragLen %u outside [100, 2^20)", frag_len);
+  PA_REQUIRE(frag_len >= 100 && frag_len <= 0xffffu, "pa_fragani: fragLen %u outside [100, 65535]", frag_len);
   PA_HIP(hipSetDevice(c->device));
   const int w = window_size_for((int)k, (int)frag_len);
   PA_REQUIRE(w >= 1 && w <= 64, "pa_fragani: winnowing window %d outside [1,64] for k=%u fragLen=%u", w, k, frag_len);

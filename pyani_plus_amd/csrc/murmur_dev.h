@@ -51,17 +51,14 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k) {
 // (word * c1 or c2); everything after it is computed here.
 constexpr uint64_t kC1 = 0x87c37b91114253d5ULL, kC2 = 0x4cf5ad432745937fULL;
 
-// h*5 + c as shift-and-add.  Left to itself hipcc turns this back into two quarter-rate
-// v_mad_u64_u32; the empty asm keeps the shifted value opaque so it stays three full-rate ops.
+// h*5 + c.  Left to itself hipcc turns this into two v_mad_u64_u32 plus fix-ups; gfx950 has a 64-bit
+// shift-and-add (v_lshl_add_u64, shift 0..4), so (h << 2) + h is one instruction and + c a second.
 __device__ __forceinline__ uint64_t times5_plus(uint64_t h, uint64_t c) {
-  uint64_t t = h << 2;
-  asm volatile("" : "+v"(t));
-  return t + h + c;
+  uint64_t t;
+  asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(t) : "v"(h));
+  return t + c;
 }
 
-// Everything up to, but not including, the last `k ^= k >> 33` of the two fmix64 calls: the hash is
-// (X ^ X>>33) + (Y ^ Y>>33).  That last step only touches the low 31 bits, so the high words of X and Y
-// already decide -- up to one carry -- whether the hash can be <= max_hash (see kmer_hash.hip).
 template <int K>
 __device__ __forceinline__ void murmur3_pre_final(const uint64_t (&P)[4], uint64_t &X, uint64_t &Y) {
   uint64_t h1 = 42, h2 = 42;

@@ -137,6 +137,24 @@ def test_pair_counts_match_oracle(engine, sizes, universe):
             assert np.array_equal(got, want[q_range[0] : q_range[1], s_range[0] : s_range[1]])
 
 
+def test_pair_counts_with_extreme_hash_values(engine):
+    """0 and 2^64-1 are legal hashes; the hash dictionary keeps the latter (its empty marker) aside."""
+    top = np.uint64(2**64 - 1)
+    sketches = [
+        np.array([0, 5, top], dtype=np.uint64),
+        np.array([top], dtype=np.uint64),
+        np.array([0, 7], dtype=np.uint64),
+        np.array([], dtype=np.uint64),
+        np.array([5, 7, 2**63, top], dtype=np.uint64),
+    ]
+    sk = engine.sketches_from_host(sketches)
+    want = oracle.pair_counts(sketches)
+    for algo in (0, 1, 2, 3):
+        assert np.array_equal(engine.pair_counts(sk, algo=algo).cpu().numpy().view(np.uint32), want), f"algo {algo}"
+    got = engine.pair_counts(sk, (0, 5), (2, 4), algo=3).cpu().numpy().view(np.uint32)  # tile without the top hash
+    assert np.array_equal(got, want[:, 2:4])
+
+
 def test_device_ani_within_one_ulp_of_libm(engine):
     from pyani_plus_amd.engine import ani_host
 
