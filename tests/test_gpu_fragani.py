@@ -108,6 +108,32 @@ def test_pairs_equal_oracle_on_random_genomes(engine):
     _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
 
 
+def test_repeat_families_take_the_long_segment_paths(engine):
+    """Tandem repeats give (fragment, genome) segments of thousands of seed hits: more than the mapping wave
+    stages in LDS (512: sorted by frag_sort_kernel, read in place) and, for the 60-copy genome, more than one
+    LDS sort takes (8 192: the whole batch is radix-sorted instead)."""
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = rng.choice(acgt, size=3_000)
+    flank = rng.choice(acgt, size=9_000)
+
+    def with_copies(copies: int, rate: float) -> bytes:
+        parts = [flank[:4_500]]
+        for _ in range(copies):
+            u = unit.copy()
+            hit = rng.random(u.size) < rate
+            u[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+            parts.append(u)
+        parts.append(flank[4_500:])
+        return np.concatenate(parts).tobytes()
+
+    genomes = [with_copies(8, 0.0), with_copies(8, 0.02), with_copies(60, 0.001)]
+    texts = [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)]
+    total, matched, _ = _check_against_oracle(engine, texts, [[g] for g in genomes])
+    # copies of one unit compete for the same reference bins, so not every fragment is kept even against itself
+    assert 0 < matched[2, 2] <= total[2] and matched[0, 1] > 0
+
+
 def test_viral_fixture_rows(engine):
     files = sorted((GOLDEN / "viral_example").glob("*.f*"))
     texts = [read_fasta_bytes(p) for p in files]
