@@ -132,6 +132,9 @@ def test_repeat_families_take_the_long_segment_paths(engine):
     total, matched, _ = _check_against_oracle(engine, texts, [[g] for g in genomes])
     # copies of one unit compete for the same reference bins, so not every fragment is kept even against itself
     assert 0 < matched[2, 2] <= total[2] and matched[0, 1] > 0
+    # without the 60-copy genome the batch stays on the bucketed path and its 2 000-hit segments go through
+    # frag_sort_kernel
+    _check_against_oracle(engine, texts[:2], [[g] for g in genomes[:2]])
 
 
 def test_viral_fixture_rows(engine):
