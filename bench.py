@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--mixed-lengths", action="store_true", help="log-uniform 100 kb - 10 Mb genomes (BASELINE configs[4])")
     ap.add_argument("--cpu-sample-genomes", type=int, default=0, help="genomes sketched by the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive passes (keeps a rocprof kernel trace to the timed steps' launches)")
     return ap.parse_args()
 
 
@@ -307,7 +308,7 @@ def main():
             },
             "device": engine.device_info()["name"],
         }
-        if world == 1:
+        if world == 1 and not args.no_pcie:
             # PCIe-inclusive passes, reported beside (never inside) `value`: packed arena in pinned host
             # memory -> HBM, one step, f64 matrices back to pinned host memory.  "plain": the whole arena
             # (bases + mask bitmap) is copied, then the resident step runs.  "streamed": the mask crosses as
