@@ -325,12 +325,15 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
                                                             uint32_t *__restrict__ mini_id, uint32_t *__restrict__ post_start,
                                                             int32_t *__restrict__ prev_same,
                                                             const uint32_t *__restrict__ mini_wpos,
+                                                            const uint32_t *__restrict__ contig_genome,
                                                             uint64_t *__restrict__ post_cw) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= m) return;
   const uint32_t id = pos[i] + flags[i] - 1u, me = sorted_idx[i];
   mini_id[me] = id;
-  post_cw[i] = ((uint64_t)mini_contig[me] << 24) | mini_wpos[me];  // the posting as the low 44 bits of a hit key
+  // the posting as the low 44 bits of a hit key, its genome on top so that bucketing needs no second lookup
+  const uint32_t mc = mini_contig[me];
+  post_cw[i] = ((uint64_t)contig_genome[mc] << 44) | ((uint64_t)mc << 24) | mini_wpos[me];
   if (flags[i]) post_start[id] = i;
   if (i == m - 1) post_start[n_ids] = m;
   int32_t ps = -1;
@@ -479,8 +482,8 @@ constexpr int kBucketWaves = 4;
 __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     uint32_t n_frags, const uint32_t *__restrict__ q_pos, const uint32_t *__restrict__ q_id,
     const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ hit_off, const uint32_t *__restrict__ post_start,
-    const uint64_t *__restrict__ post_cw, const uint32_t *__restrict__ contig_genome, uint32_t n_genomes,
-    const uint32_t *__restrict__ tab_min_hits, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+    const uint64_t *__restrict__ post_cw, uint32_t n_genomes, const uint32_t *__restrict__ tab_min_hits,
+    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
     uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t seg_cap, uint32_t *__restrict__ counters) {
   extern __shared__ uint32_t bk_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
       const uint32_t id = q_id[(uint64_t)f * kQMax + i];
       const uint32_t lo = post_start[id], n = post_start[id + 1] - lo;
       for (uint32_t t = sub; t < n; t += 8)
-        atomicAdd(&hist[contig_genome[(uint32_t)(post_cw[lo + t] >> 24)]], 1u);
+        atomicAdd(&hist[(uint32_t)(post_cw[lo + t] >> 44)], 1u);
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -544,8 +547,8 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
       const uint32_t qp = q_pos[(uint64_t)f * kQMax + i];
       for (uint32_t t = sub; t < n; t += 8) {
         const uint64_t cw = post_cw[lo + t];
-        const uint32_t slot = base + atomicAdd(&hist[contig_genome[(uint32_t)(cw >> 24)]], 1u);
-        keys[slot] = ((uint64_t)f << 44) | cw;
+        const uint32_t slot = base + atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
+        keys[slot] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
         vals[slot] = qp;
       }
     }
@@ -1226,7 +1229,8 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
   hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
                      n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
-                     W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.post_cw.as<uint64_t>());
+                     W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
+                     W.post_cw.as<uint64_t>());
   const uint32_t *d_sorted_idx = vals[which];
 
   // ---- tables indexed by sketch size
@@ -1347,8 +1351,8 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(bucket_hits_kernel, dim3(ceil_div_u64(nf, kBucketWaves)), dim3(kBucketWaves * 64), lds_bytes,
                            c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
-                           W.hit_off.as<uint32_t>(), W.post_start.as<uint32_t>(), W.post_cw.as<uint64_t>(),
-                           W.contig_genome.as<uint32_t>(), n_genomes, W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
+                           W.hit_off.as<uint32_t>(), W.post_start.as<uint32_t>(), W.post_cw.as<uint64_t>(), n_genomes,
+                           W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
                            W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters);
         PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters, 16, hipMemcpyDeviceToHost, c->stream));
         PA_HIP(hipStreamSynchronize(c->stream));
