@@ -555,6 +555,61 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
   }
 }
 
+// Chance matches with unrelated genomes still leave millions of listed segments with a handful of hits and
+// no valid L1 run.  One THREAD settles each segment of <= 8 hits here (sort its keys in registers, test the
+// run condition of map_segments_kernel exactly) so that the mapping kernel does not spend a workgroup
+// launch and a dozen dependent loads on it; longer segments pass through.
+constexpr uint32_t kTinySegment = 8;
+__global__ __launch_bounds__(kThreads) void prefilter_segments_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh,
+    uint32_t n_segs, const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ tab_min_hits, uint32_t frag_len,
+    uint32_t *__restrict__ out_a0, uint32_t *__restrict__ out_nh, uint32_t *__restrict__ counter) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t a0 = 0, nh = 0;
+  bool keep = false;
+  if (i < n_segs) {
+    a0 = seg_a0[i];
+    nh = seg_nh[i];
+    if (nh > kTinySegment) {
+      keep = true;
+    } else {
+      uint64_t k[kTinySegment];
+#pragma unroll
+      for (uint32_t j = 0; j < kTinySegment; ++j) k[j] = j < nh ? keys[a0 + j] : ~0ULL;
+#pragma unroll
+      for (uint32_t pass = 0; pass < kTinySegment; ++pass)  // odd-even transposition sort: 8 passes sort 8 keys
+#pragma unroll
+        for (uint32_t j = pass & 1u; j + 1 < kTinySegment; j += 2) {
+          const uint64_t lo = k[j] < k[j + 1] ? k[j] : k[j + 1], hi = k[j] < k[j + 1] ? k[j + 1] : k[j];
+          k[j] = lo;
+          k[j + 1] = hi;
+        }
+      const uint32_t s = q_s[(uint32_t)(k[0] >> 44)];
+      const uint32_t mh = s ? tab_min_hits[s] : 0xffffffffu;
+#pragma unroll
+      for (uint32_t a = 0; a < kTinySegment; ++a) {
+#pragma unroll
+        for (uint32_t z = a; z < kTinySegment; ++z) {  // z = a + mh - 1
+          if (z + 1 == a + mh && z < nh && ((k[a] >> 24) & 0xfffffu) == ((k[z] >> 24) & 0xfffffu) &&
+              (uint32_t)(k[z] & 0xffffffu) - (uint32_t)(k[a] & 0xffffffu) < frag_len)
+            keep = true;
+        }
+      }
+    }
+  }
+  const uint64_t km = __ballot(keep);
+  if (km == 0) return;
+  uint32_t slot0 = 0;
+  if (lane == (uint32_t)__builtin_ctzll(km)) slot0 = atomicAdd(counter, (uint32_t)__popcll(km));
+  slot0 = __shfl(slot0, __builtin_ctzll(km), 64);
+  if (keep) {
+    const uint32_t slot = slot0 + (uint32_t)__popcll(km & ((1ULL << lane) - 1ULL));
+    out_a0[slot] = a0;
+    out_nh[slot] = nh;
+  }
+}
+
 // the listed segments longer than kHitCap, as (start, length) pairs for frag_sort_kernel
 __global__ __launch_bounds__(kThreads) void big_segments_kernel(const uint32_t *__restrict__ seg_a0,
                                                                 const uint32_t *__restrict__ seg_nh, uint32_t n_segs,
@@ -1022,7 +1077,7 @@ struct FragWork {
   DevBuf contig_start, contig_len, contig_genome, block_counts, block_offsets, mini_hash, mini_wpos, mini_contig,
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
-      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, post_cw, seg_a0, seg_nh, genome_first_contig,
+      tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
       contig_bucket_off, bucket_first;
   ~FragWork() {
     DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
@@ -1030,7 +1085,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -1434,10 +1489,10 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                              W.seg_start.as<uint32_t>(), W.seg_list.as<uint32_t>(), n_keep, W.seg_a0.as<uint32_t>(),
                              W.seg_nh.as<uint32_t>());
       }
-      auto launch_map = [&](uint32_t first, uint32_t count, uint32_t hit_cap) {
+      auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap) {
         if (count == 0) return;
         hipLaunchKernelGGL(map_segments_kernel, dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap), c->stream, hk[hw],
-                           hv[hw], W.seg_a0.as<uint32_t>() + first, W.seg_nh.as<uint32_t>() + first, count, presorted,
+                           hv[hw], list_a0, list_nh, count, presorted,
                            W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(), W.q_hash.as<uint32_t>(),
                            W.q_s.as<uint32_t>(), W.frag_genome_local.as<uint32_t>(), frag_len, count_windows,
                            W.tab_min_hits.as<uint32_t>(), W.tab_min_shared.as<uint32_t>(),
@@ -1447,10 +1502,22 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                            W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap);
       };
       if (use_buckets) {
-        launch_map(0, n_keep, (uint32_t)kHitCapSmall);
-        launch_map(large_at, n_large, (uint32_t)kHitCap);
+        if (n_keep) {
+          PA_TRY(W.seg2_a0.reserve((uint64_t)n_keep * 4 + 16));
+          PA_TRY(W.seg2_nh.reserve((uint64_t)n_keep * 4 + 16));
+          PA_HIP(hipMemsetAsync(d_seg_counters + 6, 0, 4, c->stream));
+          hipLaunchKernelGGL(prefilter_segments_kernel, dim3(ceil_div_u64(n_keep, kThreads)), dim3(kThreads), 0, c->stream,
+                             hk[hw], W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, W.q_s.as<uint32_t>(),
+                             W.tab_min_hits.as<uint32_t>(), frag_len, W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(),
+                             d_seg_counters + 6);
+          PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters + 6, 4, hipMemcpyDeviceToHost, c->stream));
+          PA_HIP(hipStreamSynchronize(c->stream));
+          const uint32_t n_small = *reinterpret_cast<const uint32_t *>(c->h_pinned);
+          launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall);
+        }
+        launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, n_large, (uint32_t)kHitCap);
       } else {
-        launch_map(0, n_keep, (uint32_t)kHitCap);
+        launch_map(W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, (uint32_t)kHitCap);
       }
     }
     PA_TRY(W.matched.reserve((uint64_t)nq * n_genomes * 4));
