@@ -59,6 +59,11 @@ __device__ __forceinline__ uint64_t times5_plus(uint64_t h, uint64_t c) {
   return t + c;
 }
 
+// Everything up to, but not including, the last `k ^= k >> 33` of the two fmix64 calls: the hash is
+// (X ^ X>>33) + (Y ^ Y>>33).  That last step only touches the low 31 bits, so the high words of X and Y
+// already decide -- up to one carry -- whether the hash can be <= max_hash (see kmer_hash.hip).
+// (The 64-bit multiplies are left to hipcc: v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3_u32.  A hand-written
+// chain of three v_mad_u64_u32 + one add was measured at the same 12.8 ms.)
 template <int K>
 __device__ __forceinline__ void murmur3_pre_final(const uint64_t (&P)[4], uint64_t &X, uint64_t &Y) {
   uint64_t h1 = 42, h2 = 42;
