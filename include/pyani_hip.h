@@ -238,6 +238,15 @@ PA_API double pa_fragani_identity(uint32_t shared, uint32_t s, uint32_t k);
 PA_API int64_t pa_fasta_records(const uint8_t *h_text, uint64_t n_text, uint64_t *h_rec_start, uint64_t *h_rec_len,
                          uint64_t cap);
 
+/* ---- bulk writer of sourmash-format `.sig` files (the cache of pyani_plus/methods/sourmash.py:57-66) ----
+ * File i = heads[i] + "h0,h1,..." + mids[i] + md5sum + tails[i], where the hashes are
+ * h_mins[h_off[i] .. h_off[i+1]) in decimal and md5sum = md5(str(ksize) + concatenated decimals), sourmash's
+ * checksum of a sketch.  The three text parts come from the caller (json.dumps of everything around the
+ * `mins` list and the `md5sum` value).  Files are written to <path>.tmp and renamed; n_threads 0 = all cores. */
+PA_API int pa_write_sigs(uint32_t n_files, const char *const *paths, const char *const *heads, const char *const *mids,
+                         const char *const *tails, uint32_t ksize, const uint64_t *h_mins, const uint64_t *h_off,
+                         uint32_t n_threads);
+
 /* ---- bulk writer of the reference's JSON column file (pyani_plus/private_cli.py:454-504) ----
  * Writes prefix + rows + suffix, rows byte-identical to json.dumps of
  * {"query_hash", "subject_hash", "identity", "cov_query"} dicts (", " separated, `null` where

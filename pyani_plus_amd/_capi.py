@@ -60,6 +60,7 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [_vp, _vp, _vp, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp, _u64p],
     ),
+    "pa_write_sigs": (C.c_int, [C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32]),
     "pa_mask_runs": (C.c_int64, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
     "pa_mask_from_runs": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_uint64]),
     "pa_sketch_streamed": (

@@ -105,6 +105,35 @@ def get_engine(device: int = 0):
     return _ENGINE
 
 
+# Sketches this process has just written, keyed by signature file: when prepare and compute run in one
+# process (rundb.run_sourmash_hip) the column worker takes them from here instead of parsing the files it
+# wrote a moment ago.  The files stay the contract between processes; an entry is only used while its file
+# still has the size and mtime it had when written.
+_RECENT: dict[str, tuple] = {}
+_RECENT_LIMIT_BYTES = 1 << 30
+_recent_bytes = 0
+
+
+def _remember_sketch(sig_file: Path, ksize: int, max_hash: int, mins: np.ndarray) -> None:
+    global _recent_bytes  # noqa: PLW0603
+    if _recent_bytes + mins.nbytes > _RECENT_LIMIT_BYTES:
+        _RECENT.clear()
+        _recent_bytes = 0
+    stat = sig_file.stat()
+    _RECENT[str(sig_file)] = (int(ksize), int(max_hash), stat.st_size, stat.st_mtime_ns, mins)
+    _recent_bytes += mins.nbytes
+
+
+def _recall_sketch(sig_file: Path, ksize: int, max_hash: int):
+    entry = _RECENT.get(str(sig_file))
+    if entry is None or entry[0] != int(ksize) or entry[1] != int(max_hash):
+        return None
+    stat = sig_file.stat()
+    if (stat.st_size, stat.st_mtime_ns) != entry[2:4]:
+        return None
+    return entry[4]
+
+
 def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, preloaded=None) -> Iterator:
     """Build the sketch signatures in ``cache/sourmash_k={kmersize}_scaled={N}``.
 
@@ -153,15 +182,17 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, pr
                     log_sys_exit(logger, info.message)
         eng = engine or get_engine()
         sketches = eng.sketch(eng.upload(arena), config.kmersize, scaled, max_hash=max_hash).to_host()
-        for entry, mins in zip(batch, sketches):
-            sig.write_sig(
-                sig_dir / f"{entry.genome_hash}.sig",
-                name=entry.genome_hash,
-                filename=str(fasta_dir / entry.fasta_filename),
-                ksize=config.kmersize,
-                max_hash=max_hash,
-                mins=mins,
-            )
+        sig_files = [sig_dir / f"{entry.genome_hash}.sig" for entry in batch]
+        sig.write_sigs(
+            sig_files,
+            names=[entry.genome_hash for entry in batch],
+            filenames=[str(fasta_dir / entry.fasta_filename) for entry in batch],
+            ksize=config.kmersize,
+            max_hash=max_hash,
+            sketches=sketches,
+        )
+        for sig_file, mins in zip(sig_files, sketches):
+            _remember_sketch(sig_file, config.kmersize, max_hash, mins)
         batch, batch_bytes = [], 0
 
     pending: list = []
@@ -209,7 +240,9 @@ def compute_sourmash_matrices(
         sig_file = cache / f"{genome_hash}.sig"
         if not sig_file.is_file():
             log_sys_exit(logger, f"Missing sourmash signature file '{sig_file}'")
-        mins, _ = sig.read_sig(sig_file, ksize=kmersize, max_hash=max_hash)
+        mins = _recall_sketch(sig_file, kmersize, max_hash)
+        if mins is None:
+            mins, _ = sig.read_sig(sig_file, ksize=kmersize, max_hash=max_hash)
         sketches.append(mins)
     nq = len(queries)
     sizes = np.array([len(s) for s in sketches], dtype=np.uint64)

@@ -53,6 +53,58 @@ def write_sig(path: Path, *, name: str, filename: str, ksize: int, max_hash: int
     tmp.replace(path)
 
 
+def write_sigs(paths, *, names, filenames, ksize: int, max_hash: int, sketches) -> None:
+    """Write many signatures at once through the native threaded writer (``pa_write_sigs``).
+
+    Same bytes as ``write_sig`` for every file: everything around the hash list is formatted here with
+    ``json.dumps``, the decimal hashes and the sketch md5 natively."""
+    import ctypes as C
+
+    from . import _capi
+
+    n = len(paths)
+    if n == 0:
+        return
+    lib = _capi.load_library()
+    heads, mids, tails = [], [], []
+    for name, filename in zip(names, filenames):
+        obj = [
+            {
+                "class": "sourmash_signature",
+                "email": "",
+                "hash_function": "0.murmur64",
+                "filename": filename,
+                "name": name,
+                "license": "CC0",
+                "signatures": [
+                    {"num": 0, "ksize": int(ksize), "seed": 42, "max_hash": int(max_hash), "mins": [], "md5sum": "", "molecule": "DNA"}
+                ],
+                "version": 0.4,
+            }
+        ]
+        text = json.dumps(obj, separators=(",", ":"))
+        marker = '"mins":[],"md5sum":""'
+        at = text.rindex(marker)  # the last occurrence is the real one even if a file name contains the marker
+        heads.append(text[: at + len('"mins":[')].encode())
+        mids.append(b'],"md5sum":"')
+        tails.append(text[at + len(marker) - 1 :].encode())
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum([len(s) for s in sketches], out=off[1:])
+    flat = np.concatenate([np.asarray(s, dtype=np.uint64) for s in sketches]) if int(off[-1]) else np.zeros(1, dtype=np.uint64)
+    flat = np.ascontiguousarray(flat)
+
+    def c_strings(items):
+        return (C.c_char_p * n)(*items)
+
+    path_bytes = [str(p).encode() for p in paths]
+    _capi.check(
+        lib.pa_write_sigs(
+            n, c_strings(path_bytes), c_strings(heads), c_strings(mids), c_strings(tails), int(ksize), flat.ctypes.data, off.ctypes.data, 0
+        ),
+        "pa_write_sigs",
+    )
+
+
 def _read_single_sketch_fast(text: str, ksize: int | None, max_hash: int | None):
     """Files with exactly one sketch (what singlesketch and this backend write): parse the long
     ``mins`` list with numpy instead of the JSON decoder; anything unusual falls back to json."""

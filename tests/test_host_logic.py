@@ -403,3 +403,28 @@ def test_mask_runs_round_trip():
     assert np.array_equal(rebuilt, bits)
     assert np.all(start[1:] > start[:-1] + length[:-1])  # maximal runs: never adjacent
     assert mask_runs(np.zeros(4, dtype=np.uint32), 128)[0].size == 0
+
+
+def test_native_sig_writer_equals_python_writer_and_fixture(tmp_path):
+    """pa_write_sigs (threaded, native decimals + md5) writes the same bytes as sig.write_sig, which writes the
+    same bytes as `sourmash scripts singlesketch` (fixture .sig files)."""
+    rng = np.random.default_rng(1)
+    sketches = [np.sort(rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)) for n in (0, 1, 5000, 17)]
+    names = ["a", 'b"q', "ü-name", "d"]
+    files = ["/x/y.fa", "C:\\\\p\\q.fa", 'we"ird "mins":[],"md5sum":"" name.fa', "ŝ.fasta"]
+    for i, (mins, name, filename) in enumerate(zip(sketches, names, files)):
+        sig.write_sig(tmp_path / f"py{i}.sig", name=name, filename=filename, ksize=31, max_hash=123456789, mins=mins)
+    sig.write_sigs([tmp_path / f"c{i}.sig" for i in range(4)], names=names, filenames=files, ksize=31, max_hash=123456789, sketches=sketches)
+    for i in range(4):
+        assert (tmp_path / f"c{i}.sig").read_bytes() == (tmp_path / f"py{i}.sig").read_bytes()
+    # and against a reference fixture, through its own name / filename strings
+    name = "viral_example"
+    md5 = sorted(FIXTURE_SETS[name][1])[0]
+    fixture = GOLDEN / name / "sourmash" / f"{md5}.sig"
+    want = json.loads(fixture.read_text())[0]
+    sketch = want["signatures"][0]
+    sig.write_sigs(
+        [tmp_path / "fixture.sig"], names=[want["name"]], filenames=[want["filename"]], ksize=sketch["ksize"],
+        max_hash=sketch["max_hash"], sketches=[np.array(sketch["mins"], dtype=np.uint64)],
+    )  # fmt: skip
+    assert (tmp_path / "fixture.sig").read_bytes() == fixture.read_bytes()

@@ -1,0 +1,45 @@
+"""Whole path on files at a size between BASELINE configs[0] and configs[1]: N synthetic 5 Mb genomes written
+as FASTA files, then FASTA directory -> database with N^2 comparisons through rundb.run_sourmash_hip.
+
+    python tools/config2_file.py [n_genomes=200] [length=5000000]
+Prints the wall time of the run and of its parts (threaded FASTA front-end, device work, JSON + SQLite).
+"""
+import logging
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from pyani_plus_amd import rundb  # noqa: E402
+from pyani_plus_amd.synth import RATES  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+length = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
+rng = np.random.default_rng(20260802)
+acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+roots = rng.integers(0, 4, size=(8, length), dtype=np.uint8)
+logging.basicConfig(level=logging.WARNING)
+with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+    fasta = Path(tmp) / "genomes"
+    fasta.mkdir()
+    t0 = time.perf_counter()
+    for g in range(n):
+        seq = roots[g % 8].copy()
+        hit = rng.random(length) < RATES[(g // 8) % len(RATES)]
+        seq[hit] = (seq[hit] + rng.integers(1, 4, size=int(hit.sum()), dtype=np.uint8)) & 3
+        text = acgt[seq]
+        with (fasta / f"genome_{g:05d}.fasta").open("wb") as handle:
+            handle.write(b">genome_%d synthetic\n" % g)
+            handle.write(b"\n".join(text[i : i + 100_000].tobytes() for i in range(0, length, 100_000)))
+            handle.write(b"\n")
+    print(f"wrote {n} FASTA files ({n * length / 1e9:.2f} Gb) in {time.perf_counter() - t0:.1f} s", flush=True)
+    for rep in range(2):
+        db = Path(tmp) / f"run{rep}.sqlite"
+        t0 = time.perf_counter()
+        run = rundb.run_sourmash_hip(fasta, db)
+        dt = time.perf_counter() - t0
+        print(f"rep {rep}: files -> database in {dt:.2f} s for {n} genomes = {n * n / dt:.3e} pairs/s end to end", flush=True)
