@@ -17,6 +17,7 @@
 //
 // The per-ordered-pair cost drops from O(|Q|+|S|) merge steps to
 // O(|Q|/32) word operations; the result is the exact integer |Q n S|.
+#include <algorithm>
 #include <vector>
 
 #include "pa_internal.h"
@@ -199,8 +200,10 @@ __global__ __launch_bounds__(kThreads) void table_insert_kernel(const uint64_t *
     }
     uint32_t slot = slot_of(h, cap);
     for (;;) {
-      // most postings repeat a key that is already there: look before paying for the atomic
-      unsigned long long k = __builtin_nontemporal_load(&table[slot].key);
+      // most postings repeat a key that is already there: look before paying for the atomic.  A plain,
+      // cached load (a non-temporal one was 1.5x slower): the popular keys are then served by L2, and a stale
+      // line can only show "empty" for a slot that has been taken since, which the CAS below corrects.
+      unsigned long long k = *reinterpret_cast<volatile const unsigned long long *>(&table[slot].key);
       if (k == kEmptyKey) k = atomicCAS(&table[slot].key, (unsigned long long)kEmptyKey, (unsigned long long)h);
       if (k == kEmptyKey) { won_slot[won++] = slot; break; }
       if (k == h) break;
@@ -218,14 +221,23 @@ __global__ __launch_bounds__(kThreads) void table_insert_kernel(const uint64_t *
   if (won_special) special[0] = local;
 }
 
-// ids of the postings [p0, p1); postings of tile subjects (SET_BITS) also set their bit in the row
+// ids of the postings [p0, p1); postings of tile subjects (SET_BITS) also set their bit in the row.  With
+// SET_BITS the grid is two-dimensional -- blockIdx.y is the subject, blockIdx.x a 256-posting piece of its sketch
+// -- so the column comes from the block index and not from a search in the offsets.
 template <bool SET_BITS>
 __global__ __launch_bounds__(kThreads) void table_lookup_kernel(
     const uint64_t *__restrict__ hashes, uint64_t p0, uint64_t p1, const DictEntry *__restrict__ table, uint32_t cap,
     const uint32_t *__restrict__ special, uint32_t *__restrict__ ids_csr, const uint64_t *__restrict__ off, uint32_t n,
     uint32_t t0, uint32_t w32, uint32_t *__restrict__ rows) {
-  const uint64_t p = p0 + (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-  if (p >= p1) return;
+  uint64_t p;
+  if constexpr (SET_BITS) {
+    const uint64_t beg = off[t0 + blockIdx.y];
+    p = beg + (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (p >= off[t0 + blockIdx.y + 1]) return;
+  } else {
+    p = p0 + (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (p >= p1) return;
+  }
   const uint64_t h = hashes[p];
   uint32_t id = kNone;
   if (h == kEmptyKey) {
@@ -242,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void table_lookup_kernel(
   }
   ids_csr[p] = id;
   if constexpr (SET_BITS) {
-    const uint32_t col = owner_of(off, n, p) - t0;
+    const uint32_t col = blockIdx.y;
     atomicOr(&rows[(uint64_t)id * w32 + (col >> 5)], 1u << (col & 31u));
   }
 }
@@ -402,10 +414,13 @@ int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_
       PA_TRY(c->bitrows.reserve(row_bytes));
       PA_HIP(hipMemsetAsync(c->bitrows.p, 0, row_bytes, c->stream));
       const DictEntry *table = c->dict_keys[0].as<DictEntry>();
-      if (pt1 > pt0)
-        hipLaunchKernelGGL(table_lookup_kernel<true>, dim3(ceil_div_u64(pt1 - pt0, kThreads)), dim3(kThreads), 0,
+      if (pt1 > pt0) {
+        uint64_t longest = 0;
+        for (uint32_t g = t0; g < t1; ++g) longest = std::max(longest, h_off[g + 1] - h_off[g]);
+        hipLaunchKernelGGL(table_lookup_kernel<true>, dim3(ceil_div_u64(longest, kThreads), cols), dim3(kThreads), 0,
                            c->stream, d_hashes, pt0, pt1, table, cap, d_counter + 1, d_ids, d_off, n, t0, w32,
                            c->bitrows.as<uint32_t>());
+      }
       // query postings outside the tile's own range
       const uint64_t a0 = pq0, a1 = pq1 < pt0 ? pq1 : pt0;  // part before the tile
       const uint64_t b0 = pq0 > pt1 ? pq0 : pt1, b1 = pq1;  // part after the tile
