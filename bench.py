@@ -299,6 +299,8 @@ def main():
                     "measured_cycles_per_wave_step": per_launch_s * 2.4e9 * 1024 / max(1.0, sum(lengths[g0:g1]) / 64.0),
                     "clock_ghz_assumed": 2.4,
                     "simds": 1024,
+                    "note": "model = static instruction mix x measured issue costs; measured/model near 1 means the "
+                    "kernel runs at the VALU issue limit of its instruction stream",
                 },
             },
             "phases_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
