@@ -111,32 +111,35 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
     if ((d1 & d2) != 0xffffffffu) {  // at least one usable window in this block
       constexpr uint64_t kMask = (K == 32) ? ~0ULL : ((1ULL << (2 * K)) - 1);
       constexpr uint32_t kMaskHi = (uint32_t)(kMask >> 32);
-      constexpr int kTopShift = 2 * (K - 1);  // where a new base enters the LSB-first register
-      // F_msb: base 0 of the window in the top bits (lexicographic order == integer order)
-      // F_lsb: base j of the window at bits 2j (== the packed stream layout)
-      // revcomp in MSB-first form is ~F_lsb, in LSB-first form ~F_msb.
-      uint64_t f_msb = 0, f_lsb = 0;
-      // warm-up: the K-1 bases before this block
+      // Two packed streams over the 96 positions this thread sees (32 of look-back + its 64): F, the
+      // bases as stored (base j at bits 2j: already the byte order murmur wants), and R, their reverse
+      // complement (reverse the order of the 2-bit groups, flip the bits).  The window ending at block
+      // position e is K groups of F starting at group e + 33 - K and, as its reverse complement, K groups of
+      // R starting at group 63 - e.  Both are funnel shifts by compile-time amounts -- no rolling registers,
+      // no warm-up over the K-1 preceding bases, no dependency from one window to the next.  And because
+      // the MSB-first (lexicographic) form of one strand is the complement of the LSB-first form of the
+      // other, "forward <= reverse complement" in lexicographic order is simply F-window <= R-window.
+      uint32_t fw[8] = {pw.x, pw.y, cur.x, cur.y, cur.z, cur.w, 0u, 0u};
+      uint32_t rw[6];
 #pragma unroll
-      for (int j = 32 - (K - 1); j < 32; ++j) {
-        const uint32_t word = (j < 16) ? pw.x : pw.y;
-        const uint64_t b = (word >> (2 * (j & 15))) & 3u;
-        f_msb = ((f_msb << 2) | b) & kMask;
-        f_lsb = (f_lsb >> 2) | (b << kTopShift);
+      for (int j = 0; j < 6; ++j) {
+        const uint32_t x = __builtin_bitreverse32(fw[5 - j]);  // groups reversed, bits inside a group too
+        rw[j] = ~(((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1));
       }
-      const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
 #pragma unroll 1
       for (int wi = 0; wi < 4; ++wi) {
-        uint32_t word = words[wi];
-        uint32_t badw = (bad[wi >> 1] >> (16 * (wi & 1))) & 0xffffu;
-#pragma unroll 4
+        // fw[0] is the dword holding group 16*wi; rw[3..5] hold R groups 48-16*wi .. 95-16*wi
+        const uint32_t badw = (bad[wi >> 1] >> (16 * (wi & 1))) & 0xffffu;
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const uint64_t b = word & 3u;
-          word >>= 2;
-          f_msb = ((f_msb << 2) | b) & kMask;
-          f_lsb = (f_lsb >> 2) | (b << kTopShift);
-          const uint64_t r_msb = f_lsb ^ kMask;
-          const uint64_t canon = (f_msb <= r_msb) ? f_lsb : (f_msb ^ kMask);
+          constexpr int kOff = 33 - K;
+          const int q = i + kOff, dq = q >> 4, fo = 2 * (q & 15), ro = 30 - 2 * i;
+          const uint32_t f_lo = fo ? alignbit(fw[dq + 1], fw[dq], fo) : fw[dq];
+          const uint32_t f_hi = fo ? alignbit(fw[dq + 2], fw[dq + 1], fo) : fw[dq + 1];
+          const uint32_t r_lo = ro ? alignbit(rw[4], rw[3], ro) : rw[3];
+          const uint32_t r_hi = ro ? alignbit(rw[5], rw[4], ro) : rw[4];
+          const uint64_t f_lsb = u64_of(f_lo, f_hi) & kMask, r_lsb = u64_of(r_lo, r_hi) & kMask;
+          const uint64_t canon = (f_lsb <= r_lsb) ? f_lsb : r_lsb;
           const uint32_t clo = (uint32_t)canon, chi = (uint32_t)(canon >> 32);
           uint64_t P[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -177,6 +180,12 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
             }
           }
         }
+        // next 16 positions: slide both streams by one dword
+#pragma unroll
+        for (int j = 0; j < 7; ++j) fw[j] = fw[j + 1];
+        fw[7] = 0u;
+#pragma unroll
+        for (int j = 5; j > 0; --j) rw[j] = rw[j - 1];
       }
     }
   }
