@@ -65,8 +65,7 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
   __shared__ uint32_t s_hi[LUT ? kWords : 1][256];
 
   const uint32_t tid = threadIdx.x;
-  const uint32_t max_hi_plus1 = (uint32_t)(max_hash >> 32) + 1u;
-  const bool keep_all = max_hi_plus1 == 0u;  // max_hash.hi == 0xffffffff: the high-word screen cannot reject
+  const uint32_t max_hi = (uint32_t)(max_hash >> 32);
   if (tid == 0) s_n = 0;
   if constexpr (LUT) {
 #pragma unroll
@@ -158,13 +157,13 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
           (void)kMaskHi;
           // Screen on the high words: hash = (X ^ X>>33) + (Y ^ Y>>33) has high word X.hi + Y.hi + carry, so
           // it can be <= max_hash only if X.hi + Y.hi is <= max_hash.hi or is 0xffffffff (carry wraps it to
-          // 0): one 32-bit add and compare for the 999 in 1000 windows that are dropped.
+          // 0): one 32-bit add and two compares for the 999 in 1000 windows that are dropped.
           uint64_t X, Y;
           murmur3_pre_final<K>(P, X, Y);
           const uint32_t sum_hi = (uint32_t)(X >> 32) + (uint32_t)(Y >> 32);
-          if ((keep_all || sum_hi + 1u <= max_hi_plus1) && !((badw >> i) & 1u)) {
+          if (sum_hi <= max_hi || sum_hi == 0xffffffffu) {
             const uint64_t h = (X ^ (X >> 33)) + (Y ^ (Y >> 33));
-            if (h > max_hash) continue;
+            if (h > max_hash || ((badw >> i) & 1u)) continue;  // validity is only looked at for the 1 in 1000
             const uint32_t slot = atomicAdd(&s_n, 1u);
             if (slot < kStageCap) {
               s_hash[slot] = h;
