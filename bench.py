@@ -294,8 +294,8 @@ def main():
                 # VALU-issue view of the same launch: static instruction mix of
                 # kmer_hash_kernel<31,true> x measured issue costs (profiles/r01_ubench_valu_gfx950.txt)
                 "valu": {
-                    "instr_per_window": 93.5,
-                    "model_cycles_per_wave_step": 24.6875 * 2.7 + 68.8125 * 4.4,
+                    "instr_per_window": 92.5,
+                    "model_cycles_per_wave_step": 24.6875 * 2.7 + 67.8125 * 4.4,
                     "measured_cycles_per_wave_step": per_launch_s * 2.4e9 * 1024 / max(1.0, sum(lengths[g0:g1]) / 64.0),
                     "clock_ghz_assumed": 2.4,
                     "simds": 1024,

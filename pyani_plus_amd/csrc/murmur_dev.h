@@ -73,8 +73,12 @@ __device__ __forceinline__ void murmur3_pre_final(const uint64_t (&P)[4], uint64
   for (int i = 0; i < nblocks; ++i) {
     const uint64_t k1 = rotl64(P[2 * i], 31) * kC2;
     h1 ^= k1;
-    h1 = rotl64(h1, 27) + h2;
-    h1 = times5_plus(h1, 0x52dce729ULL);
+    if (i == 0) {  // h2 is still the seed: (rotl(h1) + 42) * 5 + c = rotl(h1) * 5 + (5 * 42 + c), one 64-bit add less
+      h1 = times5_plus(rotl64(h1, 27), 5ULL * 42ULL + 0x52dce729ULL);
+    } else {
+      h1 = rotl64(h1, 27) + h2;
+      h1 = times5_plus(h1, 0x52dce729ULL);
+    }
     const uint64_t k2 = rotl64(P[2 * i + 1], 33) * kC1;
     h2 ^= k2;
     h2 = rotl64(h2, 31) + h1;
