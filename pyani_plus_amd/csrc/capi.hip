@@ -231,7 +231,7 @@ int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint6
       ProfScope prof(c, PA_PROF_SKETCH_SORT);
       const int st = pa_sketch_from_regions(c, c->cand_keys[0].as<uint64_t>(), c->region_off.as<uint64_t>(),
                                             c->region_cursor.as<uint32_t>(), d_overflow, n_genomes,
-                                            (uint32_t)longest_region, d_hashes, cap_hashes, d_off, h_total, &overflow);
+                                            (uint32_t)longest_region, max_hash, d_hashes, cap_hashes, d_off, h_total, &overflow);
       if (st != PA_OK) return st;
     }
     if (!overflow) return PA_OK;

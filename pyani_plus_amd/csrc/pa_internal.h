@@ -136,8 +136,8 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
 // sketch_lds.hip: per-genome regions -> sorted unique CSR sketches, one workgroup and one LDS sort per genome
 constexpr uint32_t kLdsSortMax = 16384;  // longest region the LDS sort takes
 int pa_sketch_from_regions(pa_ctx *c, uint64_t *d_regions, const uint64_t *d_region_off, const uint32_t *d_cursor,
-                           const uint32_t *d_overflow, uint32_t n_genomes, uint32_t longest_region, uint64_t *d_hashes,
-                           uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total, bool *h_overflow);
+                           const uint32_t *d_overflow, uint32_t n_genomes, uint32_t longest_region, uint64_t max_hash,
+                           uint64_t *d_hashes, uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total, bool *h_overflow);
 
 // sketch_build.hip
 int pa_build_sketch_csr(pa_ctx *c, const uint64_t *d_sorted_hash, const uint32_t *d_sorted_genome,

@@ -14,6 +14,8 @@
 //
 // Six launches instead of the ~45 of the 9-pass global sort.  Regions that overflow (low-complexity
 // genomes, tiny `scaled`) or genomes too long for LDS make pa_sketch fall back to sketch_build.hip.
+#include <algorithm>
+
 #include "pa_internal.h"
 
 namespace {
@@ -30,12 +32,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
   return v;
 }
 
+constexpr uint32_t kBuckets = kSortThreads;  // one bucket per thread
+constexpr uint32_t kBucketCap = 48;          // longest bucket a single thread sorts by insertion
+
 __global__ __launch_bounds__(kSortThreads) void genome_sort_kernel(uint64_t *__restrict__ regions,
                                                                    const uint64_t *__restrict__ region_off,
                                                                    const uint32_t *__restrict__ cursor,
-                                                                   uint32_t *__restrict__ uniq) {
+                                                                   uint32_t *__restrict__ uniq, uint32_t key_shift,
+                                                                   uint32_t key_mult) {
   extern __shared__ uint64_t s_key[];
   __shared__ uint32_t s_wave[kSortWaves];
+  __shared__ uint32_t s_count[kBuckets], s_cursor[kBuckets];
+  __shared__ uint32_t s_longest;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t g = blockIdx.x;
   uint64_t *__restrict__ region = regions + region_off[g];
@@ -45,12 +53,61 @@ __global__ __launch_bounds__(kSortThreads) void genome_sort_kernel(uint64_t *__r
     if (tid == 0) uniq[g] = 0;
     return;
   }
+  // Hashes are spread evenly over [0, max_hash], so 1 024 equal value ranges take ~5 keys each: count, scan,
+  // scatter into LDS, and every thread finishes its own range with an insertion sort.  A range with more
+  // than kBucketCap keys (sequence that is anything but random) sends the genome to the bitonic network
+  // instead, which costs the same for any input.
+  auto bucket_of = [&](uint64_t key) -> uint32_t {
+    const uint32_t b = (uint32_t)(((key >> key_shift) * (uint64_t)key_mult) >> 32);
+    return b < kBuckets ? b : kBuckets - 1u;
+  };
+  s_count[tid] = 0;
+  if (tid == 0) s_longest = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < n; i += kSortThreads) atomicAdd(&s_count[bucket_of(region[i])], 1u);
+  __syncthreads();
+  const uint32_t my_count = s_count[tid];
+  {
+    const uint32_t incl = wave_incl_scan(my_count, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    uint32_t longest = my_count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor(longest, o, 64));
+    if (lane == 0) atomicMax(&s_longest, longest);
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < (int)wave; ++w) base += s_wave[w];
+    s_cursor[tid] = base + incl - my_count;
+  }
+  __syncthreads();
+  const uint32_t my_start = s_cursor[tid];
+  const bool by_buckets = s_longest <= kBucketCap;
+  __syncthreads();  // everyone has read its start before the cursors move
+  if (by_buckets) {
+    for (uint32_t i = tid; i < n; i += kSortThreads) {
+      const uint64_t key = region[i];
+      s_key[atomicAdd(&s_cursor[bucket_of(key)], 1u)] = key;
+    }
+    __syncthreads();
+    for (uint32_t i = 1; i < my_count; ++i) {
+      const uint64_t key = s_key[my_start + i];
+      uint32_t j = i;
+      while (j > 0 && s_key[my_start + j - 1] > key) {
+        s_key[my_start + j] = s_key[my_start + j - 1];
+        --j;
+      }
+      s_key[my_start + j] = key;
+    }
+    __syncthreads();
+  }
   uint32_t np2 = 2;
   while (np2 < n) np2 <<= 1;
-  for (uint32_t i = tid; i < np2; i += kSortThreads) s_key[i] = i < n ? region[i] : ~0ULL;
-  __syncthreads();
+  if (!by_buckets) {
+    for (uint32_t i = tid; i < np2; i += kSortThreads) s_key[i] = i < n ? region[i] : ~0ULL;
+    __syncthreads();
+  }
   // bitonic network; pads equal the largest key, so the first n slots end up holding the n real keys
-  for (uint32_t k = 2; k <= np2; k <<= 1) {
+  for (uint32_t k = 2; !by_buckets && k <= np2; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
       for (uint32_t t = tid; t < (np2 >> 1); t += kSortThreads) {
         const uint32_t i = 2u * t - (t & (j - 1u));  // bit j clear
@@ -128,8 +185,9 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint64_t *__restrict_
 }  // namespace
 
 int pa_sketch_from_regions(pa_ctx *c, uint64_t *d_regions, const uint64_t *d_region_off, const uint32_t *d_cursor,
-                           const uint32_t *d_overflow, uint32_t n_genomes, uint32_t longest_region, uint64_t *d_hashes,
-                           uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total, bool *h_overflow) {
+                           const uint32_t *d_overflow, uint32_t n_genomes, uint32_t longest_region, uint64_t max_hash,
+                           uint64_t *d_hashes, uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total,
+                           bool *h_overflow) {
   PA_REQUIRE(longest_region <= kLdsSortMax, "LDS sort: region of %u candidates exceeds %u", longest_region, kLdsSortMax);
   uint32_t np2 = 2;
   while (np2 < longest_region) np2 <<= 1;
@@ -139,8 +197,13 @@ int pa_sketch_from_regions(pa_ctx *c, uint64_t *d_regions, const uint64_t *d_reg
   uint64_t *d_total = c->counters.as<uint64_t>() + 1;
   PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(genome_sort_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  // value ranges of the bucket sort: equal shares of [0, max_hash]
+  const int key_bits = max_hash ? 64 - __builtin_clzll(max_hash) : 1;
+  const uint32_t key_shift = key_bits > 32 ? (uint32_t)key_bits - 32u : 0u;
+  const uint64_t top = (max_hash >> key_shift) + 1;  // (key >> shift) < top <= 2^32
+  const uint32_t key_mult = (uint32_t)std::min<uint64_t>(((uint64_t)kBuckets << 32) / top, 0xffffffffull);
   hipLaunchKernelGGL(genome_sort_kernel, dim3(n_genomes), dim3(kSortThreads), lds_bytes, c->stream, d_regions,
-                     d_region_off, d_cursor, d_uniq);
+                     d_region_off, d_cursor, d_uniq, key_shift, key_mult);
   hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(kSortThreads), 0, c->stream, d_uniq, n_genomes, d_off, d_total);
   PA_HIP(hipGetLastError());
   // one round trip for both scalars: [0] total, [1] overflow flag

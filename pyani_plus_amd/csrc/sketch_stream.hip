@@ -151,7 +151,7 @@ int pa_sketch_streamed(pa_ctx *c, const uint32_t *h_packed, const uint64_t *h_ru
     ProfScope prof(c, PA_PROF_SKETCH_SORT);
     status = pa_sketch_from_regions(c, c->cand_keys[0].as<uint64_t>(), c->region_off.as<uint64_t>(),
                                     c->region_cursor.as<uint32_t>(), d_overflow, n_genomes, (uint32_t)longest_region,
-                                    d_hashes, cap_hashes, d_off, h_total, &overflow);
+                                    max_hash, d_hashes, cap_hashes, d_off, h_total, &overflow);
   } else {
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamSynchronize(c->stream);

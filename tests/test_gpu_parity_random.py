@@ -87,6 +87,12 @@ def test_sketch_staging_overflow_and_capacity_retry(engine):
     got = engine.sketch(engine.upload(arena), k, 1000).to_host()
     assert np.array_equal(got[0], oracle.sketch_seq(repeat, k, 1000)) and got[0].size >= 1
     assert np.array_equal(got[1], oracle.sketch_seq(rand, k, 1000))
+    # a repeat small enough for the genome's candidate region: the LDS sort sees one value range with far more
+    # keys than its per-thread insertion sort takes and switches to the bitonic network
+    few = kmer * 150 + rand[:200_000]
+    arena = pack_genomes([few, rand[:100_000]], fasta=False)
+    got = engine.sketch(engine.upload(arena), k, 1000).to_host()
+    assert np.array_equal(got[0], oracle.sketch_seq(few, k, 1000)) and np.array_equal(got[1], oracle.sketch_seq(rand[:100_000], k, 1000))
     # scaled=1: every window survives -> staging overflow path, duplicates collapse
     small = pack_genomes([rand[:50_000], (b"ACGT" * 3000)], fasta=False)
     got = engine.sketch(engine.upload(small), k, 1).to_host()
