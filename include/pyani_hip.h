@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 1
+#define PA_ABI_VERSION 2
 
 /* every entry point below is exported with default visibility */
 #define PA_API __attribute__((visibility("default")))
@@ -178,18 +178,32 @@ PA_API int pa_sketch_streamed(pa_ctx *ctx, const uint32_t *h_packed, const uint6
 #define PA_PAIRS_BITROW_HASH 3 /* dictionary by hash table (subjects of the tile only) + bit-row column sums */
 PA_API int pa_pair_counts(pa_ctx *ctx, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n,
                    uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts, int algo);
+/* Same, for a caller that already has the CSR offsets on the host (h_off[n+1] == the content of d_off: sketch
+ * sizes read from a `.sig` cache, or received with the multi-GPU all-gather).  The default algorithm then runs
+ * without any host round trip; with h_off == NULL this is pa_pair_counts. */
+PA_API int pa_pair_counts_ex(pa_ctx *ctx, const uint64_t *d_hashes, const uint64_t *d_off, const uint64_t *h_off,
+                      uint32_t n, uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts, int algo);
+/* Multi-GPU overlap: build the hash dictionary of one subject tile from its n_postings hashes (a rank's own
+ * sketches, contiguous in device memory) while the sketch all-gather is still in flight -- the exchange that
+ * replaces the `.sig` file lists handed to `sourmash sig collect` (pyani_plus/methods/sourmash.py:162-183).
+ * The next pa_pair_counts(_ex) with the default algorithm must cover a single subject tile (<= 2048 columns)
+ * holding exactly these postings; it then skips its own insert.  Any other pair call drops the preparation. */
+PA_API int pa_pair_dict_prepare(pa_ctx *ctx, const uint64_t *d_subject_hashes, uint64_t n_postings);
 
 /* ---- counts -> ANI ----
  * cov_query = (I/|Q|)^(1/k), identity = max(cov_query, (I/|S|)^(1/k));
  * I == 0 -> NaN in both (the reference's NULL, sourmash.py:141-144).
  * pa_ani runs on the device (f64; <= 1 ulp from libm);
  * pa_ani_host uses the host libm `pow`, which reproduces every reference
- * fixture bit for bit, and is what the JSON/DB boundary uses. */
+ * fixture bit for bit, and is what the JSON/DB boundary uses; rows are split over
+ * n_threads host threads (0 = up to 64 of the cores), and with `symmetric` != 0 (square
+ * block, queries and subjects are the same genomes in the same order) one pow per
+ * ordered pair is computed instead of two: (I/|S|)^(1/k) of (q,s) is cov_query of (s,q). */
 PA_API int pa_ani(pa_ctx *ctx, const uint32_t *d_counts, const uint64_t *d_off, uint32_t q0, uint32_t q1,
            uint32_t s0, uint32_t s1, uint32_t k, double *d_identity, double *d_cov_query);
 PA_API int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, const uint64_t *h_s_sizes,
                 uint32_t nq, uint32_t ns, uint32_t k, double *h_identity, double *h_cov_query,
-                uint8_t *h_is_null);
+                uint8_t *h_is_null, int symmetric, uint32_t n_threads);
 
 /* ---- bottom-m MinHash + Mash Jaccard (the mode BASELINE.json configs[1] names) ----
  * NOT a reference code path: pyani-plus only ever sketches with `scaled=N`
@@ -262,7 +276,10 @@ PA_API int pa_write_comparisons_json(const char *path, const char *prefix, const
 #define PA_PROF_PAIR_DICT 2   /* dictionary sort + ids + bit-row build */
 #define PA_PROF_PAIR_COUNT 3  /* bit-row column-sum / merge kernel */
 #define PA_PROF_ANI 4
-#define PA_PROF_NPHASES 5
+#define PA_PROF_FRAG_INDEX 5 /* fragment ANI: minimizers, hash dictionary, postings */
+#define PA_PROF_FRAG_SEED 6  /* fragment ANI: fragment sketches, seed hits bucketed by reference genome */
+#define PA_PROF_FRAG_MAP 7   /* fragment ANI: prefilter + map_segments_kernel + per-pair reduction */
+#define PA_PROF_NPHASES 8
 PA_API int pa_prof_enable(pa_ctx *ctx, int on);
 PA_API int pa_prof_reset(pa_ctx *ctx);
 /* total milliseconds and number of timed launches of a phase (syncs the stream) */

@@ -15,11 +15,12 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "_lib" / "libpyani_hip.so"
 
+ABI_VERSION = 2
 PA_OK = 0
 PA_E_CAPACITY = -4
 PA_PAIRS_AUTO, PA_PAIRS_BITROW, PA_PAIRS_MERGE, PA_PAIRS_BITROW_HASH = 0, 1, 2, 3
 PA_ALIGN_BASES = 64
-PROF_PHASES = {"kmer_hash": 0, "sketch_sort": 1, "pair_dict": 2, "pair_count": 3, "ani": 4}
+PROF_PHASES = {"kmer_hash": 0, "sketch_sort": 1, "pair_dict": 2, "pair_count": 3, "ani": 4, "frag_index": 5, "frag_seed": 6, "frag_map": 7}
 
 _u8p = C.POINTER(C.c_uint8)
 _u32p = C.POINTER(C.c_uint32)
@@ -71,8 +72,13 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_int],
     ),
+    "pa_pair_counts_ex": (
+        C.c_int,
+        [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_int],
+    ),
+    "pa_pair_dict_prepare": (C.c_int, [_vp, _vp, C.c_uint64]),
     "pa_ani": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
-    "pa_ani_host": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "pa_ani_host": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_int, C.c_uint32]),
     "pa_sketch_bottom": (
         C.c_int,
         [_vp, _vp, _vp, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, _u64p],
@@ -145,8 +151,8 @@ def load_library() -> C.CDLL:
             raise HipBackendError(f"{LIB_PATH} does not export {name}") from err
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.pa_abi_version() != 1:
-        raise HipBackendError(f"ABI version mismatch: library reports {lib.pa_abi_version()}, binding expects 1")
+    if lib.pa_abi_version() != ABI_VERSION:
+        raise HipBackendError(f"ABI version mismatch: library reports {lib.pa_abi_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

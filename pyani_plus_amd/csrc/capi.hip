@@ -279,25 +279,30 @@ int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint6
 }
 
 // ---- pairs ----------------------------------------------------------------------
-int pa_pair_counts(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint32_t q0, uint32_t q1,
-                   uint32_t s0, uint32_t s1, uint32_t *d_counts, int algo) {
+int pa_pair_counts_ex(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, const uint64_t *h_off, uint32_t n,
+                      uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts, int algo) {
   PA_REQUIRE(c && d_off, "pa_pair_counts: null argument");
   PA_REQUIRE(q0 <= q1 && q1 <= n && s0 <= s1 && s1 <= n, "pa_pair_counts: ranges [%u,%u) x [%u,%u) outside [0,%u)", q0,
              q1, s0, s1, n);
   PA_REQUIRE(algo == PA_PAIRS_AUTO || algo == PA_PAIRS_BITROW || algo == PA_PAIRS_MERGE || algo == PA_PAIRS_BITROW_HASH,
              "pa_pair_counts: unknown algo %d", algo);
   PA_HIP(hipSetDevice(c->device));
-  if (q0 == q1 || s0 == s1) return PA_OK;  // empty tile: nothing to write
+  if (q0 == q1 || s0 == s1) { c->dict_prepared = false; return PA_OK; }  // empty tile: nothing to write
   PA_REQUIRE(d_counts != nullptr, "pa_pair_counts: null counts buffer");
   uint64_t total = 0;
-  PA_HIP(hipMemcpyAsync(c->h_pinned, d_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-  PA_HIP(hipStreamSynchronize(c->stream));
-  total = c->h_pinned[0];
+  if (h_off) {
+    total = h_off[n];
+  } else {
+    PA_HIP(hipMemcpyAsync(c->h_pinned, d_off + n, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    total = c->h_pinned[0];
+  }
   PA_REQUIRE(total == 0 || d_hashes, "pa_pair_counts: null hashes");
+  if (algo != PA_PAIRS_AUTO && algo != PA_PAIRS_BITROW_HASH) c->dict_prepared = false;
   switch (algo) {
     case PA_PAIRS_AUTO:
     case PA_PAIRS_BITROW_HASH:
-      return pa_pairs_bitrow_hash(c, d_hashes, d_off, n, total, q0, q1, s0, s1, d_counts);
+      return pa_pairs_bitrow_hash(c, d_hashes, d_off, h_off, n, total, q0, q1, s0, s1, d_counts);
     case PA_PAIRS_BITROW:
       return pa_pairs_bitrow(c, d_hashes, d_off, n, total, q0, q1, s0, s1, d_counts);
     case PA_PAIRS_MERGE:
@@ -306,6 +311,17 @@ int pa_pair_counts(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, u
       pa_set_error("pa_pair_counts: unknown algo %d", algo);
       return PA_E_INVALID;
   }
+}
+
+int pa_pair_counts(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint32_t q0, uint32_t q1,
+                   uint32_t s0, uint32_t s1, uint32_t *d_counts, int algo) {
+  return pa_pair_counts_ex(c, d_hashes, d_off, nullptr, n, q0, q1, s0, s1, d_counts, algo);
+}
+
+int pa_pair_dict_prepare(pa_ctx *c, const uint64_t *d_subject_hashes, uint64_t n_postings) {
+  PA_REQUIRE(c && (n_postings == 0 || d_subject_hashes), "pa_pair_dict_prepare: null argument");
+  PA_HIP(hipSetDevice(c->device));
+  return pa_pair_dict_prepare_impl(c, d_subject_hashes, n_postings);
 }
 
 int pa_ani(pa_ctx *c, const uint32_t *d_counts, const uint64_t *d_off, uint32_t q0, uint32_t q1, uint32_t s0,

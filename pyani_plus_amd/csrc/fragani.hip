@@ -24,6 +24,8 @@
 #include <vector>
 
 #include "murmur_dev.h"
+#include <optional>
+
 #include "pa_internal.h"
 #include "wave_dev.h"
 
@@ -1220,6 +1222,8 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   PA_TRY(stage_contigs(c, W, h_contig_start, h_contig_len, h_contig_genome, n_contigs, n_genomes, arena_bases));
 
   // ---- 1. minimizers of every contig
+  std::optional<ProfScope> prof;  // phases timed for bench.py: index build, seeding, mapping
+  prof.emplace(c, PA_PROF_FRAG_INDEX);
   uint32_t m = 0;
   PA_TRY(dispatch_minimizers(c, W, d_packed, d_mask, arena_bases, n_contigs, k, w, &m));
   PA_TRY(W.contig_mini_off.reserve((uint64_t)(n_contigs + 2) * 4));
@@ -1261,7 +1265,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   const uint64_t total_bins = contig_bin_off[n_contigs];
   const uint32_t n_frags = (uint32_t)frag_contig.size();
   for (uint64_t i = 0; i < (uint64_t)n_genomes * n_genomes; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
-  if (m == 0 || n_frags == 0) { PA_HIP(hipStreamSynchronize(c->stream)); return PA_OK; }
+  if (m == 0 || n_frags == 0) { prof.reset(); PA_HIP(hipStreamSynchronize(c->stream)); return PA_OK; }
 
   // ---- 2. dictionary of minimizer hashes: ids, postings, same-hash links
   for (int b = 0; b < 2; ++b) { PA_TRY(W.keys[b].reserve((uint64_t)m * 8)); PA_TRY(W.vals[b].reserve((uint64_t)m * 4)); }
@@ -1335,6 +1339,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                          "mapping kernel", frag_len, most_contigs);
   const bool use_buckets = !force_sorted && (uint64_t)kBucketWaves * n_genomes * 4u <= 128u * 1024u;
   PA_HIP(hipMemsetAsync(d_overflow, 0, 8, c->stream));
+  prof.reset();
   for (uint32_t g0 = 0; g0 < n_genomes;) {
     uint32_t g1 = g0 + 1;
     while (g1 < n_genomes && genome_frag_off[g1 + 1] - genome_frag_off[g0] <= kMaxBatchFrags &&
@@ -1358,6 +1363,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
     PA_TRY(W.hit_off.reserve((uint64_t)nf * 4));
     const uint32_t gw = ceil_div_u64(nf, kThreads / 64);
     PA_HIP(hipMemsetAsync(d_max_hits, 0, 8, c->stream));  // [0] most hits, [1] longest sketch of a fragment
+    prof.emplace(c, PA_PROF_FRAG_SEED);
     hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, W.frag_contig.as<uint32_t>(),
                        W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
@@ -1489,6 +1495,8 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                              W.seg_start.as<uint32_t>(), W.seg_list.as<uint32_t>(), n_keep, W.seg_a0.as<uint32_t>(),
                              W.seg_nh.as<uint32_t>());
       }
+      prof.reset();
+      prof.emplace(c, PA_PROF_FRAG_MAP);
       auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap) {
         if (count == 0) return;
         hipLaunchKernelGGL(map_segments_kernel, dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap), c->stream, hk[hw],
@@ -1526,6 +1534,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                        W.table.as<unsigned long long>(), total_bins, W.genome_bin_off.as<uint32_t>(), n_genomes,
                        W.ident_tab.as<double>(), W.matched.as<uint32_t>(), W.ident_sum.as<double>());
     PA_HIP(hipGetLastError());
+    prof.reset();
     PA_HIP(hipMemcpyAsync(h_matched + (uint64_t)g0 * n_genomes, W.matched.p, (uint64_t)nq * n_genomes * 4,
                           hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipMemcpyAsync(h_ident_sum + (uint64_t)g0 * n_genomes, W.ident_sum.p, (uint64_t)nq * n_genomes * 8,

@@ -87,6 +87,10 @@ struct pa_ctx {
   // workspaces (pair phase)
   DevBuf dict_keys[2], dict_vals[2];
   DevBuf ids, post_genome, bitrows;
+  // dictionary built ahead of the pair phase by pa_pair_dict_prepare (multi-GPU overlap)
+  bool dict_prepared = false;
+  uint64_t dict_prepared_postings = 0;
+  uint32_t dict_prepared_cap = 0;
   hipStream_t copy_stream = nullptr;  // uploads of pa_sketch_streamed, created on first use
   void *frag_work = nullptr;  // fragment-ANI workspace (fragani.hip), created on first use
   // pinned host scalars
@@ -149,8 +153,10 @@ int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, 
                     uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts);
 int pa_dense_ids_sorted(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t P,
                         uint64_t *n_distinct);
-int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t total,
-                         uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts);
+int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, const uint64_t *h_off /*nullable*/,
+                         uint32_t n, uint64_t total, uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1,
+                         uint32_t *d_counts);
+int pa_pair_dict_prepare_impl(pa_ctx *c, const uint64_t *d_subject_hashes, uint64_t n_postings);
 int pa_pairs_merge(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint32_t q0,
                    uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts);
 

@@ -10,6 +10,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
+#include <thread>
+#include <vector>
 
 #include "../../include/pyani_hip.h"
 
@@ -196,31 +199,77 @@ extern "C" int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_pac
   return PA_OK;
 }
 
+// Strict containment-ANI transform: host libm `pow`, the arithmetic that reproduces every reference fixture
+// bit for bit.  Rows are split over host threads; with `symmetric` (queries and
+// subjects are the same genomes in the same order) the match-side value (I/|S|)^(1/k) of pair (q, s) is the
+// query-side value of pair (s, q) -- same integers, same division, same pow -- so one pow per ordered pair
+// is computed and identity = max(cov[q][s], cov[s][q]) is taken in a second pass.
 extern "C" int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, const uint64_t *h_s_sizes,
                            uint32_t nq, uint32_t ns, uint32_t k, double *h_identity, double *h_cov_query,
-                           uint8_t *h_is_null) {
+                           uint8_t *h_is_null, int symmetric, uint32_t n_threads) {
   if (!h_counts || !h_q_sizes || !h_s_sizes || !h_identity || !h_cov_query || k == 0) {
     pa_set_error("pa_ani_host: null argument or k == 0");
     return PA_E_INVALID;
   }
-  const double inv_k = 1.0 / (double)k;
-  for (uint32_t q = 0; q < nq; ++q) {
-    const double qs = (double)h_q_sizes[q];
-    for (uint32_t s = 0; s < ns; ++s) {
-      const uint64_t idx = (uint64_t)q * ns + s;
-      const uint32_t c = h_counts[idx];
-      if (c == 0) {
-        h_identity[idx] = NAN;
-        h_cov_query[idx] = NAN;
-        if (h_is_null) h_is_null[idx] = 1;
-        continue;
-      }
-      const double qa = std::pow((double)c / qs, inv_k);
-      const double ma = std::pow((double)c / (double)h_s_sizes[s], inv_k);
-      h_identity[idx] = qa > ma ? qa : ma;
-      h_cov_query[idx] = qa;
-      if (h_is_null) h_is_null[idx] = 0;
-    }
+  if (symmetric && nq != ns) {
+    pa_set_error("pa_ani_host: symmetric needs a square block, got %u x %u", nq, ns);
+    return PA_E_INVALID;
   }
+  const double inv_k = 1.0 / (double)k;
+  uint32_t nt = n_threads ? n_threads : std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+  nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, (uint32_t)(((uint64_t)nq * ns) / 16384u + 1u)));
+  nt = std::min(nt, std::max(1u, nq));
+  auto rows = [&](uint32_t t, uint32_t *r0, uint32_t *r1) {
+    *r0 = (uint32_t)((uint64_t)nq * t / nt);
+    *r1 = (uint32_t)((uint64_t)nq * (t + 1) / nt);
+  };
+  auto pass1 = [&](uint32_t t) {
+    uint32_t r0, r1;
+    rows(t, &r0, &r1);
+    for (uint32_t q = r0; q < r1; ++q) {
+      const double qs = (double)h_q_sizes[q];
+      for (uint32_t s = 0; s < ns; ++s) {
+        const uint64_t idx = (uint64_t)q * ns + s;
+        const uint32_t c = h_counts[idx];
+        if (c == 0) {
+          h_identity[idx] = NAN;
+          h_cov_query[idx] = NAN;
+          if (h_is_null) h_is_null[idx] = 1;
+          continue;
+        }
+        const double qa = std::pow((double)c / qs, inv_k);
+        h_cov_query[idx] = qa;
+        if (!symmetric) {
+          const double ma = std::pow((double)c / (double)h_s_sizes[s], inv_k);
+          h_identity[idx] = qa > ma ? qa : ma;
+        }
+        if (h_is_null) h_is_null[idx] = 0;
+      }
+    }
+  };
+  auto pass2 = [&](uint32_t t) {  // symmetric only: identity = max(cov[q][s], cov[s][q]), blocked for the transposed reads
+    uint32_t r0, r1;
+    rows(t, &r0, &r1);
+    constexpr uint32_t kB = 64;
+    for (uint32_t qb = r0; qb < r1; qb += kB)
+      for (uint32_t sb = 0; sb < ns; sb += kB)
+        for (uint32_t q = qb; q < std::min(qb + kB, r1); ++q)
+          for (uint32_t s = sb; s < std::min(sb + kB, ns); ++s) {
+            const uint64_t idx = (uint64_t)q * ns + s;
+            if (h_counts[idx] == 0) continue;
+            const double qa = h_cov_query[idx], ma = h_cov_query[(uint64_t)s * ns + q];
+            h_identity[idx] = qa > ma ? qa : ma;
+          }
+  };
+  auto run = [&](auto &&fn) {
+    if (nt == 1) { fn(0u); return; }
+    std::vector<std::thread> pool;
+    pool.reserve(nt - 1);
+    for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(fn, t);
+    fn(0u);
+    for (auto &th : pool) th.join();
+  };
+  run(pass1);
+  if (symmetric) run(pass2);
   return PA_OK;
 }

@@ -159,6 +159,16 @@ __global__ __launch_bounds__(kThreads) void row_sum_kernel(const uint32_t *__res
   for (uint32_t x = tid; x < tile_cols; x += kThreads) out[x] = s_cnt[x];
 }
 
+// Zero the first U rows of the bit-row table, U read on the device (the number of distinct subject hashes the
+// insert kernel has just counted): the grid is sized for the upper bound (one row per subject posting) and the
+// blocks past U * w32 words leave at once, so the host never waits for U.
+__global__ __launch_bounds__(kThreads) void zero_rows_kernel(uint4 *__restrict__ rows, const uint32_t *__restrict__ d_u,
+                                                             uint32_t w32) {
+  const uint64_t n16 = ((uint64_t)(*d_u ? *d_u : 1u) * w32) / 4u;  // 16-byte pieces (w32 is a multiple of 4)
+  const uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i < n16) rows[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // ---- hash dictionary (PA_PAIRS_BITROW_HASH): dense ids without sorting -------------------------
 // Open addressing, linear probing, load 2/3.  Only the hashes of the tile's SUBJECTS are inserted; the
 // winner of a slot draws the dense id.  Key and id share one 16-byte entry, so a probe costs one HBM
@@ -368,51 +378,89 @@ int pa_pairs_bitrow(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, 
 }
 
 
-int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint64_t total,
-                         uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1, uint32_t *d_counts) {
+// Build the tile's dictionary from a flat run of subject postings (dense ids drawn by the slot winners).
+static int dict_insert(pa_ctx *c, const uint64_t *d_postings, uint64_t n_post, uint32_t *cap_out) {
+  const uint64_t cap64 = n_post + n_post / 2 + 1024;  // load <= 2/3
+  PA_REQUIRE(cap64 < (1ULL << 32), "pair phase: tile with %llu subject postings is too large for the hash dictionary",
+             (unsigned long long)n_post);
+  uint32_t *d_counter = reinterpret_cast<uint32_t *>(c->counters.as<uint64_t>() + 4);  // [0] counter, [1] special id
+  PA_TRY(c->dict_keys[0].reserve(cap64 * sizeof(DictEntry)));
+  PA_HIP(hipMemsetAsync(c->dict_keys[0].p, 0xff, cap64 * sizeof(DictEntry), c->stream));
+  PA_HIP(hipMemsetAsync(d_counter, 0, 4, c->stream));
+  PA_HIP(hipMemsetAsync(d_counter + 1, 0xff, 4, c->stream));
+  if (n_post)
+    hipLaunchKernelGGL(table_insert_kernel, dim3(ceil_div_u64(n_post, kThreads * kInsertPerThread)), dim3(kThreads), 0,
+                       c->stream, d_postings, (uint64_t)0, n_post, c->dict_keys[0].as<DictEntry>(), (uint32_t)cap64,
+                       d_counter, d_counter + 1);
+  PA_HIP(hipGetLastError());
+  *cap_out = (uint32_t)cap64;
+  return PA_OK;
+}
+
+// Multi-GPU overlap: a rank's dictionary needs only the hashes of its own subject
+// columns, which it has before the sketch all-gather starts.  pa_pair_dict_prepare enqueues the insert on the
+// context's stream and remembers it; the next pa_pair_counts(_ex) whose (single) subject tile holds exactly
+// n_postings postings takes the prepared dictionary instead of building one.
+int pa_pair_dict_prepare_impl(pa_ctx *c, const uint64_t *d_subject_hashes, uint64_t n_postings) {
+  ProfScope prof(c, PA_PROF_PAIR_DICT);
+  c->dict_prepared = false;
+  uint32_t cap = 0;
+  PA_TRY(dict_insert(c, d_subject_hashes, n_postings, &cap));
+  c->dict_prepared = true;
+  c->dict_prepared_postings = n_postings;
+  c->dict_prepared_cap = cap;
+  return PA_OK;
+}
+
+int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_off, const uint64_t *h_off_in,
+                         uint32_t n, uint64_t total, uint32_t q0, uint32_t q1, uint32_t s0, uint32_t s1,
+                         uint32_t *d_counts) {
   const uint32_t nq = q1 - q0, ns = s1 - s0;
+  const bool prepared = c->dict_prepared;
+  c->dict_prepared = false;  // a prepared dictionary is used by the next call or not at all
   if (nq == 0 || ns == 0) return PA_OK;
   if (total == 0) {
     PA_HIP(hipMemsetAsync(d_counts, 0, (uint64_t)nq * ns * sizeof(uint32_t), c->stream));
     return PA_OK;
   }
   PA_REQUIRE(total < (1ULL << 32), "pair phase: %llu postings exceed the 32-bit index space", (unsigned long long)total);
-  // CSR offsets of the genome ranges involved (host copy of four entries per tile would need a sync each;
-  // one copy of the whole offset array is cheaper than that for any n)
-  std::vector<uint64_t> h_off(n + 1);
-  PA_HIP(hipMemcpyAsync(h_off.data(), d_off, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-  PA_HIP(hipStreamSynchronize(c->stream));
+  // CSR offsets on the host: handed in by a caller that has them (sketch sizes known from the all-gather or a
+  // .sig cache), otherwise one copy of the whole array -- the only host round trip of the pair phase.
+  std::vector<uint64_t> h_off_own;
+  const uint64_t *h_off = h_off_in;
+  if (!h_off) {
+    h_off_own.resize(n + 1);
+    PA_HIP(hipMemcpyAsync(h_off_own.data(), d_off, (uint64_t)(n + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    h_off = h_off_own.data();
+  }
   PA_TRY(c->ids.reserve(total * sizeof(uint32_t)));
   uint32_t *d_ids = c->ids.as<uint32_t>();
   uint32_t *d_counter = reinterpret_cast<uint32_t *>(c->counters.as<uint64_t>() + 4);  // [0] counter, [1] special id
+  PA_REQUIRE(!prepared || ns <= kMaxTileSubjects, "pair phase: a prepared dictionary serves one tile of at most %u subjects",
+             kMaxTileSubjects);
   for (uint32_t t0 = s0; t0 < s1; t0 += kMaxTileSubjects) {
     const uint32_t t1 = (s1 - t0 > kMaxTileSubjects) ? t0 + kMaxTileSubjects : s1;
     const uint32_t cols = t1 - t0;
     const int tpr = (int)((cols + 127u) / 128u);  // threads per row: row width = tpr*128 columns
     const uint32_t w32 = (uint32_t)tpr * 4u;
     const uint64_t pt0 = h_off[t0], pt1 = h_off[t1], pq0 = h_off[q0], pq1 = h_off[q1];
-    uint64_t U = 0;
     uint32_t cap = 0;
     {
       ProfScope prof(c, PA_PROF_PAIR_DICT);
-      const uint64_t cap64 = (pt1 - pt0) + (pt1 - pt0) / 2 + 1024;  // load <= 2/3
-      PA_REQUIRE(cap64 < (1ULL << 32), "pair phase: tile with %llu subject postings is too large for the hash dictionary",
-                 (unsigned long long)(pt1 - pt0));
-      cap = (uint32_t)cap64;
-      PA_TRY(c->dict_keys[0].reserve(cap64 * sizeof(DictEntry)));
-      PA_HIP(hipMemsetAsync(c->dict_keys[0].p, 0xff, cap64 * sizeof(DictEntry), c->stream));
-      PA_HIP(hipMemsetAsync(d_counter, 0, 4, c->stream));
-      PA_HIP(hipMemsetAsync(d_counter + 1, 0xff, 4, c->stream));
-      if (pt1 > pt0)
-        hipLaunchKernelGGL(table_insert_kernel, dim3(ceil_div_u64(pt1 - pt0, kThreads * kInsertPerThread)),
-                           dim3(kThreads), 0, c->stream, d_hashes, pt0, pt1, c->dict_keys[0].as<DictEntry>(), cap,
-                           d_counter, d_counter + 1);
-      PA_HIP(hipMemcpyAsync(c->h_pinned, d_counter, 4, hipMemcpyDeviceToHost, c->stream));
-      PA_HIP(hipStreamSynchronize(c->stream));
-      U = *reinterpret_cast<uint32_t *>(c->h_pinned);
-      const uint64_t row_bytes = (U ? U : 1) * w32 * sizeof(uint32_t);
-      PA_TRY(c->bitrows.reserve(row_bytes));
-      PA_HIP(hipMemsetAsync(c->bitrows.p, 0, row_bytes, c->stream));
+      if (prepared) {
+        PA_REQUIRE(c->dict_prepared_postings == pt1 - pt0,
+                   "pair phase: the prepared dictionary holds %llu postings, the subject tile has %llu",
+                   (unsigned long long)c->dict_prepared_postings, (unsigned long long)(pt1 - pt0));
+        cap = c->dict_prepared_cap;
+      } else {
+        PA_TRY(dict_insert(c, d_hashes + pt0, pt1 - pt0, &cap));
+      }
+      // rows: one per distinct subject hash, at most one per subject posting; zeroed up to the device-side count
+      const uint64_t row_bound = (pt1 - pt0) ? (pt1 - pt0) : 1;
+      PA_TRY(c->bitrows.reserve(row_bound * w32 * sizeof(uint32_t)));
+      hipLaunchKernelGGL(zero_rows_kernel, dim3(ceil_div_u64(row_bound * w32 / 4u, kThreads)), dim3(kThreads), 0,
+                         c->stream, c->bitrows.as<uint4>(), d_counter, w32);
       const DictEntry *table = c->dict_keys[0].as<DictEntry>();
       if (pt1 > pt0) {
         uint64_t longest = 0;

@@ -50,39 +50,88 @@ def shard_bounds_by_cost(costs, world: int) -> list[tuple[int, int]]:
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def allgather_sketches(torch, dist, local_hashes, local_sizes, shard_sizes: list[int], group=None):
+def allgather_sketches(torch, dist, local_hashes, local_sizes, shard_sizes: list[int], group=None, *, while_in_flight=None):
     """All-gather variable-length CSR sketches.
 
     local_hashes: int64 tensor [>= sum(local_sizes)] (u64 bit patterns), this rank's
                   concatenated sketches; local_sizes: int64 tensor [n_local].
     shard_sizes:  number of genomes owned by each rank (known to all by construction).
-    Returns (hashes int64 [total], off int64 [n_total+1]) with genomes in rank order.
+    while_in_flight: optional callable, run after the payload all-gather has been started and
+                  before it is waited for -- work that needs only this rank's own sketches
+                  (``HipEngine.pair_dict_prepare``) overlaps the exchange that way.
+    Returns (hashes int64 [total], off int64 [n_total+1] on the device, off_host uint64 [n_total+1])
+    with genomes in rank order.
 
     Two collectives: the per-genome sizes (padded to the largest shard) and the payload
-    (padded to the largest per-rank total).  At N=10^4, |S|=5*10^3 the payload is 400 MB,
-    i.e. ~50 MB per xGMI link: not worth a hand-rolled ring.
+    (padded to the largest per-rank total).  Between them sits the path's ONE host round trip:
+    the gathered sizes (n_total integers) come to the host, which gives every rank the padded
+    payload length and the CSR offsets the pair phase wants on the host anyway.  The payload is
+    sent straight from ``local_hashes`` when that buffer is long enough (no staging copy) and
+    the gathered buffer is returned as it is when all ranks hold the same number of hashes.
+    At N=10^4, |S|=5*10^3 the payload is 400 MB, i.e. ~50 MB per xGMI link: not worth a
+    hand-rolled ring.
     """
     world = len(shard_sizes)
     dev = local_hashes.device
-    max_n = max(shard_sizes) if shard_sizes else 0
-    sizes_pad = torch.zeros(max(max_n, 1), dtype=torch.int64, device=dev)
+    max_n = max(max(shard_sizes) if shard_sizes else 0, 1)
+    sizes_pad = torch.zeros(max_n, dtype=torch.int64, device=dev)
     sizes_pad[: local_sizes.numel()] = local_sizes
-    all_sizes = torch.empty(world * max(max_n, 1), dtype=torch.int64, device=dev)
+    all_sizes = torch.empty(world * max_n, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_sizes, sizes_pad, group=group)
-    all_sizes = all_sizes.view(world, -1)
-    totals = all_sizes.sum(dim=1)
-    totals_host = totals.cpu().tolist()
-    max_total = max(1, int(max(totals_host)))
-    payload = torch.zeros(max_total, dtype=torch.int64, device=dev)
-    local_total = int(local_sizes.sum().item()) if local_sizes.numel() else 0
-    payload[:local_total] = local_hashes[:local_total]
+    sizes_host = all_sizes.view(world, max_n).cpu().numpy()  # the one host round trip
+    per_rank = [sizes_host[r, : shard_sizes[r]] for r in range(world)]
+    totals = [int(x.sum()) for x in per_rank]
+    max_total = max(1, max(totals))
+    off_host = np.zeros(sum(shard_sizes) + 1, dtype=np.uint64)
+    np.cumsum(np.concatenate(per_rank) if per_rank else np.zeros(0, np.int64), out=off_host[1:])
+
+    if local_hashes.numel() >= max_total:
+        payload = local_hashes[:max_total]  # the tail past this rank's own total is never read back
+    else:
+        payload = torch.zeros(max_total, dtype=torch.int64, device=dev)
+        rank = dist.get_rank(group)
+        payload[: totals[rank]] = local_hashes[: totals[rank]]
     gathered = torch.empty(world * max_total, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(gathered, payload, group=group)
-    gathered = gathered.view(world, max_total)
-    hashes = torch.cat([gathered[r, : int(totals_host[r])] for r in range(world)]) if world else payload[:0]
-    sizes = torch.cat([all_sizes[r, : shard_sizes[r]] for r in range(world)])
-    off = torch.zeros(sizes.numel() + 1, dtype=torch.int64, device=dev)
-    off[1:] = torch.cumsum(sizes, dim=0)
+    work = dist.all_gather_into_tensor(gathered, payload, group=group, async_op=True)
+    if while_in_flight is not None:
+        while_in_flight()
+    work.wait()
+    if all(t == max_total for t in totals):
+        hashes = gathered
+    else:
+        gathered = gathered.view(world, max_total)
+        hashes = torch.cat([gathered[r, : totals[r]] for r in range(world)])
     if hashes.numel() == 0:
         hashes = torch.zeros(1, dtype=torch.int64, device=dev)
-    return hashes.contiguous(), off
+    off = torch.from_numpy(off_host.astype(np.int64)).to(dev, non_blocking=True)
+    return hashes.contiguous(), off, off_host
+
+
+def sharded_pair_step(engine, torch, dist, sk_local, shard_sizes: list[int], q_range, s_range, *, backend: str = "nccl", group=None,
+                      overlap: bool = True):
+    """Phase 2 + 3 of the multi-GPU path on one rank: all-gather the sketches, count this rank's subject columns.
+
+    ``sk_local`` are this rank's sketches (``HipEngine.sketch``), ``s_range`` its subject columns in global
+    genome numbering.  When those columns are exactly the rank's own genomes (the uniform-length case) and fit
+    one subject tile, the dictionary of the tile is built from ``sk_local`` while the payload is in flight.
+    With ``backend != "nccl"`` the collectives run on host copies (plumbing check on boxes with fewer GPUs
+    than ranks).  Returns (all sketches as DeviceSketches, counts tensor [nq, ns])."""
+    from .engine import DeviceSketches
+
+    rank = dist.get_rank(group)
+    own0 = sum(shard_sizes[:rank])
+    own = (own0, own0 + shard_sizes[rank])
+    n_total = sum(shard_sizes)
+    can_overlap = overlap and tuple(s_range) == own and 0 < shard_sizes[rank] <= 2048 and sk_local.total > 0
+    hook = (lambda: engine.pair_dict_prepare(sk_local.hashes, sk_local.total)) if can_overlap else None
+    sizes = sk_local.off[1:] - sk_local.off[:-1]
+    if backend == "nccl":
+        hashes, off, off_host = allgather_sketches(torch, dist, sk_local.hashes, sizes, shard_sizes, group, while_in_flight=hook)
+    else:
+        hashes, off, off_host = allgather_sketches(
+            torch, dist, sk_local.hashes[: max(1, sk_local.total)].cpu(), sizes.cpu(), shard_sizes, group, while_in_flight=hook
+        )
+        hashes, off = hashes.to(engine.device), off.to(engine.device)
+    sk = DeviceSketches(hashes, off, n_total, int(off_host[-1]), off_host)
+    counts = engine.pair_counts(sk, tuple(q_range), tuple(s_range))
+    return sk, counts

@@ -171,6 +171,7 @@ class DeviceArena:
     packed: "object"  # torch.int32 tensor
     mask: "object"
     genome_start: np.ndarray  # host uint64 [n+1]
+    dirty: "object" = None  # torch.int64 tensor: one bit per 64-position block that needs its mask words (built on first use)
 
     @property
     def n_genomes(self) -> int:
@@ -223,13 +224,19 @@ class DeviceSketches:
     off: "object"  # torch.int64 tensor [n+1]
     n: int
     total: int
+    host_off: np.ndarray | None = None  # uint64 [n+1] copy of `off` when the host has it (pair phase needs no round trip then)
+
+    def offsets_host(self) -> np.ndarray:
+        if self.host_off is None:
+            self.host_off = np.ascontiguousarray(self.off.cpu().numpy().astype(np.uint64))
+        return self.host_off
 
     def sizes(self) -> np.ndarray:
-        off = self.off.cpu().numpy().astype(np.uint64)
+        off = self.offsets_host()
         return (off[1:] - off[:-1]).astype(np.uint64)
 
     def to_host(self) -> list[np.ndarray]:
-        off = self.off.cpu().numpy()
+        off = self.offsets_host().astype(np.int64)
         flat = self.hashes[: self.total].cpu().numpy().view(np.uint64)
         return [flat[int(off[g]) : int(off[g + 1])].copy() for g in range(self.n)]
 
@@ -293,7 +300,8 @@ class HipEngine:
         if flat.size == 0:
             flat = np.zeros(1, dtype=np.uint64)
         return DeviceSketches(
-            t.from_numpy(flat.view(np.int64).copy()).to(self.device), t.from_numpy(off).to(self.device), len(sketches), int(off[-1])
+            t.from_numpy(flat.view(np.int64).copy()).to(self.device), t.from_numpy(off).to(self.device), len(sketches), int(off[-1]),
+            np.ascontiguousarray(off.astype(np.uint64)),
         )
 
     # -- the three device steps
@@ -362,11 +370,20 @@ class HipEngine:
         q0, q1 = q_range or (0, sk.n)
         s0, s1 = s_range or (0, sk.n)
         counts = t.empty((q1 - q0, s1 - s0), dtype=t.int32, device=self.device)
+        h_off = sk.offsets_host()  # one small copy per sketch set, cached; the pair phase itself then never waits for the host
+        assert h_off.dtype == np.uint64 and len(h_off) == sk.n + 1
         check(
-            self.lib.pa_pair_counts(self.ctx, sk.hashes.data_ptr(), sk.off.data_ptr(), sk.n, q0, q1, s0, s1, counts.data_ptr(), algo),
+            self.lib.pa_pair_counts_ex(
+                self.ctx, sk.hashes.data_ptr(), sk.off.data_ptr(), h_off.ctypes.data, sk.n, q0, q1, s0, s1, counts.data_ptr(), algo,
+            ),  # fmt: skip
             "pa_pair_counts",
         )
         return counts
+
+    def pair_dict_prepare(self, subject_hashes, n_postings: int) -> None:
+        """Enqueue the dictionary build of one subject tile from its ``n_postings`` contiguous hashes (multi-GPU
+        overlap with the sketch all-gather); the next default-algorithm ``pair_counts`` over that tile uses it."""
+        check(self.lib.pa_pair_dict_prepare(self.ctx, subject_hashes.data_ptr(), int(n_postings)), "pa_pair_dict_prepare")
 
     def ani(self, counts, sk: DeviceSketches, k: int, q_range=None, s_range=None):
         """Device f64 (identity, cov_query); NaN marks the reference's NULL."""
@@ -473,18 +490,28 @@ class HipEngine:
         return out
 
 
-def ani_host(counts: np.ndarray, q_sizes, s_sizes, k: int) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
-    """Strict (host libm ``pow``) containment-ANI transform used at the JSON/DB boundary."""
+def ani_host(counts: np.ndarray, q_sizes, s_sizes, k: int, *, symmetric: bool = False, threads: int = 0, out=None):
+    """Strict (host libm ``pow``) containment-ANI transform used at the JSON/DB boundary.
+
+    ``symmetric``: the block is square and rows and columns are the same genomes in the same order (one
+    ``pow`` per ordered pair instead of two).  ``out`` = (identity, cov_query, is_null) arrays to fill."""
     lib = _capi.load_library()
     counts = np.ascontiguousarray(counts, dtype=np.uint32)
     nq, ns = counts.shape
     q_sizes = np.ascontiguousarray(q_sizes, dtype=np.uint64)
     s_sizes = np.ascontiguousarray(s_sizes, dtype=np.uint64)
-    ident = np.empty((nq, ns), dtype=np.float64)
-    cov = np.empty((nq, ns), dtype=np.float64)
-    null = np.empty((nq, ns), dtype=np.uint8)
+    if out is None:
+        ident = np.empty((nq, ns), dtype=np.float64)
+        cov = np.empty((nq, ns), dtype=np.float64)
+        null = np.empty((nq, ns), dtype=np.uint8)
+    else:
+        ident, cov, null = out
+        assert ident.shape == cov.shape == null.shape == (nq, ns) and ident.flags.c_contiguous and cov.flags.c_contiguous
     check(
-        lib.pa_ani_host(counts.ctypes.data, q_sizes.ctypes.data, s_sizes.ctypes.data, nq, ns, k, ident.ctypes.data, cov.ctypes.data, null.ctypes.data),
+        lib.pa_ani_host(
+            counts.ctypes.data, q_sizes.ctypes.data, s_sizes.ctypes.data, nq, ns, k, ident.ctypes.data, cov.ctypes.data, null.ctypes.data,
+            int(bool(symmetric)), int(threads),
+        ),  # fmt: skip
         "pa_ani_host",
     )
-    return ident, cov, null.astype(bool)
+    return ident, cov, null.view(np.bool_) if null.dtype == np.uint8 else null

@@ -38,7 +38,8 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         sizes = torch.tensor([len(s) for s in local], dtype=torch.int64)
         flat = np.concatenate(local) if local else np.zeros(0, np.uint64)
         hashes = torch.from_numpy(flat.view(np.int64).copy()) if flat.size else torch.zeros(1, dtype=torch.int64)
-        all_hashes, off = allgather_sketches(torch, dist, hashes, sizes, [b - a for a, b in bounds])
+        all_hashes, off, off_host = allgather_sketches(torch, dist, hashes, sizes, [b - a for a, b in bounds])
+        assert np.array_equal(off_host.astype(np.int64), off.numpy())
         off_np = off.numpy()
         gathered = [all_hashes.numpy().view(np.uint64)[off_np[g] : off_np[g + 1]] for g in range(len(LENGTHS))]
         counts = oracle.pair_counts(gathered, (0, len(LENGTHS)), (g0, g1))  # this rank's subject columns
