@@ -135,8 +135,16 @@ PA_API void pa_fasta_batch_free(pa_fasta_batch *batch);
  * 61489146912365176 @300 and 18446744073709552 @1000). */
 PA_API uint64_t pa_max_hash(uint64_t scaled);
 
+/* ---- the arena's third array: which 64-position blocks need their mask words ----
+ * The mask is a third of the arena's bytes and almost all zero; the hash kernel reads it only for the blocks
+ * this bitmap flags (bit b of word w <-> block 64*w + b: the block, or the 32 positions before it, hold an
+ * invalid position; block 0 always).  ceil(arena_bases / 4096) uint64 words.  Built once per arena (it
+ * belongs to the layout like the mask itself); entry points that take `d_dirty` accept NULL and then build
+ * it into a buffer of the context on every call, which costs one pass over the mask. */
+PA_API int pa_arena_dirty(pa_ctx *ctx, const uint32_t *d_mask, uint64_t arena_bases, uint64_t *d_dirty);
+
 /* ---- sketch: arena -> sorted unique hashes per genome ----
- * d_packed/d_mask: arena of `arena_bases` positions (multiple of 64).
+ * d_packed/d_mask/d_dirty: arena of `arena_bases` positions (multiple of 64).
  * h_genome_start[n_genomes+1]: first position of each genome (multiples of 64,
  * ascending; last entry = arena_bases).
  * For every window of k valid bases inside one record: canonical k-mer ->
@@ -145,8 +153,8 @@ PA_API uint64_t pa_max_hash(uint64_t scaled);
  * d_off[n_genomes+1] CSR offsets.  *h_total = total hashes.  If the total
  * exceeds cap_hashes the call returns PA_E_CAPACITY with *h_total = required
  * size and writes nothing to d_hashes. */
-PA_API int pa_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
-              const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
+PA_API int pa_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty,
+              uint64_t arena_bases, const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
               uint64_t *d_hashes, uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total);
 
 /* ---- sketch straight from a host arena, upload hidden behind the hash kernel ----
@@ -156,8 +164,8 @@ PA_API int pa_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_ma
  * zero -- crosses the bus as a few integers; pa_mask_from_runs rebuilds it in d_mask (arena_bases/8 bytes).
  * pa_sketch_streamed = pa_mask_from_runs + chunked upload of h_packed (page-locked for a truly asynchronous
  * copy) into d_packed (arena_bases/4 bytes) on a second stream while the hash kernel works on the chunks
- * that have arrived + the rest of pa_sketch.  Same outputs and error behaviour as pa_sketch; d_packed and
- * d_mask hold the complete arena afterwards. */
+ * that have arrived + the rest of pa_sketch.  Same outputs and error behaviour as pa_sketch; d_packed,
+ * d_mask and d_dirty (NULL: not wanted) hold the complete arena afterwards. */
 PA_API int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, uint64_t *h_run_start, uint64_t *h_run_len,
                             uint64_t cap);
 PA_API int pa_mask_from_runs(pa_ctx *ctx, const uint64_t *h_run_start, const uint64_t *h_run_len, uint32_t n_runs,
@@ -165,8 +173,8 @@ PA_API int pa_mask_from_runs(pa_ctx *ctx, const uint64_t *h_run_start, const uin
 PA_API int pa_sketch_streamed(pa_ctx *ctx, const uint32_t *h_packed, const uint64_t *h_run_start,
                               const uint64_t *h_run_len, uint32_t n_runs, uint64_t arena_bases,
                               const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
-                              uint32_t *d_packed, uint32_t *d_mask, uint64_t *d_hashes, uint64_t cap_hashes,
-                              uint64_t *d_off, uint64_t *h_total);
+                              uint32_t *d_packed, uint32_t *d_mask, uint64_t *d_dirty, uint64_t *d_hashes,
+                              uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total);
 
 /* ---- pairs: CSR sketches -> intersection counts ----
  * d_hashes/d_off describe n sketches (any source: pa_sketch, a `.sig` cache,
@@ -213,7 +221,7 @@ PA_API int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, cons
  * pa_sketch (cap_hashes >= n*m).  pa_pair_mash: per ordered pair, among the min(m, |A u B|) smallest
  * hashes of the union (= denom) how many are in both (= common).  pa_ani_mash:
  * 1 + ln(2j/(1+j))/k with j = common/denom; NaN when common == 0. */
-PA_API int pa_sketch_bottom(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+PA_API int pa_sketch_bottom(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty, uint64_t arena_bases,
                      const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint32_t m, uint64_t *d_hashes,
                      uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total);
 PA_API int pa_pair_mash(pa_ctx *ctx, const uint64_t *d_hashes, const uint64_t *d_off, uint32_t n, uint32_t q0, uint32_t q1,

@@ -57,16 +57,17 @@ SIGNATURES: dict[str, tuple] = {
     "pa_fasta_batch_arena_bases": (C.c_uint64, [_vp]),
     "pa_fasta_batch_copy_arena": (C.c_int, [_vp, _vp, _vp, _vp]),
     "pa_fasta_batch_free": (None, [_vp]),
+    "pa_arena_dirty": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "pa_sketch": (
         C.c_int,
-        [_vp, _vp, _vp, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp, _u64p],
+        [_vp, _vp, _vp, _vp, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp, _u64p],
     ),
     "pa_write_sigs": (C.c_int, [C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32]),
     "pa_mask_runs": (C.c_int64, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
     "pa_mask_from_runs": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_uint64]),
     "pa_sketch_streamed": (
         C.c_int,
-        [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _vp, _vp, _vp, C.c_uint64, _vp, _u64p],
+        [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64, _vp, _u64p],
     ),
     "pa_pair_counts": (
         C.c_int,
@@ -81,7 +82,7 @@ SIGNATURES: dict[str, tuple] = {
     "pa_ani_host": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_int, C.c_uint32]),
     "pa_sketch_bottom": (
         C.c_int,
-        [_vp, _vp, _vp, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, _u64p],
+        [_vp, _vp, _vp, _vp, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, _u64p],
     ),
     "pa_pair_mash": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
     "pa_ani_mash": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void mash_ani_kernel(const uint32_t *__re
 
 extern "C" {
 
-int pa_sketch_bottom(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+int pa_sketch_bottom(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty, uint64_t arena_bases,
                      const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint32_t m, uint64_t *d_hashes,
                      uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total) {
   PA_REQUIRE(c && d_off && h_total && h_genome_start, "pa_sketch_bottom: null argument");
@@ -220,7 +220,7 @@ int pa_sketch_bottom(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask
     int st = PA_E_CAPACITY;
     for (int attempt = 0; attempt < 2 && st == PA_E_CAPACITY; ++attempt) {
       PA_TRY(tmp_hashes.reserve(cap * 8));
-      st = pa_sketch(c, d_packed, d_mask, arena_bases, h_genome_start, n_genomes, k, max_hash, tmp_hashes.as<uint64_t>(),
+      st = pa_sketch(c, d_packed, d_mask, d_dirty, arena_bases, h_genome_start, n_genomes, k, max_hash, tmp_hashes.as<uint64_t>(),
                      cap, tmp_off.as<uint64_t>(), &total);
       if (st == PA_E_CAPACITY) cap = total;
     }

@@ -87,7 +87,7 @@ void pa_ctx_destroy(pa_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->cand_keys[0], &c->cand_keys[1], &c->cand_vals[0], &c->cand_vals[1], &c->genome_blk,
-                    &c->counters, &c->hist, &c->flags, &c->scan_tmp, &c->region_off, &c->region_cursor, &c->dict_keys[0], &c->dict_keys[1],
+                    &c->counters, &c->hist, &c->flags, &c->scan_tmp, &c->region_off, &c->region_cursor, &c->dirty, &c->dict_keys[0], &c->dict_keys[1],
                     &c->dict_vals[0], &c->dict_vals[1], &c->ids, &c->post_genome, &c->bitrows};
   for (DevBuf *b : bufs) b->release();
   pa_fragani_release(c);
@@ -167,7 +167,7 @@ int pa_memset_d(pa_ctx *c, void *d_dst, int value, uint64_t bytes) {
 }
 
 // ---- sketch -------------------------------------------------------------------
-int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty_in, uint64_t arena_bases,
               const uint64_t *h_genome_start, uint32_t n_genomes, uint32_t k, uint64_t max_hash, uint64_t *d_hashes,
               uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total) {
   PA_REQUIRE(c && d_off && h_total && h_genome_start, "pa_sketch: null argument");
@@ -213,6 +213,8 @@ int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint6
     PA_HIP(hipMemcpyAsync(c->region_off.p, region_off.data(), (uint64_t)(n_genomes + 1) * sizeof(uint64_t),
                           hipMemcpyHostToDevice, c->stream));
   }
+  const uint64_t *d_dirty = nullptr;
+  PA_TRY(pa_dirty_or_build(c, d_mask, n_blocks, d_dirty_in, &d_dirty));
   PA_HIP(hipStreamSynchronize(c->stream));  // blk and region_off are stack-owned vectors
 
   if (use_regions) {
@@ -222,7 +224,7 @@ int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint6
     PA_HIP(hipMemsetAsync(d_overflow, 0, sizeof(uint32_t), c->stream));
     {
       ProfScope prof(c, PA_PROF_KMER_HASH);
-      PA_TRY(pa_launch_kmer_hash(c, d_packed, d_mask, n_blocks, c->genome_blk.as<uint32_t>(), n_genomes, k, max_hash,
+      PA_TRY(pa_launch_kmer_hash(c, d_packed, d_mask, d_dirty, n_blocks, c->genome_blk.as<uint32_t>(), n_genomes, k, max_hash,
                                  c->cand_keys[0].as<uint64_t>(), nullptr, 0, nullptr, c->region_off.as<uint64_t>(),
                                  c->region_cursor.as<uint32_t>(), d_overflow));
     }
@@ -249,7 +251,7 @@ int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint6
     PA_HIP(hipMemsetAsync(d_count, 0, sizeof(uint64_t), c->stream));
     {
       ProfScope prof(c, PA_PROF_KMER_HASH);
-      PA_TRY(pa_launch_kmer_hash(c, d_packed, d_mask, n_blocks, c->genome_blk.as<uint32_t>(), n_genomes, k, max_hash,
+      PA_TRY(pa_launch_kmer_hash(c, d_packed, d_mask, d_dirty, n_blocks, c->genome_blk.as<uint32_t>(), n_genomes, k, max_hash,
                                  c->cand_keys[0].as<uint64_t>(), c->cand_vals[0].as<uint32_t>(), cap, d_count));
     }
     PA_HIP(hipMemcpyAsync(c->h_pinned, d_count, sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));

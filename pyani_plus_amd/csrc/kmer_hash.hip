@@ -6,8 +6,11 @@
 // seed 42, keep the first word when it is <= max_hash.
 //
 // Work decomposition: one thread per 64-base arena block (one 16-byte packed
-// load + one 8-byte mask load, both perfectly coalesced), plus a 32-base
-// look-back into the previous block to warm the rolling k-mer registers.
+// load, perfectly coalesced), plus a 32-base look-back into the previous block.
+// The invalid-position mask is read only by the blocks the arena's `dirty`
+// bitmap flags (one bit per block: the block or the 32 positions before it hold
+// an invalid position) -- a handful per genome -- so the kernel streams the
+// packed bases and nothing else.
 // The kernel is integer-VALU bound (12 64-bit multiplies + ~170 other VALU per
 // window against 0.375 byte of HBM input), so there is no LDS tiling of the
 // input; LDS only stages the rare survivors (1 in `scaled`) so that the global
@@ -23,6 +26,8 @@ using namespace pa_dev;
 
 constexpr int kThreads = 256;
 constexpr uint32_t kStageCap = 1024;  // LDS staging slots per workgroup
+
+constexpr int pow2_floor(int k) { int c = 1; while (2 * c <= k) c *= 2; return c; }
 
 // largest g with genome_blk[g] <= blk   (genome_blk has n+1 ascending entries)
 __device__ __forceinline__ uint32_t find_genome(const uint32_t *__restrict__ genome_blk, uint32_t n, uint32_t blk) {
@@ -50,12 +55,12 @@ __device__ __forceinline__ void region_append(uint64_t *__restrict__ regions, co
 // LUT = false keeps the arithmetic form (ablation / cross-check, PA_KMER_VARIANT=0).
 template <int K, bool LUT>
 __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
-    const uint4 *__restrict__ packed, const uint2 *__restrict__ mask, uint32_t n_blocks64,
+    const uint4 *__restrict__ packed, const uint2 *__restrict__ mask, const uint64_t *__restrict__ dirty, uint32_t n_blocks64,
     const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash,
     uint64_t *__restrict__ cand_hash, uint32_t *__restrict__ cand_genome, uint64_t cap,
     unsigned long long *__restrict__ count, const uint64_t *__restrict__ region_off, uint32_t *__restrict__ cursor,
     uint32_t *__restrict__ overflow, uint32_t blk0) {
-  static_assert(K >= 4 && K <= 32, "k-mer state is one 64-bit register pair");
+  static_assert(K >= 1 && K <= 32, "a k-mer is one 64-bit register pair");
   __shared__ uint64_t s_hash[kStageCap];
   __shared__ uint32_t s_blk[kStageCap];
   __shared__ uint32_t s_n;
@@ -66,6 +71,8 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
 
   const uint32_t tid = threadIdx.x;
   const uint32_t max_hi = (uint32_t)(max_hash >> 32);
+  const bool take_all = max_hi == 0xffffffffu;  // scaled = 1: no screen
+  const uint32_t screen_hi = max_hi + 1u;
   if (tid == 0) s_n = 0;
   if constexpr (LUT) {
 #pragma unroll
@@ -80,18 +87,20 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
   const uint32_t t = blk0 + blockIdx.x * kThreads + tid;  // blk0: first arena block of this launch (streamed uploads)
   if (t < n_blocks64) {
     const uint4 cur = packed[t];
-    const uint2 m = mask[t];
     uint2 pw = make_uint2(0u, 0u);
-    uint32_t pm = 0xffffffffu;
-    if (t > 0) {
-      pw = reinterpret_cast<const uint2 *>(packed)[2 * (uint64_t)t - 1];  // bases -32..-1
-      pm = mask[t - 1].y;
-    }
-    // ---- which windows are usable: dilate the invalid-position bitset by K ----
-    // bit i of (d0,d1,d2) <-> base i-32; window ending at base e is bad iff any of
-    // bases e-K+1..e is invalid, i.e. bit (32+e) of OR_{s<K} (M << s).
-    uint32_t d0 = pm, d1 = m.x, d2 = m.y;
-    {
+    if (t > 0) pw = reinterpret_cast<const uint2 *>(packed)[2 * (uint64_t)t - 1];  // bases -32..-1
+    // ---- which windows are usable.  Clean blocks (all but a few per genome) have none to exclude and never
+    // touch the mask; the dirty word of a wave's 64 blocks is one uniform load (blk0 is a multiple of 64).
+    uint32_t d1 = 0u, d2 = 0u;
+    const uint32_t wave_blk = __builtin_amdgcn_readfirstlane(t & ~63u);
+    const uint64_t dirty_word = dirty[wave_blk >> 6];
+    if ((dirty_word >> (t & 63u)) & 1ull) {
+      // dilate the invalid-position bitset by K: bit i of (d0,d1,d2) <-> base i-32; the window ending at base e
+      // is bad iff any of bases e-K+1..e is invalid, i.e. bit (32+e) of OR_{s<K} (M << s).
+      const uint2 m = mask[t];
+      uint32_t d0 = t > 0 ? mask[t - 1].y : 0xffffffffu;
+      d1 = m.x;
+      d2 = m.y;
       int c = 1;
 #pragma unroll
       for (; 2 * c <= K; c *= 2) {
@@ -99,7 +108,7 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
         d1 |= alignbit(d1, d0, 32 - c);
         d0 |= d0 << c;
       }
-      constexpr int cc = (K >= 32) ? 32 : (K >= 16) ? 16 : (K >= 8) ? 8 : 4;
+      constexpr int cc = pow2_floor(K);  // width covered by the doubling rounds
       constexpr int r = K - cc;
       if constexpr (r > 0) {
         d2 |= alignbit(d2, d1, 32 - r);
@@ -155,13 +164,15 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
             }
           }
           (void)kMaskHi;
-          // Screen on the high words: hash = (X ^ X>>33) + (Y ^ Y>>33) has high word X.hi + Y.hi + carry, so
-          // it can be <= max_hash only if X.hi + Y.hi is <= max_hash.hi or is 0xffffffff (carry wraps it to
-          // 0): one 32-bit add and two compares for the 999 in 1000 windows that are dropped.
-          uint64_t X, Y;
-          murmur3_pre_final<K>(P, X, Y);
-          const uint32_t sum_hi = (uint32_t)(X >> 32) + (uint32_t)(Y >> 32);
-          if (sum_hi <= max_hi || sum_hi == 0xffffffffu) {
+          // Screen on the high words: hash = (X ^ X>>33) + (Y ^ Y>>33) has high word X.hi + Y.hi + carry, so it can
+          // be <= max_hash only if X.hi + Y.hi is <= max_hash.hi or is 0xffffffff (the carry wraps it to 0) -- one
+          // unsigned compare of X.hi + Y.hi + 1 against max_hash.hi + 1.  The sum of the two high words is linear in
+          // the inputs of the last multiply (murmur_dev.h), so the 999 in 1000 windows that are dropped never form
+          // X and Y: 2 mul_hi + 2 mul_lo + 4 adds + 1 compare instead of two 64-bit multiplies, an add and 2 compares.
+          uint64_t U, V;
+          murmur3_pre_last_mul<K>(P, U, V);
+          if (take_all || last_mul_high_sum_plus1(U, V) <= screen_hi) {
+            const uint64_t X = U * kF2, Y = V * kF2;
             const uint64_t h = (X ^ (X >> 33)) + (Y ^ (Y >> 33));
             if (h > max_hash || ((badw >> i) & 1u)) continue;  // validity is only looked at for the 1 in 1000
             const uint32_t slot = atomicAdd(&s_n, 1u);
@@ -225,13 +236,13 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
 }
 
 template <int K, bool LUT>
-int launch_variant(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+int launch_variant(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty, uint64_t n_blocks64,
            const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
            uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count, const uint64_t *d_region_off, uint32_t *d_cursor,
            uint32_t *d_overflow, uint64_t blk0, hipStream_t stream) {
   const uint32_t grid = ceil_div_u64(n_blocks64 - blk0, kThreads);
   hipLaunchKernelGGL((kmer_hash_kernel<K, LUT>), dim3(grid), dim3(kThreads), 0, stream ? stream : c->stream,
-                     reinterpret_cast<const uint4 *>(d_packed), reinterpret_cast<const uint2 *>(d_mask),
+                     reinterpret_cast<const uint4 *>(d_packed), reinterpret_cast<const uint2 *>(d_mask), d_dirty,
                      (uint32_t)n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap,
                      reinterpret_cast<unsigned long long *>(d_count), d_region_off, d_cursor, d_overflow, (uint32_t)blk0);
   PA_HIP(hipGetLastError());
@@ -239,7 +250,7 @@ int launch_variant(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, 
 }
 
 template <int K>
-int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty, uint64_t n_blocks64,
            const uint32_t *d_genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *d_cand_hash,
            uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count, const uint64_t *d_region_off, uint32_t *d_cursor,
            uint32_t *d_overflow, uint64_t blk0, hipStream_t stream) {
@@ -247,16 +258,17 @@ int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t
     const char *v = getenv("PA_KMER_VARIANT");
     return v && v[0] == '0';
   }();
-  if (arithmetic)
-    return launch_variant<K, false>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
+  if constexpr (K == 31)  // the ablation build exists for the benchmarked k only
+    if (arithmetic)
+      return launch_variant<K, false>(c, d_packed, d_mask, d_dirty, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
                                     d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
-  return launch_variant<K, true>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
+  return launch_variant<K, true>(c, d_packed, d_mask, d_dirty, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash,
                                  d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
 }
 
 }  // namespace
 
-int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty, uint64_t n_blocks64,
                         const uint32_t *d_genome_blk, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
                         uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count,
                         const uint64_t *d_region_off, uint32_t *d_cursor, uint32_t *d_overflow, uint64_t blk0,
@@ -264,12 +276,15 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
   PA_REQUIRE(n_blocks64 < (1ULL << 32), "arena too large: %llu blocks of 64 bases", (unsigned long long)n_blocks64);
   if (n_blocks64 <= blk0) return PA_OK;
 #define PA_K_CASE(KK) \
-  case KK: return launch<KK>(c, d_packed, d_mask, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
+  case KK: return launch<KK>(c, d_packed, d_mask, d_dirty, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
+  PA_REQUIRE((blk0 & 63u) == 0, "k-mer hash launch must start at a multiple of 64 blocks, not %llu", (unsigned long long)blk0);
   switch (k) {
-    PA_K_CASE(15) PA_K_CASE(16) PA_K_CASE(17) PA_K_CASE(19) PA_K_CASE(21) PA_K_CASE(23) PA_K_CASE(25)
-    PA_K_CASE(27) PA_K_CASE(29) PA_K_CASE(31) PA_K_CASE(32)
+    PA_K_CASE(1) PA_K_CASE(2) PA_K_CASE(3) PA_K_CASE(4) PA_K_CASE(5) PA_K_CASE(6) PA_K_CASE(7) PA_K_CASE(8)
+    PA_K_CASE(9) PA_K_CASE(10) PA_K_CASE(11) PA_K_CASE(12) PA_K_CASE(13) PA_K_CASE(14) PA_K_CASE(15) PA_K_CASE(16)
+    PA_K_CASE(17) PA_K_CASE(18) PA_K_CASE(19) PA_K_CASE(20) PA_K_CASE(21) PA_K_CASE(22) PA_K_CASE(23) PA_K_CASE(24)
+    PA_K_CASE(25) PA_K_CASE(26) PA_K_CASE(27) PA_K_CASE(28) PA_K_CASE(29) PA_K_CASE(30) PA_K_CASE(31) PA_K_CASE(32)
     default:
-      pa_set_error("k=%u is not compiled in (supported: 15,16,17,19,21,23,25,27,29,31,32)", k);
+      pa_set_error("k=%u outside [1,32]", k);
       return PA_E_INVALID;
   }
 #undef PA_K_CASE

@@ -59,13 +59,17 @@ __device__ __forceinline__ uint64_t times5_plus(uint64_t h, uint64_t c) {
   return t + c;
 }
 
-// Everything up to, but not including, the last `k ^= k >> 33` of the two fmix64 calls: the hash is
-// (X ^ X>>33) + (Y ^ Y>>33).  That last step only touches the low 31 bits, so the high words of X and Y
-// already decide -- up to one carry -- whether the hash can be <= max_hash (see kmer_hash.hip).
+constexpr uint64_t kF1 = 0xff51afd7ed558ccdULL, kF2 = 0xc4ceb9fe1a85ec53ULL;  // fmix64 multipliers
+
+// Everything up to, but not including, the LAST multiply of the two fmix64 calls: with U and V the values this
+// returns, the hash is h = fin(U*kF2) + fin(V*kF2), fin(x) = x ^ (x >> 33).  fin only touches the low 31 bits, so
+// the high word of h is hi32(U*kF2) + hi32(V*kF2) + at most one carry -- and that sum of two high words is linear:
+//   hi32(U*c) + hi32(V*c) = mulhi(U.lo, c.lo) + mulhi(V.lo, c.lo) + (U.lo + V.lo)*c.hi + (U.hi + V.hi)*c.lo  (mod 2^32)
+// which is what the FracMinHash screen of kmer_hash.hip tests before anything else of the last step is computed.
 // (The 64-bit multiplies are left to hipcc: v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3_u32.  A hand-written
-// chain of three v_mad_u64_u32 + one add was measured at the same 12.8 ms.)
+// chain of three v_mad_u64_u32 + one add was measured at the same speed.)
 template <int K>
-__device__ __forceinline__ void murmur3_pre_final(const uint64_t (&P)[4], uint64_t &X, uint64_t &Y) {
+__device__ __forceinline__ void murmur3_pre_last_mul(const uint64_t (&P)[4], uint64_t &U, uint64_t &V) {
   uint64_t h1 = 42, h2 = 42;
   constexpr int nblocks = K / 16;
   constexpr int tail = K % 16;
@@ -88,16 +92,24 @@ __device__ __forceinline__ void murmur3_pre_final(const uint64_t (&P)[4], uint64
   if constexpr (tail > 0) h1 ^= rotl64(P[2 * nblocks], 31) * kC2;
   h1 ^= (uint64_t)K; h2 ^= (uint64_t)K;
   h1 += h2; h2 += h1;
-  h1 ^= h1 >> 33; h1 *= 0xff51afd7ed558ccdULL; h1 ^= h1 >> 33; h1 *= 0xc4ceb9fe1a85ec53ULL;
-  h2 ^= h2 >> 33; h2 *= 0xff51afd7ed558ccdULL; h2 ^= h2 >> 33; h2 *= 0xc4ceb9fe1a85ec53ULL;
-  X = h1;
-  Y = h2;
+  h1 ^= h1 >> 33; h1 *= kF1; h1 ^= h1 >> 33;
+  h2 ^= h2 >> 33; h2 *= kF1; h2 ^= h2 >> 33;
+  U = h1;
+  V = h2;
+}
+
+// X.hi + Y.hi + 1 (mod 2^32) for X = U*kF2, Y = V*kF2, without forming X and Y (see above)
+__device__ __forceinline__ uint32_t last_mul_high_sum_plus1(uint64_t U, uint64_t V) {
+  constexpr uint32_t c0 = (uint32_t)kF2, c1 = (uint32_t)(kF2 >> 32);
+  const uint32_t u0 = (uint32_t)U, u1 = (uint32_t)(U >> 32), v0 = (uint32_t)V, v1 = (uint32_t)(V >> 32);
+  return (__umulhi(u0, c0) + __umulhi(v0, c0) + 1u) + ((u0 + v0) * c1 + (u1 + v1) * c0);
 }
 
 template <int K>
 __device__ __forceinline__ uint64_t murmur3_from_products(const uint64_t (&P)[4]) {
-  uint64_t X, Y;
-  murmur3_pre_final<K>(P, X, Y);
+  uint64_t U, V;
+  murmur3_pre_last_mul<K>(P, U, V);
+  const uint64_t X = U * kF2, Y = V * kF2;
   return (X ^ (X >> 33)) + (Y ^ (Y >> 33));
 }
 

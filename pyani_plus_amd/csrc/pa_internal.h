@@ -84,6 +84,7 @@ struct pa_ctx {
   DevBuf hist;                        // radix histograms / scan scratch
   DevBuf flags, scan_tmp;             // compaction
   DevBuf region_off, region_cursor;   // per-genome candidate regions (LDS-sort path)
+  DevBuf dirty;                       // dirty-block bitmap for callers that pass none
   // workspaces (pair phase)
   DevBuf dict_keys[2], dict_vals[2];
   DevBuf ids, post_genome, bitrows;
@@ -128,14 +129,21 @@ int pa_exclusive_scan_u32(pa_ctx *c, const uint32_t *d_in, uint32_t *d_out, uint
 void pa_fragani_release(pa_ctx *c);
 
 // kmer_hash.hip
-int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t n_blocks64,
+int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty, uint64_t n_blocks64,
                         const uint32_t *d_genome_blk, uint32_t n_genomes, uint32_t k, uint64_t max_hash,
                         uint64_t *d_cand_hash, uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count,
                         const uint64_t *d_region_off = nullptr, uint32_t *d_cursor = nullptr,
                         uint32_t *d_overflow = nullptr, uint64_t blk0 = 0, hipStream_t stream = nullptr);
-// The launch covers arena blocks [blk0, n_blocks64) on `stream` (default: the context's).
+// The launch covers arena blocks [blk0, n_blocks64) on `stream` (default: the context's); blk0 is a multiple of 64.
+// d_dirty: one bit per block, set when the block needs its mask words (pa_build_dirty).
 // With d_region_off != nullptr the survivors of genome g go, unordered, to d_cand_hash[region_off[g] + i),
 // i < cursor[g] (zeroed by the caller); *d_overflow is set if a region was too small.
+
+// Dirty bitmap of an arena (sketch_stream.hip): bit b of word w <-> block 64*w + b holds an invalid position, or
+// the 32 positions before it do, or it is block 0.  ceil(n_blocks64 / 64) words.
+int pa_build_dirty(pa_ctx *c, const uint32_t *d_mask, uint64_t n_blocks64, uint64_t *d_dirty, hipStream_t stream = nullptr);
+// The bitmap the caller handed in, or one built into the context's own buffer when it handed in none.
+int pa_dirty_or_build(pa_ctx *c, const uint32_t *d_mask, uint64_t n_blocks64, const uint64_t *d_dirty, const uint64_t **out);
 
 // sketch_lds.hip: per-genome regions -> sorted unique CSR sketches, one workgroup and one LDS sort per genome
 constexpr uint32_t kLdsSortMax = 16384;  // longest region the LDS sort takes

@@ -11,8 +11,13 @@
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/pyani_hip.h"
 
@@ -199,6 +204,73 @@ extern "C" int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_pac
   return PA_OK;
 }
 
+// ---- a small persistent pool of host threads --------------------------------------------------------------
+// pa_ani_host is called once per column tile; creating 64 threads per call costs more than the pows of a
+// sparse tile.  Workers are created on first demand, sleep between jobs and are never joined (the pool lives as
+// long as the process; a forked child starts its own).
+namespace {
+class HostPool {
+ public:
+  static HostPool &get() {
+    static HostPool *pool = nullptr;
+    static pid_t owner = 0;
+    static std::mutex guard;
+    std::lock_guard<std::mutex> lock(guard);
+    if (!pool || owner != getpid()) {  // first use, or we are a forked child whose copy has no threads
+      pool = new HostPool();
+      owner = getpid();
+    }
+    return *pool;
+  }
+  // fn(worker, n_workers) on n_workers threads (the caller is worker 0); returns when all are done
+  template <typename F>
+  void run(uint32_t n_workers, F &&fn) {
+    if (n_workers <= 1) { fn(0u, 1u); return; }
+    std::function<void(uint32_t, uint32_t)> job = fn;
+    {
+      std::unique_lock<std::mutex> lock(m_);
+      while (threads_ < n_workers - 1) {
+        const uint32_t id = ++threads_;
+        std::thread([this, id] { worker(id); }).detach();
+      }
+      job_ = &job;
+      job_workers_ = n_workers;
+      pending_ = n_workers - 1;
+      ++generation_;
+    }
+    wake_.notify_all();
+    fn(0u, n_workers);
+    std::unique_lock<std::mutex> lock(m_);
+    done_.wait(lock, [this] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void worker(uint32_t id) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(uint32_t, uint32_t)> *job = nullptr;
+      uint32_t n = 0;
+      {
+        std::unique_lock<std::mutex> lock(m_);
+        wake_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (id < job_workers_) { job = job_; n = job_workers_; }
+      }
+      if (!job) continue;
+      (*job)(id, n);
+      std::unique_lock<std::mutex> lock(m_);
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable wake_, done_;
+  const std::function<void(uint32_t, uint32_t)> *job_ = nullptr;
+  uint32_t job_workers_ = 0, pending_ = 0, threads_ = 0;
+  uint64_t generation_ = 0;
+};
+}  // namespace
+
 // Strict containment-ANI transform: host libm `pow`, the arithmetic that reproduces every reference fixture
 // bit for bit.  Rows are split over host threads; with `symmetric` (queries and
 // subjects are the same genomes in the same order) the match-side value (I/|S|)^(1/k) of pair (q, s) is the
@@ -217,59 +289,54 @@ extern "C" int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, 
   }
   const double inv_k = 1.0 / (double)k;
   uint32_t nt = n_threads ? n_threads : std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 64u);
-  nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, (uint32_t)(((uint64_t)nq * ns) / 16384u + 1u)));
+  nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, (uint32_t)(((uint64_t)nq * ns) / 8192u + 1u)));
   nt = std::min(nt, std::max(1u, nq));
-  auto rows = [&](uint32_t t, uint32_t *r0, uint32_t *r1) {
-    *r0 = (uint32_t)((uint64_t)nq * t / nt);
-    *r1 = (uint32_t)((uint64_t)nq * (t + 1) / nt);
-  };
-  auto pass1 = [&](uint32_t t) {
-    uint32_t r0, r1;
-    rows(t, &r0, &r1);
-    for (uint32_t q = r0; q < r1; ++q) {
-      const double qs = (double)h_q_sizes[q];
-      for (uint32_t s = 0; s < ns; ++s) {
-        const uint64_t idx = (uint64_t)q * ns + s;
-        const uint32_t c = h_counts[idx];
-        if (c == 0) {
-          h_identity[idx] = NAN;
-          h_cov_query[idx] = NAN;
-          if (h_is_null) h_is_null[idx] = 1;
-          continue;
+  // rows are dealt in small blocks through a shared counter: NULL-heavy rows cost nothing, dense ones a pow each
+  constexpr uint32_t kRowBlock = 4;
+  std::atomic<uint32_t> next1{0}, next2{0};
+  auto pass1 = [&](uint32_t, uint32_t) {
+    for (;;) {
+      const uint32_t r0 = next1.fetch_add(kRowBlock), r1 = std::min(nq, r0 + kRowBlock);
+      if (r0 >= nq) break;
+      for (uint32_t q = r0; q < r1; ++q) {
+        const double qs = (double)h_q_sizes[q];
+        for (uint32_t s = 0; s < ns; ++s) {
+          const uint64_t idx = (uint64_t)q * ns + s;
+          const uint32_t c = h_counts[idx];
+          if (c == 0) {
+            h_identity[idx] = NAN;
+            h_cov_query[idx] = NAN;
+            if (h_is_null) h_is_null[idx] = 1;
+            continue;
+          }
+          const double qa = std::pow((double)c / qs, inv_k);
+          h_cov_query[idx] = qa;
+          if (!symmetric) {
+            const double ma = std::pow((double)c / (double)h_s_sizes[s], inv_k);
+            h_identity[idx] = qa > ma ? qa : ma;
+          }
+          if (h_is_null) h_is_null[idx] = 0;
         }
-        const double qa = std::pow((double)c / qs, inv_k);
-        h_cov_query[idx] = qa;
-        if (!symmetric) {
-          const double ma = std::pow((double)c / (double)h_s_sizes[s], inv_k);
-          h_identity[idx] = qa > ma ? qa : ma;
-        }
-        if (h_is_null) h_is_null[idx] = 0;
       }
     }
   };
-  auto pass2 = [&](uint32_t t) {  // symmetric only: identity = max(cov[q][s], cov[s][q]), blocked for the transposed reads
-    uint32_t r0, r1;
-    rows(t, &r0, &r1);
+  auto pass2 = [&](uint32_t, uint32_t) {  // symmetric only: identity = max(cov[q][s], cov[s][q]), blocked for the transposed reads
     constexpr uint32_t kB = 64;
-    for (uint32_t qb = r0; qb < r1; qb += kB)
+    for (;;) {
+      const uint32_t qb = next2.fetch_add(kB), qe = std::min(nq, qb + kB);
+      if (qb >= nq) break;
       for (uint32_t sb = 0; sb < ns; sb += kB)
-        for (uint32_t q = qb; q < std::min(qb + kB, r1); ++q)
+        for (uint32_t q = qb; q < qe; ++q)
           for (uint32_t s = sb; s < std::min(sb + kB, ns); ++s) {
             const uint64_t idx = (uint64_t)q * ns + s;
             if (h_counts[idx] == 0) continue;
             const double qa = h_cov_query[idx], ma = h_cov_query[(uint64_t)s * ns + q];
             h_identity[idx] = qa > ma ? qa : ma;
           }
+    }
   };
-  auto run = [&](auto &&fn) {
-    if (nt == 1) { fn(0u); return; }
-    std::vector<std::thread> pool;
-    pool.reserve(nt - 1);
-    for (uint32_t t = 1; t < nt; ++t) pool.emplace_back(fn, t);
-    fn(0u);
-    for (auto &th : pool) th.join();
-  };
-  run(pass1);
-  if (symmetric) run(pass2);
+  HostPool &pool = HostPool::get();
+  pool.run(nt, pass1);
+  if (symmetric) pool.run(std::min<uint32_t>(nt, (nq + 63u) / 64u), pass2);
   return PA_OK;
 }

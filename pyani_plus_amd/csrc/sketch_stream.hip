@@ -42,9 +42,49 @@ __global__ __launch_bounds__(kThreads) void mask_from_runs_kernel(const uint64_t
   mask[w] = bits;
 }
 
+// one thread per 64-block word of the bitmap; a block's mask is one uint2
+__global__ __launch_bounds__(kThreads) void dirty_kernel(const uint2 *__restrict__ mask, uint64_t n_blocks64,
+                                                         uint64_t *__restrict__ dirty) {
+  // one wave per bitmap word: lane l looks at block 64*w + l, a ballot makes the word
+  const uint64_t w = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+  const uint64_t t = w * 64u + (threadIdx.x & 63u);
+  bool d = false;
+  if (t < n_blocks64) {
+    const uint2 m = mask[t];
+    d = (m.x | m.y) != 0u || t == 0 || mask[t - 1].y != 0u;
+  }
+  const uint64_t word = __ballot(d);
+  if ((threadIdx.x & 63u) == 0 && w * 64u < n_blocks64) dirty[w] = word;
+}
+
 }  // namespace
 
+int pa_build_dirty(pa_ctx *c, const uint32_t *d_mask, uint64_t n_blocks64, uint64_t *d_dirty, hipStream_t stream) {
+  if (n_blocks64 == 0) return PA_OK;
+  const uint64_t words = (n_blocks64 + 63) / 64;
+  hipLaunchKernelGGL(dirty_kernel, dim3(ceil_div_u64(words * 64, kThreads)), dim3(kThreads), 0, stream ? stream : c->stream,
+                     reinterpret_cast<const uint2 *>(d_mask), n_blocks64, d_dirty);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+int pa_dirty_or_build(pa_ctx *c, const uint32_t *d_mask, uint64_t n_blocks64, const uint64_t *d_dirty, const uint64_t **out) {
+  if (d_dirty) { *out = d_dirty; return PA_OK; }
+  PA_TRY(c->dirty.reserve(((n_blocks64 + 63) / 64 + 1) * 8));
+  PA_TRY(pa_build_dirty(c, d_mask, n_blocks64, c->dirty.as<uint64_t>()));
+  *out = c->dirty.as<uint64_t>();
+  return PA_OK;
+}
+
 extern "C" {
+
+int pa_arena_dirty(pa_ctx *c, const uint32_t *d_mask, uint64_t arena_bases, uint64_t *d_dirty) {
+  PA_REQUIRE(c && (arena_bases == 0 || (d_mask && d_dirty)), "pa_arena_dirty: null argument");
+  PA_REQUIRE((arena_bases % PA_ALIGN_BASES) == 0, "pa_arena_dirty: arena_bases %llu is not a multiple of %u",
+             (unsigned long long)arena_bases, PA_ALIGN_BASES);
+  PA_HIP(hipSetDevice(c->device));
+  return pa_build_dirty(c, d_mask, arena_bases / PA_ALIGN_BASES, d_dirty);
+}
 
 int pa_mask_from_runs(pa_ctx *c, const uint64_t *h_run_start, const uint64_t *h_run_len, uint32_t n_runs,
                       uint32_t *d_mask, uint64_t arena_bases) {
@@ -74,8 +114,8 @@ int pa_mask_from_runs(pa_ctx *c, const uint64_t *h_run_start, const uint64_t *h_
 
 int pa_sketch_streamed(pa_ctx *c, const uint32_t *h_packed, const uint64_t *h_run_start, const uint64_t *h_run_len,
                        uint32_t n_runs, uint64_t arena_bases, const uint64_t *h_genome_start, uint32_t n_genomes,
-                       uint32_t k, uint64_t max_hash, uint32_t *d_packed, uint32_t *d_mask, uint64_t *d_hashes,
-                       uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total) {
+                       uint32_t k, uint64_t max_hash, uint32_t *d_packed, uint32_t *d_mask, uint64_t *d_dirty,
+                       uint64_t *d_hashes, uint64_t cap_hashes, uint64_t *d_off, uint64_t *h_total) {
   PA_REQUIRE(c && d_off && h_total && h_genome_start, "pa_sketch_streamed: null argument");
   PA_REQUIRE((arena_bases % PA_ALIGN_BASES) == 0, "pa_sketch_streamed: arena_bases %llu is not a multiple of %u",
              (unsigned long long)arena_bases, PA_ALIGN_BASES);
@@ -87,6 +127,11 @@ int pa_sketch_streamed(pa_ctx *c, const uint32_t *h_packed, const uint64_t *h_ru
   PA_TRY(pa_mask_from_runs(c, h_run_start, h_run_len, n_runs, d_mask, arena_bases));
 
   const uint64_t n_blocks = arena_bases / PA_ALIGN_BASES;
+  if (!d_dirty) {
+    PA_TRY(c->dirty.reserve(((n_blocks + 63) / 64 + 1) * 8));
+    d_dirty = c->dirty.as<uint64_t>();
+  }
+  PA_TRY(pa_build_dirty(c, d_mask, n_blocks, d_dirty));
   PA_REQUIRE(n_blocks < (1ULL << 32), "pa_sketch_streamed: arena too large");
   const double frac = (max_hash == UINT64_MAX) ? 1.0 : ((double)max_hash + 1.0) / 18446744073709551616.0;
   std::vector<uint64_t> region_off(n_genomes + 1, 0);
@@ -107,8 +152,8 @@ int pa_sketch_streamed(pa_ctx *c, const uint32_t *h_packed, const uint64_t *h_ru
   const bool overlap = n_genomes > 0 && longest_region <= kLdsSortMax && arena_bases > 0;
   if (!overlap) {  // long genomes / tiny scaled: plain upload, general sketch path
     PA_HIP(hipMemcpyAsync(d_packed, h_packed, arena_bases / 4, hipMemcpyHostToDevice, c->stream));
-    return pa_sketch(c, d_packed, d_mask, arena_bases, h_genome_start, n_genomes, k, max_hash, d_hashes, cap_hashes, d_off,
-                     h_total);
+    return pa_sketch(c, d_packed, d_mask, d_dirty, arena_bases, h_genome_start, n_genomes, k, max_hash, d_hashes, cap_hashes,
+                     d_off, h_total);
   }
   if (!c->copy_stream) PA_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   PA_TRY(c->genome_blk.reserve((uint64_t)(n_genomes + 1) * sizeof(uint32_t)));
@@ -141,7 +186,7 @@ int pa_sketch_streamed(pa_ctx *c, const uint32_t *h_packed, const uint64_t *h_ru
         pa_set_error("pa_sketch_streamed: chunk upload failed");
         break;
       }
-      status = pa_launch_kmer_hash(c, d_packed, d_mask, b1, c->genome_blk.as<uint32_t>(), n_genomes, k, max_hash,
+      status = pa_launch_kmer_hash(c, d_packed, d_mask, d_dirty, b1, c->genome_blk.as<uint32_t>(), n_genomes, k, max_hash,
                                    c->cand_keys[0].as<uint64_t>(), nullptr, 0, nullptr, c->region_off.as<uint64_t>(),
                                    c->region_cursor.as<uint32_t>(), d_overflow, b0, c->stream);
     }
@@ -160,8 +205,8 @@ int pa_sketch_streamed(pa_ctx *c, const uint32_t *h_packed, const uint64_t *h_ru
   if (status != PA_OK) return status;
   if (!overflow) return PA_OK;
   // a region overflowed (repeats, low-complexity sequence): the arena is resident now, take the general path
-  return pa_sketch(c, d_packed, d_mask, arena_bases, h_genome_start, n_genomes, k, max_hash, d_hashes, cap_hashes, d_off,
-                   h_total);
+  return pa_sketch(c, d_packed, d_mask, d_dirty, arena_bases, h_genome_start, n_genomes, k, max_hash, d_hashes, cap_hashes,
+                   d_off, h_total);
 }
 
 }  // extern "C"

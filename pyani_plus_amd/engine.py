@@ -304,6 +304,16 @@ class HipEngine:
             np.ascontiguousarray(off.astype(np.uint64)),
         )
 
+    def arena_dirty(self, arena: DeviceArena):
+        """The arena's dirty-block bitmap (``pa_arena_dirty``), built on first use and kept with the arena."""
+        if arena.dirty is None:
+            t = self.torch
+            words = (arena.arena_bases // 64 + 63) // 64
+            dirty = t.empty(max(words, 1), dtype=t.int64, device=self.device)
+            check(self.lib.pa_arena_dirty(self.ctx, arena.mask.data_ptr(), arena.arena_bases, dirty.data_ptr()), "pa_arena_dirty")
+            arena.dirty = dirty
+        return arena.dirty
+
     # -- the three device steps
     def sketch(self, arena: DeviceArena, k: int, scaled: int, *, max_hash: int | None = None) -> DeviceSketches:
         t = self.torch
@@ -314,10 +324,11 @@ class HipEngine:
         off = t.empty(n + 1, dtype=t.int64, device=self.device)
         gs = np.ascontiguousarray(arena.genome_start, dtype=np.uint64)
         total = C.c_uint64(0)
+        dirty = self.arena_dirty(arena)
         for _attempt in range(2):
             hashes = t.empty(max(cap, 1), dtype=t.int64, device=self.device)
             st = self.lib.pa_sketch(
-                self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases,
+                self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), dirty.data_ptr(), arena.arena_bases,
                 gs.ctypes.data_as(C.POINTER(C.c_uint64)), n, k, mh, hashes.data_ptr(), cap, off.data_ptr(), C.byref(total),
             )  # fmt: skip
             if st == _capi.PA_E_CAPACITY:
@@ -345,6 +356,8 @@ class HipEngine:
                 t.empty(max(bases // 32, 1), dtype=t.int32, device=self.device),
                 host.genome_start.copy(),
             )
+        if arena.dirty is None:
+            arena.dirty = t.empty(max((bases // 64 + 63) // 64, 1), dtype=t.int64, device=self.device)
         frac = 1.0 if mh >= 2**64 - 1 else (mh + 1) / 2.0**64
         cap = int(bases * frac * 1.25) + 4096
         off = t.empty(n + 1, dtype=t.int64, device=self.device)
@@ -355,7 +368,7 @@ class HipEngine:
             st = self.lib.pa_sketch_streamed(
                 self.ctx, host.packed.data_ptr(), host.run_start.ctypes.data, host.run_len.ctypes.data, len(host.run_start),
                 bases, gs.ctypes.data_as(C.POINTER(C.c_uint64)), n, k, mh, arena.packed.data_ptr(), arena.mask.data_ptr(),
-                hashes.data_ptr(), cap, off.data_ptr(), C.byref(total),
+                arena.dirty.data_ptr(), hashes.data_ptr(), cap, off.data_ptr(), C.byref(total),
             )  # fmt: skip
             if st == _capi.PA_E_CAPACITY:
                 cap = int(total.value)
@@ -408,7 +421,7 @@ class HipEngine:
         total = C.c_uint64(0)
         check(
             self.lib.pa_sketch_bottom(
-                self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases,
+                self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), self.arena_dirty(arena).data_ptr(), arena.arena_bases,
                 gs.ctypes.data_as(C.POINTER(C.c_uint64)), n, k, m, hashes.data_ptr(), n * m, off.data_ptr(), C.byref(total),
             ),  # fmt: skip
             "pa_sketch_bottom",
