@@ -277,6 +277,14 @@ PA_API int pa_write_comparisons_json(const char *path, const char *prefix, const
                               const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
                               const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null);
 
+/* Progressive form: `path` was written by pa_write_comparisons_json (possibly with no rows) and ends with
+ * `suffix`; append one more block of rows in front of the suffix (file_has_rows: rows are already there, so a
+ * ", " goes first).  The file is a complete JSON document after every call -- an interrupted worker leaves
+ * the finished subject tiles behind, as pyani_plus/private_cli.py:1863-1894 does by re-dumping its list. */
+PA_API int pa_append_comparisons_json(const char *path, const char *suffix, int file_has_rows,
+                               const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
+                               const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null);
+
 /* ---- in-library HIP-event timing of the kernels (bench.py roofline) ----
  * Phases are timed with hipEvents on the context's stream when enabled. */
 #define PA_PROF_KMER_HASH 0   /* k-mer hash + threshold filter kernel */

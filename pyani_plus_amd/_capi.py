@@ -99,6 +99,10 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp],
     ),
+    "pa_append_comparisons_json": (
+        C.c_int,
+        [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp],
+    ),
     "pa_prof_enable": (C.c_int, [_vp, C.c_int]),
     "pa_prof_reset": (C.c_int, [_vp]),
     "pa_prof_get": (C.c_int, [_vp, C.c_int, _f64p, _u64p]),

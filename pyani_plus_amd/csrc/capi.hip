@@ -95,7 +95,7 @@ void pa_ctx_destroy(pa_ctx *c) {
     for (auto &pr : ph.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); c->copy_stream = nullptr; }
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -103,7 +103,7 @@ void pa_ctx_destroy(pa_ctx *c) {
 int pa_ctx_set_stream(pa_ctx *c, void *hip_stream) {
   PA_REQUIRE(c != nullptr, "null context");
   PA_HIP(hipStreamSynchronize(c->stream));
-  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  // the copy stream of pa_sketch_streamed does not depend on the compute stream: it stays as it is
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   c->stream = reinterpret_cast<hipStream_t>(hip_stream);  // nullptr = the default stream
   c->own_stream = false;

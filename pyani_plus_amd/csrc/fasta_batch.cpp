@@ -39,10 +39,10 @@ struct FileResult {
 bool read_file(const std::string &path, std::vector<uint8_t> &raw, std::string &err) {
   FILE *f = fopen(path.c_str(), "rb");
   if (!f) { err = "Input " + path + " not found"; return false; }
-  fseek(f, 0, SEEK_END);
-  const long sz = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  raw.resize(sz > 0 ? (size_t)sz : 0);
+  if (fseeko(f, 0, SEEK_END) != 0) { fclose(f); err = "Cannot seek in " + path; return false; }
+  const off_t sz = ftello(f);
+  if (sz < 0 || fseeko(f, 0, SEEK_SET) != 0) { fclose(f); err = "Cannot size " + path; return false; }
+  raw.resize((size_t)sz);
   const size_t got = raw.empty() ? 0 : fread(raw.data(), 1, raw.size(), f);
   fclose(f);
   if (got != raw.size()) { err = "Short read on " + path; return false; }
@@ -62,22 +62,38 @@ bool gunzip(const std::vector<uint8_t> &raw, std::vector<uint8_t> &out, std::str
     if (isize > raw.size() / 2 && isize < raw.size() * 1100) guess = isize + 64;
   }
   if (out.size() < guess) out.resize(guess);
-  zs.next_in = const_cast<Bytef *>(raw.data());
-  zs.avail_in = (uInt)raw.size();
+  // zlib counts in 32-bit `uInt`s: both sides are fed in pieces of at most 1 GiB
+  const uint8_t *in = raw.data();
+  size_t in_left = raw.size();
+  zs.next_in = const_cast<Bytef *>(in);
+  zs.avail_in = 0;
   size_t have = 0;
   for (;;) {
+    if (zs.avail_in == 0 && in_left) {
+      const size_t piece = std::min<size_t>(in_left, 1u << 30);
+      zs.next_in = const_cast<Bytef *>(in);
+      zs.avail_in = (uInt)piece;
+      in += piece;
+      in_left -= piece;
+    }
     if (have == out.size()) out.resize(out.size() * 2);
     zs.next_out = out.data() + have;
     zs.avail_out = (uInt)std::min<size_t>(out.size() - have, 1u << 30);
     const int rc = inflate(&zs, Z_NO_FLUSH);
     have = (size_t)(zs.next_out - out.data());
     if (rc == Z_STREAM_END) {
-      if (zs.avail_in == 0) break;
+      if (zs.avail_in == 0 && in_left == 0) break;
+      // Python's gzip module, which the reference reads with (pyani_plus/utils.py:178-196), accepts zero
+      // padding after the last member: nothing but NUL bytes left means end of file
+      bool only_zeros = true;
+      for (uInt i = 0; i < zs.avail_in && only_zeros; ++i) only_zeros = zs.next_in[i] == 0;
+      for (size_t i = 0; i < in_left && only_zeros; ++i) only_zeros = in[i] == 0;
+      if (only_zeros) break;
       if (inflateReset(&zs) != Z_OK) { err = "inflateReset failed"; inflateEnd(&zs); return false; }  // next member
       continue;
     }
     if (rc != Z_OK) { err = "corrupt gzip stream"; inflateEnd(&zs); return false; }
-    if (zs.avail_in == 0 && zs.avail_out != 0) { err = "truncated gzip stream"; inflateEnd(&zs); return false; }
+    if (zs.avail_in == 0 && in_left == 0 && zs.avail_out != 0) { err = "truncated gzip stream"; inflateEnd(&zs); return false; }
   }
   inflateEnd(&zs);
   out.resize(have);

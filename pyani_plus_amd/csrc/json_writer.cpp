@@ -16,7 +16,10 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+
 #include "../../include/pyani_hip.h"
+#include "host_pool.h"
 
 void pa_set_error(const char *fmt, ...);
 
@@ -68,35 +71,16 @@ inline char *put_double(char *p, char *end, double v) {
   return p;
 }
 
-}  // namespace
-
-extern "C" int pa_write_comparisons_json(const char *path, const char *prefix, const char *suffix,
-                                         const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
-                                         uint32_t ns, const double *identity, const double *cov_query,
-                                         const uint8_t *is_null) {
-  if (!path || !prefix || !suffix || (nq && !q_hashes) || (ns && !s_hashes) || !identity || !cov_query || !is_null) {
-    pa_set_error("pa_write_comparisons_json: null argument");
-    return PA_E_INVALID;
-  }
-  FILE *f = fopen(path, "wb");
-  if (!f) { pa_set_error("cannot open %s for writing", path); return PA_E_INVALID; }
-  std::vector<char> buf(1 << 22);
+// rows [q0, q1) x all subjects of one block, formatted into `out`; `first` = no ", " before the first row
+void format_rows(std::vector<char> &out, bool first, const char *const *q_hashes, const size_t *qlen, uint32_t q0,
+                 uint32_t q1, const char *const *s_hashes, const size_t *slen, uint32_t ns, const double *identity,
+                 const double *cov_query, const uint8_t *is_null) {
   size_t fill = 0;
-  auto flush = [&]() -> bool {
-    const bool ok = fwrite(buf.data(), 1, fill, f) == fill;
-    fill = 0;
-    return ok;
-  };
-  bool ok = fwrite(prefix, 1, strlen(prefix), f) == strlen(prefix);
-  std::vector<size_t> qlen(nq), slen(ns);
-  for (uint32_t q = 0; q < nq; ++q) qlen[q] = strlen(q_hashes[q]);
-  for (uint32_t s = 0; s < ns; ++s) slen[s] = strlen(s_hashes[s]);
-  bool first = true;
-  for (uint32_t q = 0; q < nq && ok; ++q) {
+  for (uint32_t q = q0; q < q1; ++q) {
     for (uint32_t s = 0; s < ns; ++s) {
-      if (fill + qlen[q] + slen[s] + 256 > buf.size()) { if (!flush()) { ok = false; break; } }
-      char *p = buf.data() + fill;
-      char *const end = buf.data() + buf.size();
+      if (fill + qlen[q] + slen[s] + 256 > out.size()) out.resize(out.size() * 2 + qlen[q] + slen[s] + 256);
+      char *p = out.data() + fill;
+      char *const end = out.data() + out.size();
       if (!first) { memcpy(p, ", ", 2); p += 2; }
       first = false;
       memcpy(p, "{\"query_hash\": \"", 16); p += 16;
@@ -109,10 +93,78 @@ extern "C" int pa_write_comparisons_json(const char *path, const char *prefix, c
       memcpy(p, ", \"cov_query\": ", 15); p += 15;
       if (is_null[idx]) { memcpy(p, "null", 4); p += 4; } else p = put_double(p, end, cov_query[idx]);
       *p++ = '}';
-      fill = (size_t)(p - buf.data());
+      fill = (size_t)(p - out.data());
     }
   }
-  ok = ok && flush() && fwrite(suffix, 1, strlen(suffix), f) == strlen(suffix);
+  out.resize(fill);
+}
+
+// all rows of a block through `f`: host threads format runs of query rows, the caller writes them in order
+bool write_block(FILE *f, bool first, const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
+                 const double *identity, const double *cov_query, const uint8_t *is_null) {
+  if (nq == 0 || ns == 0) return true;
+  std::vector<size_t> qlen(nq), slen(ns);
+  for (uint32_t q = 0; q < nq; ++q) qlen[q] = strlen(q_hashes[q]);
+  for (uint32_t s = 0; s < ns; ++s) slen[s] = strlen(s_hashes[s]);
+  const uint32_t rows_per_chunk = std::max<uint32_t>(1u, (uint32_t)(16384u / ns));  // ~16k comparisons = ~2.5 MB of text
+  const uint32_t n_chunks = (nq + rows_per_chunk - 1) / rows_per_chunk;
+  const uint32_t nt = pa_host_threads(n_chunks, 1, 0);
+  std::vector<std::vector<char>> bufs(nt);
+  bool ok = true;
+  for (uint32_t c0 = 0; c0 < n_chunks && ok; c0 += nt) {
+    const uint32_t in_round = std::min(nt, n_chunks - c0);
+    HostPool::get().run(in_round, [&](uint32_t w, uint32_t) {
+      const uint32_t c = c0 + w, q0 = c * rows_per_chunk, q1 = std::min(nq, q0 + rows_per_chunk);
+      bufs[w].resize(std::max<size_t>(bufs[w].capacity(), 1 << 20));
+      format_rows(bufs[w], first && c == 0, q_hashes, qlen.data(), q0, q1, s_hashes, slen.data(), ns, identity, cov_query,
+                  is_null);
+    });
+    for (uint32_t w = 0; w < in_round && ok; ++w) ok = fwrite(bufs[w].data(), 1, bufs[w].size(), f) == bufs[w].size();
+  }
+  return ok;
+}
+
+}  // namespace
+
+extern "C" int pa_write_comparisons_json(const char *path, const char *prefix, const char *suffix,
+                                         const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
+                                         uint32_t ns, const double *identity, const double *cov_query,
+                                         const uint8_t *is_null) {
+  if (!path || !prefix || !suffix || (nq && !q_hashes) || (ns && !s_hashes) || ((uint64_t)nq * ns && (!identity || !cov_query || !is_null))) {
+    pa_set_error("pa_write_comparisons_json: null argument");
+    return PA_E_INVALID;
+  }
+  FILE *f = fopen(path, "wb");
+  if (!f) { pa_set_error("cannot open %s for writing", path); return PA_E_INVALID; }
+  bool ok = fwrite(prefix, 1, strlen(prefix), f) == strlen(prefix);
+  ok = ok && write_block(f, true, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+  ok = ok && fwrite(suffix, 1, strlen(suffix), f) == strlen(suffix);
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { pa_set_error("short write to %s", path); return PA_E_INVALID; }
+  return PA_OK;
+}
+
+// Progressive form (the reference re-serialises its whole list every 100 000 rows so that an interrupted
+// worker leaves the completed comparisons behind, pyani_plus/private_cli.py:1863-1894): the file written by
+// pa_write_comparisons_json ends with `suffix`; this call moves the suffix back by one block of rows, so the
+// file is a complete JSON document after every call and no row is ever formatted twice.
+extern "C" int pa_append_comparisons_json(const char *path, const char *suffix, int file_has_rows,
+                                          const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
+                                          uint32_t ns, const double *identity, const double *cov_query,
+                                          const uint8_t *is_null) {
+  if (!path || !suffix || (nq && !q_hashes) || (ns && !s_hashes) || ((uint64_t)nq * ns && (!identity || !cov_query || !is_null))) {
+    pa_set_error("pa_append_comparisons_json: null argument");
+    return PA_E_INVALID;
+  }
+  FILE *f = fopen(path, "r+b");
+  if (!f) { pa_set_error("cannot open %s for appending", path); return PA_E_INVALID; }
+  const size_t ls = strlen(suffix);
+  std::vector<char> tail(ls + 1, 0);
+  bool ok = fseeko(f, -(off_t)ls, SEEK_END) == 0 && fread(tail.data(), 1, ls, f) == ls && memcmp(tail.data(), suffix, ls) == 0;
+  if (!ok) { fclose(f); pa_set_error("%s does not end with the expected JSON suffix", path); return PA_E_INVALID; }
+  ok = fseeko(f, -(off_t)ls, SEEK_END) == 0;
+  ok = ok && write_block(f, !file_has_rows, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+  ok = ok && fwrite(suffix, 1, ls, f) == ls;
   ok = (fclose(f) == 0) && ok;
   if (!ok) { pa_set_error("short write to %s", path); return PA_E_INVALID; }
   return PA_OK;

@@ -20,6 +20,7 @@
 #include <unistd.h>
 
 #include "../../include/pyani_hip.h"
+#include "host_pool.h"
 
 void pa_set_error(const char *fmt, ...);
 
@@ -203,73 +204,6 @@ extern "C" int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_pac
   if (n_invalid) *n_invalid = invalid;
   return PA_OK;
 }
-
-// ---- a small persistent pool of host threads --------------------------------------------------------------
-// pa_ani_host is called once per column tile; creating 64 threads per call costs more than the pows of a
-// sparse tile.  Workers are created on first demand, sleep between jobs and are never joined (the pool lives as
-// long as the process; a forked child starts its own).
-namespace {
-class HostPool {
- public:
-  static HostPool &get() {
-    static HostPool *pool = nullptr;
-    static pid_t owner = 0;
-    static std::mutex guard;
-    std::lock_guard<std::mutex> lock(guard);
-    if (!pool || owner != getpid()) {  // first use, or we are a forked child whose copy has no threads
-      pool = new HostPool();
-      owner = getpid();
-    }
-    return *pool;
-  }
-  // fn(worker, n_workers) on n_workers threads (the caller is worker 0); returns when all are done
-  template <typename F>
-  void run(uint32_t n_workers, F &&fn) {
-    if (n_workers <= 1) { fn(0u, 1u); return; }
-    std::function<void(uint32_t, uint32_t)> job = fn;
-    {
-      std::unique_lock<std::mutex> lock(m_);
-      while (threads_ < n_workers - 1) {
-        const uint32_t id = ++threads_;
-        std::thread([this, id] { worker(id); }).detach();
-      }
-      job_ = &job;
-      job_workers_ = n_workers;
-      pending_ = n_workers - 1;
-      ++generation_;
-    }
-    wake_.notify_all();
-    fn(0u, n_workers);
-    std::unique_lock<std::mutex> lock(m_);
-    done_.wait(lock, [this] { return pending_ == 0; });
-    job_ = nullptr;
-  }
-
- private:
-  void worker(uint32_t id) {
-    uint64_t seen = 0;
-    for (;;) {
-      const std::function<void(uint32_t, uint32_t)> *job = nullptr;
-      uint32_t n = 0;
-      {
-        std::unique_lock<std::mutex> lock(m_);
-        wake_.wait(lock, [&] { return generation_ != seen; });
-        seen = generation_;
-        if (id < job_workers_) { job = job_; n = job_workers_; }
-      }
-      if (!job) continue;
-      (*job)(id, n);
-      std::unique_lock<std::mutex> lock(m_);
-      if (--pending_ == 0) done_.notify_all();
-    }
-  }
-  std::mutex m_;
-  std::condition_variable wake_, done_;
-  const std::function<void(uint32_t, uint32_t)> *job_ = nullptr;
-  uint32_t job_workers_ = 0, pending_ = 0, threads_ = 0;
-  uint64_t generation_ = 0;
-};
-}  // namespace
 
 // Strict containment-ANI transform: host libm `pow`, the arithmetic that reproduces every reference fixture
 // bit for bit.  Rows are split over host threads; with `symmetric` (queries and

@@ -49,7 +49,7 @@ def write_sig(path: Path, *, name: str, filename: str, ksize: int, max_hash: int
         }
     ]
     tmp = Path(str(path) + ".tmp")
-    tmp.write_text(json.dumps(obj, separators=(",", ":")))  # single line, no trailing newline
+    tmp.write_text(json.dumps(obj, separators=(",", ":"), ensure_ascii=False), encoding="utf-8")  # single line, no trailing newline; raw UTF-8 as sourmash (serde_json) writes it
     tmp.replace(path)
 
 
@@ -82,7 +82,7 @@ def write_sigs(paths, *, names, filenames, ksize: int, max_hash: int, sketches) 
                 "version": 0.4,
             }
         ]
-        text = json.dumps(obj, separators=(",", ":"))
+        text = json.dumps(obj, separators=(",", ":"), ensure_ascii=False)  # non-ASCII file names stay raw UTF-8, as in sourmash's files
         marker = '"mins":[],"md5sum":""'
         at = text.rindex(marker)  # the last occurrence is the real one even if a file name contains the marker
         heads.append(text[: at + len('"mins":[')].encode())
@@ -131,7 +131,7 @@ def _read_single_sketch_fast(text: str, ksize: int | None, max_hash: int | None)
 
 def read_sig(path: Path, *, ksize: int | None = None, max_hash: int | None = None) -> tuple[np.ndarray, dict]:
     """Return (ascending uint64 hashes, sketch dict) of the DNA sketch with the wanted k."""
-    text = Path(path).read_text()
+    text = Path(path).read_text(encoding="utf-8")
     fast = _read_single_sketch_fast(text, ksize, max_hash)
     if fast is not None:
         return fast

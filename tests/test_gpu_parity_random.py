@@ -43,7 +43,7 @@ def _random_fasta(rng, n_records, max_len, *, lower=False, n_runs=0) -> bytes:
     return b"".join(out)
 
 
-@pytest.mark.parametrize("k", [15, 16, 21, 31, 32])
+@pytest.mark.parametrize("k", [15, 16, 21, 31, 32, 7, 20, 24, 30])
 @pytest.mark.parametrize("scaled", [1, 7, 1000])
 def test_sketch_random_fasta_matches_oracle(engine, k, scaled):
     from pyani_plus_amd.engine import pack_genomes
@@ -65,6 +65,21 @@ def test_sketch_random_fasta_matches_oracle(engine, k, scaled):
         want, total = oracle.sketch_fasta_text(text, k, scaled)
         assert arena.residues[g] == total
         assert np.array_equal(got[g], want), f"genome {g}: {len(got[g])} vs {len(want)} (k={k}, scaled={scaled})"
+
+
+def test_sketch_every_kmer_size_matches_oracle(engine):
+    """The reference hands any --kmersize to sourmash (pyani_plus/public_cli_args.py:229,
+    pyani_plus/methods/sourmash.py:75-76): every k from 1 to 32 is compiled in and equals the oracle."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(99)
+    texts = [_random_fasta(rng, 2, 6000, n_runs=3), _random_fasta(rng, 1, 9000, lower=True), b">tiny\nACGTTGCA\n"]
+    dev = engine.upload(pack_genomes(texts))
+    for k in range(1, 33):
+        got = engine.sketch(dev, k, 3).to_host()
+        for g, text in enumerate(texts):
+            want, _total = oracle.sketch_fasta_text(text, k, 3)
+            assert np.array_equal(got[g], want), f"k={k} genome {g}: {len(got[g])} vs {len(want)}"
 
 
 def test_sketch_staging_overflow_and_capacity_retry(engine):
@@ -267,10 +282,10 @@ def test_degenerate_inputs_and_error_codes(engine):
     assert tuple(engine.pair_counts(empty).shape) == (0, 0)
     # unsupported k, bad ranges, bad algo -> error codes with messages, no crash
     one = pack_genomes([b"ACGT" * 100], fasta=False)
-    with pytest.raises(_capi.HipBackendError, match="not compiled in"):
-        engine.sketch(engine.upload(one), 20, 10)
     with pytest.raises(_capi.HipBackendError, match=r"outside \[1,32\]"):
         engine.sketch(engine.upload(one), 33, 10)
+    with pytest.raises(_capi.HipBackendError, match=r"outside \[1,32\]"):
+        engine.sketch(engine.upload(one), 0, 10)
     good = engine.sketch(engine.upload(one), 31, 10)
     with pytest.raises(_capi.HipBackendError, match="ranges"):
         engine.pair_counts(good, (0, 2), (0, 1))
@@ -281,7 +296,7 @@ def test_degenerate_inputs_and_error_codes(engine):
     # arena size not a multiple of 64 is rejected before any launch
     total = C.c_uint64(0)
     gs = (C.c_uint64 * 2)(0, 100)
-    st = lib.pa_sketch(engine.ctx, one_ptr := engine.upload(one).packed.data_ptr(), one_ptr, 100, gs, 1, 31, 1, None, 0, good.off.data_ptr(), C.byref(total))
+    st = lib.pa_sketch(engine.ctx, one_ptr := engine.upload(one).packed.data_ptr(), one_ptr, None, 100, gs, 1, 31, 1, None, 0, good.off.data_ptr(), C.byref(total))
     assert st == -1 and b"multiple of 64" in lib.pa_last_error()
 
 
