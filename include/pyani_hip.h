@@ -238,13 +238,15 @@ PA_API int pa_ani_mash(pa_ctx *ctx, const uint32_t *d_common, const uint32_t *d_
  * fastANI line); h_matched[q*n+r] = kept (orthologous) fragments, h_ident_sum[q*n+r] = sum of their
  * identities in percent, so ANI(q,r) = sum/matched, reported by fastANI when matched/total >= minFraction
  * (pyani_plus/methods/fastani.py:98-120 parses exactly these three numbers).
+ * Only the reference genomes [ref0, ref1) are mapped against (columns outside stay 0): the reference's worker is
+ * called once per subject column (pyani_plus/private_cli.py:976-1063), and a column costs one column's mappings.
  * Algorithm and its tolerance-only parity: oracle/fragani_oracle.c.  k in {12,14,15,16}; fragLen in
  * [100, 65535]; contigs listed genome by genome, at most 65535 per genome and 2^20-1 in all; at most 2^20-1
  * fragments per genome.  The workspace (about 12 GB for 1000 x 5 Mb genomes) stays in the context. */
 PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
-               uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t *h_total_frags,
-               uint32_t *h_matched, double *h_ident_sum);
+               uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t ref0, uint32_t ref1,
+               uint32_t *h_total_frags, uint32_t *h_matched, double *h_ident_sum);
 /* stage 1 alone (testing): the winnowed minimizers of every contig, in arena order */
 PA_API int pa_fragani_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                       const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,

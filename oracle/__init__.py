@@ -14,6 +14,8 @@ from .pyoracle import (  # noqa: F401
     fragani_map,
     fragani_minimizers,
     fragani_pair,
+    fragani_get_option,
+    fragani_set_option,
     fragani_tables,
     fragani_window_size,
     intersect,

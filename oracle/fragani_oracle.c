@@ -35,10 +35,26 @@
 
 uint64_t orc_murmur3_h1(const uint8_t *data, uint32_t len, uint32_t seed);
 
+/* ------------------------------------------------------------------ variant switches
+ * The five RESTATEMENT choices can be switched at run time so that tools/fragani_bisect.py can measure, on
+ * the reference's 25 fastANI rows, what each of them costs (table in profiles/ and DESIGN.md).  The defaults
+ * are the variant the HIP path implements. */
+enum { OPT_WINDOW_RULE = 0, OPT_BIN_RULE = 1, OPT_L2_RULE = 2, OPT_CONF = 3, OPT_COUNT = 4 };
+static double g_opt[OPT_COUNT] = {
+    1.0, /* OPT_WINDOW_RULE: 0 = sketch sizes 10, 60, 110, ... (round 1); 1 = 1, 2, 5, 10, 20, 30, ... (Mashmap's list) */
+    1.0, /* OPT_BIN_RULE:    0 = (pos + fragLen/2) / fragLen (round 1); 1 = pos / (fragLen - 20) (fastANI's bucket) */
+    0.0, /* OPT_L2_RULE:     0 = Jaccard at the window starts the seed hits imply; 1 = slide over reference minimizer positions,
+                                  position = mean of the first and last optimum (Mashmap's slide) */
+    0.9, /* OPT_CONF:        confidence level of the identity bounds */
+};
+ORC_API void orc_fragani_set_option(int which, double value) { if (which >= 0 && which < OPT_COUNT) g_opt[which] = value; }
+ORC_API double orc_fragani_get_option(int which) { return (which >= 0 && which < OPT_COUNT) ? g_opt[which] : NAN; }
+
 #define PERC_IDENTITY 80.0
 /* RESTATEMENT: confidence level of the identity bounds.  Mashmap's documented default is 0.75; 0.9
- * reproduces the fastANI fixtures markedly better (kept-fragment counts of the 83 % pairs). */
-#define CONF_LEVEL 0.9
+ * reproduces the fastANI fixtures markedly better (kept-fragment counts of the 83 % pairs) and, with
+ * Mashmap's list of sketch sizes, gives the winnowing window 24 that fastANI logs for k=16, fragLen=3000. */
+#define CONF_LEVEL (g_opt[OPT_CONF])
 #define PVAL_CUTOFF 1e-3
 #define REF_SIZE 5e6
 
@@ -114,9 +130,16 @@ static double estimate_pvalue(int s, int k, int len_query) {
 /* winnowing window: smallest sketch size (10, 60, 110, ...) whose random-match p-value over a 5 Mb
  * reference is <= 1e-3, then w = 2*fragLen/sketch */
 ORC_API int orc_fragani_window_size(int k, int frag_len) {
-  int s;
-  for (s = 10; s < frag_len; s += 50)
-    if (estimate_pvalue(s, k, frag_len) <= PVAL_CUTOFF) break;
+  int s = 0;
+  if (g_opt[OPT_WINDOW_RULE] == 0.0) {
+    for (s = 10; s < frag_len; s += 50)
+      if (estimate_pvalue(s, k, frag_len) <= PVAL_CUTOFF) break;
+  } else { /* Mashmap tries 1, 2, 5, then every multiple of 10 below the fragment length */
+    static const int first[3] = {1, 2, 5};
+    int found = 0;
+    for (int i = 0; i < 3 && !found; ++i) { s = first[i]; found = estimate_pvalue(s, k, frag_len) <= PVAL_CUTOFF; }
+    for (int t = 10; t < frag_len && !found; t += 10) { s = t; found = estimate_pvalue(s, k, frag_len) <= PVAL_CUTOFF; }
+  }
   int w = (int)(2.0 * frag_len / s);
   if (w < 1) w = 1;
   if (w > frag_len) w = frag_len;
@@ -338,6 +361,34 @@ static int map_fragments(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q
        * fragment's own sketch holds for the fragment.  Best = most shared; ties: lowest contig,
        * then smallest start. */
       int best_shared = -1, best_seq = -1; int64_t best_pos = 0;
+      if (g_opt[OPT_L2_RULE] != 0.0) {
+        /* Mashmap's slide: a window starts at every reference minimizer position of the candidate range and
+         * holds the minimizers recorded in [start, start + count_windows); per candidate the position is the
+         * mean of the first and the last start with the most shared minimizers */
+        for (size_t ci = 0; ci < nc; ++ci) {
+          const int32_t cseq = cands[ci].seq;
+          int c_best = -1; int64_t c_first = 0, c_last = 0;
+          size_t b = lower_bound_pos(rpos.v, rpos.n, cseq, cands[ci].start);
+          for (; b < rpos.n && rpos.v[b].seq == cseq && (int64_t)rpos.v[b].wpos <= cands[ci].end; ++b) {
+            const int64_t pstart = rpos.v[b].wpos;
+            if (b > 0 && rpos.v[b - 1].seq == cseq && rpos.v[b - 1].wpos == pstart) continue;
+            const size_t e = lower_bound_pos(rpos.v, rpos.n, cseq, pstart + count_windows);
+            const size_t nw = e - b;
+            if (nw > win_cap) { win_cap = nw * 2 + 64; winh = (uint32_t *)realloc(winh, win_cap * sizeof(uint32_t)); }
+            for (size_t t = 0; t < nw; ++t) winh[t] = rpos.v[b + t].hash;
+            qsort(winh, nw, sizeof(uint32_t), cmp_u32);
+            size_t u = 0;
+            for (size_t t = 0; t < nw; ++t) if (t == 0 || winh[t] != winh[t - 1]) winh[u++] = winh[t];
+            const int sh = shared_in_bottom_s(qh, s, winh, (int)u);
+            if (sh > c_best) { c_best = sh; c_first = c_last = pstart; }
+            else if (sh == c_best) c_last = pstart;
+          }
+          const int64_t pos = (c_first + c_last) / 2;
+          if (c_best > best_shared || (c_best == best_shared && c_best >= 0 && (cseq < best_seq || (cseq == best_seq && pos < best_pos)))) {
+            best_shared = c_best; best_seq = cseq; best_pos = pos;
+          }
+        }
+      } else
       for (size_t ci = 0; ci < nc; ++ci) {
         const int32_t cseq = cands[ci].seq;
         for (size_t a = 0; a < nh; ++a) {
@@ -399,16 +450,19 @@ static int cmp_bin(const void *a, const void *b) {
   return x->ref_pos < y->ref_pos ? -1 : x->ref_pos > y->ref_pos; /* ref_pos holds the bin here */
 }
 
-/* ANI of one ordered pair.  One-to-one step: per reference bin = (window id + fragLen/2) / fragLen of a
- * contig keep the fragment with the largest J = shared/s (equal J means equal identity); ANI = mean
- * identity of the kept fragments summed in (contig, bin) order; NaN when kept/total < min_fraction. */
+/* ANI of one ordered pair.  One-to-one step: per reference bin = window id / (fragLen - 20) of a contig
+ * (fastANI's bucket; OPT_BIN_RULE 0 = the round-1 form) keep the fragment with the largest J = shared/s (equal J
+ * means equal identity); ANI = mean identity of the kept fragments summed in (contig, bin) order.  Reported (else
+ * NaN) when the kept fragments cover min_fraction of the SHORTER genome, kept * fragLen >= min_fraction *
+ * min(len_q, len_r), lengths counting contigs of at least one fragment: fastANI's output rule. */
 ORC_API int orc_fragani_pair(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q_contigs, const uint8_t *r_seq,
                              const uint64_t *r_off, uint32_t r_contigs, int k, int frag_len, double min_fraction,
                              int window, double *ani_out, int *matched_out, int *total_out) {
   const int w = window > 0 ? window : orc_fragani_window_size(k, frag_len);
   FragMap *maps; int n, total;
   if (map_fragments(q_seq, q_off, q_contigs, r_seq, r_off, r_contigs, k, frag_len, w, &maps, &n, &total)) return -1;
-  for (int i = 0; i < n; ++i) maps[i].ref_pos = (maps[i].ref_pos + frag_len / 2) / frag_len;
+  for (int i = 0; i < n; ++i)
+    maps[i].ref_pos = g_opt[OPT_BIN_RULE] == 0.0 ? (maps[i].ref_pos + frag_len / 2) / frag_len : maps[i].ref_pos / (frag_len - 20);
   qsort(maps, (size_t)n, sizeof(FragMap), cmp_bin);
   double sum = 0.0; int matched = 0;
   for (int i = 0; i < n;) {
@@ -421,6 +475,10 @@ ORC_API int orc_fragani_pair(const uint8_t *q_seq, const uint64_t *q_off, uint32
   }
   free(maps);
   *total_out = total; *matched_out = matched;
-  *ani_out = (matched > 0 && total > 0 && (double)matched / total >= min_fraction) ? sum / matched : NAN;
+  uint64_t len_q = 0, len_r = 0;
+  for (uint32_t c = 0; c < q_contigs; ++c) if (q_off[c + 1] - q_off[c] >= (uint64_t)frag_len) len_q += q_off[c + 1] - q_off[c];
+  for (uint32_t c = 0; c < r_contigs; ++c) if (r_off[c + 1] - r_off[c] >= (uint64_t)frag_len) len_r += r_off[c + 1] - r_off[c];
+  const double shorter = (double)(len_q < len_r ? len_q : len_r);
+  *ani_out = (matched > 0 && total > 0 && (double)matched * frag_len >= min_fraction * shorter) ? sum / matched : NAN;
   return 0;
 }

@@ -179,8 +179,24 @@ def _load_frag() -> C.CDLL:
         lib.orc_fragani_map.argtypes = [C.c_char_p, _u64p, C.c_uint32, C.c_char_p, _u64p, C.c_uint32, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p, i32p, C.POINTER(C.c_int)]
         lib.orc_fragani_pair.restype = C.c_int
         lib.orc_fragani_pair.argtypes = [C.c_char_p, _u64p, C.c_uint32, C.c_char_p, _u64p, C.c_uint32, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        lib.orc_fragani_set_option.restype = None
+        lib.orc_fragani_set_option.argtypes = [C.c_int, C.c_double]
+        lib.orc_fragani_get_option.restype = C.c_double
+        lib.orc_fragani_get_option.argtypes = [C.c_int]
         _frag_typed = True
     return lib
+
+
+FRAGANI_OPTIONS = {"window_rule": 0, "bin_rule": 1, "l2_rule": 2, "conf": 3}
+
+
+def fragani_set_option(name: str, value: float) -> None:
+    """Switch one of the oracle's restatement choices (tools/fragani_bisect.py); process-wide."""
+    _load_frag().orc_fragani_set_option(FRAGANI_OPTIONS[name], float(value))
+
+
+def fragani_get_option(name: str) -> float:
+    return float(_load_frag().orc_fragani_get_option(FRAGANI_OPTIONS[name]))
 
 
 def fragani_window_size(k: int, frag_len: int) -> int:

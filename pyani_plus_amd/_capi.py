@@ -86,7 +86,7 @@ SIGNATURES: dict[str, tuple] = {
     ),
     "pa_pair_mash": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
     "pa_ani_mash": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
-    "pa_fragani": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "pa_fragani": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "pa_fragani_sketch": (
         C.c_int,
         [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_uint64, _u64p],

@@ -83,15 +83,20 @@ int relaxed_min_hits(int s, int k) {
   }
   return best;
 }
+// Winnowing window: the smallest sketch size of Mashmap's list 1, 2, 5, 10, 20, 30, ... whose random-match p-value
+// over a 5 Mb reference is <= 1e-3, then w = 2*fragLen/sketch (24 for k=16, fragLen=3000: the window fastANI logs).
 int window_size_for(int k, int frag_len) {
-  int s;
-  for (s = 10; s < frag_len; s += 50) {
+  auto passes = [&](int s) {
     const double px = 1.0 / (1.0 + std::pow(4.0, k) / frag_len);
     const double r = px * px / (px + px - px * px);
     const int x = relaxed_min_hits(s, k);
     const double comp = x == 0 ? 1.0 : 1.0 - binom_cdf(x - 1, s, r);
-    if (kRefSize * comp <= kPvalCutoff) break;
-  }
+    return kRefSize * comp <= kPvalCutoff;
+  };
+  int s = 1;
+  bool found = false;
+  for (int cand : {1, 2, 5}) { s = cand; if ((found = passes(s))) break; }
+  for (int cand = 10; cand < frag_len && !found; cand += 10) { s = cand; found = passes(s); }
   int w = (int)(2.0 * frag_len / s);
   if (w < 1) w = 1;
   if (w > frag_len) w = frag_len;
@@ -486,7 +491,8 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ hit_off, const uint32_t *__restrict__ post_start,
     const uint64_t *__restrict__ post_cw, uint32_t n_genomes, const uint32_t *__restrict__ tab_min_hits,
     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-    uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t seg_cap, uint32_t *__restrict__ counters) {
+    uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t seg_cap, uint32_t *__restrict__ counters,
+    uint32_t ref0, uint32_t ref1) {
   extern __shared__ uint32_t bk_lds[];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * kBucketWaves + wave;
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     const uint32_t cnt = g < n_genomes ? hist[g] : 0u;
     const uint32_t off = carry + wave_excl_scan(cnt, lane);
     if (g < n_genomes) hist[g] = off;
-    const bool keep = cnt >= mh;
+    const bool keep = cnt >= mh && g >= ref0 && g < ref1;  // only the reference genomes asked for are mapped
     const uint64_t km = __ballot(keep);
     if (km) {
       // short segments fill the list from the front, the ones over kHitCapSmall hits from the back: the two
@@ -680,12 +686,15 @@ __global__ __launch_bounds__(kThreads) void segment_keep_kernel(const uint64_t *
                                                                 const uint32_t *__restrict__ seg_start, uint32_t n_segs,
                                                                 const uint32_t *__restrict__ q_s,
                                                                 const uint32_t *__restrict__ tab_min_hits,
-                                                                uint32_t *__restrict__ keep) {
+                                                                const uint32_t *__restrict__ contig_genome, uint32_t ref0,
+                                                                uint32_t ref1, uint32_t *__restrict__ keep) {
   const uint32_t seg = blockIdx.x * kThreads + threadIdx.x;
   if (seg >= n_segs) return;
   const uint32_t a0 = seg_start[seg], nh = seg_start[seg + 1] - a0;
-  const uint32_t s = q_s[(uint32_t)(keys[a0] >> 44)];
-  keep[seg] = (s != 0 && nh >= tab_min_hits[s]) ? 1u : 0u;
+  const uint64_t key = keys[a0];
+  const uint32_t s = q_s[(uint32_t)(key >> 44)];
+  const uint32_t g = contig_genome[(key >> 24) & 0xfffffu];
+  keep[seg] = (s != 0 && nh >= tab_min_hits[s] && g >= ref0 && g < ref1) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(kThreads) void segment_list_kernel(const uint32_t *__restrict__ keep,
@@ -1033,7 +1042,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   if (have_best && best_shared >= tab_min_shared[s] && lane == 0) {
     const uint64_t jq = ((uint64_t)best_shared << 30) / s;
     const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
-    const uint64_t bin = contig_bin_off[best_c] + (best_p + frag_len / 2u) / frag_len;
+    const uint64_t bin = contig_bin_off[best_c] + best_p / (frag_len - 20u);  // fastANI buckets the reference by fragLen - 20
     atomicMax(&table[(uint64_t)frag_genome_local[f] * table_stride + bin], packed);
   }
 }
@@ -1209,9 +1218,10 @@ int pa_fragani_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mas
 
 int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
-               uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t *h_total_frags,
-               uint32_t *h_matched, double *h_ident_sum) {
+               uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t ref0, uint32_t ref1,
+               uint32_t *h_total_frags, uint32_t *h_matched, double *h_ident_sum) {
   PA_REQUIRE(c && d_packed && d_mask && h_total_frags && h_matched && h_ident_sum, "pa_fragani: null argument");
+  PA_REQUIRE(ref0 <= ref1 && ref1 <= n_genomes, "pa_fragani: reference range [%u,%u) outside [0,%u)", ref0, ref1, n_genomes);
   PA_REQUIRE(frag_len >= 100 && frag_len <= 0xffffu, "pa_fragani: fragLen %u outside [100, 65535]", frag_len);
   PA_HIP(hipSetDevice(c->device));
   const int w = window_size_for((int)k, (int)frag_len);
@@ -1251,7 +1261,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
     const uint32_t nf = h_contig_len[ci] / frag_len;
     for (uint32_t f = 0; f < nf; ++f) { frag_contig.push_back(ci); frag_no.push_back(f); }
     h_total_frags[h_contig_genome[ci]] += nf;
-    contig_bin_off[ci + 1] = contig_bin_off[ci] + h_contig_len[ci] / frag_len + 2;
+    contig_bin_off[ci + 1] = contig_bin_off[ci] + h_contig_len[ci] / (frag_len - 20u) + 2;
   }
   for (uint32_t g = 0; g < n_genomes; ++g) genome_frag_off[g + 1] = genome_frag_off[g] + h_total_frags[g];
   {
@@ -1414,7 +1424,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                            c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
                            W.hit_off.as<uint32_t>(), W.post_start.as<uint32_t>(), W.post_cw.as<uint64_t>(), n_genomes,
                            W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
-                           W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters);
+                           W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters, ref0, ref1);
         PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters, 16, hipMemcpyDeviceToHost, c->stream));
         PA_HIP(hipStreamSynchronize(c->stream));
         const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(c->h_pinned);
@@ -1480,7 +1490,8 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
         // here, one thread each, instead of spending a workgroup launch on each in the mapping kernel
         const uint32_t gs = ceil_div_u64(n_segs, kThreads);
         hipLaunchKernelGGL(segment_keep_kernel, dim3(gs), dim3(kThreads), 0, c->stream, hk[hw],
-                           W.seg_start.as<uint32_t>(), n_segs, W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(), hf);
+                           W.seg_start.as<uint32_t>(), n_segs, W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(),
+                           W.contig_genome.as<uint32_t>(), ref0, ref1, hf);
         PA_TRY(pa_exclusive_scan_u32(c, hf, hp, n_segs, W.scalars.as<uint64_t>()));
         PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
         PA_HIP(hipStreamSynchronize(c->stream));

@@ -448,10 +448,12 @@ class HipEngine:
         return out
 
     # -- fastANI-style fragment ANI (BASELINE configs[3])
-    def fragani(self, arena: DeviceArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000):
+    def fragani(self, arena: DeviceArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000, ref_range=None):
         """All ordered genome pairs: (total_frags[n], matched[n, n], ident_sum[n, n]) as numpy arrays;
-        ANI(q, r) = ident_sum / matched (percent), rows = query."""
+        ANI(q, r) = ident_sum / matched (percent), rows = query.  ``ref_range`` = (r0, r1) maps the queries against
+        those reference genomes only (the other columns stay 0)."""
         n = arena.n_genomes
+        r0, r1 = ref_range if ref_range is not None else (0, n)
         cs = np.ascontiguousarray(contig_start, dtype=np.uint64)
         cl = np.ascontiguousarray(contig_len, dtype=np.uint32)
         cg = np.ascontiguousarray(contig_genome, dtype=np.uint32)
@@ -461,7 +463,7 @@ class HipEngine:
         check(
             self.lib.pa_fragani(
                 self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,
-                cg.ctypes.data, len(cs), n, k, frag_len, total.ctypes.data, matched.ctypes.data, ident_sum.ctypes.data,
+                cg.ctypes.data, len(cs), n, k, frag_len, int(r0), int(r1), total.ctypes.data, matched.ctypes.data, ident_sum.ctypes.data,
             ),  # fmt: skip
             "pa_fragani",
         )

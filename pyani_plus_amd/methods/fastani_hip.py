@@ -19,8 +19,8 @@ Where the reference runs ``fastANI --ql <queries> -r <subject> -o out --fragLen 
     sim_errors = total - matched
     cov_query  = matched / total
 
-Parity with fastANI itself is tolerance-only (oracle/fragani_oracle.c): ANI within 0.3 percentage
-points and kept fragments within 5 % on the reference's 25 fixture rows.
+Parity with fastANI itself is tolerance-only (oracle/fragani_oracle.c; the tolerance on the reference's 25
+fixture rows is stated in tests/test_fragani_oracle.py and DESIGN.md 4.5).
 """
 
 from __future__ import annotations
@@ -45,8 +45,29 @@ def get_fastani_hip() -> ExternalToolData:
     return get_sourmash_hip()
 
 
-def fragment_ani_matrices(fasta_files: list[Path], *, kmersize: int, fragsize: int, engine=None):
-    """(total_frags[n], matched[n, n], ani_percent[n, n]) for the given FASTA files, rows = query."""
+def fastani_print_round(ani_percent: float) -> float:
+    """fastANI writes the identity through a C++ stream with the default precision: six significant digits
+    (``82.9124``, ``99.9953``, ``100``).  The reference parses that text (pyani_plus/methods/fastani.py:98-120),
+    so the stored identity carries exactly those digits."""
+    return float(f"{ani_percent:.6g}")
+
+
+def mappable_lengths(contig_len, contig_genome, n_genomes: int, fragsize: int) -> np.ndarray:
+    """Genome length as fastANI counts it for its minFraction test: contigs shorter than one fragment do not count."""
+    contig_len = np.asarray(contig_len, dtype=np.int64)
+    keep = contig_len >= fragsize
+    return np.bincount(np.asarray(contig_genome, dtype=np.int64)[keep], weights=contig_len[keep], minlength=n_genomes).astype(np.int64)
+
+
+def is_reported(matches: int, frags: int, fragsize: int, minmatch: float, len_query: int, len_subject: int) -> bool:
+    """fastANI prints a line when the matched fragments cover at least ``minFraction`` of the SHORTER genome:
+    ``matches * fragLen >= minFraction * min(len_q, len_s)`` -- not of the query's fragment count.  A long
+    query against a short reference is therefore still reported."""
+    return frags > 0 and matches > 0 and matches * fragsize >= minmatch * min(len_query, len_subject)
+
+
+def fragment_ani_matrices(fasta_files: list[Path], *, kmersize: int, fragsize: int, engine=None, ref_range=None):
+    """(total_frags[n], matched[n, n], ani_percent[n, n], mappable_length[n]) for the given FASTA files, rows = query."""
     from ..engine import load_fasta_files
 
     infos, arena = load_fasta_files(fasta_files)
@@ -54,10 +75,12 @@ def fragment_ani_matrices(fasta_files: list[Path], *, kmersize: int, fragsize: i
         if info.status != 0:
             raise ValueError(info.message)
     eng = engine or get_engine()
-    total, matched, ident_sum = eng.fragani(eng.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize)
+    total, matched, ident_sum = eng.fragani(
+        eng.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize, ref_range=ref_range
+    )
     with np.errstate(invalid="ignore", divide="ignore"):
         ani = np.where(matched > 0, ident_sum / np.maximum(matched, 1), np.nan)
-    return total, matched, ani
+    return total, matched, ani, mappable_lengths(arena.contig_len, arena.contig_genome, arena.n_genomes, fragsize)
 
 
 def compute_fastani_hip(  # noqa: PLR0913
@@ -75,7 +98,14 @@ def compute_fastani_hip(  # noqa: PLR0913
     cache: Path = Path(),  # noqa: ARG001
     engine=None,
 ) -> int:
-    """Run many-vs-subject (all-vs-all when ``subject_hash == ""``) and log the column(s) to JSON."""
+    """Run many-vs-subject (all-vs-all when ``subject_hash == ""``) and log the column(s) to JSON.
+
+    A single subject column maps the queries against that one reference genome only (``ref_range``), as one
+    ``fastANI -r subject`` process does.  Library failures end the worker through ``log_sys_exit`` like a failing
+    tool (pyani_plus/utils.py:262-283); a failing save returns 2."""
+    from .._capi import HipBackendError
+    from .sourmash_hip import backend_failure
+
     uname = platform.uname()
     configuration = run.configuration
     tool = get_fastani_hip()
@@ -95,22 +125,23 @@ def compute_fastani_hip(  # noqa: PLR0913
     subjects = [subject_hash] if subject_hash else queries
     genomes = sorted(set(queries) | set(subjects))
     index = {h: i for i, h in enumerate(genomes)}
+    ref_range = (index[subject_hash], index[subject_hash] + 1) if subject_hash else None
     db_entries: list[dict] = []
     try:
-        total, matched, ani = fragment_ani_matrices(
-            [Path(fasta_dir) / hash_to_filename[h] for h in genomes], kmersize=kmersize, fragsize=fragsize, engine=engine
+        total, matched, ani, lengths = fragment_ani_matrices(
+            [Path(fasta_dir) / hash_to_filename[h] for h in genomes], kmersize=kmersize, fragsize=fragsize, engine=engine, ref_range=ref_range
         )
         for q in queries:
             qi = index[q]
             for s in subjects:
                 si = index[s]
                 frags, matches = int(total[qi]), int(matched[qi, si])
-                reported = frags > 0 and matches > 0 and matches / frags >= minmatch  # fastANI prints a line
+                reported = is_reported(matches, frags, fragsize, minmatch, int(lengths[qi]), int(lengths[si]))  # fastANI prints a line
                 db_entries.append(
                     {
                         "query_hash": q,
                         "subject_hash": s,
-                        "identity": float(ani[qi, si]) / 100.0 if reported else None,
+                        "identity": fastani_print_round(float(ani[qi, si])) / 100.0 if reported else None,
                         # proxy values, private_cli.py:1072-1080
                         "aln_length": round(fragsize * matches) if reported else None,
                         "sim_errors": frags - matches if reported else None,
@@ -125,6 +156,8 @@ def compute_fastani_hip(  # noqa: PLR0913
         logger.error("Interrupted with %d completed %s comparisons", len(db_entries), METHOD)  # noqa: TRY400
         run.status = "Worker interrupted"
         session.commit()
+    except HipBackendError as err:
+        backend_failure(logger, f"{METHOD} comparison", err)
     try:
         wire.export_json_db_entries(logger, json_filename, configuration, db_entries)
     except Exception:  # pragma: no cover

@@ -210,7 +210,10 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, pr
     yield from pending
 
 
-def compute_sourmash_matrices(
+DEVICE_TILE_COLUMNS = 2048  # subject columns evaluated (and flushed to the column file) per device call
+
+
+def iter_sourmash_tiles(  # noqa: PLR0913
     logger: logging.Logger,
     subject_hashes,
     query_hashes,
@@ -220,9 +223,11 @@ def compute_sourmash_matrices(
     scaled: int,
     engine=None,
     algo: int = _capi.PA_PAIRS_AUTO,
-):
-    """``(queries, subjects, query_containment_ani, max_containment_ani, is_null)`` for the sorted
-    query x subject block: the array form of what ``compute_sourmash_tile`` yields row by row."""
+    tile_columns: int = DEVICE_TILE_COLUMNS,
+) -> Iterator[tuple]:
+    """Yield ``(queries, tile_subjects, query_containment_ani, max_containment_ani, is_null)`` for one tile of
+    subject columns after the other (sorted queries x sorted subjects).  The sketches are read and uploaded once;
+    every tile is one device call followed by the strict host transform."""
     cache = Path(cache)
     if not cache.is_dir():
         msg = f"Given cache directory '{cache}' does not exist"
@@ -231,6 +236,8 @@ def compute_sourmash_matrices(
 
     queries = sorted(query_hashes)
     subjects = sorted(subject_hashes)
+    if not queries or not subjects:
+        return
     extra_subjects = sorted(set(subjects) - set(queries))
     order = queries + extra_subjects  # CSR order: queries first, then subjects not among them
     index = {h: i for i, h in enumerate(order)}
@@ -246,27 +253,56 @@ def compute_sourmash_matrices(
         sketches.append(mins)
     nq = len(queries)
     sizes = np.array([len(s) for s in sketches], dtype=np.uint64)
-    if not queries or not subjects:
-        empty = np.zeros((nq, len(subjects)))
-        return queries, subjects, empty, empty.copy(), np.zeros((nq, len(subjects)), dtype=bool)
     eng = engine or get_engine()
     dsk = eng.sketches_from_host(sketches)
-    sub_idx = np.array([index[s] for s in subjects])
-    # contiguous subject range if possible (all-vs-all, or a single subject column)
-    lo, hi = int(sub_idx.min()), int(sub_idx.max()) + 1
-    if hi - lo != len(sub_idx):
-        lo, hi = 0, len(order)  # scattered subjects: compute the covering block, pick columns below
-    counts = eng.pair_counts(dsk, (0, nq), (lo, hi), algo=algo).cpu().numpy().view(np.uint32)
-    counts = np.ascontiguousarray(counts[:, sub_idx - lo])
-    ident, cov, null = ani_host(counts, sizes[:nq], sizes[sub_idx], kmersize)
-    # the reference refuses a self-comparison that is not exactly one (sourmash.py:119-127)
-    sub_pos = {s: i for i, s in enumerate(subjects)}
-    for qi, q in enumerate(queries):
-        si = sub_pos.get(q)
-        if si is not None and not null[qi, si] and ident[qi, si] != 1.0:
-            msg = f"Expected {METHOD} {q} vs self to be one, not {ident[qi, si]!r}"
-            raise ValueError(msg)
-    return queries, subjects, cov, ident, null
+    tile_columns = max(1, int(tile_columns))
+    for t0 in range(0, len(subjects), tile_columns):
+        tile = subjects[t0 : t0 + tile_columns]
+        sub_idx = np.array([index[s] for s in tile])
+        # contiguous subject range if possible (all-vs-all, or a single subject column)
+        lo, hi = int(sub_idx.min()), int(sub_idx.max()) + 1
+        if hi - lo != len(sub_idx):
+            lo, hi = 0, len(order)  # scattered subjects: compute the covering block, pick columns below
+        counts = eng.pair_counts(dsk, (0, nq), (lo, hi), algo=algo).cpu().numpy().view(np.uint32)
+        counts = np.ascontiguousarray(counts[:, sub_idx - lo])
+        square = len(tile) == nq and tile == queries  # one tile, all-vs-all: one pow per ordered pair
+        ident, cov, null = ani_host(counts, sizes[:nq], sizes[sub_idx], kmersize, symmetric=square)
+        # the reference refuses a self-comparison that is not exactly one (sourmash.py:119-127)
+        sub_pos = {s: i for i, s in enumerate(tile)}
+        for qi, q in enumerate(queries):
+            si = sub_pos.get(q)
+            if si is not None and not null[qi, si] and ident[qi, si] != 1.0:
+                msg = f"Expected {METHOD} {q} vs self to be one, not {ident[qi, si]!r}"
+                raise ValueError(msg)
+        yield queries, tile, cov, ident, null
+
+
+def compute_sourmash_matrices(
+    logger: logging.Logger,
+    subject_hashes,
+    query_hashes,
+    cache: Path,
+    *,
+    kmersize: int,
+    scaled: int,
+    engine=None,
+    algo: int = _capi.PA_PAIRS_AUTO,
+):
+    """``(queries, subjects, query_containment_ani, max_containment_ani, is_null)`` for the sorted
+    query x subject block: the array form of what ``compute_sourmash_tile`` yields row by row."""
+    queries, subjects = sorted(query_hashes), sorted(subject_hashes)
+    nq, ns = len(queries), len(subjects)
+    if not Path(cache).is_dir():
+        msg = f"Given cache directory '{cache}' does not exist"
+        raise ValueError(msg)
+    if not queries or not subjects:
+        empty = np.zeros((nq, ns))
+        return queries, subjects, empty, empty.copy(), np.zeros((nq, ns), dtype=bool)
+    tiles = list(iter_sourmash_tiles(logger, subjects, queries, cache, kmersize=kmersize, scaled=scaled, engine=engine, algo=algo))
+    if len(tiles) == 1:
+        return tiles[0]
+    return (queries, subjects, np.concatenate([t[2] for t in tiles], axis=1), np.concatenate([t[3] for t in tiles], axis=1),
+            np.concatenate([t[4] for t in tiles], axis=1))  # fmt: skip
 
 
 def compute_sourmash_tile(
@@ -295,6 +331,13 @@ def compute_sourmash_tile(
                 yield q, s, float(cov[qi, si]), float(ident[qi, si])
 
 
+def backend_failure(logger: logging.Logger, what: str, err: Exception):
+    """The reference turns every failed tool call into ``log_sys_exit("Return code N from: <cmd>" + the tool's
+    ERROR lines)`` (pyani_plus/utils.py:262-283).  There is no process here, so the analogue of the command is
+    the library call and the analogue of the tool's output is ``pa_last_error`` (already in ``err``)."""
+    log_sys_exit(logger, f"{what} failed in {_capi.LIB_PATH.name}: {err}")
+
+
 def compute_sourmash_hip(  # noqa: PLR0913
     logger: logging.Logger,
     tmp_dir: Path,  # noqa: ARG001 - no intermediate files are needed
@@ -309,11 +352,16 @@ def compute_sourmash_hip(  # noqa: PLR0913
     *,
     cache: Path = Path(),
     engine=None,
+    tile_columns: int = DEVICE_TILE_COLUMNS,
 ) -> int:
     """Run many-vs-subject (or all-vs-all when ``subject_hash == ""``) and log to JSON.
 
     Field mapping as private_cli.py:1875-1887: ``identity`` <- max-containment ANI,
     ``cov_query`` <- query-containment ANI; ``aln_length``/``sim_errors``/``cov_subject`` unset.
+    Subject columns are evaluated ``tile_columns`` at a time and the column file grows by one tile after
+    each (complete JSON after every tile), so an interrupt keeps the finished tiles -- the behaviour of the
+    reference's flush every 100 000 rows (private_cli.py:1863-1894).  A failing library call ends the worker
+    through ``log_sys_exit`` like a failing tool does (utils.py:262-283); a failing save returns 2.
     """
     configuration = run.configuration
     tool = get_sourmash_hip()
@@ -326,9 +374,13 @@ def compute_sourmash_hip(  # noqa: PLR0913
             f"Missing sourmash signatures directory '{sig_cache}' - check cache setting '{cache}'.",
         )
     scaled = parse_scaled(configuration.extra)
-    result = None
     try:
-        result = compute_sourmash_matrices(
+        writer = wire.ColumnFileWriter(logger, json_filename, configuration)
+    except Exception:
+        logger.exception("Unexpected exception saving JSON:")
+        return RECORDING_FAILED
+    try:
+        tiles = iter_sourmash_tiles(
             logger,
             {subject_hash} if subject_hash else set(query_hashes),
             set(query_hashes),
@@ -336,20 +388,20 @@ def compute_sourmash_hip(  # noqa: PLR0913
             kmersize=configuration.kmersize,
             scaled=scaled,
             engine=engine,
+            tile_columns=tile_columns,
         )
-    except KeyboardInterrupt:  # pragma: no cover
-        # abort gracefully (private_cli.py:1889-1894); the device step is all-or-nothing
-        logger.error("Interrupted with 0 completed %s comparisons", METHOD)  # noqa: TRY400
+        for queries, subjects, cov, ident, null in tiles:
+            try:
+                # identity <- max-containment ANI, cov_query <- query-containment ANI (private_cli.py:1879-1880)
+                writer.append(queries, subjects, ident, cov, null)
+            except Exception:
+                logger.exception("Unexpected exception saving JSON:")
+                return RECORDING_FAILED
+    except KeyboardInterrupt:
+        # abort gracefully (private_cli.py:1889-1894): the finished tiles are in the file already
+        logger.error("Interrupted with %d completed %s comparisons", writer.rows, METHOD)  # noqa: TRY400
         run.status = "Worker interrupted"
         session.commit()
-    try:
-        if result is None:
-            wire.export_json_db_entries(logger, json_filename, configuration, [])
-        else:
-            queries, subjects, cov, ident, null = result
-            # identity <- max-containment ANI, cov_query <- query-containment ANI (private_cli.py:1879-1880)
-            wire.export_json_matrices(logger, json_filename, configuration, queries, subjects, ident, cov, null)
-    except Exception:  # pragma: no cover
-        logger.exception("Unexpected exception saving JSON:")
-        return RECORDING_FAILED
+    except _capi.HipBackendError as err:
+        backend_failure(logger, f"{METHOD} comparison", err)
     return 0

@@ -74,6 +74,57 @@ def export_json_matrices(
     logger.debug("Saved %d comparisons to %s", nq * ns, json_filename)
 
 
+class ColumnFileWriter:
+    """The column file written progressively, one block of comparisons at a time.
+
+    The reference re-dumps its whole list after every 100 000 rows so that an interrupted worker leaves the
+    completed comparisons behind (pyani_plus/private_cli.py:1863-1894).  Here the file is created with an empty
+    ``comparisons`` list and every ``append`` moves the closing ``]}`` back by one block (native
+    ``pa_append_comparisons_json``): the file is a complete JSON document after every call, and no row is
+    formatted twice."""
+
+    SUFFIX = "]}"
+
+    def __init__(self, logger: logging.Logger, json_filename: Path, configuration) -> None:
+        self.logger = logger
+        self.path = Path(json_filename)
+        self.rows = 0
+        export_json_matrices(logger, self.path, configuration, [], [], _empty(), _empty(), _empty(bool))
+
+    def append(self, queries: list[str], subjects: list[str], identity, cov_query, is_null) -> None:
+        import ctypes as C
+
+        import numpy as np
+
+        from . import _capi
+
+        nq, ns = len(queries), len(subjects)
+        if nq == 0 or ns == 0:
+            return
+        lib = _capi.load_library()
+        identity = np.ascontiguousarray(identity, dtype=np.float64)
+        cov_query = np.ascontiguousarray(cov_query, dtype=np.float64)
+        null = np.ascontiguousarray(is_null, dtype=np.uint8)
+        assert identity.shape == (nq, ns) == cov_query.shape == null.shape
+        q_arr = (C.c_char_p * nq)(*[q.encode() for q in queries])
+        s_arr = (C.c_char_p * ns)(*[s.encode() for s in subjects])
+        _capi.check(
+            lib.pa_append_comparisons_json(
+                str(self.path).encode(), self.SUFFIX.encode(), int(self.rows > 0), q_arr, nq, s_arr, ns,
+                identity.ctypes.data, cov_query.ctypes.data, null.ctypes.data,
+            ),  # fmt: skip
+            "pa_append_comparisons_json",
+        )
+        self.rows += nq * ns
+        self.logger.debug("Saved %d comparisons to %s", self.rows, self.path)
+
+
+def _empty(dtype=float):
+    import numpy as np
+
+    return np.zeros((0, 0), dtype=dtype)
+
+
 def load_json_comparisons(json_filename: Path) -> dict:
     """Parse a column file and check the fields ``import_json_comparisons`` requires
     (pyani_plus/private_cli.py:555-605)."""

@@ -5,8 +5,9 @@ tolerance on the 25 output rows the reference holds
 (tests/fixtures/{viral,bacterial}_example/intermediates/fastANI/all_vs_*.fastani, byte-compared by the
 reference itself at tests/snakemake/test_fastani_workflow.py:67-86):
     total fragments   exact  (= sum over contigs of floor(len / fragLen))
-    kept fragments    within 5 % of the total (and within 1 for the phages)
+    kept fragments    within 2.5 % of the total (and within 1 for the phages)
     ANI               within 0.3 percentage points
+(tools/fragani_bisect.py measures each restatement choice against the 25 rows.)
 """
 
 from __future__ import annotations
@@ -20,7 +21,8 @@ import pytest
 import oracle
 from tests.helpers import GOLDEN, read_fasta_bytes
 
-ANI_TOL = 0.3
+ANI_TOL = 0.3  # percentage points
+MATCHED_TOL = 0.025  # kept fragments, as a fraction of the total fragments
 K, FRAG = 16, 3000
 
 
@@ -39,8 +41,8 @@ def fixture_rows(name: str) -> list[tuple[str, str, float, int, int]]:
 
 
 def test_parameters():
-    assert oracle.fragani_window_size(16, 3000) == 23
-    assert oracle.fragani_window_size(15, 2000) == 19
+    assert oracle.fragani_window_size(16, 3000) == 24  # the window fastANI logs for its defaults
+    assert oracle.fragani_window_size(15, 2000) == 20
     min_hits, min_shared = oracle.fragani_tables(16, 300)
     assert np.all(np.diff(min_hits[1:]) >= 0) and min_hits[1] == 1
     assert np.all(min_shared[1:] >= 0) and min_shared[260] >= min_hits[260] - 1
@@ -83,7 +85,7 @@ def test_bacterial_rows_within_tolerance(q, r):
     ani, matched, total = rows[(q, r)]
     got_ani, got_m, got_t = oracle.fragani_pair(contigs_of(GOLDEN / "bacterial_example" / q), contigs_of(GOLDEN / "bacterial_example" / r), K, FRAG, 0.2)
     assert got_t == total  # 1338 / 1825 / 1347 / 1551: sum over contigs of floor(len / 3000)
-    assert abs(got_m - matched) <= 0.05 * total
+    assert abs(got_m - matched) <= MATCHED_TOL * total
     assert abs(got_ani - ani) <= ANI_TOL
 
 
@@ -98,4 +100,8 @@ def test_min_fraction_and_unrelated_genomes():
     assert m == 5 and t == 10 and ani > 99.9
     ani, m, t = oracle.fragani_pair([half], [a], min_fraction=0.6)
     assert math.isnan(ani) and m == 5  # below minFraction: fastANI prints nothing
+    # minFraction is relative to the SHORTER genome: a long query against a short reference is still reported
+    c = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=270_000).tobytes()
+    ani, m, t = oracle.fragani_pair([a + c], [a], min_fraction=0.2)  # 10 of 100 fragments, but all of the 30 kb reference
+    assert t == 100 and m == 10 and ani > 99.9
     assert oracle.fragani_pair([a[:2999]], [a])[2] == 0  # shorter than one fragment

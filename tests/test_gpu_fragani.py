@@ -10,7 +10,7 @@ import pytest
 
 import oracle
 from tests.helpers import GOLDEN, read_fasta_bytes
-from tests.test_fragani_oracle import ANI_TOL, contigs_of, fixture_rows
+from tests.test_fragani_oracle import ANI_TOL, MATCHED_TOL, contigs_of, fixture_rows
 
 pytestmark = pytest.mark.gpu
 K, FRAG = 16, 3000
@@ -160,7 +160,7 @@ def test_bacterial_fixture_rows(engine):
     for q, r, ani, m, t in fixture_rows("bacterial_example"):
         qi, ri = names.index(q), names.index(r)
         assert total[qi] == t
-        assert abs(int(matched[qi, ri]) - m) <= 0.05 * t
+        assert abs(int(matched[qi, ri]) - m) <= MATCHED_TOL * t
         assert abs(ident_sum[qi, ri] / matched[qi, ri] - ani) <= ANI_TOL, (q, r)
     for qi, ri in ((1, 0), (0, 2)):
         ani, m, t = oracle.fragani_pair(contigs_of(files[qi]), contigs_of(files[ri]), K, FRAG, 0.0)
@@ -208,6 +208,23 @@ def test_plugin_column_matches_reference_matrices(engine, tmp_path):
     col = json.loads(out.read_text())["comparisons"]
     assert [(e["query_hash"], e["subject_hash"]) for e in col] == [(q, subject) for q in sorted(hash_to_filename)]
     assert all(abs(e["identity"] - rows[(e["query_hash"], subject)]["identity"]) < 1e-12 for e in col)
+    # a size-asymmetric pair: minFraction is taken of the SHORTER genome (fastANI's rule), not of the query's fragments
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    short = rng.choice(acgt, size=45_000).tobytes()
+    long_ = short + rng.choice(acgt, size=255_000).tobytes()
+    asym = tmp_path / "asym"
+    asym.mkdir()
+    (asym / "short.fasta").write_bytes(b">short\n" + short + b"\n")
+    (asym / "long.fasta").write_bytes(b">long\n" + long_ + b"\n")
+    h2f = {md5_hex((asym / n).read_bytes()): n for n in ("short.fasta", "long.fasta")}
+    f2h = {n: h for h, n in h2f.items()}
+    run2 = rundb.Run(2, cfg, str(asym), [], "Testing")
+    assert fastani_hip.compute_fastani_hip(logging.getLogger("t"), tmp_path, _S(), run2, out, asym, h2f, {}, {h: 1 for h in h2f}, "", engine=engine) == 0
+    got = {(e["query_hash"], e["subject_hash"]): e for e in json.loads(out.read_text())["comparisons"]}
+    lq = got[(f2h["long.fasta"], f2h["short.fasta"])]
+    assert lq["identity"] is not None and lq["identity"] > 0.999 and abs(lq["cov_query"] - 0.15) < 0.011 and lq["sim_errors"] >= 84
+    assert got[(f2h["short.fasta"], f2h["long.fasta"])]["cov_query"] == 1.0
     cfg.minmatch = 1.5
     assert fastani_hip.compute_fastani_hip(logging.getLogger("t"), tmp_path, _S(), run, out, GOLDEN / "viral_example", hash_to_filename, {}, lengths, subject, engine=engine) == 0
     assert all(e["identity"] is None and e["cov_query"] is None for e in json.loads(out.read_text())["comparisons"])

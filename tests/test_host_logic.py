@@ -232,6 +232,88 @@ def test_compute_error_paths(tmp_path):
         )
 
 
+def _prepared_bacteria(tmp_path):
+    scaled, genomes = FIXTURE_SETS["bacterial_example"]
+    run = _make_run(GOLDEN / "bacterial_example", genomes, scaled)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    list(sourmash_hip.prepare_genomes(LOGGER, run, cache, engine=OracleEngine()))
+    boundary = json.loads((GOLDEN / "bacterial_example" / "boundary.json").read_text())
+    return run, cache, {g["genome_hash"]: g["length"] for g in boundary["genomes"]}, boundary
+
+
+def test_compute_in_subject_tiles_keeps_finished_tiles_on_interrupt(tmp_path):
+    """Subject tiles are flushed one by one (the reference's 100 000-row flush, private_cli.py:1863-1894):
+    tiled output == single-tile output; Ctrl-C after tile 1 keeps tile 1, sets the status, returns 0."""
+    run, cache, query_hashes, boundary = _prepared_bacteria(tmp_path)
+    key = lambda e: (e["query_hash"], e["subject_hash"])  # noqa: E731
+    want = sorted(boundary["column_json"]["comparisons"], key=key)
+    json_file = tmp_path / "tiled.json"
+    rc = sourmash_hip.compute_sourmash_hip(
+        LOGGER, tmp_path, _Session(), run, json_file, tmp_path, {}, {}, query_hashes, "", cache=cache, engine=OracleEngine(), tile_columns=1
+    )
+    data = wire.load_json_comparisons(json_file)
+    assert rc == 0 and sorted(data["comparisons"], key=key) == want
+    # rows arrive tile by tile: the first four rows are all queries against the first (sorted) subject
+    subjects = sorted(query_hashes)
+    assert {e["subject_hash"] for e in data["comparisons"][:4]} == {subjects[0]}
+
+    class Interrupting(OracleEngine):
+        calls = 0
+
+        def pair_counts(self, *args, **kwargs):
+            self.calls += 1
+            if self.calls == 2:
+                raise KeyboardInterrupt
+            return super().pair_counts(*args, **kwargs)
+
+    session = _Session()
+    rc = sourmash_hip.compute_sourmash_hip(
+        LOGGER, tmp_path, session, run, json_file, tmp_path, {}, {}, query_hashes, "", cache=cache, engine=Interrupting(), tile_columns=1
+    )
+    kept = wire.load_json_comparisons(json_file)["comparisons"]
+    assert rc == 0 and run.status == "Worker interrupted" and session.commits == 1
+    assert sorted(kept, key=key) == [e for e in want if e["subject_hash"] == subjects[0]]
+
+
+def test_backend_failure_and_save_failure_follow_the_reference_conventions(tmp_path):
+    """A failing library call ends the worker like a failing tool (utils.py:262-283: SystemExit with the message);
+    a column file that cannot be written returns RECORDING_FAILED = 2 (private_cli.py:1896-1902)."""
+    from pyani_plus_amd._capi import HipBackendError
+
+    run, cache, query_hashes, _boundary = _prepared_bacteria(tmp_path)
+
+    class Failing(OracleEngine):
+        def pair_counts(self, *args, **kwargs):
+            raise HipBackendError("pa_pair_counts failed with status -2: hipErrorLaunchFailure (test)")
+
+    with pytest.raises(SystemExit, match=r"sourmash-hip comparison failed in libpyani_hip\.so: pa_pair_counts failed with status -2"):
+        sourmash_hip.compute_sourmash_hip(
+            LOGGER, tmp_path, _Session(), run, tmp_path / "f.json", tmp_path, {}, {}, query_hashes, "", cache=cache, engine=Failing()
+        )
+    rc = sourmash_hip.compute_sourmash_hip(
+        LOGGER, tmp_path, _Session(), run, tmp_path / "no_such_dir" / "f.json", tmp_path, {}, {}, query_hashes, "", cache=cache, engine=OracleEngine()
+    )
+    assert rc == sourmash_hip.RECORDING_FAILED == 2
+
+
+def test_fastani_output_conventions():
+    """What fastANI prints, as the reference parses it (pyani_plus/methods/fastani.py:98-120): six significant
+    digits, and a line only when the kept fragments cover minFraction of the shorter genome."""
+    from pyani_plus_amd.methods import fastani_hip
+
+    assert fastani_hip.fastani_print_round(82.91243619) == 82.9124
+    assert fastani_hip.fastani_print_round(99.99531) == 99.9953
+    assert fastani_hip.fastani_print_round(100.0) == 100.0
+    assert fastani_hip.fastani_print_round(99.999996) == 100.0
+    # 300 of 1666 fragments of a 5 Mb query against a 1 Mb reference: 18 % of the query's fragments, 90 % of the reference
+    assert fastani_hip.is_reported(300, 1666, 3000, 0.2, 5_000_000, 1_000_000)
+    assert not fastani_hip.is_reported(300, 1666, 3000, 0.2, 5_000_000, 5_000_000)
+    assert not fastani_hip.is_reported(0, 10, 3000, 0.2, 30_000, 30_000) and not fastani_hip.is_reported(0, 0, 3000, 0.2, 0, 0)
+    lens = fastani_hip.mappable_lengths([5000, 2999, 3000, 100], [0, 0, 1, 1], 3, 3000)
+    assert lens.tolist() == [5000, 3000, 0]
+
+
 @pytest.mark.parametrize("name", list(FIXTURE_SETS))
 def test_run_driver_database_matches_reference(name, tmp_path):
     scaled, genomes = FIXTURE_SETS[name]
