@@ -354,8 +354,10 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
     sec = min(times[1:])
     prof = engine.prof_get()
     ani = np.where(matched > 0, ident_sum / np.maximum(matched, 1), np.nan)
-    if not np.all(np.diag(matched) == total):
-        raise SystemExit("PARITY FAILURE (fragment ANI): a genome does not map all its fragments onto itself")
+    # against itself a genome keeps (nearly) every fragment: fastANI's own self rows read 1820/1825, 1346/1347, ...,
+    # because fragments can compete for one reference bucket of fragLen - 20 positions
+    if not np.all(np.diag(matched) >= 0.99 * total):
+        raise SystemExit("PARITY FAILURE (fragment ANI): a genome maps fewer than 99 % of its fragments onto itself")
     # CPU leg + parity: the oracle on a few ordered pairs of related genomes (about 2 s per pair on one core)
     g1 = min(n - 1, args.species)
     pairs = [(0, g1), (g1, 0), (0, 0)]

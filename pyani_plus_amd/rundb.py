@@ -30,6 +30,7 @@ from pathlib import Path
 import numpy as np
 
 from . import wire
+from ._capi import HipBackendError
 from .methods import sourmash_hip
 
 FASTA_EXTENSIONS = {".fasta", ".fas", ".fna", ".fa"}  # pyani_plus/__init__.py:48
@@ -265,6 +266,70 @@ def import_json_comparisons(logger: logging.Logger, conn, json_filename: Path) -
     return len(rows)
 
 
+INSERT_COMPARISON = (
+    "INSERT OR IGNORE INTO comparisons (query_hash, subject_hash, configuration_id, identity, aln_length, "
+    "sim_errors, cov_query, uname_system, uname_release, uname_machine) VALUES (?,?,?,?,?,?,?,?,?,?)"
+)
+
+
+def ingest_matrices(conn, run: Run, queries: list[str], subjects: list[str], identity, cov_query, is_null, *,
+                    chunk_rows: int = 1_000_000) -> int:
+    """Comparison rows straight from the result matrices (the reference goes through one
+    Python dict per row, a JSON file and its re-parse: pyani_plus/private_cli.py:1863-1888, 507-614).
+
+    Rows go in query-major with ascending subjects -- the order of the UNIQUE(query_hash, subject_hash,
+    configuration_id) index when both lists are sorted, so the index grows by appends -- in chunks of
+    ``chunk_rows`` through one ``executemany`` each."""
+    import platform
+
+    uname = platform.uname()
+    cid = run.configuration_id
+    nq, ns = len(queries), len(subjects)
+    identity = np.asarray(identity, dtype=np.float64)
+    cov_query = np.asarray(cov_query, dtype=np.float64)
+    null = np.asarray(is_null, dtype=bool)
+    rows_per_chunk = max(1, chunk_rows // max(ns, 1))
+    constants = (uname.system, uname.release, uname.machine)
+    for q0 in range(0, nq, rows_per_chunk):
+        q1 = min(nq, q0 + rows_per_chunk)
+        ident = identity[q0:q1].astype(object)
+        cov = cov_query[q0:q1].astype(object)
+        ident[null[q0:q1]] = None
+        cov[null[q0:q1]] = None
+        rows = (
+            (q, s, cid, i, None, None, c, *constants)
+            for q, irow, crow in zip(queries[q0:q1], ident, cov)
+            for s, i, c in zip(subjects, irow, crow)
+        )
+        conn.executemany(INSERT_COMPARISON, rows)
+    conn.commit()
+    return nq * ns
+
+
+def cache_matrices(conn, run: Run, hashes: list[str], identity, cov_query, is_null) -> dict[str, str]:
+    """``cache_comparisons`` from matrices that are already in memory (rows = query, columns = subject, both in
+    ``hashes`` order = sorted md5): same strings as the SELECT-based form, without reading 10^8 rows back."""
+    import pandas as pd
+
+    assert hashes == sorted(hashes)
+    n = len(hashes)
+    ident = np.where(is_null, np.nan, identity)
+    cov = np.where(is_null, np.nan, cov_query)
+    nan = np.full((n, n), np.nan)
+    mats = {"identity": ident, "cov_query": cov, "aln_length": nan, "sim_errors": nan, "hadamard": ident * cov}
+    out = {
+        f"df_{key}": pd.DataFrame(data=mat, index=hashes, columns=hashes, dtype=float).to_json(orient="split")
+        for key, mat in mats.items()
+    }
+    conn.execute(
+        "UPDATE runs SET df_identity=?, df_cov_query=?, df_aln_length=?, df_sim_errors=?, df_hadamard=? WHERE run_id=?",
+        (out["df_identity"], out["df_cov_query"], out["df_aln_length"], out["df_sim_errors"], out["df_hadamard"],
+         run.run_id),
+    )
+    conn.commit()
+    return out
+
+
 def cache_comparisons(conn, run: Run) -> dict[str, str]:
     """Fill runs.df_* with the N x N matrices (rows = query, columns = subject, sorted md5)."""
     import pandas as pd
@@ -299,6 +364,48 @@ def cache_comparisons(conn, run: Run) -> dict[str, str]:
     return out
 
 
+def _compute_direct(logger, conn, run: Run, cache_dir: Path, tmp_dir: Path, engine, mark):
+    """Subject tiles -> binary column files + matrices in host memory -> rows inserted in index order."""
+    config = run.configuration
+    hashes = sorted(a.genome_hash for a in run.fasta_hashes)
+    n = len(hashes)
+    ident = np.empty((n, n), dtype=np.float64)
+    cov = np.empty((n, n), dtype=np.float64)
+    null = np.empty((n, n), dtype=bool)
+    sig_cache = sourmash_hip.sig_cache_dir(cache_dir, config.kmersize, config.extra)
+    col = 0
+    try:
+        for t, (queries, tile, t_cov, t_ident, t_null) in enumerate(
+            sourmash_hip.iter_sourmash_tiles(
+                logger, hashes, hashes, sig_cache, kmersize=config.kmersize, scaled=sourmash_hip.parse_scaled(config.extra), engine=engine
+            )
+        ):
+            assert queries == hashes and tile == hashes[col : col + len(tile)]
+            wire.save_tile(tmp_dir / f"{sourmash_hip.METHOD}.run_{run.run_id}.tile_{t}.npz", config, queries, tile, t_ident, t_cov, t_null)
+            ident[:, col : col + len(tile)] = t_ident
+            cov[:, col : col + len(tile)] = t_cov
+            null[:, col : col + len(tile)] = t_null
+            col += len(tile)
+    except HipBackendError as err:
+        sourmash_hip.backend_failure(logger, f"{sourmash_hip.METHOD} comparison", err)
+    mark("pairs_and_tile_files")
+    conn.execute("PRAGMA synchronous=OFF")
+    conn.execute("PRAGMA cache_size=-1048576")
+    rows = ingest_matrices(conn, run, hashes, hashes, ident, cov, null)
+    conn.execute("PRAGMA synchronous=FULL")
+    mark("insert_rows")
+    return rows, hashes, ident, cov, null
+
+
+def import_tile(logger: logging.Logger, conn, run: Run, tile_file: Path) -> int:
+    """Import one binary column file written by ``wire.save_tile`` (resuming a direct-ingest run)."""
+    config, queries, subjects, ident, cov, null = wire.load_tile(tile_file)
+    for key in wire.CONFIG_FIELDS:
+        if config[key] != getattr(run.configuration, key):
+            sourmash_hip.log_sys_exit(logger, f"Tile file {tile_file} configuration does not match the run ({key})")
+    return ingest_matrices(conn, run, queries, subjects, ident, cov, null)
+
+
 # ------------------------------------------------------------------ the run itself
 def run_sourmash_hip(  # noqa: PLR0913
     fasta: Path,
@@ -311,11 +418,30 @@ def run_sourmash_hip(  # noqa: PLR0913
     temp: Path | None = None,
     logger: logging.Logger | None = None,
     engine=None,
+    ingest: str = "json",
+    timings: dict | None = None,
 ) -> Run:
     """FASTA directory -> database with all N^2 comparisons and cached matrices.
 
     Counterpart of ``pyani-plus sourmash <fasta> -d <db> --create-db`` (call stack in
-    SURVEY.md section 3.1) with the snakemake layer replaced by one in-process call."""
+    SURVEY.md section 3.1) with the snakemake layer replaced by one in-process call.
+
+    ``ingest="json"`` goes through the reference's column file (worker -> JSON -> importer), what two
+    processes of the reference would do.  ``ingest="direct"`` keeps the subject tiles as binary column
+    files (``wire.save_tile``) plus in-memory matrices, inserts the rows in index order straight from them and
+    writes the matrix cache from memory: the form that stays feasible at N = 10^4 (10^8 rows).
+    ``timings`` (a dict) receives the wall seconds of the phases."""
+    import time
+
+    clock = time.perf_counter
+    marks = {"start": clock()}
+
+    def mark(name: str) -> None:
+        marks[name] = clock()
+        if timings is not None:
+            prev = list(marks)[-2]
+            timings[name] = marks[name] - marks[prev]
+
     logger = logger or logging.getLogger("pyani_plus_amd")
     fasta = Path(fasta)
     fasta_names = check_fasta(logger, fasta)
@@ -340,12 +466,14 @@ def run_sourmash_hip(  # noqa: PLR0913
         seen.add(md5)
         filename_to_md5[filename] = md5
         db_genome(conn, filename, md5, info.length, info.description)
+    mark("fasta_front_end")
     run = add_run(
         conn, config, " ".join(sys.argv), fasta, "Initialising",
         f"{len(filename_to_md5)} genomes using {sourmash_hip.METHOD}" if name is None else name, filename_to_md5,
     )  # fmt: skip
     session = Session(conn, run)
     n = len(filename_to_md5)
+    direct = None
     if count_run_comparisons(conn, run) == n * n:
         logger.info("Database already has all %d=%d^2 comparisons", n * n, n)
     else:
@@ -360,22 +488,32 @@ def run_sourmash_hip(  # noqa: PLR0913
         for _ in sourmash_hip.prepare_genomes(logger, run, cache_dir, engine=engine, preloaded=preloaded):
             pass
         del arena, preloaded
+        mark("sketch_and_signatures")
         tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
-        json_file = tmp_dir / f"{sourmash_hip.METHOD}.run_{run.run_id}.column_0.json"
         hash_to_filename = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}
-        lengths = dict(conn.execute("SELECT genome_hash, length FROM genomes"))
-        status = sourmash_hip.compute_sourmash_hip(
-            logger, tmp_dir, session, run, json_file, fasta, hash_to_filename,
-            {v: k for k, v in hash_to_filename.items()}, {h: lengths[h] for h in hash_to_filename}, "",
-            cache=cache_dir, engine=engine,
-        )  # fmt: skip
-        if status:
-            sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
-        import_json_comparisons(logger, conn, json_file)
-    done = count_run_comparisons(conn, run)
+        if ingest == "direct":
+            direct = _compute_direct(logger, conn, run, cache_dir, tmp_dir, engine, mark)
+        else:
+            json_file = tmp_dir / f"{sourmash_hip.METHOD}.run_{run.run_id}.column_0.json"
+            lengths = dict(conn.execute("SELECT genome_hash, length FROM genomes"))
+            status = sourmash_hip.compute_sourmash_hip(
+                logger, tmp_dir, session, run, json_file, fasta, hash_to_filename,
+                {v: k for k, v in hash_to_filename.items()}, {h: lengths[h] for h in hash_to_filename}, "",
+                cache=cache_dir, engine=engine,
+            )  # fmt: skip
+            if status:
+                sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
+            mark("pairs_and_column_file")
+            import_json_comparisons(logger, conn, json_file)
+            mark("import_column_file")
+    done = count_run_comparisons(conn, run) if direct is None else direct[0]
     if done != n * n:
         sourmash_hip.log_sys_exit(logger, f"Only have {done} of {n}^2={n * n} {sourmash_hip.METHOD} comparisons needed")
-    cache_comparisons(conn, run)
+    if direct is None:
+        cache_comparisons(conn, run)
+    else:
+        cache_matrices(conn, run, *direct[1:])
+    mark("matrix_cache")
     run.status = "Done"
     session.commit()
     conn.close()

@@ -74,6 +74,30 @@ def export_json_matrices(
     logger.debug("Saved %d comparisons to %s", nq * ns, json_filename)
 
 
+def save_tile(path: Path, configuration, queries: list[str], subjects: list[str], identity, cov_query, is_null) -> None:
+    """One subject tile as a binary column file: the JSON form costs ~170 bytes and two
+    float-to-text conversions per comparison, 17 GB at N = 10^4; this is 17 bytes per comparison and no text."""
+    import numpy as np
+
+    np.savez(
+        path,
+        configuration=np.array(json.dumps(configuration_dict(configuration))),
+        queries=np.array(queries),
+        subjects=np.array(subjects),
+        identity=np.asarray(identity, dtype=np.float64),
+        cov_query=np.asarray(cov_query, dtype=np.float64),
+        is_null=np.asarray(is_null, dtype=bool),
+    )
+
+
+def load_tile(path: Path):
+    import numpy as np
+
+    with np.load(path) as data:
+        return (json.loads(str(data["configuration"])), [str(x) for x in data["queries"]], [str(x) for x in data["subjects"]],
+                data["identity"], data["cov_query"], data["is_null"])  # fmt: skip
+
+
 class ColumnFileWriter:
     """The column file written progressively, one block of comparisons at a time.
 

@@ -339,6 +339,38 @@ def test_run_driver_database_matches_reference(name, tmp_path):
     assert again.run_id == 2 and again.status == "Done"
 
 
+@pytest.mark.parametrize("name", list(FIXTURE_SETS))
+def test_direct_ingest_writes_the_same_database_as_the_json_route(name, tmp_path):
+    """binary tile files + rows inserted from the matrices + matrix cache from memory give the
+    database the reference's JSON route gives (rows, NULLs and the five cached matrix strings)."""
+    import sqlite3
+
+    scaled, _genomes = FIXTURE_SETS[name]
+    timings = {}
+    rundb.run_sourmash_hip(GOLDEN / name, tmp_path / "json.sqlite", cache=tmp_path / "c1", scaled=scaled, engine=OracleEngine(), temp=tmp_path)
+    run = rundb.run_sourmash_hip(GOLDEN / name, tmp_path / "direct.sqlite", cache=tmp_path / "c2", scaled=scaled, engine=OracleEngine(),
+                                 temp=tmp_path, ingest="direct", timings=timings)
+
+    def dump(db):
+        conn = sqlite3.connect(db)
+        rows = conn.execute("SELECT query_hash, subject_hash, configuration_id, identity, cov_query, aln_length, sim_errors, uname_system "
+                            "FROM comparisons ORDER BY 1, 2").fetchall()
+        dfs = conn.execute("SELECT status, df_identity, df_cov_query, df_aln_length, df_sim_errors, df_hadamard FROM runs").fetchall()
+        conn.close()
+        return rows, dfs
+
+    assert dump(tmp_path / "json.sqlite") == dump(tmp_path / "direct.sqlite")
+    assert {"fasta_front_end", "sketch_and_signatures", "pairs_and_tile_files", "insert_rows", "matrix_cache"} <= set(timings)
+    # the tile file alone restores the rows (resume): import it into a database that has the run but no comparisons
+    tile = next(tmp_path.glob("*.tile_0.npz"))
+    conn = rundb.connect_to_db(tmp_path / "direct.sqlite")
+    conn.execute("DELETE FROM comparisons")
+    conn.commit()
+    assert rundb.import_tile(LOGGER, conn, rundb.load_run(conn, run.run_id), tile) == len(_genomes) ** 2
+    conn.close()
+    assert dump(tmp_path / "json.sqlite")[0] == [(*r[:2], r[2], *r[3:]) for r in dump(tmp_path / "direct.sqlite")[0]]
+
+
 def test_driver_rejects_duplicates_and_bad_gzip(tmp_path):
     d = tmp_path / "in"
     d.mkdir()

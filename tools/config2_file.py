@@ -1,8 +1,8 @@
 """Whole path on files at a size between BASELINE configs[0] and configs[1]: N synthetic 5 Mb genomes written
 as FASTA files, then FASTA directory -> database with N^2 comparisons through rundb.run_sourmash_hip.
 
-    python tools/config2_file.py [n_genomes=200] [length=5000000]
-Prints the wall time of the run and of its parts (threaded FASTA front-end, device work, JSON + SQLite).
+    python tools/config2_file.py [n_genomes=200] [length=5000000] [ingest=json|direct]
+Prints the wall time of the run and of its parts (threaded FASTA front-end, device work, column files, SQLite, matrix cache).
 """
 import logging
 import sys
@@ -19,6 +19,7 @@ from pyani_plus_amd.synth import RATES  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 length = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
+ingest = sys.argv[3] if len(sys.argv) > 3 else "json"
 rng = np.random.default_rng(20260802)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 roots = rng.integers(0, 4, size=(8, length), dtype=np.uint8)
@@ -40,6 +41,8 @@ with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
     for rep in range(2):
         db = Path(tmp) / f"run{rep}.sqlite"
         t0 = time.perf_counter()
-        run = rundb.run_sourmash_hip(fasta, db)
+        timings = {}
+        run = rundb.run_sourmash_hip(fasta, db, ingest=ingest, timings=timings)
         dt = time.perf_counter() - t0
-        print(f"rep {rep}: files -> database in {dt:.2f} s for {n} genomes = {n * n / dt:.3e} pairs/s end to end", flush=True)
+        print(f"rep {rep} ({ingest}): files -> database in {dt:.2f} s for {n} genomes = {n * n / dt:.3e} pairs/s end to end; "
+              + ", ".join(f"{k} {v:.2f}" for k, v in timings.items()) + f"; database {db.stat().st_size / 1e6:.0f} MB", flush=True)
