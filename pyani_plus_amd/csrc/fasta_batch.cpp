@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/pyani_hip.h"
+#include "host_pool.h"
 #include "md5.h"
 
 void pa_set_error(const char *fmt, ...);
@@ -254,13 +255,22 @@ int pa_fasta_batch_copy_arena(const pa_fasta_batch *b, uint32_t *h_packed, uint3
     const FileResult &r = b->files[i];
     h_genome_start[i] = pos;
     if (r.status != PA_OK) continue;  // failed files occupy no space
-    if (r.n_bases) {
-      memcpy(h_packed + pos / 16, r.packed.data(), r.n_bases / 4);
-      memcpy(h_mask + pos / 32, r.mask.data(), r.n_bases / 8);
-    }
     pos += r.n_bases;
   }
   h_genome_start[b->files.size()] = pos;
+  // the genomes land in disjoint ranges: copy them on the host pool (2 GB at N = 1000 is 0.25 s on one core)
+  const size_t n = b->files.size();
+  std::atomic<size_t> next{0};
+  HostPool::get().run(pa_host_threads(pos, 32u << 20, 0), [&](uint32_t, uint32_t) {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) break;
+      const FileResult &r = b->files[i];
+      if (r.status != PA_OK || !r.n_bases) continue;
+      memcpy(h_packed + h_genome_start[i] / 16, r.packed.data(), r.n_bases / 4);
+      memcpy(h_mask + h_genome_start[i] / 32, r.mask.data(), r.n_bases / 8);
+    }
+  });
   return PA_OK;
 }
 

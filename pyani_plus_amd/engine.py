@@ -40,6 +40,7 @@ class HostArena:
     contig_start: np.ndarray | None = None
     contig_len: np.ndarray | None = None
     contig_genome: np.ndarray | None = None
+    pinned_packed: "object" = None  # torch tensor owning ``packed`` when the loader wrote it into page-locked memory
 
     @property
     def n_genomes(self) -> int:
@@ -110,11 +111,13 @@ class LoadedFasta:
     gzip: bool
 
 
-def load_fasta_files(paths, threads: int = 0) -> tuple[list[LoadedFasta], HostArena]:
+def load_fasta_files(paths, threads: int = 0, *, pinned: bool = False) -> tuple[list[LoadedFasta], HostArena]:
     """Read, gunzip, md5, parse and pack FASTA files on host threads.
 
     Returns per-file metadata (failed files carry ``status != 0`` and the reference's error
-    text in ``message``) and the arena of the files that loaded, in order."""
+    text in ``message``) and the arena of the files that loaded, in order.  ``pinned``: the packed bases are
+    written into page-locked memory (a torch tensor kept in ``arena.pinned_packed``), ready for
+    ``HipEngine.sketch_streamed`` without a staging copy."""
     import os
 
     lib = _capi.load_library()
@@ -148,8 +151,15 @@ def load_fasta_files(paths, threads: int = 0) -> tuple[list[LoadedFasta], HostAr
                 k_rec = int(rn.value)
                 rec_tables.append((np.ctypeslib.as_array(rs_p, (k_rec,)).copy(), np.ctypeslib.as_array(rl_p, (k_rec,)).copy()) if k_rec else (np.zeros(0, np.uint64), np.zeros(0, np.uint64)))
         total = int(lib.pa_fasta_batch_arena_bases(batch))
-        packed = np.zeros(max(total // 16, 1), dtype=np.uint32)
-        mask = np.zeros(max(total // 32, 1), dtype=np.uint32)
+        pinned_packed = None
+        if pinned:
+            import torch
+
+            pinned_packed = torch.empty(max(total // 16, 1), dtype=torch.int32, pin_memory=torch.cuda.is_available())
+            packed = pinned_packed.numpy().view(np.uint32)
+        else:
+            packed = np.empty(max(total // 16, 1), dtype=np.uint32)
+        mask = np.empty(max(total // 32, 1), dtype=np.uint32)
         starts_all = np.zeros(n + 1, dtype=np.uint64)
         check(lib.pa_fasta_batch_copy_arena(batch, packed.ctypes.data, mask.ctypes.data, starts_all.ctypes.data), "pa_fasta_batch_copy_arena")
         keep = [i for i, info in enumerate(infos) if info.status == 0]
@@ -159,7 +169,7 @@ def load_fasta_files(paths, threads: int = 0) -> tuple[list[LoadedFasta], HostAr
         c_genome = np.concatenate([np.full(len(rs), g, dtype=np.uint32) for g, (rs, _rl) in enumerate(rec_tables)]) if rec_tables else np.zeros(0, np.uint32)
         return infos, HostArena(
             packed[: total // 16], mask[: total // 32], starts, ok_residues, ok_records, ok_invalid,
-            c_start.astype(np.uint64), c_len, c_genome,
+            c_start.astype(np.uint64), c_len, c_genome, pinned_packed[: max(total // 16, 1)] if pinned_packed is not None else None,
         )
     finally:
         lib.pa_fasta_batch_free(batch)
@@ -341,7 +351,10 @@ class HipEngine:
     def pin_arena(self, arena: HostArena) -> PinnedArena:
         """Page-lock the packed bases and reduce the mask to runs (done once, outside any timed region)."""
         t = self.torch
-        packed = t.from_numpy(np.ascontiguousarray(arena.packed).view(np.int32)).pin_memory()
+        if arena.pinned_packed is not None:
+            packed = arena.pinned_packed  # the loader wrote straight into page-locked memory
+        else:
+            packed = t.from_numpy(np.ascontiguousarray(arena.packed).view(np.int32)).pin_memory()
         start, length = mask_runs(arena.mask, int(arena.genome_start[-1]))
         return PinnedArena(packed, start, length, np.ascontiguousarray(arena.genome_start, dtype=np.uint64).copy())
 

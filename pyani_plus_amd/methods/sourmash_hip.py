@@ -134,16 +134,68 @@ def _recall_sketch(sig_file: Path, ksize: int, max_hash: int):
     return entry[4]
 
 
-def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, preloaded=None) -> Iterator:
+def sketch_fasta_batches(logger: logging.Logger, paths: list[Path], *, kmersize: int, scaled: int, engine=None,
+                         batch_bases: int = PREPARE_BATCH_BASES, needed=None) -> Iterator[tuple[list, list, list]]:
+    """FASTA files -> sketches, batch by batch, with the host front-end of batch i+1 running while batch i is on
+    the device (the reference reads every genome serially and three times,
+    pyani_plus/public_cli.py:158-173, pyani_plus/methods/sourmash.py:67-83).
+
+    Per batch: the threaded loader (read + gunzip + md5 + parse + 2-bit pack, ``pa_fasta_batch_load``) writes the
+    packed bases into page-locked memory on a background thread; the device side takes them with
+    ``pa_sketch_streamed`` (mask as runs, chunks uploaded on a copy stream behind the hash kernel).
+    Yields ``(batch_paths, infos, sketches)``; a file that fails to load ends the run through ``log_sys_exit``
+    with the reference's message.  ``needed(info) -> bool`` (optional) says whether a loaded file still needs its
+    sketch: a batch none of whose files does is not sent to the device and yields ``None`` sketches."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from ..engine import load_fasta_files, max_hash_for_scaled
+
+    paths = [Path(p) for p in paths]
+    if not paths:
+        return
+    batches: list[list[Path]] = [[]]
+    size = 0
+    for path in paths:
+        est = 4 * path.stat().st_size if path.name.endswith(".gz") and path.is_file() else (path.stat().st_size if path.is_file() else 0)
+        if batches[-1] and size + est > batch_bases:
+            batches.append([])
+            size = 0
+        batches[-1].append(path)
+        size += est
+    max_hash = max_hash_for_scaled(scaled)
+    eng = engine
+    streamed = engine is None or hasattr(engine, "sketch_streamed")  # the oracle-backed test engine has no device to stream to
+    with ThreadPoolExecutor(max_workers=1) as loader:
+        pending = loader.submit(load_fasta_files, batches[0], pinned=streamed)
+        for i, batch in enumerate(batches):
+            infos, arena = pending.result()
+            if i + 1 < len(batches):
+                pending = loader.submit(load_fasta_files, batches[i + 1], pinned=streamed)
+            for info in infos:
+                if info.status != 0:
+                    log_sys_exit(logger, info.message)
+            if needed is not None and not any(needed(info) for info in infos):
+                yield batch, infos, [None] * len(infos)
+                continue
+            if eng is None:
+                eng = get_engine()
+            if streamed:
+                _dev, sk = eng.sketch_streamed(eng.pin_arena(arena), kmersize, scaled, max_hash=max_hash)
+            else:
+                sk = eng.sketch(eng.upload(arena), kmersize, scaled, max_hash=max_hash)
+            yield batch, infos, sk.to_host()
+
+
+def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, presketched: dict | None = None) -> Iterator:
     """Build the sketch signatures in ``cache/sourmash_k={kmersize}_scaled={N}``.
 
     Yields the run's FASTA entries as their signatures are completed (progress bar),
     skipping genomes whose ``.sig`` already exists -- the contract of
     pyani_plus/methods/sourmash.py:34-84.
 
-    ``preloaded`` = ``(paths, arena)`` from an earlier ``load_fasta_files(paths)`` lets a caller that has
-    just read the files for their checksums (``rundb.run_sourmash_hip``) hand the packed genomes over
-    instead of having them read a second time; it is used when every genome still needs its signature.
+    ``presketched`` = ``{genome_hash: mins}`` from an earlier ``sketch_fasta_batches`` pass lets a caller that
+    has just read the files for their checksums (``rundb.run_sourmash_hip``) hand the sketches over instead of
+    having the genomes read and hashed a second time; genomes not in it are sketched here.
     """
     config = run.configuration
     if config.method != METHOD:
@@ -153,6 +205,8 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, pr
     if not config.extra:
         log_sys_exit(logger, f"{METHOD} requires extra setting, default is scaled={SCALED}")
     scaled = parse_scaled(config.extra)
+    if not 1 <= int(config.kmersize) <= 32:
+        log_sys_exit(logger, f"{METHOD} supports k-mer sizes 1 to 32, not {config.kmersize}")
     if not Path(cache).is_dir():
         msg = f"Cache directory '{cache}' does not exist"
         raise ValueError(msg)
@@ -161,53 +215,52 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, pr
     sig_dir.mkdir(exist_ok=True)
     fasta_dir = Path(run.fasta_directory)
 
-    from ..engine import load_fasta_files, max_hash_for_scaled
+    from ..engine import max_hash_for_scaled
 
     max_hash = max_hash_for_scaled(scaled)
-    batch: list = []
-    batch_bytes = 0
 
-    def flush() -> None:
-        nonlocal batch, batch_bytes
-        if not batch:
-            return
-        # threaded host front-end: read + gunzip + parse + 2-bit pack, then ONE batched sketch launch
-        paths = [fasta_dir / entry.fasta_filename for entry in batch]
-        if preloaded is not None and [Path(p) for p in preloaded[0]] == paths:
-            arena = preloaded[1]
-        else:
-            infos, arena = load_fasta_files(paths)
-            for info in infos:
-                if info.status != 0:
-                    log_sys_exit(logger, info.message)
-        eng = engine or get_engine()
-        sketches = eng.sketch(eng.upload(arena), config.kmersize, scaled, max_hash=max_hash).to_host()
-        sig_files = [sig_dir / f"{entry.genome_hash}.sig" for entry in batch]
+    def write(entries: list, sketches: list[np.ndarray]) -> None:
+        sig_files = [sig_dir / f"{entry.genome_hash}.sig" for entry in entries]
         sig.write_sigs(
             sig_files,
-            names=[entry.genome_hash for entry in batch],
-            filenames=[str(fasta_dir / entry.fasta_filename) for entry in batch],
+            names=[entry.genome_hash for entry in entries],
+            filenames=[str(fasta_dir / entry.fasta_filename) for entry in entries],
             ksize=config.kmersize,
             max_hash=max_hash,
             sketches=sketches,
         )
         for sig_file, mins in zip(sig_files, sketches):
             _remember_sketch(sig_file, config.kmersize, max_hash, mins)
-        batch, batch_bytes = [], 0
 
-    pending: list = []
-    for entry in run.fasta_hashes:
-        if not (sig_dir / f"{entry.genome_hash}.sig").is_file():
-            batch.append(entry)
-            fasta_file = fasta_dir / entry.fasta_filename
-            batch_bytes += 4 * fasta_file.stat().st_size if fasta_file.is_file() else 0  # gz expands ~4x
-        pending.append(entry)
-        if batch_bytes >= PREPARE_BATCH_BASES and preloaded is None:
-            flush()
-            yield from pending
-            pending = []
-    flush()
-    yield from pending
+    entries = list(run.fasta_hashes)
+    missing = [e for e in entries if not (sig_dir / f"{e.genome_hash}.sig").is_file()]
+    have = [e for e in missing if presketched is not None and e.genome_hash in presketched]
+    if have:
+        write(have, [presketched[e.genome_hash] for e in have])
+    todo = [e for e in missing if presketched is None or e.genome_hash not in presketched]
+    done_until = 0  # entries are yielded in run order, each once its signature exists
+    by_path = {fasta_dir / e.fasta_filename: e for e in todo}
+    todo_set = {id(e) for e in todo}
+
+    def ready() -> Iterator:
+        nonlocal done_until
+        while done_until < len(entries) and id(entries[done_until]) not in todo_set:
+            yield entries[done_until]
+            done_until += 1
+
+    yield from ready()
+    if todo:
+        try:
+            for batch_paths, _infos, sketches in sketch_fasta_batches(
+                logger, list(by_path), kmersize=config.kmersize, scaled=scaled, engine=engine
+            ):
+                batch_entries = [by_path[p] for p in batch_paths]
+                write(batch_entries, sketches)
+                todo_set.difference_update(id(e) for e in batch_entries)
+                yield from ready()
+        except _capi.HipBackendError as err:
+            backend_failure(logger, f"{METHOD} sketching", err)
+    yield from ready()
 
 
 DEVICE_TILE_COLUMNS = 2048  # subject columns evaluated (and flushed to the column file) per device call

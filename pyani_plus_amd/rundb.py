@@ -452,21 +452,30 @@ def run_sourmash_hip(  # noqa: PLR0913
     )
     filename_to_md5: dict[Path, str] = {}
     seen: set[str] = set()
-    from .engine import load_fasta_files
-
-    # one threaded pass per file: md5 of the decompressed bytes, length, first title
-    infos, arena = load_fasta_files(fasta_names)
-    for filename, info in zip(fasta_names, infos):
-        if info.status != 0:
-            sourmash_hip.log_sys_exit(logger, info.message)
-        md5 = info.md5
-        if md5 in seen:
-            dups = "\n" + "\n".join(sorted({str(k) for k, v in filename_to_md5.items() if v == md5} | {str(filename)}))
-            sourmash_hip.log_sys_exit(logger, f"Multiple genomes with same MD5 checksum {md5}:{dups}")
-        seen.add(md5)
-        filename_to_md5[filename] = md5
-        db_genome(conn, filename, md5, info.length, info.description)
-    mark("fasta_front_end")
+    # One pass over the files: md5 of the decompressed bytes, length, first title AND the sketches -- the host
+    # front-end of the next batch of files runs while the device hashes the current one (sketch_fasta_batches).
+    presketched: dict[str, np.ndarray] = {}
+    own_cache = cache is None
+    cache_dir = Path(tempfile.mkdtemp(prefix="pyani_hip_cache_")) if own_cache else Path(cache)
+    cache_dir.mkdir(parents=True, exist_ok=True)
+    sig_dir = sourmash_hip.sig_cache_dir(cache_dir, kmersize, f"scaled={scaled}")
+    try:
+        for batch_paths, infos, sketches in sourmash_hip.sketch_fasta_batches(
+            logger, fasta_names, kmersize=kmersize, scaled=scaled, engine=engine, needed=lambda info: not (sig_dir / f"{info.md5}.sig").is_file()
+        ):
+            for filename, info, mins in zip(batch_paths, infos, sketches):
+                md5 = info.md5
+                if md5 in seen:
+                    dups = "\n" + "\n".join(sorted({str(k) for k, v in filename_to_md5.items() if v == md5} | {str(filename)}))
+                    sourmash_hip.log_sys_exit(logger, f"Multiple genomes with same MD5 checksum {md5}:{dups}")
+                seen.add(md5)
+                filename_to_md5[filename] = md5
+                if mins is not None:
+                    presketched[md5] = mins
+                db_genome(conn, filename, md5, info.length, info.description)
+    except HipBackendError as err:
+        sourmash_hip.backend_failure(logger, f"{sourmash_hip.METHOD} sketching", err)
+    mark("fasta_front_end_and_sketch")
     run = add_run(
         conn, config, " ".join(sys.argv), fasta, "Initialising",
         f"{len(filename_to_md5)} genomes using {sourmash_hip.METHOD}" if name is None else name, filename_to_md5,
@@ -479,16 +488,10 @@ def run_sourmash_hip(  # noqa: PLR0913
     else:
         run.status = "Running"
         session.commit()
-        own_cache = cache is None
-        cache_dir = Path(tempfile.mkdtemp(prefix="pyani_hip_cache_")) if own_cache else Path(cache)
-        cache_dir.mkdir(parents=True, exist_ok=True)
-        # the genomes were packed while their checksums were taken: sketch them from memory
-        ordered = [fasta / a.fasta_filename for a in run.fasta_hashes]
-        preloaded = (fasta_names, arena) if ordered == list(fasta_names) else None
-        for _ in sourmash_hip.prepare_genomes(logger, run, cache_dir, engine=engine, preloaded=preloaded):
+        # the genomes were sketched while their checksums were taken: only the signature files remain to be written
+        for _ in sourmash_hip.prepare_genomes(logger, run, cache_dir, engine=engine, presketched=presketched):
             pass
-        del arena, preloaded
-        mark("sketch_and_signatures")
+        mark("signature_files")
         tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
         hash_to_filename = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}
         if ingest == "direct":

@@ -360,7 +360,7 @@ def test_direct_ingest_writes_the_same_database_as_the_json_route(name, tmp_path
         return rows, dfs
 
     assert dump(tmp_path / "json.sqlite") == dump(tmp_path / "direct.sqlite")
-    assert {"fasta_front_end", "sketch_and_signatures", "pairs_and_tile_files", "insert_rows", "matrix_cache"} <= set(timings)
+    assert {"fasta_front_end_and_sketch", "signature_files", "pairs_and_tile_files", "insert_rows", "matrix_cache"} <= set(timings)
     # the tile file alone restores the rows (resume): import it into a database that has the run but no comparisons
     tile = next(tmp_path.glob("*.tile_0.npz"))
     conn = rundb.connect_to_db(tmp_path / "direct.sqlite")
