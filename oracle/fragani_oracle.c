@@ -43,7 +43,7 @@ enum { OPT_WINDOW_RULE = 0, OPT_BIN_RULE = 1, OPT_L2_RULE = 2, OPT_CONF = 3, OPT
 static double g_opt[OPT_COUNT] = {
     1.0, /* OPT_WINDOW_RULE: 0 = sketch sizes 10, 60, 110, ... (round 1); 1 = 1, 2, 5, 10, 20, 30, ... (Mashmap's list) */
     1.0, /* OPT_BIN_RULE:    0 = (pos + fragLen/2) / fragLen (round 1); 1 = pos / (fragLen - 20) (fastANI's bucket) */
-    0.0, /* OPT_L2_RULE:     0 = Jaccard at the window starts the seed hits imply; 1 = slide over reference minimizer positions,
+    1.0, /* OPT_L2_RULE:     0 = Jaccard at the window starts the seed hits imply (round 1); 1 = slide over reference minimizer positions,
                                   position = mean of the first and last optimum (Mashmap's slide) */
     0.9, /* OPT_CONF:        confidence level of the identity bounds */
 };

@@ -716,27 +716,23 @@ __global__ __launch_bounds__(kThreads) void segments_from_list_kernel(const uint
   seg_nh[i] = seg_start[seg + 1] - seg_start[seg];
 }
 
-constexpr int kSeenCap = 64;
-constexpr uint32_t kRefCap = 512;    // reference minimizers whose query rank is cached per segment
-constexpr uint32_t kRefSlack = 96;   // entries cached before the first window that asks for them
+constexpr uint32_t kRefCap = 512;    // reference minimizers of one stretch (the windows of up to 64 starts) held in LDS
 // LDS of one segment's wave, carved from dynamic shared memory so that the query-hash arrays are only as
-// long as the longest fragment sketch of the batch (s_cap): ~7 KB per wave instead of 17 KB, which is what
+// long as the longest fragment sketch of the batch (s_cap): ~8 KB per wave instead of 17 KB, which is what
 // sets how many of these latency-bound waves a CU keeps in flight.
 struct EvalShared {
   uint32_t *qh;        // [s_cap] the fragment's sketch, ascending
-  uint32_t *cnt;       // [s_cap + 64] reference-only hashes per query-rank gap
-  uint32_t *matched;   // [kQMax / 32] bitset over query ranks
+  uint32_t *cnt;       // [s_cap + 64] counting-sort buckets over (query rank, is-match) / reference-only hashes per rank gap
+  uint32_t *matched;   // [kQMax / 32] bitset over query ranks (cooperative evaluation of one over-long window)
   uint32_t *hw;        // [kHitCap] window id of each staged hit
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
-  uint16_t *hq;        // [kHitCap] query window id of each staged hit
-  uint16_t *run;       // [kHitCap] inclusive prefix count of valid L1 runs starting at or before this index
-  uint32_t *seen_c, *seen_p;  // [kSeenCap] window starts already evaluated for this segment
   uint16_t *ref_rank;  // [kRefCap] bit 15: the hash is one of the query's; bits 0-14: its rank among them
-  int16_t *ref_prev;   // [kRefCap] previous occurrence of the same hash, relative to the cache start (-1: before)
-  uint16_t *ref_w;     // [kRefCap] window id relative to the first cached minimizer's
+  int16_t *ref_prev;   // [kRefCap] previous occurrence of the same hash, relative to the stretch start (-1: before)
+  uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
+  uint16_t *ord;       // [kRefCap] the stretch in (rank, reference-only before match) order
 };
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap) {
-  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 10u + (uint32_t)kSeenCap * 8u + kRefCap * 6u;
+  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + kRefCap * 8u;
 }
 __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap) {
   EvalShared sh;
@@ -744,26 +740,20 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   sh.cnt = sh.qh + s_cap;
   sh.matched = sh.cnt + s_cap + 64u;
   sh.hw = sh.matched + kQMax / 32;
-  sh.seen_c = sh.hw + hit_cap;
-  sh.seen_p = sh.seen_c + kSeenCap;
-  sh.hc = reinterpret_cast<uint16_t *>(sh.seen_p + kSeenCap);
-  sh.hq = sh.hc + hit_cap;
-  sh.run = sh.hq + hit_cap;
-  sh.ref_rank = sh.run + hit_cap;
+  sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
+  sh.ref_rank = sh.hc + hit_cap;
   sh.ref_prev = reinterpret_cast<int16_t *>(sh.ref_rank + kRefCap);
   sh.ref_w = reinterpret_cast<uint16_t *>(sh.ref_prev + kRefCap);
+  sh.ord = sh.ref_w + kRefCap;
   return sh;
 }
 
-// Number of the first n (<= 512) ascending entries of w that are < target: two rounds of a 64-way search,
-// every lane looks at one entry per round (uniform arguments, uniform result).
-__device__ __forceinline__ uint32_t lds_count_below(const uint16_t *w, uint32_t n, uint32_t target, uint32_t lane) {
-  const uint32_t i1 = lane * 8u;
-  const uint32_t c1 = (uint32_t)__popcll(__ballot(i1 < n && (uint32_t)w[i1] < target));
-  if (c1 == 0) return 0;
-  const uint32_t i2 = (c1 - 1u) * 8u + 1u + lane;
-  const uint32_t c2 = (uint32_t)__popcll(__ballot(lane < 7u && i2 < n && (uint32_t)w[i2] < target));
-  return (c1 - 1u) * 8u + 1u + c2;
+// fetch-and-add on a 16-bit LDS counter through a 32-bit atomic on the word that holds it (little-endian halves;
+// the counts stay below 2^16, so the low half never carries into the high one)
+__device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t idx) {
+  uint32_t *word = reinterpret_cast<uint32_t *>(counters) + (idx >> 1);
+  const uint32_t old = atomicAdd(word, (idx & 1u) ? 0x10000u : 1u);
+  return (idx & 1u) ? (old >> 16) : (old & 0xffffu);
 }
 
 // one wave per (fragment, reference genome) segment
@@ -781,6 +771,8 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   extern __shared__ uint32_t eval_lds[];
   const EvalShared sh = eval_carve(eval_lds, s_cap, hit_cap);
   const uint32_t lane = threadIdx.x;
+  (void)run_g;
+  (void)vals;
   if (blockIdx.x >= n_segs) return;
   const uint32_t a0 = seg_a0[blockIdx.x];
   uint32_t nh = seg_nh[blockIdx.x];
@@ -799,22 +791,19 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   auto HC = [&](uint32_t i) -> uint32_t {
     return staged ? hc_base + sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu;
   };
-  auto HQ = [&](uint32_t i) -> uint32_t { return staged ? sh.hq[i] : vals[a0 + i]; };
-  auto RUN = [&](uint32_t i) -> uint32_t { return staged ? sh.run[i] : run_g[a0 + i]; };
   for (uint32_t i = lane; i < s; i += 64) sh.qh[i] = q_hash[(uint64_t)f * kQMax + i];
   if (staged) {
     for (uint32_t i = lane; i < nh; i += 64) {
       const uint64_t key = keys[a0 + i];
       sh.hw[i] = (uint32_t)(key & 0xffffffu);
       sh.hc[i] = (uint16_t)(((uint32_t)(key >> 24) & 0xfffffu) - hc_base);
-      sh.hq[i] = (uint16_t)vals[a0 + i];
     }
     if (!presorted) {
       // the bucketing pass leaves a segment's hits in no particular order: bitonic sort by (contig, window)
       // in LDS, padded to a power of two with keys above any real one
       uint32_t np2 = 2;
       while (np2 < nh) np2 <<= 1;
-      for (uint32_t i = nh + lane; i < np2; i += 64) { sh.hw[i] = 0xffffffffu; sh.hc[i] = 0xffffu; sh.hq[i] = 0; }
+      for (uint32_t i = nh + lane; i < np2; i += 64) { sh.hw[i] = 0xffffffffu; sh.hc[i] = 0xffffu; }
       __syncthreads();
       for (uint32_t k = 2; k <= np2; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -825,9 +814,6 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
             if ((ka > kb) == up && ka != kb) {
               sh.hw[i] = (uint32_t)kb; sh.hc[i] = (uint16_t)(kb >> 32);
               sh.hw[l] = (uint32_t)ka; sh.hc[l] = (uint16_t)(ka >> 32);
-              const uint16_t qa = sh.hq[i];
-              sh.hq[i] = sh.hq[l];
-              sh.hq[l] = qa;
             }
           }
           __syncthreads();
@@ -835,172 +821,41 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       }
     }
   }
-  __syncthreads();
-  // L1: run a is valid when hits a .. a+mh-1 share a contig and span < frag_len window ids
-  uint32_t n_runs;
-  {
-    uint32_t carry = 0;
-    for (uint32_t i0 = 0; i0 < nh; i0 += 64) {
-      const uint32_t i = i0 + lane;
-      uint32_t v = 0;
-      if (i + mh <= nh && HC(i) == HC(i + mh - 1) && HW(i + mh - 1) - HW(i) < frag_len) v = 1;
-      const uint32_t ex = wave_excl_scan(v, lane);
-      if (i < nh) { if (staged) sh.run[i] = (uint16_t)(carry + ex + v); else run_g[a0 + i] = carry + ex + v; }
-      carry += wave_sum(v);
-    }
-    n_runs = carry;
-  }
-  if (n_runs == 0) return;
-  __threadfence_block();
-  __syncthreads();
-  uint32_t best_shared = 0, best_c = 0xffffffffu, best_p = 0xffffffffu;
-  bool have_best = false;
-  // Substitutions shift the window a minimizer is first seen in, so the hits of one true location imply a
-  // handful of distinct starts over and over (~20 candidates, few distinct): remember the evaluated ones.
-  // The result of a start does not depend on when it is evaluated, so skipping repeats changes nothing.
-  uint32_t n_seen = 0;
-  // cnt / matched start clean and every evaluation clears what it read
   for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
   if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
   __syncthreads();
-  // The windows a segment asks about start within a few minimizers of each other, so the rank of every
-  // reference minimizer among the query hashes (a 9-step search) and its duplicate link are worked out
-  // once per stretch of kRefCap minimizers and reused by all of them.
-  // The cache also keeps the window ids, so where a window begins and ends among the reference minimizers
-  // is a two-round LDS search; only the first window of a stretch walks the bucket index in HBM.
-  uint32_t cache_c = 0xffffffffu, cache_lo = 0, cache_hi = 0, cache_wbase = 0, cache_pmin = 1, cache_wmax = 0;
-  for (uint32_t chunk = 0; chunk < nh; chunk += 64) {
-   // lane-parallel: does hit `chunk + lane` qualify, and which window start does it imply?
-   uint32_t my_c = 0, my_p = 0;
-   bool my_q = false;
-   if (chunk + lane < nh) {
-    const uint32_t a = chunk + lane;
-    const uint32_t c = HC(a), v = HW(a);
-    // hit a is evaluated iff some valid run [x..y] on its contig has y.w - L + 1 <= v <= x.w + count_windows
-    // <=> a valid run lies inside the hits whose window ids are in [v - count_windows, v + frag_len - 1]
-    uint32_t lo = 0, hi = a;  // first index with (contig, wpos) >= (c, v - count_windows)
-    const uint32_t vlo = v > count_windows ? v - count_windows : 0u;
+
+  // number of seed hits of this segment on contig c with window id in [w0, w1): an upper bound of the minimizers a
+  // reference window [w0, w1) can share with the fragment (every occurrence of every query hash is a hit)
+  auto hits_between = [&](uint32_t c, uint32_t w0, uint32_t w1) -> uint32_t {
+    uint32_t lo = 0, hi = nh;
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
       const uint32_t mc = HC(mid);
-      if (mc < c || (mc == c && HW(mid) < vlo)) lo = mid + 1; else hi = mid;
+      if (mc < c || (mc == c && HW(mid) < w0)) lo = mid + 1; else hi = mid;
     }
     const uint32_t first = lo;
-    lo = a; hi = nh;  // first index with (contig, wpos) > (c, v + frag_len - 1)
-    const uint32_t vhi = v + frag_len - 1u;
+    hi = nh;
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
       const uint32_t mc = HC(mid);
-      if (mc < c || (mc == c && HW(mid) <= vhi)) lo = mid + 1; else hi = mid;
+      if (mc < c || (mc == c && HW(mid) < w1)) lo = mid + 1; else hi = mid;
     }
-    const uint32_t end = lo;  // hits [first, end)
-    if (end >= first + mh) {
-      const uint32_t last_run = end - mh;  // runs starting in [first, last_run]
-      const uint32_t before = first ? RUN(first - 1) : 0u;
-      my_q = RUN(last_run) > before;
-    }
-    const uint32_t qa = HQ(a);
-    my_c = c;
-    my_p = v > qa ? v - qa : 0u;
-   }
-   uint64_t todo = __ballot(my_q);
-   while (todo) {
-    const int bit = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    const uint32_t c = __shfl(my_c, bit, 64), p = __shfl(my_p, bit, 64);
-    {
-      bool seen = false;
-      for (uint32_t base = 0; base < n_seen && !seen; base += 64) {
-        const uint32_t x = base + lane;
-        seen = __any(x < n_seen && sh.seen_p[x] == p && sh.seen_c[x] == c);
-      }
-      if (seen) continue;
-      if (n_seen < (uint32_t)kSeenCap) {
-        if (lane == 0) { sh.seen_c[n_seen] = c; sh.seen_p[n_seen] = p; }
-        ++n_seen;
-      }
-    }
-    // ---- winnowed-MinHash Jaccard numerator of the fragment vs the reference window starting at p
-    uint32_t b0, e;
-    if (c == cache_c && p >= cache_pmin && p + count_windows <= cache_wmax) {
-      const uint32_t n = cache_hi - cache_lo;
-      const uint32_t tb = p > cache_wbase ? p - cache_wbase : 0u;
-      const uint32_t b = cache_lo + lds_count_below(sh.ref_w, n, tb, lane);
-      const uint32_t te = p + count_windows > cache_wbase ? p + count_windows - cache_wbase : 0u;
-      e = cache_lo + lds_count_below(sh.ref_w, n, te, lane);
-      const bool fresh = b < cache_hi && p >= cache_wbase && (uint32_t)sh.ref_w[b - cache_lo] == p - cache_wbase;
-      b0 = (!fresh && b > cache_lo) ? b - 1 : b;  // cache_lo is the contig's first minimizer whenever b can equal it
-    } else {
-      const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
-      const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
-      const uint32_t b = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p);
-      e = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p + count_windows);
-      const bool fresh = b < m1 && mini_wpos[b] == p;
-      b0 = (!fresh && b > m0) ? b - 1 : b;
-      if (e - b0 <= kRefCap) {  // cache the stretch around this window: all loads first, then the rank searches
-        uint32_t lo = b0 > m0 + kRefSlack ? b0 - kRefSlack : m0;
-        if (e > lo + kRefCap) lo = e - kRefCap;
-        uint32_t hi = min(m1, lo + kRefCap);
-        constexpr int kPer = (int)(kRefCap / 64u);
-        uint32_t hh[kPer], ww[kPer];
-        int32_t pp[kPer];
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-          const uint32_t t = lo + (uint32_t)q * 64u + lane;
-          const bool in = t < hi;
-          hh[q] = in ? mini_hash[t] : 0u;
-          ww[q] = in ? mini_wpos[t] : 0xffffffffu;
-          pp[q] = in ? prev_same[t] : -1;
-        }
-        const uint32_t wbase = __shfl(ww[0], 0, 64);
-        // window ids are kept as 16-bit offsets: stop the stretch where they no longer fit
-        uint32_t fit = hi - lo;
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-          const uint64_t far = __ballot(lo + (uint32_t)q * 64u + lane < hi && ww[q] - wbase > 0xfffeu);
-          if (far && fit == hi - lo) fit = (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(far);
-        }
-        hi = lo + fit;
-        if (e <= hi) {
-          __syncthreads();
-#pragma unroll
-          for (int q = 0; q < kPer; ++q) {
-            const uint32_t x = (uint32_t)q * 64u + lane;
-            if (lo + x < hi) {
-              const uint32_t r = lower_bound_u32(sh.qh, 0, s, hh[q]);
-              sh.ref_rank[x] = (uint16_t)(r | ((r < s && sh.qh[r] == hh[q]) ? 0x8000u : 0u));
-              sh.ref_prev[x] = (int16_t)(pp[q] >= (int32_t)lo ? pp[q] - (int32_t)lo : -1);
-              sh.ref_w[x] = (uint16_t)(ww[q] - wbase);
-            }
-          }
-          cache_c = c; cache_lo = lo; cache_hi = hi; cache_wbase = wbase;
-          cache_pmin = lo == m0 ? 0u : wbase + 1u;
-          __syncthreads();
-          cache_wmax = hi == m1 ? 0xffffffffu : wbase + (uint32_t)sh.ref_w[hi - lo - 1u];
-        }
-      }
-    }
-    if (c == cache_c && b0 >= cache_lo && e <= cache_hi) {
-      const int32_t rel0 = (int32_t)(b0 - cache_lo);
-      for (uint32_t t = b0 + lane; t < e; t += 64) {
-        const uint32_t x = t - cache_lo;
-        if ((int32_t)sh.ref_prev[x] >= rel0) continue;  // the same hash already counted inside this window
-        const uint32_t rr = sh.ref_rank[x], r = rr & 0x7fffu;
-        if (rr & 0x8000u) atomicOr(&sh.matched[r >> 5], 1u << (r & 31u));
-        else atomicAdd(&sh.cnt[r], 1u);
-      }
-    } else {  // a window of more than kRefCap minimizers: straight from HBM
-      for (uint32_t t = b0 + lane; t < e; t += 64) {
-        if (prev_same[t] >= (int32_t)b0) continue;
-        const uint32_t h = mini_hash[t];
-        const uint32_t r = lower_bound_u32(sh.qh, 0, s, h);
-        if (r < s && sh.qh[r] == h) atomicOr(&sh.matched[r >> 5], 1u << (r & 31u));
-        else atomicAdd(&sh.cnt[r], 1u);
-      }
+    return lo - first;
+  };
+
+  // One over-long window (more than kRefCap minimizers: low-complexity or N-riddled sequence) straight from HBM,
+  // the whole wave on it: reference-only hashes are counted per query-rank gap, matches set a bit, one scan
+  // gives how many of the fragment's smallest hashes sit in the bottom-s of the union.  Uniform result.
+  auto eval_window_coop = [&](uint32_t b0, uint32_t e) -> uint32_t {
+    for (uint32_t t = b0 + lane; t < e; t += 64) {
+      if (prev_same[t] >= (int32_t)b0) continue;  // the same hash already counted inside this window
+      const uint32_t h = mini_hash[t];
+      const uint32_t r = lower_bound_u32(sh.qh, 0, s, h);
+      if (r < s && sh.qh[r] == h) atomicOr(&sh.matched[r >> 5], 1u << (r & 31u));
+      else atomicAdd(&sh.cnt[r], 1u);
     }
     __syncthreads();
-    // x = reference-only hashes among the s smallest of the union: bucket r (between query ranks r-1 and r)
-    // contributes min(cnt[r], max(0, s - r - prefix(r)))
     uint32_t x;
     {
       const uint32_t per = s / 64u + 1u;  // buckets per lane: s + 1 of them
@@ -1014,7 +869,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         const uint32_t r = lane * per + q;
         if (r <= s) {
           const uint32_t cr = sh.cnt[r];
-          sh.cnt[r] = 0;  // ready for the next window
+          sh.cnt[r] = 0;  // ready for the next use
           const int32_t room = (int32_t)s - (int32_t)r - (int32_t)prefix;
           if (room > 0) acc += cr < (uint32_t)room ? cr : (uint32_t)room;
           prefix += cr;
@@ -1033,13 +888,233 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       shared = __popc(m);
     }
     shared = wave_sum(shared);
-    if (!have_best || shared > best_shared || (shared == best_shared && (c < best_c || (c == best_c && p < best_p)))) {
-      have_best = true; best_shared = shared; best_c = c; best_p = p;
-    }
     __syncthreads();
-   }
+    return shared;
+  };
+
+  int32_t best_shared = -1;
+  uint32_t best_c = 0xffffffffu, best_p = 0;
+
+  // ---- L2 as Mashmap slides it: a window starts at every reference minimizer position of the candidate range
+  // and holds the minimizers recorded in [start, start + count_windows); per candidate the position is the mean
+  // of the first and the last start with the most shared minimizers.  One LANE per start: the stretch of
+  // minimizers the up to 64 windows of a group cover (~300) is ranked against the fragment's hashes once, put in
+  // (rank, reference-only before match) order by a counting sort, and every lane walks that one list keeping
+  // what lies in its own window -- a union walk that stops at the s-th element.  Starts whose seed-hit count
+  // cannot reach the best so far are never evaluated, which leaves one or two groups per candidate.
+  auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce) {
+    const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
+    const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
+    const uint32_t b_lo = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, cs);
+    const uint32_t b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + 1u);
+    if (b_lo >= b_hi) return;
+    (void)m0;
+    int32_t c_best = -1;
+    uint32_t c_first = 0, c_last = 0;
+    const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
+    // the group whose starts see the most seed hits goes first: it sets the bar the others are pruned against
+    uint32_t g_first = 0;
+    if (n_groups > 1) {
+      uint32_t top = 0;
+      for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t b = b_lo + g * 64u + lane;
+        uint32_t ub = 0;
+        if (b < b_hi) { const uint32_t wp = mini_wpos[b]; ub = hits_between(c, wp, wp + count_windows); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ub = max(ub, (uint32_t)__shfl_xor((int)ub, o, 64));
+        if (ub > top) { top = ub; g_first = g; }
+      }
+    }
+    for (uint32_t gi = 0; gi < n_groups; ++gi) {
+      const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
+      const uint32_t sb = b_lo + g * 64u;
+      const uint32_t b = sb + lane;
+      const bool has = b < b_hi;
+      const uint32_t wp = has ? mini_wpos[b] : 0u;
+      const int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a start must reach to matter (ties matter)
+      bool pending = has && (int32_t)hits_between(c, wp, wp + count_windows) >= bar;
+      while (__any(pending)) {
+        const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
+        const uint32_t base = sb + first_lane;  // stretch = minimizers [base, base + n)
+        const uint32_t n = min(m1 - base, kRefCap);
+        constexpr int kPer = (int)(kRefCap / 64u);
+        uint32_t hh[kPer], ww[kPer];
+        int32_t pp[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint32_t x = (uint32_t)q * 64u + lane;
+          const bool in = x < n;
+          hh[q] = in ? mini_hash[base + x] : 0u;
+          ww[q] = in ? mini_wpos[base + x] : 0xffffffffu;
+          pp[q] = in ? prev_same[base + x] : -1;
+        }
+        const uint32_t wbase = __shfl(ww[0], 0, 64);
+        __syncthreads();
+        // ranks among the fragment's hashes, duplicate links and window ids of the stretch; buckets of the counting sort
+        const uint32_t n_keys = 2u * (s + 1u);
+        uint16_t *bucket = reinterpret_cast<uint16_t *>(sh.cnt);  // 2 (s + 1) 16-bit counters in the 4 (s_cap + 64) bytes
+        for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;
+        __syncthreads();
+        uint32_t key[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint32_t x = (uint32_t)q * 64u + lane;
+          key[q] = 0;
+          if (x < n) {
+            const uint32_t r = lower_bound_u32(sh.qh, 0, s, hh[q]);
+            const bool is_match = r < s && sh.qh[r] == hh[q];
+            sh.ref_rank[x] = (uint16_t)(r | (is_match ? 0x8000u : 0u));
+            sh.ref_prev[x] = (int16_t)(pp[q] >= (int32_t)base ? pp[q] - (int32_t)base : -1);
+            const uint32_t dw = ww[q] - wbase;
+            sh.ref_w[x] = (uint16_t)(dw > 0xfffeu ? 0xffffu : dw);  // far beyond any window of this stretch
+            key[q] = 2u * r + (is_match ? 1u : 0u);
+          }
+        }
+        // stable order is not needed: entries of one key are interchangeable in the union walk
+        uint32_t slot[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint32_t x = (uint32_t)q * 64u + lane;
+          slot[q] = 0;
+          if (x < n) slot[q] = atomicAdd_u16(bucket, key[q]);
+        }
+        __syncthreads();
+        {  // exclusive scan of the buckets (n_keys <= 1026): each lane owns a run of them
+          const uint32_t per = (n_keys + 63u) / 64u;
+          uint32_t local = 0;
+          for (uint32_t q = 0; q < per; ++q) { const uint32_t i = lane * per + q; if (i < n_keys) local += bucket[i]; }
+          uint32_t run = wave_excl_scan(local, lane);
+          for (uint32_t q = 0; q < per; ++q) {
+            const uint32_t i = lane * per + q;
+            if (i < n_keys) { const uint32_t v = bucket[i]; bucket[i] = (uint16_t)run; run += v; }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint32_t x = (uint32_t)q * 64u + lane;
+          if (x < n) sh.ord[bucket[key[q]] + slot[q]] = (uint16_t)x;
+        }
+        __syncthreads();
+        // every pending lane: where its window ends inside the stretch, and whether the stretch holds all of it
+        const uint32_t xb = b - base;  // meaningful for pending lanes (b >= base)
+        uint32_t xe = 0;
+        bool covered = false;
+        if (pending) {
+          const uint32_t target = wp + count_windows - wbase;
+          uint32_t lo = xb, hi = n;
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)sh.ref_w[mid] < target) lo = mid + 1; else hi = mid; }
+          xe = lo;
+          covered = xe < n || base + n == m1;
+        }
+        const bool first_uncovered = __shfl((int)covered, (int)first_lane, 64) == 0;
+        uint32_t f_shared = 0;
+        bool done_now = pending && covered;
+        if (first_uncovered) {
+          // the first pending window alone is longer than the stretch: the whole wave takes it from HBM
+          const uint32_t wp0 = __shfl(wp, (int)first_lane, 64);
+          const uint32_t e0 = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, wp0 + count_windows);
+          __syncthreads();
+          for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;  // sh.cnt back to zero for the cooperative form
+          __syncthreads();
+          const uint32_t v = eval_window_coop(base, e0);
+          if (lane == first_lane) { f_shared = v; done_now = true; }
+        } else {
+          // union walk: the stretch in (rank, reference-only first) order; a lane keeps what lies in its window and is
+          // the first occurrence of its hash there.  k = reference-only hashes taken so far; an entry of rank r sits at
+          // position r + k of the union and counts while that is < s.
+          uint32_t k = 0;
+          bool walking = done_now;
+          for (uint32_t j = 0; j < n && __any(walking); ++j) {
+            const uint32_t x = sh.ord[j];
+            const uint32_t rr = sh.ref_rank[x], r = rr & 0x7fffu;
+            const int32_t pv = sh.ref_prev[x];
+            if (walking && x >= xb && x < xe && pv < (int32_t)xb) {
+              if (r + k >= s) walking = false;
+              else if (rr & 0x8000u) ++f_shared;
+              else ++k;
+            }
+          }
+          __syncthreads();
+          for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;  // leave sh.cnt clean
+          __syncthreads();
+        }
+        // fold the evaluated starts into the candidate's optimum: most shared; first and last position of it
+        const uint64_t dm = __ballot(done_now);
+        int32_t group_best = -1;
+        {
+          uint32_t v = done_now ? f_shared + 1u : 0u;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+          group_best = (int32_t)v - 1;
+        }
+        if (dm && group_best >= c_best) {
+          const uint64_t top = __ballot(done_now && (int32_t)f_shared == group_best);
+          const uint32_t w_first = __shfl(wp, __builtin_ctzll(top), 64), w_last = __shfl(wp, 63 - __builtin_clzll(top), 64);
+          if (group_best > c_best) { c_best = group_best; c_first = w_first; c_last = w_last; }
+          else { c_first = min(c_first, w_first); c_last = max(c_last, w_last); }
+        }
+        pending = pending && !done_now;
+        // whoever can no longer reach the bar drops out
+        const int32_t bar2 = c_best > best_shared ? c_best : best_shared;
+        if (pending && (int32_t)hits_between(c, wp, wp + count_windows) < bar2) pending = false;
+      }
+    }
+    if (c_best < 0) return;
+    const uint32_t pos = (c_first + c_last) / 2u;
+    if (c_best > best_shared || (c_best == best_shared && (c < best_c || (c == best_c && pos < best_p)))) {
+      best_shared = c_best; best_c = c; best_p = pos;
+    }
+  };
+
+  // ---- L1: run a is valid when hits a .. a+mh-1 share a contig and span < frag_len window ids; its candidate range
+  // of window starts is [y.w - fragLen + 1, x.w]; ranges that touch on one contig merge (hits are in (contig, window)
+  // order, so both ends only grow and "touches the merged range" is "touches the previous run's")
+  bool have_cur = false, have_prev = false;
+  uint32_t cur_c = 0, cur_cs = 0, cur_ce = 0, prev_c = 0, prev_ce = 0;
+  for (uint32_t chunk = 0; chunk < nh; chunk += 64) {
+    const uint32_t i = chunk + lane;
+    bool v = false;
+    uint32_t c_i = 0, cs_i = 0, ce_i = 0;
+    if (i + mh <= nh) {
+      c_i = HC(i);
+      ce_i = HW(i);
+      const uint32_t yw = HW(i + mh - 1);
+      v = HC(i + mh - 1) == c_i && yw - ce_i < frag_len;
+      cs_i = yw + 1u > frag_len ? yw + 1u - frag_len : 0u;
+    }
+    const uint64_t vm = __ballot(v);
+    if (!vm) continue;
+    // the valid run before this lane's: in this chunk, or carried over from the chunks before
+    const uint64_t below = vm & ((1ULL << lane) - 1ULL);
+    const int pl = below ? 63 - __builtin_clzll(below) : 0;
+    const uint32_t sc = __shfl(c_i, pl, 64), se = __shfl(ce_i, pl, 64);
+    const bool hp = below ? true : have_prev;
+    const uint32_t pc = below ? sc : prev_c, pe = below ? se : prev_ce;
+    const bool brk = v && (!hp || pc != c_i || cs_i > pe);
+    uint64_t bm = __ballot(brk);
+    // valid runs before the first break of the chunk extend the carried candidate
+    const uint64_t head = bm ? vm & ((1ULL << __builtin_ctzll(bm)) - 1ULL) : vm;
+    if (head && have_cur) cur_ce = max(cur_ce, (uint32_t)__shfl(ce_i, 63 - __builtin_clzll(head), 64));
+    while (bm) {
+      const int bit = __builtin_ctzll(bm);
+      bm &= bm - 1;
+      if (have_cur) process_candidate(cur_c, cur_cs, cur_ce);
+      const uint64_t upto = bm ? ((1ULL << __builtin_ctzll(bm)) - 1ULL) : ~0ULL;
+      const uint64_t mine = vm & upto & ~((1ULL << bit) - 1ULL);  // the valid runs of this group inside the chunk
+      cur_c = __shfl(c_i, bit, 64);
+      cur_cs = __shfl(cs_i, bit, 64);
+      cur_ce = __shfl(ce_i, 63 - __builtin_clzll(mine), 64);
+      have_cur = true;
+    }
+    const int last = 63 - __builtin_clzll(vm);
+    prev_c = __shfl(c_i, last, 64);
+    prev_ce = __shfl(ce_i, last, 64);
+    have_prev = true;
   }
-  if (have_best && best_shared >= tab_min_shared[s] && lane == 0) {
+  if (have_cur) process_candidate(cur_c, cur_cs, cur_ce);
+
+  if (best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s] && lane == 0) {
     const uint64_t jq = ((uint64_t)best_shared << 30) / s;
     const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
     const uint64_t bin = contig_bin_off[best_c] + best_p / (frag_len - 20u);  // fastANI buckets the reference by fragLen - 20
