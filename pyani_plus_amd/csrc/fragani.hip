@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   // (rank, reference-only before match) order by a counting sort, and every lane walks that one list keeping
   // what lies in its own window -- a union walk that stops at the s-th element.  Starts whose seed-hit count
   // cannot reach the best so far are never evaluated, which leaves one or two groups per candidate.
-  auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce) {
+  auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) {
     const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
     const uint32_t b_lo = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, cs);
@@ -912,18 +912,15 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     int32_t c_best = -1;
     uint32_t c_first = 0, c_last = 0;
     const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
-    // the group whose starts see the most seed hits goes first: it sets the bar the others are pruned against
+    // A start matters only if its window can hold min_shared minimizers of the fragment (less is never reported) and
+    // reach the best so far.  The group holding the candidate's first seed hit goes first -- for a true mapping the
+    // window that starts there is at or next to the optimum -- and sets the bar the other groups are pruned against:
+    // first per group (seed hits between its first start and the end of its last window), then per start.
+    const int32_t floor_bar = (int32_t)tab_min_shared[s];
     uint32_t g_first = 0;
     if (n_groups > 1) {
-      uint32_t top = 0;
-      for (uint32_t g = 0; g < n_groups; ++g) {
-        const uint32_t b = b_lo + g * 64u + lane;
-        uint32_t ub = 0;
-        if (b < b_hi) { const uint32_t wp = mini_wpos[b]; ub = hits_between(c, wp, wp + count_windows); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ub = max(ub, (uint32_t)__shfl_xor((int)ub, o, 64));
-        if (ub > top) { top = ub; g_first = g; }
-      }
+      const uint32_t at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
+      g_first = at > b_lo ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
     }
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
       const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
@@ -931,7 +928,12 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       const uint32_t b = sb + lane;
       const bool has = b < b_hi;
       const uint32_t wp = has ? mini_wpos[b] : 0u;
-      const int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a start must reach to matter (ties matter)
+      int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a start must reach to matter (ties matter)
+      if (bar < floor_bar) bar = floor_bar;
+      if (gi > 0) {  // uniform bound for the whole group
+        const uint32_t w_lo = __shfl(wp, 0, 64), w_hi = __shfl(wp, (int)min(63u, b_hi - sb - 1u), 64);
+        if ((int32_t)hits_between(c, w_lo, w_hi + count_windows) < bar) continue;
+      }
       bool pending = has && (int32_t)hits_between(c, wp, wp + count_windows) >= bar;
       while (__any(pending)) {
         const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
@@ -1056,8 +1058,11 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         }
         pending = pending && !done_now;
         // whoever can no longer reach the bar drops out
-        const int32_t bar2 = c_best > best_shared ? c_best : best_shared;
-        if (pending && (int32_t)hits_between(c, wp, wp + count_windows) < bar2) pending = false;
+        if (__any(pending)) {
+          int32_t bar2 = c_best > best_shared ? c_best : best_shared;
+          if (bar2 < floor_bar) bar2 = floor_bar;
+          if (pending && (int32_t)hits_between(c, wp, wp + count_windows) < bar2) pending = false;
+        }
       }
     }
     if (c_best < 0) return;
@@ -1071,7 +1076,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   // of window starts is [y.w - fragLen + 1, x.w]; ranges that touch on one contig merge (hits are in (contig, window)
   // order, so both ends only grow and "touches the merged range" is "touches the previous run's")
   bool have_cur = false, have_prev = false;
-  uint32_t cur_c = 0, cur_cs = 0, cur_ce = 0, prev_c = 0, prev_ce = 0;
+  uint32_t cur_c = 0, cur_cs = 0, cur_ce = 0, cur_fw = 0, prev_c = 0, prev_ce = 0;
   for (uint32_t chunk = 0; chunk < nh; chunk += 64) {
     const uint32_t i = chunk + lane;
     bool v = false;
@@ -1099,11 +1104,12 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     while (bm) {
       const int bit = __builtin_ctzll(bm);
       bm &= bm - 1;
-      if (have_cur) process_candidate(cur_c, cur_cs, cur_ce);
+      if (have_cur) process_candidate(cur_c, cur_cs, cur_ce, cur_fw);
       const uint64_t upto = bm ? ((1ULL << __builtin_ctzll(bm)) - 1ULL) : ~0ULL;
       const uint64_t mine = vm & upto & ~((1ULL << bit) - 1ULL);  // the valid runs of this group inside the chunk
       cur_c = __shfl(c_i, bit, 64);
       cur_cs = __shfl(cs_i, bit, 64);
+      cur_fw = __shfl(ce_i, bit, 64);  // window id of the first hit of the candidate's first run
       cur_ce = __shfl(ce_i, 63 - __builtin_clzll(mine), 64);
       have_cur = true;
     }
@@ -1112,7 +1118,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     prev_ce = __shfl(ce_i, last, 64);
     have_prev = true;
   }
-  if (have_cur) process_candidate(cur_c, cur_cs, cur_ce);
+  if (have_cur) process_candidate(cur_c, cur_cs, cur_ce, cur_fw);
 
   if (best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s] && lane == 0) {
     const uint64_t jq = ((uint64_t)best_shared << 30) / s;

@@ -23,12 +23,14 @@ starts = arena.genome_start[:-1].copy()
 lens = np.full(n, length, dtype=np.uint32)
 genome = np.arange(n, dtype=np.uint32)
 t = eng.torch
+eng.prof_enable(True)
 for rep in range(2):
+    eng.prof_reset()
     t.cuda.synchronize()
     t0 = time.perf_counter()
     total, matched, ident_sum = eng.fragani(arena, starts, lens, genome, k, frag)
     dt = time.perf_counter() - t0
-    print(f"rep {rep}: {n}x{n} pairs in {dt:.3f} s -> {n * n / dt:.3e} pairs/s", flush=True)
+    print(f"rep {rep}: {n}x{n} pairs in {dt:.3f} s -> {n * n / dt:.3e} pairs/s", {k: round(v[0], 1) for k, v in eng.prof_get().items() if k.startswith("frag")}, flush=True)
 ani = np.where(matched > 0, ident_sum / np.maximum(matched, 1), np.nan)
 related = ~np.isnan(ani)
 print("fragments per genome", int(total[0]), "pairs with mappings", int(related.sum()), "ANI range", float(np.nanmin(ani)), float(np.nanmax(ani)))

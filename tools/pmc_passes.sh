@@ -1,22 +1,29 @@
 #!/bin/bash
-# rocprofv3 counter passes over the k-mer hash kernel (tools/pmc_hash.py), one --pmc set per run.
-# Usage on the GPU box (from the repo root):  bash tools/pmc_passes.sh <tag> [n_genomes]
+# rocprofv3 counter passes, one --pmc set per run (never combined with runtime/sys traces).
+# Usage on the GPU box (from the repo root):
+#   bash tools/pmc_passes.sh <tag> <kernel-name filter> <python script> [script args...]
+# e.g. bash tools/pmc_passes.sh r02_hash kmer_hash tools/pmc_hash.py 1000
 set -u
 TAG=${1:-r02}
-N=${2:-1000}
+FILTER=${2:-kmer_hash}
+shift 2
+if [ $# -eq 0 ]; then set -- tools/pmc_hash.py 1000; fi
 ROOT=$(pwd)
+SCRIPT=$ROOT/$1
+shift
 OUT=$ROOT/gpurun_out/${TAG}_pmc
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L > "$OUT/counters_available.txt" 2>&1
+[ -f "$OUT/../counters_available.txt" ] || rocprofv3 -L > "$OUT/../counters_available.txt" 2>&1
 run_pass() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 "$ROOT/tools/pmc_hash.py" "$N" > "$OUT/$name.log" 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 "$SCRIPT" "${ARGS[@]}" > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
+ARGS=("$@")
 run_pass sq_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run_pass sq_wait SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
-cd "$ROOT" && python3 tools/pmc_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
+cd "$ROOT" && python3 tools/pmc_summary.py "$OUT" "$FILTER" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

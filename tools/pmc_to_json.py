@@ -44,6 +44,7 @@ out = {
     "kernel_ms_by_pass": dur,
     "waves_per_simd_avg": mean("SQ_WAVE_CYCLES") * 4 / simds / cycles,
     "valu_instr_per_wave_window": mean("SQ_INSTS_VALU") / (1000 * 5_000_064 / 64.0),
+    "valu_instr_per_wave_window_note": "SQ_INSTS_VALU / (arena positions / 64); tools/pmc_hash.py hashes 1000 genomes of 5 000 064 arena positions",
 }
 dst.write_text(json.dumps(out, indent=1) + "\n")
 print(json.dumps(out, indent=1))

@@ -1,0 +1,19 @@
+#!/bin/bash
+# The rocprofv3 evidence of a round, gathered in one gpurun call:  bash tools/profile_round.sh <tag>
+# (kernel-trace statistics of the bench command and of the fragment-ANI run, counter passes of the two dominant
+# kernels).  Results land under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
+set -u
+TAG=${1:-r02}
+ROOT=$(pwd)
+mkdir -p "$ROOT/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/${TAG}_stats_bench" -- python3 "$ROOT/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-pcie --no-also > "$ROOT/gpurun_out/${TAG}_stats_bench.json" 2> "$ROOT/gpurun_out/${TAG}_stats_bench.err"
+echo "bench stats rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/${TAG}_stats_fragani" -- python3 "$ROOT/tools/bench_fragani.py" 1000 0 > "$ROOT/gpurun_out/${TAG}_stats_fragani.log" 2>&1
+echo "fragani stats rc=$?"
+cd "$ROOT"
+bash tools/pmc_passes.sh ${TAG}_hash kmer_hash tools/pmc_hash.py 1000
+bash tools/pmc_passes.sh ${TAG}_fragmap map_segments tools/bench_fragani.py 300 0
+for d in gpurun_out/${TAG}_stats_bench gpurun_out/${TAG}_stats_fragani; do
+  f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "== $f"; head -12 "$f"; }
+done

@@ -112,6 +112,16 @@ KERNEL(k_alignbyte, DECL32, REP8(OP_ALIGNBYTE), SINK32)
 KERNEL(k_addco1, DECL32, REP8(OP_ADDCO1), SINK32)
 KERNEL(k_fma, DECL32, REP8(OP_FMA), SINK32)
 KERNEL(k_min, DECL32, REP8(OP_MIN), SINK32)
+// the canonical-strand select of the hash kernel: one 64-bit compare feeding two v_cndmask (per iteration: 1 + 2 ops)
+#define OP_CMPSEL(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x) : "v"(k) : "vcc");
+KERNEL(k_cmpsel, DECL32, REP8(OP_CMPSEL), SINK32)
+#define OP_CMPSEL2(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_cndmask_b32 %0, %1, %0, vcc" : "+v"(x) : "v"(k) : "vcc");
+KERNEL(k_cmpsel2, DECL32, REP8(OP_CMPSEL2), SINK32)
+#define OP_CMPSELMASK(x) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, 0, -1, vcc\n\tv_and_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1" : "+v"(x) : "v"(k) : "vcc");
+KERNEL(k_cmpselmask, DECL32, REP8(OP_CMPSELMASK), SINK32)
+#define OP_MINU32x2(x) asm volatile("v_min_u32 %0, %0, %1\n\tv_max_u32 %0, %0, %1" : "+v"(x) : "v"(k));
+KERNEL(k_minmax, DECL32, REP8(OP_MINU32x2), SINK32)
+
 // mixed stream: does a cheap op hide behind an expensive one? 4 xor + 4 alignbit per iteration
 #define OP_MIX(x) asm volatile("v_xor_b32 %0, %0, %1\n\tv_alignbit_b32 %0, %0, %1, 7" : "+v"(x) : "v"(k));
 KERNEL(k_mix, DECL32, REP8(OP_MIX), SINK32)
@@ -203,6 +213,8 @@ int main() {
       {"v_pk_mul_lo_u16", k_pkmul16, 8}, {"v_pk_mad_u16", k_pkmad16, 8}, {"v_mad_u32_u16", k_madu16, 8},
       {"v_dot2_u32_u16", k_dot2, 8}, {"v_dot4_u32_u8", k_dot4, 8}, {"v_alignbyte_b32", k_alignbyte, 8},
       {"v_add_co_u32 (alone)", k_addco1, 8}, {"v_fma_f32", k_fma, 8}, {"v_min_u32", k_min, 8},
+      {"v_cmp_lt_u32 + v_cndmask (pair)", k_cmpsel, 8}, {"v_cmp + s_nop + 2 v_cndmask (triple)", k_cmpsel2, 8},
+      {"v_cmp + cndmask(0,-1) + and + xor (quad)", k_cmpselmask, 8}, {"v_min_u32 + v_max_u32 (pair)", k_minmax, 8},
       {"xor+alignbit pair", k_mix, 8}, {"mul_lo+xor+add triple", k_mix2, 8},
 
   };
