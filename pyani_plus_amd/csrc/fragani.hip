@@ -726,13 +726,13 @@ struct EvalShared {
   uint32_t *matched;   // [kQMax / 32] bitset over query ranks (cooperative evaluation of one over-long window)
   uint32_t *hw;        // [kHitCap] window id of each staged hit
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
-  uint16_t *ref_rank;  // [kRefCap] bit 15: the hash is one of the query's; bits 0-14: its rank among them
-  int16_t *ref_prev;   // [kRefCap] previous occurrence of the same hash, relative to the stretch start (-1: before)
   uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
-  uint16_t *ord;       // [kRefCap] the stretch in (rank, reference-only before match) order
+  uint32_t *ent;       // [kRefCap + 4] the stretch in (rank, reference-only before match) order, one packed word each:
+                       //   bits 0-8 index in the stretch, 9-18 rank among the query hashes, 19 the hash is one of them,
+                       //   20-29 index of the previous occurrence of the same hash + 1 (0: before the stretch)
 };
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap) {
-  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + kRefCap * 8u;
+  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + kRefCap * 2u + (kRefCap + 4u) * 4u;
 }
 __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap) {
   EvalShared sh;
@@ -741,10 +741,8 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   sh.matched = sh.cnt + s_cap + 64u;
   sh.hw = sh.matched + kQMax / 32;
   sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
-  sh.ref_rank = sh.hc + hit_cap;
-  sh.ref_prev = reinterpret_cast<int16_t *>(sh.ref_rank + kRefCap);
-  sh.ref_w = reinterpret_cast<uint16_t *>(sh.ref_prev + kRefCap);
-  sh.ord = sh.ref_w + kRefCap;
+  sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are even: the 32-bit array below stays aligned (to 16 bytes)
+  sh.ent = reinterpret_cast<uint32_t *>(sh.ref_w + kRefCap);
   return sh;
 }
 
@@ -825,23 +823,22 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
   __syncthreads();
 
-  // number of seed hits of this segment on contig c with window id in [w0, w1): an upper bound of the minimizers a
-  // reference window [w0, w1) can share with the fragment (every occurrence of every query hash is a hit)
-  auto hits_between = [&](uint32_t c, uint32_t w0, uint32_t w1) -> uint32_t {
-    uint32_t lo = 0, hi = nh;
+  // first hit index in [lo, hi) whose (contig, window id) is >= (c, w): the hits are in (contig, window) order
+  auto hit_lower_bound = [&](uint32_t lo, uint32_t hi, uint32_t c, uint32_t w) -> uint32_t {
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
       const uint32_t mc = HC(mid);
-      if (mc < c || (mc == c && HW(mid) < w0)) lo = mid + 1; else hi = mid;
+      if (mc < c || (mc == c && HW(mid) < w)) lo = mid + 1; else hi = mid;
     }
-    const uint32_t first = lo;
-    hi = nh;
+    return lo;
+  };
+  // the same inside an index range that lies on one contig: window ids only
+  auto hit_lower_bound_w = [&](uint32_t lo, uint32_t hi, uint32_t w) -> uint32_t {
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;
-      const uint32_t mc = HC(mid);
-      if (mc < c || (mc == c && HW(mid) < w1)) lo = mid + 1; else hi = mid;
+      if (HW(mid) < w) lo = mid + 1; else hi = mid;
     }
-    return lo - first;
+    return lo;
   };
 
   // One over-long window (more than kRefCap minimizers: low-complexity or N-riddled sequence) straight from HBM,
@@ -917,6 +914,8 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     // window that starts there is at or next to the optimum -- and sets the bar the other groups are pruned against:
     // first per group (seed hits between its first start and the end of its last window), then per start.
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
+    // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, ce + count_windows)
+    const uint32_t h_lo = hit_lower_bound(0, nh, c, cs), h_hi = hit_lower_bound(h_lo, nh, c, ce + count_windows);
     uint32_t g_first = 0;
     if (n_groups > 1) {
       const uint32_t at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
@@ -930,11 +929,13 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       const uint32_t wp = has ? mini_wpos[b] : 0u;
       int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a start must reach to matter (ties matter)
       if (bar < floor_bar) bar = floor_bar;
-      if (gi > 0) {  // uniform bound for the whole group
-        const uint32_t w_lo = __shfl(wp, 0, 64), w_hi = __shfl(wp, (int)min(63u, b_hi - sb - 1u), 64);
-        if ((int32_t)hits_between(c, w_lo, w_hi + count_windows) < bar) continue;
+      // seed hits inside the start's window: every occurrence of every query hash is a hit, so no window shares more
+      int32_t ub = -1;
+      if (has) {
+        const uint32_t i0 = hit_lower_bound_w(h_lo, h_hi, wp);
+        ub = (int32_t)(hit_lower_bound_w(i0, h_hi, wp + count_windows) - i0);
       }
-      bool pending = has && (int32_t)hits_between(c, wp, wp + count_windows) >= bar;
+      bool pending = ub >= bar;
       while (__any(pending)) {
         const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
         const uint32_t base = sb + first_lane;  // stretch = minimizers [base, base + n)
@@ -957,19 +958,20 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         uint16_t *bucket = reinterpret_cast<uint16_t *>(sh.cnt);  // 2 (s + 1) 16-bit counters in the 4 (s_cap + 64) bytes
         for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;
         __syncthreads();
-        uint32_t key[kPer];
+        uint32_t key[kPer], packed_ent[kPer];
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
           key[q] = 0;
+          packed_ent[q] = 0;
           if (x < n) {
             const uint32_t r = lower_bound_u32(sh.qh, 0, s, hh[q]);
             const bool is_match = r < s && sh.qh[r] == hh[q];
-            sh.ref_rank[x] = (uint16_t)(r | (is_match ? 0x8000u : 0u));
-            sh.ref_prev[x] = (int16_t)(pp[q] >= (int32_t)base ? pp[q] - (int32_t)base : -1);
+            const uint32_t prev1 = pp[q] >= (int32_t)base ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
             const uint32_t dw = ww[q] - wbase;
             sh.ref_w[x] = (uint16_t)(dw > 0xfffeu ? 0xffffu : dw);  // far beyond any window of this stretch
             key[q] = 2u * r + (is_match ? 1u : 0u);
+            packed_ent[q] = x | (r << 9) | (is_match ? 1u << 19 : 0u) | (prev1 << 20);
           }
         }
         // stable order is not needed: entries of one key are interchangeable in the union walk
@@ -995,8 +997,9 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
-          if (x < n) sh.ord[bucket[key[q]] + slot[q]] = (uint16_t)x;
+          if (x < n) sh.ent[bucket[key[q]] + slot[q]] = packed_ent[q];
         }
+        if (lane < 4) sh.ent[n + lane] = 0x3ff001ffu;  // padding of the last 16-byte read: an entry no window keeps
         __syncthreads();
         // every pending lane: where its window ends inside the stretch, and whether the stretch holds all of it
         const uint32_t xb = b - base;  // meaningful for pending lanes (b >= base)
@@ -1027,14 +1030,18 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
           // position r + k of the union and counts while that is < s.
           uint32_t k = 0;
           bool walking = done_now;
-          for (uint32_t j = 0; j < n && __any(walking); ++j) {
-            const uint32_t x = sh.ord[j];
-            const uint32_t rr = sh.ref_rank[x], r = rr & 0x7fffu;
-            const int32_t pv = sh.ref_prev[x];
-            if (walking && x >= xb && x < xe && pv < (int32_t)xb) {
-              if (r + k >= s) walking = false;
-              else if (rr & 0x8000u) ++f_shared;
-              else ++k;
+          const uint4 *ent4 = reinterpret_cast<const uint4 *>(sh.ent);
+          for (uint32_t j = 0; j < n && __any(walking); j += 4) {
+            const uint4 e4 = ent4[j >> 2];  // the same four entries for every lane: one broadcast read
+            const uint32_t es[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t e = es[q], x = e & 0x1ffu, r = (e >> 9) & 0x3ffu, prev1 = e >> 20;
+              const bool mine = walking && x >= xb && x < xe && prev1 <= xb;  // in the window, first occurrence of its hash there
+              const bool fits = r + k < s;
+              f_shared += (mine && fits && (e & (1u << 19))) ? 1u : 0u;
+              k += (mine && fits && !(e & (1u << 19))) ? 1u : 0u;
+              walking = walking && !(mine && !fits);
             }
           }
           __syncthreads();
@@ -1058,10 +1065,10 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         }
         pending = pending && !done_now;
         // whoever can no longer reach the bar drops out
-        if (__any(pending)) {
+        {
           int32_t bar2 = c_best > best_shared ? c_best : best_shared;
           if (bar2 < floor_bar) bar2 = floor_bar;
-          if (pending && (int32_t)hits_between(c, wp, wp + count_windows) < bar2) pending = false;
+          pending = pending && ub >= bar2;
         }
       }
     }

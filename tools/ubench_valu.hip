@@ -147,6 +147,15 @@ __global__ __launch_bounds__(256) void k_clock(uint32_t *out, uint32_t seed, uns
 #define OP_CMP64(x) asm volatile("v_cmp_gt_u64 vcc, %0, %1" : : "v"(x), "v"(k64) : "vcc");
 #define OP_ADDCO(x) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(*(uint32_t*)&x) : "v"(k) : "vcc");
 
+// the canonical-strand select as the hash kernel has it, and candidate replacements (x: 64-bit, its low word selected)
+#define OP_SEL_KERNEL(x) asm volatile("v_cmp_lt_u64 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32 %2, %2, %3, vcc\n\tv_cndmask_b32 %3, %3, %2, vcc" : : "v"(x), "v"(k64), "v"(*(uint32_t*)&x), "v"(k) : "vcc");
+#define OP_SEL_TWICE(x) asm volatile("v_cmp_lt_u64 vcc, %0, %1\n\tv_cndmask_b32 %2, %2, %3, vcc\n\tv_cmp_lt_u64 vcc, %0, %1\n\tv_cndmask_b32 %3, %3, %2, vcc" : : "v"(x), "v"(k64), "v"(*(uint32_t*)&x), "v"(k) : "vcc");
+#define OP_SEL_SGPR(x) asm volatile("v_cmp_lt_u64 s[20:21], %0, %1\n\ts_nop 1\n\tv_cndmask_b32 %2, %2, %3, s[20:21]\n\tv_cndmask_b32 %3, %3, %2, s[20:21]" : : "v"(x), "v"(k64), "v"(*(uint32_t*)&x), "v"(k) : "s20", "s21");
+#define OP_SEL_ONE(x) asm volatile("v_cmp_lt_u64 vcc, %0, %1\n\tv_cndmask_b32 %2, %2, %3, vcc" : : "v"(x), "v"(k64), "v"(*(uint32_t*)&x), "v"(k) : "vcc");
+KERNEL(k_sel_kernel, DECL64, REP8(OP_SEL_KERNEL), SINK64)
+KERNEL(k_sel_twice, DECL64, REP8(OP_SEL_TWICE), SINK64)
+KERNEL(k_sel_sgpr, DECL64, REP8(OP_SEL_SGPR), SINK64)
+KERNEL(k_sel_one, DECL64, REP8(OP_SEL_ONE), SINK64)
 KERNEL(k_mad64, DECL64, REP8(OP_MAD64), SINK64)
 KERNEL(k_shl64, DECL64, REP8(OP_SHL64), SINK64)
 KERNEL(k_shr64, DECL64, REP8(OP_SHR64), SINK64)
@@ -215,6 +224,8 @@ int main() {
       {"v_add_co_u32 (alone)", k_addco1, 8}, {"v_fma_f32", k_fma, 8}, {"v_min_u32", k_min, 8},
       {"v_cmp_lt_u32 + v_cndmask (pair)", k_cmpsel, 8}, {"v_cmp + s_nop + 2 v_cndmask (triple)", k_cmpsel2, 8},
       {"v_cmp + cndmask(0,-1) + and + xor (quad)", k_cmpselmask, 8}, {"v_min_u32 + v_max_u32 (pair)", k_minmax, 8},
+      {"cmp64 + s_nop + 2 cndmask (as the kernel)", k_sel_kernel, 8}, {"cmp64 + cndmask, twice", k_sel_twice, 8},
+      {"cmp64 -> sgpr pair + s_nop + 2 cndmask_e64", k_sel_sgpr, 8}, {"cmp64 + 1 cndmask", k_sel_one, 8},
       {"xor+alignbit pair", k_mix, 8}, {"mul_lo+xor+add triple", k_mix2, 8},
 
   };
