@@ -147,8 +147,15 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
           const uint32_t r_lo = ro ? alignbit(rw[4], rw[3], ro) : rw[3];
           const uint32_t r_hi = ro ? alignbit(rw[5], rw[4], ro) : rw[4];
           const uint64_t f_lsb = u64_of(f_lo, f_hi) & kMask, r_lsb = u64_of(r_lo, r_hi) & kMask;
-          const uint64_t canon = (f_lsb <= r_lsb) ? f_lsb : r_lsb;
-          const uint32_t clo = (uint32_t)canon, chi = (uint32_t)(canon >> 32);
+          // Canonical strand.  Left to itself hipcc compares into VCC and selects the two words with VCC-reading
+          // v_cndmask; on gfx950 the second VCC read of such a pair is pathologically slow (36 cycles for the group
+          // against 13 with the lane mask in an ordinary SGPR pair: profiles/r02_ubench_valu_gfx950.txt), so the
+          // compare goes to an SGPR pair and both selects read that.  s_nop 1: two wait states between a VALU
+          // write of an SGPR and a VALU read of it.
+          const uint64_t fwd = __builtin_amdgcn_uicmpl(f_lsb, r_lsb, 37 /* ICMP_ULE */);
+          uint32_t clo, chi;
+          asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(clo) : "v"((uint32_t)r_lsb), "v"((uint32_t)f_lsb), "s"(fwd));
+          asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(chi) : "v"((uint32_t)(r_lsb >> 32)), "v"((uint32_t)(f_lsb >> 32)), "s"(fwd), "v"(clo));
           uint64_t P[4] = {0, 0, 0, 0};
 #pragma unroll
           for (int j = 0; j < kWords; ++j) {
