@@ -959,13 +959,29 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;
         __syncthreads();
         uint32_t key[kPer], packed_ent[kPer];
+        // ranks of the lane's kPer minimizers among the fragment's hashes: the binary searches advance together, one
+        // halving step for all of them at a time, so the LDS reads of a step are in flight at once
+        uint32_t rank[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) rank[q] = 0;
+        for (uint32_t half = 256; half > 0; half >>= 1) {  // s <= kQMax = 512: positions 0 .. s
+#pragma unroll
+          for (int q = 0; q < kPer; ++q) {
+            const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
+            if (idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {  // half = 256 down to 1 reaches at most 511: one more step for rank 512
+          if (rank[q] + 1u <= s && sh.qh[rank[q]] < hh[q]) rank[q] += 1u;
+        }
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
           key[q] = 0;
           packed_ent[q] = 0;
           if (x < n) {
-            const uint32_t r = lower_bound_u32(sh.qh, 0, s, hh[q]);
+            const uint32_t r = rank[q];
             const bool is_match = r < s && sh.qh[r] == hh[q];
             const uint32_t prev1 = pp[q] >= (int32_t)base ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
             const uint32_t dw = ww[q] - wbase;
