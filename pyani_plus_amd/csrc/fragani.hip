@@ -900,12 +900,41 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
   // what lies in its own window -- a union walk that stops at the s-th element.  Starts whose seed-hit count
   // cannot reach the best so far are never evaluated, which leaves one or two groups per candidate.
   auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) {
-    const uint32_t m0 = contig_mini_off[c], m1 = contig_mini_off[c + 1];
+    const uint32_t m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
-    const uint32_t b_lo = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, cs);
-    const uint32_t b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + 1u);
+    // first start: through the bucket index, the bucket itself searched by the whole wave (two memory round trips
+    // instead of the six or so of a binary search)
+    uint32_t b_lo;
+    {
+      uint32_t bk = cs >> kBucketShift;
+      if (bk >= nb) bk = nb;
+      const uint32_t lo = bucket_first[bb + bk];
+      const uint32_t hi = bk < nb ? bucket_first[bb + bk + 1] : lo;
+      b_lo = hi;
+      for (uint32_t base = lo; base < hi; base += 64) {
+        const uint32_t t = base + lane;
+        const uint64_t ge = __ballot(t < hi && mini_wpos[t] >= cs);
+        if (ge) { b_lo = base + (uint32_t)__builtin_ctzll(ge); break; }
+      }
+    }
+    // window ids of the first 512 starts in one batch of loads; they also say where the range ends
+    constexpr int kStartBatch = 8;
+    uint32_t wpv[kStartBatch];
+#pragma unroll
+    for (int q = 0; q < kStartBatch; ++q) {
+      const uint32_t t = b_lo + (uint32_t)q * 64u + lane;
+      wpv[q] = t < m1 ? mini_wpos[t] : 0xffffffffu;
+    }
+    uint32_t b_hi = 0xffffffffu, at = 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < kStartBatch; ++q) {
+      const uint64_t over = __ballot(wpv[q] > ce), reach = __ballot(wpv[q] >= first_hit_w);
+      if (over && b_hi == 0xffffffffu) b_hi = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(over);
+      if (reach && at == 0xffffffffu) at = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(reach);
+    }
+    if (b_hi == 0xffffffffu) b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + 1u);  // a range of more than 512 starts
+    if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
     if (b_lo >= b_hi) return;
-    (void)m0;
     int32_t c_best = -1;
     uint32_t c_first = 0, c_last = 0;
     const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
@@ -916,17 +945,19 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
     // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, ce + count_windows)
     const uint32_t h_lo = hit_lower_bound(0, nh, c, cs), h_hi = hit_lower_bound(h_lo, nh, c, ce + count_windows);
-    uint32_t g_first = 0;
-    if (n_groups > 1) {
-      const uint32_t at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
-      g_first = at > b_lo ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
-    }
+    const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
       const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
       const uint32_t sb = b_lo + g * 64u;
       const uint32_t b = sb + lane;
       const bool has = b < b_hi;
-      const uint32_t wp = has ? mini_wpos[b] : 0u;
+      uint32_t wp = 0u;
+      if (g < (uint32_t)kStartBatch) {
+#pragma unroll
+        for (int q = 0; q < kStartBatch; ++q) wp = g == (uint32_t)q ? wpv[q] : wp;
+      } else if (has) {
+        wp = mini_wpos[b];
+      }
       int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a start must reach to matter (ties matter)
       if (bar < floor_bar) bar = floor_bar;
       // seed hits inside the start's window: every occurrence of every query hash is a hit, so no window shares more

@@ -5,9 +5,11 @@ tolerance on the 25 output rows the reference holds
 (tests/fixtures/{viral,bacterial}_example/intermediates/fastANI/all_vs_*.fastani, byte-compared by the
 reference itself at tests/snakemake/test_fastani_workflow.py:67-86):
     total fragments   exact  (= sum over contigs of floor(len / fragLen))
-    kept fragments    within 2.5 % of the total (and within 1 for the phages)
-    ANI               within 0.3 percentage points
-(tools/fragani_bisect.py measures each restatement choice against the 25 rows.)
+    kept fragments    within 1 % of the total (and within 1 for the phages)
+    ANI               within 0.1 percentage points
+tools/fragani_bisect.py measures each restatement choice against the 25 rows (profiles/r02_fragani_bisect.md):
+with Mashmap's sketch-size list (window 24), fastANI's fragLen-20 reference buckets and Mashmap's slide over the
+reference minimizer positions the maximum deviations are 0.070 points and 0.71 %.
 """
 
 from __future__ import annotations
@@ -21,8 +23,8 @@ import pytest
 import oracle
 from tests.helpers import GOLDEN, read_fasta_bytes
 
-ANI_TOL = 0.3  # percentage points
-MATCHED_TOL = 0.025  # kept fragments, as a fraction of the total fragments
+ANI_TOL = 0.1  # percentage points (measured maximum over the 25 rows: 0.070)
+MATCHED_TOL = 0.01  # kept fragments, as a fraction of the total fragments (measured maximum: 0.71 %)
 K, FRAG = 16, 3000
 
 
@@ -80,7 +82,8 @@ def test_viral_rows_within_tolerance():
     "q,r", [("NC_010338.fna.gz", "NC_002696.fasta.gz"), ("NC_014100.fna.gz", "NC_011916.fas.gz"), ("NC_002696.fasta.gz", "NC_011916.fas.gz")]
 )
 def test_bacterial_rows_within_tolerance(q, r):
-    """Three of the 16 bacterial rows (an 83 %, an 86 % and a 99.99 % pair); all 16 are within the same bounds."""
+    """Three of the 16 bacterial rows (an 83 %, an 86 % and a 99.99 % pair); all 16 are within the same bounds
+    (tools/fragani_bisect.py runs them all; the GPU test checks all 16 on the device)."""
     rows = {(a, b): (ani, m, t) for a, b, ani, m, t in fixture_rows("bacterial_example")}
     ani, matched, total = rows[(q, r)]
     got_ani, got_m, got_t = oracle.fragani_pair(contigs_of(GOLDEN / "bacterial_example" / q), contigs_of(GOLDEN / "bacterial_example" / r), K, FRAG, 0.2)
