@@ -16,6 +16,7 @@
 // input; LDS only stages the rare survivors (1 in `scaled`) so that the global
 // append is one atomic per workgroup and the stores are coalesced.
 #include <cstdlib>
+#include <type_traits>
 
 #include "pa_internal.h"
 #include "murmur_dev.h"
@@ -134,18 +135,26 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
         const uint32_t x = __builtin_bitreverse32(fw[5 - j]);  // groups reversed, bits inside a group too
         rw[j] = ~(((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1));
       }
+      // Windows are taken column by column: the four windows e = i, i+16, i+32, i+48 sit at the same bit offset of
+      // consecutive dwords, so the five funnel shifts A[0..4] of the forward stream (and five of the reverse one) serve
+      // all four -- the high dword of one window is the low dword of the next: 2.5 shifts per window and stream pair
+      // instead of 4.  The shift amounts are uniform run-time values; the dword a column starts in changes once over
+      // the 16 columns (where i + 33 - K crosses a multiple of 16), hence the two loops with a constant base each.
+      auto columns = [&](auto base_tag, int i_begin, int i_end) {
+        constexpr int kBase = decltype(base_tag)::value;
 #pragma unroll 1
-      for (int wi = 0; wi < 4; ++wi) {
-        // fw[0] is the dword holding group 16*wi; rw[3..5] hold R groups 48-16*wi .. 95-16*wi
-        const uint32_t badw = (bad[wi >> 1] >> (16 * (wi & 1))) & 0xffffu;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = i_begin; i < i_end; ++i) {
           constexpr int kOff = 33 - K;
-          const int q = i + kOff, dq = q >> 4, fo = 2 * (q & 15), ro = 30 - 2 * i;
-          const uint32_t f_lo = fo ? alignbit(fw[dq + 1], fw[dq], fo) : fw[dq];
-          const uint32_t f_hi = fo ? alignbit(fw[dq + 2], fw[dq + 1], fo) : fw[dq + 1];
-          const uint32_t r_lo = ro ? alignbit(rw[4], rw[3], ro) : rw[3];
-          const uint32_t r_hi = ro ? alignbit(rw[5], rw[4], ro) : rw[4];
+          const uint32_t fo = 2u * (uint32_t)((i + kOff) & 15), ro = 30u - 2u * (uint32_t)i;
+          uint32_t A[5], B[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) {
+            A[j] = alignbit(fw[kBase + j + 1], fw[kBase + j], fo);  // a shift of 0 returns the low operand
+            B[j] = alignbit(rw[j + 1], rw[j], ro);
+          }
+#pragma unroll
+          for (int wi = 0; wi < 4; ++wi) {
+            const uint32_t f_lo = A[wi], f_hi = A[wi + 1], r_lo = B[3 - wi], r_hi = B[4 - wi];
           const uint64_t f_lsb = u64_of(f_lo, f_hi) & kMask, r_lsb = u64_of(r_lo, r_hi) & kMask;
           // Canonical strand.  Left to itself hipcc compares into VCC and selects the two words with VCC-reading
           // v_cndmask; on gfx950 the second VCC read of such a pair is pathologically slow (36 cycles for the group
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
           if (take_all || last_mul_high_sum_plus1(U, V) <= screen_hi) {
             const uint64_t X = U * kF2, Y = V * kF2;
             const uint64_t h = (X ^ (X >> 33)) + (Y ^ (Y >> 33));
-            if (h > max_hash || ((badw >> i) & 1u)) continue;  // validity is only looked at for the 1 in 1000
+            if (h > max_hash || ((bad[wi >> 1] >> (16 * (wi & 1) + i)) & 1u)) continue;  // validity is only looked at for the 1 in 1000
             const uint32_t slot = atomicAdd(&s_n, 1u);
             if (slot < kStageCap) {
               s_hash[slot] = h;
@@ -196,14 +205,12 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
               }
             }
           }
+          }
         }
-        // next 16 positions: slide both streams by one dword
-#pragma unroll
-        for (int j = 0; j < 7; ++j) fw[j] = fw[j + 1];
-        fw[7] = 0u;
-#pragma unroll
-        for (int j = 5; j > 0; --j) rw[j] = rw[j - 1];
-      }
+      };
+      constexpr int kOff0 = 33 - K, kSplit = (kOff0 & 15) ? 16 - (kOff0 & 15) : 16;
+      columns(std::integral_constant<int, (kOff0 >> 4)>{}, 0, kSplit);
+      if constexpr (kSplit < 16) columns(std::integral_constant<int, (kOff0 >> 4) + 1>{}, kSplit, 16);
     }
   }
   __syncthreads();

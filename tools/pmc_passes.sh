@@ -27,3 +27,5 @@ run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
 cd "$ROOT" && python3 tools/pmc_summary.py "$OUT" "$FILTER" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
+# the raw per-dispatch CSVs are large (gpurun brings back 64 MiB at most): keep the summary and the logs
+find "$OUT" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +

@@ -15,5 +15,11 @@ cd "$ROOT"
 bash tools/pmc_passes.sh ${TAG}_hash kmer_hash tools/pmc_hash.py 1000
 bash tools/pmc_passes.sh ${TAG}_fragmap map_segments tools/bench_fragani.py 300 0
 for d in gpurun_out/${TAG}_stats_bench gpurun_out/${TAG}_stats_fragani; do
-  f=$(find $d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && { echo "== $f"; head -12 "$f"; }
+  f=$(find $d -name "*kernel_stats.csv" | head -1)
+  if [ -n "$f" ]; then
+    # our own kernels only (the synthetic-genome generator is torch plumbing), then drop the raw traces
+    { head -1 "$f"; grep -v "at::native\|rocclr\|hiprand" "$f" | tail -n +2; } > "$d.kernel_stats.csv"
+    echo "== $d.kernel_stats.csv"; cut -c1-60,200- "$d.kernel_stats.csv" | head -14
+  fi
+  rm -rf "$d"
 done
