@@ -744,22 +744,29 @@ def run_rank(args) -> None:
         if world == 1 and not dist_path and not args.no_also and not bottom and not args.mixed_lengths:
             also = {}
             wanted = [x for x in args.also.split(",") if x]
+
+            def extra(name, fn, *fn_args):
+                """One extra run; a failure there is recorded in its own entry and never costs the headline line."""
+                try:
+                    also[name] = fn(*fn_args)
+                except (Exception, SystemExit) as err:  # noqa: BLE001
+                    also[name] = {"error": f"{type(err).__name__}: {err}"}
+                torch.cuda.empty_cache()
+
             engine.prof_enable(True)
             # order: the runs that reuse the resident arena first, then the ones that build their own
             if "bottom" in wanted:
-                also["bottom_m"] = also_bottom(engine, arena, args, n_total, lengths)
+                extra("bottom_m", also_bottom, engine, arena, args, n_total, lengths)
             if "fragani" in wanted:
-                also["fragment_ani"] = also_fragani(engine, arena, args, n_total, lengths)
+                extra("fragment_ani", also_fragani, engine, arena, args, n_total, lengths)
             engine.prof_enable(False)
             del out, sk_local, sk, counts, ident, cov
             arena = None
             torch.cuda.empty_cache()
             if "mixed" in wanted:
-                also["mixed_lengths"] = also_mixed(engine, args)
-                torch.cuda.empty_cache()
+                extra("mixed_lengths", also_mixed, engine, args)
             if "n10000" in wanted:
-                also["n10000_one_gpu"] = also_n10000(engine, args)
-                torch.cuda.empty_cache()
+                extra("n10000_one_gpu", also_n10000, engine, args)
             result["also"] = also
     if dist_path:
         dist.barrier()

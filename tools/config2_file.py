@@ -20,6 +20,7 @@ from pyani_plus_amd.synth import RATES  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 length = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
 ingest = sys.argv[3] if len(sys.argv) > 3 else "json"
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 rng = np.random.default_rng(20260802)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 roots = rng.integers(0, 4, size=(8, length), dtype=np.uint8)
@@ -38,7 +39,7 @@ with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
             handle.write(b"\n".join(text[i : i + 100_000].tobytes() for i in range(0, length, 100_000)))
             handle.write(b"\n")
     print(f"wrote {n} FASTA files ({n * length / 1e9:.2f} Gb) in {time.perf_counter() - t0:.1f} s", flush=True)
-    for rep in range(2):
+    for rep in range(reps):
         db = Path(tmp) / f"run{rep}.sqlite"
         t0 = time.perf_counter()
         timings = {}
