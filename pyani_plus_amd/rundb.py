@@ -321,13 +321,30 @@ def cache_matrices(conn, run: Run, hashes: list[str], identity, cov_query, is_nu
         f"df_{key}": pd.DataFrame(data=mat, index=hashes, columns=hashes, dtype=float).to_json(orient="split")
         for key, mat in mats.items()
     }
-    conn.execute(
-        "UPDATE runs SET df_identity=?, df_cov_query=?, df_aln_length=?, df_sim_errors=?, df_hadamard=? WHERE run_id=?",
-        (out["df_identity"], out["df_cov_query"], out["df_aln_length"], out["df_sim_errors"], out["df_hadamard"],
-         run.run_id),
-    )
-    conn.commit()
+    _store_matrix_cache(conn, run, out)
     return out
+
+
+def _store_matrix_cache(conn, run: Run, out: dict[str, str]) -> bool:
+    """``runs.df_*`` hold the matrices as JSON text (db_orm.py:442-465).  SQLite refuses a value of more than
+    10^9 bytes (SQLITE_MAX_LENGTH), which a 10 000 x 10 000 matrix exceeds (about 1.3 GB of text) -- in the
+    reference just as here.  The comparisons table is complete either way; the cache columns then stay NULL, which
+    the reference treats as "not cached yet" (db_orm.py:393-405)."""
+    try:
+        conn.execute(
+            "UPDATE runs SET df_identity=?, df_cov_query=?, df_aln_length=?, df_sim_errors=?, df_hadamard=? WHERE run_id=?",
+            (out["df_identity"], out["df_cov_query"], out["df_aln_length"], out["df_sim_errors"], out["df_hadamard"],
+             run.run_id),
+        )
+    except (sqlite3.DataError, OverflowError) as err:
+        logging.getLogger("pyani_plus_amd").warning(
+            "matrix cache of run %d not stored (%s): %d genomes give JSON strings beyond SQLite's 10^9-byte limit",
+            run.run_id, err, len(run.fasta_hashes),
+        )
+        conn.rollback()
+        return False
+    conn.commit()
+    return True
 
 
 def cache_comparisons(conn, run: Run) -> dict[str, str]:
@@ -355,12 +372,7 @@ def cache_comparisons(conn, run: Run) -> dict[str, str]:
         f"df_{key}": pd.DataFrame(data=mat, index=hashes, columns=hashes, dtype=float).to_json(orient="split")
         for key, mat in mats.items()
     }
-    conn.execute(
-        "UPDATE runs SET df_identity=?, df_cov_query=?, df_aln_length=?, df_sim_errors=?, df_hadamard=? WHERE run_id=?",
-        (out["df_identity"], out["df_cov_query"], out["df_aln_length"], out["df_sim_errors"], out["df_hadamard"],
-         run.run_id),
-    )
-    conn.commit()
+    _store_matrix_cache(conn, run, out)
     return out
 
 
