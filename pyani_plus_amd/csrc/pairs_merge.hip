@@ -39,9 +39,7 @@ __global__ __launch_bounds__(kThreads) void merge_count_kernel(const uint64_t *_
   const uint64_t *__restrict__ b = hashes + off[s];
   const uint32_t na = (uint32_t)(off[q + 1] - off[q]), nb = (uint32_t)(off[s + 1] - off[s]);
   uint32_t c = 0;
-  if (q == s) {
-    c = (lane == 0) ? na : 0;
-  } else if (na && nb) {
+  if (na && nb) {  // the diagonal is merged like any other pair: this kernel is the independent check of the bit-row path
     const uint32_t total = na + nb;
     const uint32_t per = (total + 63u) / 64u;
     const uint32_t d0 = min(lane * per, total), d1 = min(d0 + per, total);
