@@ -111,3 +111,49 @@ def test_run_driver_end_to_end_on_synthetic_fasta_files(tmp_path):
         if i_val is not None:
             assert i_val == ident[qi, si] and c_val == cov[qi, si]  # full precision in the comparisons table
     conn.close()
+
+
+def test_batched_front_end_with_prefetch_and_direct_ingest_on_gpu(tmp_path):
+    """SURVEY.md 8f rows 1 and 2 on the device: the files go through several loader batches (background prefetch,
+    pinned arenas, streamed upload) and the database is filled by the direct route; sketches equal the oracle, the
+    database equals the one the JSON route writes."""
+    import gzip
+
+    import numpy as np
+
+    import oracle
+    from pyani_plus_amd.synth import arena_to_ascii, synth_arena_numpy
+
+    n, scaled = 14, 100
+    arena = synth_arena_numpy(n, [90_000 + 7_000 * g for g in range(n)], n_species=2)
+    indir = tmp_path / "genomes"
+    indir.mkdir()
+    seqs = [arena_to_ascii(arena, g) for g in range(n)]
+    paths = []
+    for g, seq in enumerate(seqs):
+        text = b">g%d\n" % g + b"\n".join(seq[i : i + 70] for i in range(0, len(seq), 70)) + b"\n"
+        path = indir / (f"g{g:02d}.fa.gz" if g % 4 == 1 else f"g{g:02d}.fa")
+        path.write_bytes(gzip.compress(text) if g % 4 == 1 else text)
+        paths.append(path)
+    # ~3 files per batch: five batches, the loader of batch i+1 runs while batch i is on the device
+    batches = list(sourmash_hip.sketch_fasta_batches(LOGGER, sorted(paths), kmersize=K, scaled=scaled, batch_bases=300_000))
+    assert len(batches) >= 4 and sum(len(b[0]) for b in batches) == n
+    by_path = {p: mins for batch_paths, _infos, sketches in batches for p, mins in zip(batch_paths, sketches)}
+    for g, path in enumerate(paths):
+        assert np.array_equal(by_path[path], oracle.sketch_seq(seqs[g], K, scaled)), path.name
+    timings = {}
+    rundb.run_sourmash_hip(indir, tmp_path / "direct.sqlite", cache=tmp_path / "c1", scaled=scaled, temp=tmp_path, ingest="direct", timings=timings)
+    rundb.run_sourmash_hip(indir, tmp_path / "json.sqlite", cache=tmp_path / "c2", scaled=scaled, temp=tmp_path)
+
+    def dump(db):
+        conn = sqlite3.connect(db)
+        rows = conn.execute("SELECT query_hash, subject_hash, identity, cov_query FROM comparisons ORDER BY 1, 2").fetchall()
+        dfs = conn.execute("SELECT status, df_identity, df_cov_query, df_hadamard FROM runs").fetchall()
+        conn.close()
+        return rows, dfs
+
+    assert dump(tmp_path / "direct.sqlite") == dump(tmp_path / "json.sqlite")
+    assert len(dump(tmp_path / "direct.sqlite")[0]) == n * n and "insert_rows" in timings
+    # the signature files written by both runs are the same bytes apart from the cache directory in no field
+    for sig_file in (tmp_path / "c1" / f"sourmash_k={K}_scaled={scaled}").glob("*.sig"):
+        assert sig_file.read_bytes() == (tmp_path / "c2" / sig_file.parent.name / sig_file.name).read_bytes()

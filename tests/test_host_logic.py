@@ -297,6 +297,29 @@ def test_backend_failure_and_save_failure_follow_the_reference_conventions(tmp_p
     assert rc == sourmash_hip.RECORDING_FAILED == 2
 
 
+def test_strict_ani_threaded_symmetric_equals_single_thread():
+    """pa_ani_host on the host pool, with one pow per ordered pair for a square block, gives the very doubles of the
+    plain single-threaded two-pow form (the reference's arithmetic)."""
+    from pyani_plus_amd.engine import ani_host
+
+    rng = np.random.default_rng(5)
+    n = 257
+    sizes = rng.integers(50, 6000, n).astype(np.uint64)
+    counts = rng.integers(0, 50, (n, n)).astype(np.uint32)
+    counts = np.minimum(counts, counts.T)
+    counts[rng.random((n, n)) < 0.6] = 0
+    counts = np.minimum(counts, counts.T)
+    np.fill_diagonal(counts, sizes.astype(np.uint32))
+    ref = ani_host(counts, sizes, sizes, 31, symmetric=False, threads=1)
+    for kwargs in ({"symmetric": True, "threads": 0}, {"symmetric": False, "threads": 7}, {"symmetric": True, "threads": 3}):
+        got = ani_host(counts, sizes, sizes, 31, **kwargs)
+        assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got)), kwargs
+    o_ident, o_cov, o_null = oracle.ani(counts, sizes, sizes, 31)
+    assert np.array_equal(ref[2], o_null) and np.array_equal(ref[0][~o_null], o_ident[~o_null]) and np.array_equal(ref[1][~o_null], o_cov[~o_null])
+    with pytest.raises(_capi.HipBackendError, match="square"):
+        ani_host(counts[:3], sizes[:3], sizes, 31, symmetric=True)
+
+
 def test_fastani_output_conventions():
     """What fastANI prints, as the reference parses it (pyani_plus/methods/fastani.py:98-120): six significant
     digits, and a line only when the kept fragments cover minFraction of the shorter genome."""
