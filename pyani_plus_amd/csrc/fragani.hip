@@ -728,11 +728,12 @@ struct EvalShared {
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
   uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
   uint32_t *ent;       // [kRefCap + 4] the stretch in (rank, reference-only before match) order, one packed word each:
-                       //   bits 0-8 index in the stretch, 9-18 rank among the query hashes, 19 the hash is one of them,
-                       //   20-29 index of the previous occurrence of the same hash + 1 (0: before the stretch)
+                       //   bits 0-6 first lane (window start) that keeps the entry, 7-13 how many more lanes do,
+                       //   14-23 rank among the query hashes, 24 the hash is one of them
+  uint16_t *xe16;      // [64] per lane: where its window ends inside the stretch
 };
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap) {
-  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + kRefCap * 2u + (kRefCap + 4u) * 4u;
+  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + kRefCap * 2u + (kRefCap + 4u) * 4u + 128u;
 }
 __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap) {
   EvalShared sh;
@@ -743,6 +744,7 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
   sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are even: the 32-bit array below stays aligned (to 16 bytes)
   sh.ent = reinterpret_cast<uint32_t *>(sh.ref_w + kRefCap);
+  sh.xe16 = reinterpret_cast<uint16_t *>(sh.ent + kRefCap + 4u);
   return sh;
 }
 
@@ -984,17 +986,41 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         }
         const uint32_t wbase = __shfl(ww[0], 0, 64);
         __syncthreads();
-        // ranks among the fragment's hashes, duplicate links and window ids of the stretch; buckets of the counting sort
+        // window ids of the stretch, then -- per lane -- where its window ends inside the stretch and whether the
+        // stretch holds all of it.  Lanes in front of the stretch end at 0, lanes without a start at n: the ends are
+        // non-decreasing over the lanes, which is what lets an entry name the lanes that keep it as one range.
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint32_t x = (uint32_t)q * 64u + lane;
+          if (x < n) {
+            const uint32_t dw = ww[q] - wbase;
+            sh.ref_w[x] = (uint16_t)(dw > 0xfffeu ? 0xffffu : dw);  // far beyond any window of this stretch
+          }
+        }
+        __syncthreads();
+        const uint32_t xb = b - base;  // meaningful for lanes from first_lane on
+        uint32_t xe = lane < first_lane ? 0u : n;
+        bool covered = false;
+        if (has && lane >= first_lane) {
+          const uint32_t target = wp + count_windows - wbase;
+          uint32_t lo = min(xb, n), hi = n;
+          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)sh.ref_w[mid] < target) lo = mid + 1; else hi = mid; }
+          xe = lo;
+          covered = xe < n || base + n == m1;
+        }
+        sh.xe16[lane] = (uint16_t)xe;
+        // ranks among the fragment's hashes and the lanes that keep each minimizer; buckets of the counting sort
         const uint32_t n_keys = 2u * (s + 1u);
         uint16_t *bucket = reinterpret_cast<uint16_t *>(sh.cnt);  // 2 (s + 1) 16-bit counters in the 4 (s_cap + 64) bytes
         for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;
         __syncthreads();
         uint32_t key[kPer], packed_ent[kPer];
-        // ranks of the lane's kPer minimizers among the fragment's hashes: the binary searches advance together, one
-        // halving step for all of them at a time, so the LDS reads of a step are in flight at once
-        uint32_t rank[kPer];
+        // ranks of the lane's kPer minimizers among the fragment's hashes, and the first lane whose window still holds
+        // each of them: the binary searches advance together, one halving step for all of them at a time, so the LDS
+        // reads of a step are in flight at once
+        uint32_t rank[kPer], l0[kPer];
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) rank[q] = 0;
+        for (int q = 0; q < kPer; ++q) { rank[q] = 0; l0[q] = 0; }
         for (uint32_t half = 256; half > 0; half >>= 1) {  // s <= kQMax = 512: positions 0 .. s
 #pragma unroll
           for (int q = 0; q < kPer; ++q) {
@@ -1006,6 +1032,18 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         for (int q = 0; q < kPer; ++q) {  // half = 256 down to 1 reaches at most 511: one more step for rank 512
           if (rank[q] + 1u <= s && sh.qh[rank[q]] < hh[q]) rank[q] += 1u;
         }
+        for (uint32_t half = 32; half > 0; half >>= 1) {  // l0 = number of lanes whose window ends at or before x (0 .. 63 here)
+#pragma unroll
+          for (int q = 0; q < kPer; ++q) {
+            const uint32_t x = (uint32_t)q * 64u + lane, idx = l0[q] + half;
+            if ((uint32_t)sh.xe16[idx - 1] <= x) l0[q] = idx;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint32_t x = (uint32_t)q * 64u + lane;
+          if ((uint32_t)sh.xe16[l0[q]] <= x) l0[q] += 1u;  // the step to 64: no window holds the entry
+        }
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
@@ -1014,11 +1052,14 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
           if (x < n) {
             const uint32_t r = rank[q];
             const bool is_match = r < s && sh.qh[r] == hh[q];
+            // kept by lane l iff its window holds the entry (l >= l0, start at or before x) as the first occurrence of
+            // its hash (the previous one lies before the start)
             const uint32_t prev1 = pp[q] >= (int32_t)base ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
-            const uint32_t dw = ww[q] - wbase;
-            sh.ref_w[x] = (uint16_t)(dw > 0xfffeu ? 0xffffu : dw);  // far beyond any window of this stretch
+            uint32_t lane_lo = max(l0[q], prev1 + first_lane), lane_hi = min(63u, x + first_lane);
+            uint32_t span = 0;
+            if (lane_lo > lane_hi) lane_lo = 64u; else span = lane_hi - lane_lo;
             key[q] = 2u * r + (is_match ? 1u : 0u);
-            packed_ent[q] = x | (r << 9) | (is_match ? 1u << 19 : 0u) | (prev1 << 20);
+            packed_ent[q] = lane_lo | (span << 7) | (r << 14) | (is_match ? 1u << 24 : 0u);
           }
         }
         // stable order is not needed: entries of one key are interchangeable in the union walk
@@ -1046,19 +1087,8 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
           const uint32_t x = (uint32_t)q * 64u + lane;
           if (x < n) sh.ent[bucket[key[q]] + slot[q]] = packed_ent[q];
         }
-        if (lane < 4) sh.ent[n + lane] = 0x3ff001ffu;  // padding of the last 16-byte read: an entry no window keeps
+        if (lane < 4) sh.ent[n + lane] = 64u;  // padding of the last 16-byte read: an entry no lane keeps
         __syncthreads();
-        // every pending lane: where its window ends inside the stretch, and whether the stretch holds all of it
-        const uint32_t xb = b - base;  // meaningful for pending lanes (b >= base)
-        uint32_t xe = 0;
-        bool covered = false;
-        if (pending) {
-          const uint32_t target = wp + count_windows - wbase;
-          uint32_t lo = xb, hi = n;
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)sh.ref_w[mid] < target) lo = mid + 1; else hi = mid; }
-          xe = lo;
-          covered = xe < n || base + n == m1;
-        }
         const bool first_uncovered = __shfl((int)covered, (int)first_lane, 64) == 0;
         uint32_t f_shared = 0;
         bool done_now = pending && covered;
@@ -1083,11 +1113,11 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
             const uint32_t es[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const uint32_t e = es[q], x = e & 0x1ffu, r = (e >> 9) & 0x3ffu, prev1 = e >> 20;
-              const bool mine = walking && x >= xb && x < xe && prev1 <= xb;  // in the window, first occurrence of its hash there
+              const uint32_t e = es[q], r = (e >> 14) & 0x3ffu;
+              const bool mine = walking && lane - (e & 0x7fu) <= ((e >> 7) & 0x7fu);  // one of the lanes that keep the entry
               const bool fits = r + k < s;
-              f_shared += (mine && fits && (e & (1u << 19))) ? 1u : 0u;
-              k += (mine && fits && !(e & (1u << 19))) ? 1u : 0u;
+              f_shared += (mine && fits && (e & (1u << 24))) ? 1u : 0u;
+              k += (mine && fits && !(e & (1u << 24))) ? 1u : 0u;
               walking = walking && !(mine && !fits);
             }
           }
