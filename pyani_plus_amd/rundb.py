@@ -313,6 +313,9 @@ def cache_matrices(conn, run: Run, hashes: list[str], identity, cov_query, is_nu
 
     assert hashes == sorted(hashes)
     n = len(hashes)
+    if _matrix_cache_too_big(n):
+        _store_matrix_cache(conn, run, None)
+        return {}
     ident = np.where(is_null, np.nan, identity)
     cov = np.where(is_null, np.nan, cov_query)
     nan = np.full((n, n), np.nan)
@@ -325,12 +328,20 @@ def cache_matrices(conn, run: Run, hashes: list[str], identity, cov_query, is_nu
     return out
 
 
-def _store_matrix_cache(conn, run: Run, out: dict[str, str]) -> bool:
+def _matrix_cache_too_big(n: int) -> bool:
+    """A cached matrix is about 13 characters per cell ("0.9997081124,"): beyond ~7.5e7 cells its JSON text passes
+    SQLite's 10^9-byte value limit, so formatting it would be wasted work."""
+    return n * n * 13 > 950_000_000
+
+
+def _store_matrix_cache(conn, run: Run, out: dict[str, str] | None) -> bool:
     """``runs.df_*`` hold the matrices as JSON text (db_orm.py:442-465).  SQLite refuses a value of more than
     10^9 bytes (SQLITE_MAX_LENGTH), which a 10 000 x 10 000 matrix exceeds (about 1.3 GB of text) -- in the
     reference just as here.  The comparisons table is complete either way; the cache columns then stay NULL, which
     the reference treats as "not cached yet" (db_orm.py:393-405)."""
     try:
+        if out is None:
+            raise sqlite3.DataError("not attempted")
         conn.execute(
             "UPDATE runs SET df_identity=?, df_cov_query=?, df_aln_length=?, df_sim_errors=?, df_hadamard=? WHERE run_id=?",
             (out["df_identity"], out["df_cov_query"], out["df_aln_length"], out["df_sim_errors"], out["df_hadamard"],
@@ -354,6 +365,9 @@ def cache_comparisons(conn, run: Run) -> dict[str, str]:
     hashes = sorted(a.genome_hash for a in run.fasta_hashes)
     index = {h: i for i, h in enumerate(hashes)}
     n = len(hashes)
+    if _matrix_cache_too_big(n):
+        _store_matrix_cache(conn, run, None)
+        return {}
     mats = {k: np.full((n, n), np.nan, float) for k in ("identity", "cov_query", "aln_length", "sim_errors")}
     rows = conn.execute(
         "SELECT c.query_hash, c.subject_hash, c.identity, c.cov_query, c.aln_length, c.sim_errors FROM comparisons c "
