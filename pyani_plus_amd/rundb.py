@@ -470,6 +470,12 @@ def run_sourmash_hip(  # noqa: PLR0913
 
     logger = logger or logging.getLogger("pyani_plus_amd")
     fasta = Path(fasta)
+    if not 1 <= int(kmersize) <= 32:  # before any file is read
+        sourmash_hip.log_sys_exit(logger, f"{sourmash_hip.METHOD} supports k-mer sizes 1 to 32, not {kmersize}")
+    if int(scaled) < 1:
+        sourmash_hip.log_sys_exit(logger, f"scaled must be a positive integer, not {scaled}")
+    if ingest not in {"json", "direct"}:
+        sourmash_hip.log_sys_exit(logger, f"ingest must be 'json' or 'direct', not {ingest!r}")
     fasta_names = check_fasta(logger, fasta)
     tool = sourmash_hip.get_sourmash_hip()
     conn = connect_to_db(database)

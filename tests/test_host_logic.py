@@ -407,6 +407,11 @@ def test_driver_rejects_duplicates_and_bad_gzip(tmp_path):
         rundb.run_sourmash_hip(d, tmp_path / "y.sqlite", engine=OracleEngine())
     with pytest.raises(SystemExit, match="No FASTA input genomes"):
         rundb.run_sourmash_hip(tmp_path, tmp_path / "z.sqlite", engine=OracleEngine())
+    # parameters are checked before any file is read (the reference passes any --kmersize on, public_cli_args.py:229)
+    with pytest.raises(SystemExit, match="k-mer sizes 1 to 32"):
+        rundb.run_sourmash_hip(d, tmp_path / "k.sqlite", kmersize=33, engine=OracleEngine())
+    with pytest.raises(SystemExit, match="ingest must be"):
+        rundb.run_sourmash_hip(d, tmp_path / "k.sqlite", ingest="csv", engine=OracleEngine())
 
 
 def test_synthetic_generator_roundtrip():
