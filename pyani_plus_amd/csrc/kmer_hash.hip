@@ -11,10 +11,11 @@
 // bitmap flags (one bit per block: the block or the 32 positions before it hold
 // an invalid position) -- a handful per genome -- so the kernel streams the
 // packed bases and nothing else.
-// The kernel is integer-VALU bound (12 64-bit multiplies + ~170 other VALU per
-// window against 0.375 byte of HBM input), so there is no LDS tiling of the
-// input; LDS only stages the rare survivors (1 in `scaled`) so that the global
-// append is one atomic per workgroup and the stores are coalesced.
+// The kernel is integer-VALU bound (8 arithmetic 64-bit multiplies + ~60 other
+// VALU per window against 0.25 byte of HBM input; VALUBusy 105 % by counters), so
+// there is no LDS tiling of the input; LDS holds the first-multiply tables and
+// stages the rare survivors (1 in `scaled`) so that the global append is one
+// atomic per workgroup and the stores are coalesced.
 #include <cstdlib>
 #include <type_traits>
 
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_kernel(
       // bases as stored (base j at bits 2j: already the byte order murmur wants), and R, their reverse
       // complement (reverse the order of the 2-bit groups, flip the bits).  The window ending at block
       // position e is K groups of F starting at group e + 33 - K and, as its reverse complement, K groups of
-      // R starting at group 63 - e.  Both are funnel shifts by compile-time amounts -- no rolling registers,
-      // no warm-up over the K-1 preceding bases, no dependency from one window to the next.  And because
+      // R starting at group 63 - e.  Both are funnel shifts -- no rolling registers, no warm-up over the
+      // K-1 preceding bases, no dependency from one window to the next.  And because
       // the MSB-first (lexicographic) form of one strand is the complement of the LSB-first form of the
       // other, "forward <= reverse complement" in lexicographic order is simply F-window <= R-window.
       uint32_t fw[8] = {pw.x, pw.y, cur.x, cur.y, cur.z, cur.w, 0u, 0u};
