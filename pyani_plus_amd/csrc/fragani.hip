@@ -927,54 +927,32 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       const uint32_t t = b_lo + (uint32_t)q * 64u + lane;
       wpv[q] = t < m1 ? mini_wpos[t] : 0xffffffffu;
     }
-    // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, ce + count_windows)
-    const uint32_t h_lo = hit_lower_bound(0, nh, c, cs), h_hi = hit_lower_bound(h_lo, nh, c, ce + count_windows);
-    // where they are densest: the window centred on their median.  For a true mapping the optimum and every start that
-    // can tie with it lie within a few dozen starts of that one.
-    uint32_t centre_w = first_hit_w;
-    if (h_hi > h_lo) {
-      const uint32_t hm = HW((h_lo + h_hi) >> 1);
-      centre_w = hm > count_windows / 2u ? hm - count_windows / 2u : 0u;
-    }
-    centre_w = min(max(centre_w, cs), ce);
     uint32_t b_hi = 0xffffffffu, at = 0xffffffffu;
 #pragma unroll
     for (int q = 0; q < kStartBatch; ++q) {
-      const uint64_t over = __ballot(wpv[q] > ce), reach = __ballot(wpv[q] >= centre_w);
+      const uint64_t over = __ballot(wpv[q] > ce), reach = __ballot(wpv[q] >= first_hit_w);
       if (over && b_hi == 0xffffffffu) b_hi = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(over);
       if (reach && at == 0xffffffffu) at = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(reach);
     }
     if (b_hi == 0xffffffffu) b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + 1u);  // a range of more than 512 starts
-    if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, centre_w);
+    if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
     if (b_lo >= b_hi) return;
-    if (at >= b_hi) at = b_hi - 1u;
-    // The starts are evaluated 64 at a time (one per lane).  The grid of groups is laid so that the centre start sits
-    // in the middle of its group: the starts that matter then fall into one group instead of straddling two.
-    uint32_t org = b_lo;
-    {
-      uint32_t shift = (96u - ((at - b_lo) & 63u)) & 63u;
-      shift = min(shift, b_lo - contig_mini_off[c]);  // never in front of the contig's first minimizer
-      if (shift) {
-        org = b_lo - shift;
-#pragma unroll
-        for (int q = 0; q < kStartBatch; ++q) {
-          const uint32_t t = org + (uint32_t)q * 64u + lane;
-          wpv[q] = (t >= b_lo && t < m1) ? mini_wpos[t] : 0xffffffffu;
-        }
-      }
-    }
     int32_t c_best = -1;
     uint32_t c_first = 0, c_last = 0;
-    const uint32_t n_groups = (b_hi - org + 63u) / 64u;
+    const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
     // A start matters only if its window can hold min_shared minimizers of the fragment (less is never reported) and
-    // reach the best so far.  The centre group goes first and sets the bar the others are pruned against.
+    // reach the best so far.  The group holding the candidate's first seed hit goes first -- for a true mapping the
+    // window that starts there is at or next to the optimum -- and sets the bar the other groups are pruned against:
+    // first per group (seed hits between its first start and the end of its last window), then per start.
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
-    const uint32_t g_first = (at - org) / 64u;
+    // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, ce + count_windows)
+    const uint32_t h_lo = hit_lower_bound(0, nh, c, cs), h_hi = hit_lower_bound(h_lo, nh, c, ce + count_windows);
+    const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
       const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
-      const uint32_t sb = org + g * 64u;
+      const uint32_t sb = b_lo + g * 64u;
       const uint32_t b = sb + lane;
-      const bool has = b >= b_lo && b < b_hi;
+      const bool has = b < b_hi;
       uint32_t wp = 0u;
       if (g < (uint32_t)kStartBatch) {
 #pragma unroll
