@@ -757,7 +757,7 @@ __device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t i
 }
 
 // one wave per (fragment, reference genome) segment
-__global__ __launch_bounds__(64) void map_segments_kernel(
+__global__ __launch_bounds__(64, 5) void map_segments_kernel(
     uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_a0,
     const uint32_t *__restrict__ seg_nh, uint32_t n_segs, bool presorted, const uint32_t *__restrict__ contig_genome,
     const uint32_t *__restrict__ genome_first_contig, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
@@ -893,6 +893,8 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
 
   int32_t best_shared = -1;
   uint32_t best_c = 0xffffffffu, best_p = 0;
+  uint32_t half0 = 1;
+  while (2u * half0 <= s) half0 *= 2u;
 
   // ---- L2 as Mashmap slides it: a window starts at every reference minimizer position of the candidate range
   // and holds the minimizers recorded in [start, start + count_windows); per candidate the position is the mean
@@ -919,20 +921,23 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         if (ge) { b_lo = base + (uint32_t)__builtin_ctzll(ge); break; }
       }
     }
-    // window ids of the first 512 starts in one batch of loads; they also say where the range ends
+    // window ids of the first 512 starts in one batch of loads: they say where the range ends and where the first seed
+    // hit sits (the groups re-read their own 64 window ids later: they are in L2 by then, and eight registers are free)
     constexpr int kStartBatch = 8;
-    uint32_t wpv[kStartBatch];
-#pragma unroll
-    for (int q = 0; q < kStartBatch; ++q) {
-      const uint32_t t = b_lo + (uint32_t)q * 64u + lane;
-      wpv[q] = t < m1 ? mini_wpos[t] : 0xffffffffu;
-    }
     uint32_t b_hi = 0xffffffffu, at = 0xffffffffu;
+    {
+      uint32_t wpv[kStartBatch];
 #pragma unroll
-    for (int q = 0; q < kStartBatch; ++q) {
-      const uint64_t over = __ballot(wpv[q] > ce), reach = __ballot(wpv[q] >= first_hit_w);
-      if (over && b_hi == 0xffffffffu) b_hi = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(over);
-      if (reach && at == 0xffffffffu) at = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(reach);
+      for (int q = 0; q < kStartBatch; ++q) {
+        const uint32_t t = b_lo + (uint32_t)q * 64u + lane;
+        wpv[q] = t < m1 ? mini_wpos[t] : 0xffffffffu;
+      }
+#pragma unroll
+      for (int q = 0; q < kStartBatch; ++q) {
+        const uint64_t over = __ballot(wpv[q] > ce), reach = __ballot(wpv[q] >= first_hit_w);
+        if (over && b_hi == 0xffffffffu) b_hi = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(over);
+        if (reach && at == 0xffffffffu) at = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(reach);
+      }
     }
     if (b_hi == 0xffffffffu) b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + 1u);  // a range of more than 512 starts
     if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
@@ -953,13 +958,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
       const uint32_t sb = b_lo + g * 64u;
       const uint32_t b = sb + lane;
       const bool has = b < b_hi;
-      uint32_t wp = 0u;
-      if (g < (uint32_t)kStartBatch) {
-#pragma unroll
-        for (int q = 0; q < kStartBatch; ++q) wp = g == (uint32_t)q ? wpv[q] : wp;
-      } else if (has) {
-        wp = mini_wpos[b];
-      }
+      const uint32_t wp = has ? mini_wpos[b] : 0u;
       int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a start must reach to matter (ties matter)
       if (bar < floor_bar) bar = floor_bar;
       // seed hits inside the start's window: every occurrence of every query hash is a hit, so no window shares more
@@ -974,30 +973,26 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         const uint32_t base = sb + first_lane;  // stretch = minimizers [base, base + n)
         const uint32_t n = min(m1 - base, kRefCap);
         constexpr int kPer = (int)(kRefCap / 64u);
-        uint32_t hh[kPer], ww[kPer];
+        uint32_t hh[kPer];
         int32_t pp[kPer];
+        const uint32_t wbase = mini_wpos[base];
+        __syncthreads();
+        // the stretch: hashes and duplicate links into registers, window ids (relative to the first) into LDS
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
           const bool in = x < n;
           hh[q] = in ? mini_hash[base + x] : 0u;
-          ww[q] = in ? mini_wpos[base + x] : 0xffffffffu;
           pp[q] = in ? prev_same[base + x] : -1;
-        }
-        const uint32_t wbase = __shfl(ww[0], 0, 64);
-        __syncthreads();
-        // window ids of the stretch, then -- per lane -- where its window ends inside the stretch and whether the
-        // stretch holds all of it.  Lanes in front of the stretch end at 0, lanes without a start at n: the ends are
-        // non-decreasing over the lanes, which is what lets an entry name the lanes that keep it as one range.
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-          const uint32_t x = (uint32_t)q * 64u + lane;
-          if (x < n) {
-            const uint32_t dw = ww[q] - wbase;
+          if (in) {
+            const uint32_t dw = mini_wpos[base + x] - wbase;
             sh.ref_w[x] = (uint16_t)(dw > 0xfffeu ? 0xffffu : dw);  // far beyond any window of this stretch
           }
         }
         __syncthreads();
+        // per lane: where its window ends inside the stretch and whether the stretch holds all of it.  Lanes in front
+        // of the stretch end at 0, lanes without a start at n: the ends are non-decreasing over the lanes, which is what
+        // lets an entry name the lanes that keep it as one range.
         const uint32_t xb = b - base;  // meaningful for lanes from first_lane on
         uint32_t xe = lane < first_lane ? 0u : n;
         bool covered = false;
@@ -1008,6 +1003,15 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
           xe = lo;
           covered = xe < n || base + n == m1;
         }
+        // only the part of the stretch that some window of this round reaches is ranked, sorted and walked
+        uint32_t n_use = 0;
+        {
+          uint32_t v = (pending && covered) ? xe : 0u;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+          n_use = v;
+        }
+        xe = min(xe, n_use);
         sh.xe16[lane] = (uint16_t)xe;
         // ranks among the fragment's hashes and the lanes that keep each minimizer; buckets of the counting sort
         const uint32_t n_keys = 2u * (s + 1u);
@@ -1021,22 +1025,18 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         uint32_t rank[kPer], l0[kPer];
 #pragma unroll
         for (int q = 0; q < kPer; ++q) { rank[q] = 0; l0[q] = 0; }
-        for (uint32_t half = 256; half > 0; half >>= 1) {  // s <= kQMax = 512: positions 0 .. s
+        for (uint32_t half = half0; half > 0; half >>= 1) {  // half0 = largest power of two <= s: positions 0 .. 2*half0 - 1 >= s
 #pragma unroll
           for (int q = 0; q < kPer; ++q) {
             const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
-            if (idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
+            if ((uint32_t)q * 64u + lane < n_use && idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
           }
-        }
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {  // half = 256 down to 1 reaches at most 511: one more step for rank 512
-          if (rank[q] + 1u <= s && sh.qh[rank[q]] < hh[q]) rank[q] += 1u;
         }
         for (uint32_t half = 32; half > 0; half >>= 1) {  // l0 = number of lanes whose window ends at or before x (0 .. 63 here)
 #pragma unroll
           for (int q = 0; q < kPer; ++q) {
             const uint32_t x = (uint32_t)q * 64u + lane, idx = l0[q] + half;
-            if ((uint32_t)sh.xe16[idx - 1] <= x) l0[q] = idx;
+            if (x < n_use && (uint32_t)sh.xe16[idx - 1] <= x) l0[q] = idx;
           }
         }
 #pragma unroll
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
           const uint32_t x = (uint32_t)q * 64u + lane;
           key[q] = 0;
           packed_ent[q] = 0;
-          if (x < n) {
+          if (x < n_use) {
             const uint32_t r = rank[q];
             const bool is_match = r < s && sh.qh[r] == hh[q];
             // kept by lane l iff its window holds the entry (l >= l0, start at or before x) as the first occurrence of
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
           slot[q] = 0;
-          if (x < n) slot[q] = atomicAdd_u16(bucket, key[q]);
+          if (x < n_use) slot[q] = atomicAdd_u16(bucket, key[q]);
         }
         __syncthreads();
         {  // exclusive scan of the buckets (n_keys <= 1026): each lane owns a run of them
@@ -1085,9 +1085,9 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
-          if (x < n) sh.ent[bucket[key[q]] + slot[q]] = packed_ent[q];
+          if (x < n_use) sh.ent[bucket[key[q]] + slot[q]] = packed_ent[q];
         }
-        if (lane < 4) sh.ent[n + lane] = 64u;  // padding of the last 16-byte read: an entry no lane keeps
+        if (lane < 4) sh.ent[n_use + lane] = 64u;  // padding of the last 16-byte read: an entry no lane keeps
         __syncthreads();
         const bool first_uncovered = __shfl((int)covered, (int)first_lane, 64) == 0;
         uint32_t f_shared = 0;
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(64) void map_segments_kernel(
           uint32_t k = 0;
           bool walking = done_now;
           const uint4 *ent4 = reinterpret_cast<const uint4 *>(sh.ent);
-          for (uint32_t j = 0; j < n && __any(walking); j += 4) {
+          for (uint32_t j = 0; j < n_use && __any(walking); j += 4) {
             const uint4 e4 = ent4[j >> 2];  // the same four entries for every lane: one broadcast read
             const uint32_t es[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
