@@ -140,7 +140,9 @@ PA_API uint64_t pa_max_hash(uint64_t scaled);
  * this bitmap flags (bit b of word w <-> block 64*w + b: the block, or the 32 positions before it, hold an
  * invalid position; block 0 always).  ceil(arena_bases / 4096) uint64 words.  Built once per arena (it
  * belongs to the layout like the mask itself); entry points that take `d_dirty` accept NULL and then build
- * it into a buffer of the context on every call, which costs one pass over the mask. */
+ * it into a buffer of the context on every call, which costs one pass over the mask.  Like the packers above it
+ * stands in for the FASTA reader inside `sourmash scripts singlesketch` (pyani_plus/methods/sourmash.py:67-83):
+ * where that tool skips k-mers with a non-ACGT residue as it meets them, this says where they can occur at all. */
 PA_API int pa_arena_dirty(pa_ctx *ctx, const uint32_t *d_mask, uint64_t arena_bases, uint64_t *d_dirty);
 
 /* ---- sketch: arena -> sorted unique hashes per genome ----
