@@ -500,18 +500,55 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
   uint32_t *hist = bk_lds + (uint64_t)wave * n_genomes;
   const uint32_t s = q_s[f];
   const uint32_t base = hit_off[f];
-  const uint32_t sub = lane & 7u, grp = lane >> 3;
   for (uint32_t g = lane; g < n_genomes; g += 64) hist[g] = 0;
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t i0 = 0; i0 < s; i0 += 8) {
-    const uint32_t i = i0 + grp;
-    if (i < s) {
-      const uint32_t id = q_id[(uint64_t)f * kQMax + i];
-      const uint32_t lo = post_start[id], n = post_start[id + 1] - lo;
-      for (uint32_t t = sub; t < n; t += 8)
-        atomicAdd(&hist[(uint32_t)(post_cw[lo + t] >> 44)], 1u);
-    }
+  // The posting list of every minimizer of the fragment, (first posting, length), into registers: lane l holds the
+  // lists of minimizers l, l + 64, ...  Two rounds of independent loads instead of a chain of three dependent ones
+  // per group of eight lists.
+  constexpr int kListRegs = kQMax / 64;
+  uint32_t lo_r[kListRegs], n_r[kListRegs];
+#pragma unroll
+  for (int j = 0; j < kListRegs; ++j) {
+    const uint32_t i = (uint32_t)j * 64u + lane;
+    uint32_t id = 0;
+    const bool in = i < s;
+    if (in) id = q_id[(uint64_t)f * kQMax + i];
+    lo_r[j] = in ? post_start[id] : 0u;
+    n_r[j] = in ? post_start[id + 1] - lo_r[j] : 0u;
   }
+  __builtin_amdgcn_wave_barrier();
+  // Sixteen lists per step, 32 lanes' worth of slots each: a lane has eight independent posting loads in flight (the
+  // kernel waits on memory 93 % of the time; what counts is how many loads are outstanding).  Lists longer than 32
+  // (repeat families) take further rounds of the same step.
+  constexpr int kLoads = 8;
+  auto for_each_posting = [&](auto &&visit) {
+    for (uint32_t i0 = 0; i0 < s; i0 += 2u * kLoads) {
+      uint32_t lo_blk = 0, n_blk = 0;  // this lane's pair of the 64 lists i0 belongs to
+#pragma unroll
+      for (int j = 0; j < kListRegs; ++j)
+        if ((i0 >> 6) == (uint32_t)j) { lo_blk = lo_r[j]; n_blk = n_r[j]; }
+      uint32_t lo_u[kLoads], n_u[kLoads];
+      uint32_t longest = 0;
+#pragma unroll
+      for (int u = 0; u < kLoads; ++u) {
+        const uint32_t i = i0 + 2u * (uint32_t)u + (lane >> 5);  // i0 is a multiple of 16: the 16 lists share one block of 64
+        lo_u[u] = __shfl(lo_blk, (int)(i & 63u), 64);
+        n_u[u] = __shfl(n_blk, (int)(i & 63u), 64);  // 0 past the fragment's last minimizer; every lane takes part in the shuffle
+        longest = max(longest, n_u[u]);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o, 64));
+      for (uint32_t r = 0; r < longest; r += 32) {
+        const uint32_t slot = r + (lane & 31u);
+        uint64_t cw[kLoads];
+#pragma unroll
+        for (int u = 0; u < kLoads; ++u) cw[u] = slot < n_u[u] ? post_cw[lo_u[u] + slot] : 0ull;
+#pragma unroll
+        for (int u = 0; u < kLoads; ++u)
+          if (slot < n_u[u]) visit(i0 + 2u * (uint32_t)u + (lane >> 5), cw[u]);
+      }
+    }
+  };
+  for_each_posting([&](uint32_t, uint64_t cw) { atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u); });
   __builtin_amdgcn_wave_barrier();
   // exclusive scan over the genomes; list the segments worth mapping
   const uint32_t mh = s ? tab_min_hits[s] : 0xffffffffu;
@@ -547,20 +584,11 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     carry += wave_sum(cnt);
   }
   __builtin_amdgcn_wave_barrier();
-  for (uint32_t i0 = 0; i0 < s; i0 += 8) {
-    const uint32_t i = i0 + grp;
-    if (i < s) {
-      const uint32_t id = q_id[(uint64_t)f * kQMax + i];
-      const uint32_t lo = post_start[id], n = post_start[id + 1] - lo;
-      const uint32_t qp = q_pos[(uint64_t)f * kQMax + i];
-      for (uint32_t t = sub; t < n; t += 8) {
-        const uint64_t cw = post_cw[lo + t];
-        const uint32_t slot = base + atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
-        keys[slot] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
-        vals[slot] = qp;
-      }
-    }
-  }
+  // (the query window id of a hit is no longer carried along: the mapping kernel slides over reference positions)
+  for_each_posting([&](uint32_t, uint64_t cw) {
+    const uint32_t slot = base + atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
+    keys[slot] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
+  });
 }
 
 // Chance matches with unrelated genomes still leave millions of listed segments with a handful of hits and
@@ -1505,6 +1533,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   }
   PA_TRY(upload(c, W.genome_first_contig, gfc));
   PA_HIP(hipStreamSynchronize(c->stream));
+  static const bool trace = getenv("PA_FRAGANI_TRACE") != nullptr;  // per-batch sizes on stderr
   static const bool force_sorted = [] {
     const char *v = getenv("PA_FRAGANI_HITS");
     return v && v[0] == 's';
@@ -1697,6 +1726,9 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
           PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters + 6, 4, hipMemcpyDeviceToHost, c->stream));
           PA_HIP(hipStreamSynchronize(c->stream));
           const uint32_t n_small = *reinterpret_cast<const uint32_t *>(c->h_pinned);
+          if (trace)
+            fprintf(stderr, "pa_fragani: genomes %u..%u: %u fragments, %llu seed hits, %u + %u listed segments, %u left "
+                            "after the tiny-segment filter\n", g0, g1, nf, (unsigned long long)n_hits, n_keep, n_large, n_small);
           launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall);
         }
         launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, n_large, (uint32_t)kHitCap);
