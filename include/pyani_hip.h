@@ -52,7 +52,8 @@ typedef enum pa_status {
   PA_E_HIP = -2,       /* HIP runtime error (message has the hipError string) */
   PA_E_NOMEM = -3,     /* host or device allocation failed */
   PA_E_CAPACITY = -4,  /* caller buffer too small; required size reported */
-  PA_E_NODEVICE = -5   /* no usable gfx950 device */
+  PA_E_NODEVICE = -5,  /* no usable gfx950 device */
+  PA_E_IO = -6         /* database I/O failed (pa_sqlite_insert_comparisons) */
 } pa_status;
 
 typedef struct pa_ctx pa_ctx;
@@ -288,6 +289,23 @@ PA_API int pa_write_comparisons_json(const char *path, const char *prefix, const
 PA_API int pa_append_comparisons_json(const char *path, const char *suffix, int file_has_rows,
                                const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
                                const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null);
+
+/* ---- comparison rows into the run database ----
+ * Replaces, for this method, the parent process's import of the column file: parse the JSON back and
+ * INSERT OR IGNORE one row per comparison through the ORM (pyani_plus/private_cli.py:507-614,
+ * pyani_plus/db_orm.py:1076).  The n_queries x n_subjects matrices (row = query) are bound to one prepared
+ * INSERT OR IGNORE INTO comparisons (query_hash, subject_hash, configuration_id, identity, aln_length, sim_errors,
+ * cov_query, uname_*) and stepped in query-major order inside one transaction on a connection of the call's own;
+ * where is_null, identity and cov_query are NULL; aln_length and sim_errors always are (as in
+ * pyani_plus/private_cli.py:1866-1880).  *rows_inserted = rows that were not already present.  The database must
+ * exist with the reference's schema and must not be locked by another connection.  Uses the system's
+ * libsqlite3.so.0 through dlopen; PA_E_IO if that is missing or any SQLite call fails (nothing is committed). */
+PA_API int pa_sqlite_insert_comparisons(const char *database, int64_t configuration_id, const char *uname_system,
+                                        const char *uname_release, const char *uname_machine,
+                                        const char *const *query_hashes, uint32_t n_queries,
+                                        const char *const *subject_hashes, uint32_t n_subjects,
+                                        const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null,
+                                        uint64_t *rows_inserted);
 
 /* ---- in-library HIP-event timing of the kernels (bench.py roofline) ----
  * Phases are timed with hipEvents on the context's stream when enabled. */

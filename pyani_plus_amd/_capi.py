@@ -18,6 +18,7 @@ LIB_PATH = _PKG / "_lib" / "libpyani_hip.so"
 ABI_VERSION = 2
 PA_OK = 0
 PA_E_CAPACITY = -4
+PA_E_IO = -6
 PA_PAIRS_AUTO, PA_PAIRS_BITROW, PA_PAIRS_MERGE, PA_PAIRS_BITROW_HASH = 0, 1, 2, 3
 PA_ALIGN_BASES = 64
 PROF_PHASES = {"kmer_hash": 0, "sketch_sort": 1, "pair_dict": 2, "pair_count": 3, "ani": 4, "frag_index": 5, "frag_seed": 6, "frag_map": 7}
@@ -102,6 +103,10 @@ SIGNATURES: dict[str, tuple] = {
     "pa_append_comparisons_json": (
         C.c_int,
         [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp],
+    ),
+    "pa_sqlite_insert_comparisons": (
+        C.c_int,
+        [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp, _u64p],
     ),
     "pa_prof_enable": (C.c_int, [_vp, C.c_int]),
     "pa_prof_reset": (C.c_int, [_vp]),

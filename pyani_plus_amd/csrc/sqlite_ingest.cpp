@@ -1,0 +1,162 @@
+// sqlite_ingest.cpp -- comparison rows from the result matrices straight into the run database.
+//
+// "Next" row 1 of SURVEY.md section 8(f).  In the reference every comparison travels as a Python dict
+// through a JSON file, is parsed back by the parent process and reaches SQLite through SQLAlchemy's
+// INSERT OR IGNORE (pyani_plus/private_cli.py:507-614, pyani_plus/db_orm.py:1076).  Here the rows are bound
+// from the N x N matrices and stepped through one prepared statement: no per-row Python objects, which is
+// what the executemany form of rundb.ingest_matrices spends most of its two microseconds per row on.
+//
+// The image carries libsqlite3.so.0 (the library Python's own sqlite3 module links) but not its header, so
+// the dozen entry points used here are declared by hand -- the public, stable C API of SQLite 3 -- and
+// resolved with dlopen at the first call.  Without the library the call fails with PA_E_IO and
+// rundb falls back on Python's sqlite3 module (same statement, same rows).
+#include <dlfcn.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <type_traits>
+
+#include "../../include/pyani_hip.h"
+
+void pa_set_error(const char *fmt, ...);
+
+namespace {
+
+struct sqlite3;
+struct sqlite3_stmt;
+constexpr int kSqliteOk = 0, kSqliteDone = 101, kOpenReadWrite = 0x2;
+using destructor_t = void (*)(void *);
+
+struct Api {
+  void *handle = nullptr;
+  int (*open_v2)(const char *, sqlite3 **, int, const char *) = nullptr;
+  int (*close)(sqlite3 *) = nullptr;
+  int (*exec)(sqlite3 *, const char *, int (*)(void *, int, char **, char **), void *, char **) = nullptr;
+  int (*prepare_v2)(sqlite3 *, const char *, int, sqlite3_stmt **, const char **) = nullptr;
+  int (*bind_text)(sqlite3_stmt *, int, const char *, int, destructor_t) = nullptr;
+  int (*bind_int64)(sqlite3_stmt *, int, long long) = nullptr;
+  int (*bind_double)(sqlite3_stmt *, int, double) = nullptr;
+  int (*bind_null)(sqlite3_stmt *, int) = nullptr;
+  int (*step)(sqlite3_stmt *) = nullptr;
+  int (*reset)(sqlite3_stmt *) = nullptr;
+  int (*finalize)(sqlite3_stmt *) = nullptr;
+  int (*busy_timeout)(sqlite3 *, int) = nullptr;
+  int (*total_changes)(sqlite3 *) = nullptr;
+  const char *(*errmsg)(sqlite3 *) = nullptr;
+  bool ok = false;
+};
+
+const Api &api() {
+  static Api a;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    a.handle = dlopen("libsqlite3.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!a.handle) return;
+    bool all = true;
+    auto sym = [&](auto &fn, const char *name) {
+      fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(a.handle, name));
+      all = all && fn != nullptr;
+    };
+    sym(a.open_v2, "sqlite3_open_v2");
+    sym(a.close, "sqlite3_close");
+    sym(a.exec, "sqlite3_exec");
+    sym(a.prepare_v2, "sqlite3_prepare_v2");
+    sym(a.bind_text, "sqlite3_bind_text");
+    sym(a.bind_int64, "sqlite3_bind_int64");
+    sym(a.bind_double, "sqlite3_bind_double");
+    sym(a.bind_null, "sqlite3_bind_null");
+    sym(a.step, "sqlite3_step");
+    sym(a.reset, "sqlite3_reset");
+    sym(a.finalize, "sqlite3_finalize");
+    sym(a.busy_timeout, "sqlite3_busy_timeout");
+    sym(a.total_changes, "sqlite3_total_changes");
+    sym(a.errmsg, "sqlite3_errmsg");
+    a.ok = all;
+  });
+  return a;
+}
+
+constexpr const char *kInsert =
+    "INSERT OR IGNORE INTO comparisons (query_hash, subject_hash, configuration_id, identity, aln_length, "
+    "sim_errors, cov_query, uname_system, uname_release, uname_machine) VALUES (?,?,?,?,?,?,?,?,?,?)";
+
+}  // namespace
+
+extern "C" int pa_sqlite_insert_comparisons(const char *database, int64_t configuration_id, const char *uname_system,
+                                            const char *uname_release, const char *uname_machine,
+                                            const char *const *query_hashes, uint32_t n_queries,
+                                            const char *const *subject_hashes, uint32_t n_subjects,
+                                            const double *identity, const double *cov_query, const uint8_t *is_null,
+                                            uint64_t *rows_inserted) {
+  if (rows_inserted) *rows_inserted = 0;
+  if (!database || !uname_system || !uname_release || !uname_machine || (n_queries && !query_hashes) ||
+      (n_subjects && !subject_hashes) || ((uint64_t)n_queries * n_subjects && (!identity || !cov_query || !is_null))) {
+    pa_set_error("pa_sqlite_insert_comparisons: null argument");
+    return PA_E_INVALID;
+  }
+  const Api &a = api();
+  if (!a.ok) {
+    pa_set_error("pa_sqlite_insert_comparisons: libsqlite3.so.0 could not be loaded (%s)", a.handle ? "missing symbol" : dlerror());
+    return PA_E_IO;
+  }
+  sqlite3 *db = nullptr;
+  if (a.open_v2(database, &db, kOpenReadWrite, nullptr) != kSqliteOk) {
+    pa_set_error("pa_sqlite_insert_comparisons: cannot open %s: %s", database, db ? a.errmsg(db) : "out of memory");
+    if (db) a.close(db);
+    return PA_E_IO;
+  }
+  auto fail = [&](const char *what) {
+    pa_set_error("pa_sqlite_insert_comparisons: %s: %s", what, a.errmsg(db));
+    a.exec(db, "ROLLBACK", nullptr, nullptr, nullptr);
+    a.close(db);
+    return PA_E_IO;
+  };
+  a.busy_timeout(db, 30000);
+  // synchronous=OFF lasts as long as this connection: the rows are re-derivable (the tile files are on disk)
+  if (a.exec(db, "PRAGMA synchronous=OFF; PRAGMA cache_size=-1048576; BEGIN IMMEDIATE", nullptr, nullptr, nullptr) != kSqliteOk)
+    return fail("begin");
+  sqlite3_stmt *st = nullptr;
+  if (a.prepare_v2(db, kInsert, -1, &st, nullptr) != kSqliteOk) return fail("prepare");
+  const destructor_t kStatic = nullptr;  // SQLITE_STATIC: the strings outlive the statement
+  const int before = a.total_changes(db);
+  bool bad = false;
+  bad |= a.bind_int64(st, 3, configuration_id) != kSqliteOk;
+  bad |= a.bind_null(st, 5) != kSqliteOk;  // aln_length and sim_errors are never set by this method
+  bad |= a.bind_null(st, 6) != kSqliteOk;  // (pyani_plus/private_cli.py:1866-1880)
+  bad |= a.bind_text(st, 8, uname_system, -1, kStatic) != kSqliteOk;
+  bad |= a.bind_text(st, 9, uname_release, -1, kStatic) != kSqliteOk;
+  bad |= a.bind_text(st, 10, uname_machine, -1, kStatic) != kSqliteOk;
+  uint64_t stepped = 0;
+  for (uint32_t q = 0; q < n_queries && !bad; ++q) {
+    // bindings survive sqlite3_reset: the query hash is bound once per matrix row
+    bad |= a.bind_text(st, 1, query_hashes[q], -1, kStatic) != kSqliteOk;
+    const uint64_t row = (uint64_t)q * n_subjects;
+    for (uint32_t s = 0; s < n_subjects && !bad; ++s) {
+      bad |= a.bind_text(st, 2, subject_hashes[s], -1, kStatic) != kSqliteOk;
+      if (is_null[row + s]) {
+        bad |= a.bind_null(st, 4) != kSqliteOk;
+        bad |= a.bind_null(st, 7) != kSqliteOk;
+      } else {
+        bad |= a.bind_double(st, 4, identity[row + s]) != kSqliteOk;
+        bad |= a.bind_double(st, 7, cov_query[row + s]) != kSqliteOk;
+      }
+      bad |= a.step(st) != kSqliteDone;
+      a.reset(st);
+      ++stepped;
+    }
+  }
+  if (bad) {
+    a.finalize(st);
+    char what[64];
+    snprintf(what, sizeof(what), "insert of row %llu", (unsigned long long)stepped);
+    return fail(what);
+  }
+  a.finalize(st);
+  if (a.exec(db, "COMMIT", nullptr, nullptr, nullptr) != kSqliteOk) return fail("commit");
+  if (rows_inserted) *rows_inserted = (uint64_t)(uint32_t)(a.total_changes(db) - before);
+  a.close(db);
+  return PA_OK;
+}

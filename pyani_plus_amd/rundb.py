@@ -272,16 +272,63 @@ INSERT_COMPARISON = (
 )
 
 
+def _database_file(conn) -> str | None:
+    """Path of the connection's main database, or None for an in-memory / temporary one."""
+    for _seq, name, path in conn.execute("PRAGMA database_list"):
+        if name == "main":
+            return path or None
+    return None
+
+
+def ingest_matrices_native(conn, run: Run, queries: list[str], subjects: list[str], identity, cov_query, is_null) -> int | None:
+    """``ingest_matrices`` through ``pa_sqlite_insert_comparisons`` (one prepared statement stepped from C on a
+    connection of its own).  Returns the number of comparisons handled, or None when the native route does not
+    apply (in-memory database, libsqlite3.so.0 not loadable) -- the caller then uses Python's sqlite3 module."""
+    import ctypes as C
+    import platform
+
+    from . import _capi
+
+    path = _database_file(conn)
+    if path is None:
+        return None
+    nq, ns = len(queries), len(subjects)
+    if nq == 0 or ns == 0:
+        return 0
+    uname = platform.uname()
+    identity = np.ascontiguousarray(identity, dtype=np.float64)
+    cov_query = np.ascontiguousarray(cov_query, dtype=np.float64)
+    null = np.ascontiguousarray(is_null, dtype=np.uint8)
+    assert identity.shape == (nq, ns) == cov_query.shape == null.shape
+    q_arr = (C.c_char_p * nq)(*[q.encode() for q in queries])
+    s_arr = (C.c_char_p * ns)(*[s.encode() for s in subjects])
+    conn.commit()  # the call opens its own connection: nothing of ours may hold the write lock
+    inserted = C.c_uint64()
+    status = _capi.load_library().pa_sqlite_insert_comparisons(
+        path.encode(), run.configuration_id, uname.system.encode(), uname.release.encode(), uname.machine.encode(),
+        q_arr, nq, s_arr, ns, identity.ctypes.data, cov_query.ctypes.data, null.ctypes.data, C.byref(inserted),
+    )  # fmt: skip
+    if status == _capi.PA_E_IO and "libsqlite3" in _capi.last_error():
+        return None
+    _capi.check(status, "pa_sqlite_insert_comparisons")
+    return nq * ns
+
+
 def ingest_matrices(conn, run: Run, queries: list[str], subjects: list[str], identity, cov_query, is_null, *,
-                    chunk_rows: int = 1_000_000) -> int:
+                    chunk_rows: int = 1_000_000, native: bool = True) -> int:
     """Comparison rows straight from the result matrices (the reference goes through one
     Python dict per row, a JSON file and its re-parse: pyani_plus/private_cli.py:1863-1888, 507-614).
 
     Rows go in query-major with ascending subjects -- the order of the UNIQUE(query_hash, subject_hash,
-    configuration_id) index when both lists are sorted, so the index grows by appends -- in chunks of
+    configuration_id) index when both lists are sorted, so the index grows by appends.  With ``native`` the rows
+    are stepped from C (``ingest_matrices_native``); otherwise, or when that route does not apply, in chunks of
     ``chunk_rows`` through one ``executemany`` each."""
     import platform
 
+    if native:
+        done = ingest_matrices_native(conn, run, queries, subjects, identity, cov_query, is_null)
+        if done is not None:
+            return done
     uname = platform.uname()
     cid = run.configuration_id
     nq, ns = len(queries), len(subjects)

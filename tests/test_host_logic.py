@@ -394,6 +394,58 @@ def test_direct_ingest_writes_the_same_database_as_the_json_route(name, tmp_path
     assert dump(tmp_path / "json.sqlite")[0] == [(*r[:2], r[2], *r[3:]) for r in dump(tmp_path / "direct.sqlite")[0]]
 
 
+def test_native_row_insert_equals_the_python_one(tmp_path):
+    """pa_sqlite_insert_comparisons (prepared statement stepped from C) against sqlite3.executemany: same rows in
+    the same order, NULLs where is_null, INSERT OR IGNORE semantics on a second call, loud failure on a bad path."""
+    import ctypes as C
+    import hashlib
+    import sqlite3
+
+    from pyani_plus_amd import _capi
+
+    n = 37
+    hashes = sorted(hashlib.md5(str(i).encode()).hexdigest() for i in range(n))
+    rng = np.random.default_rng(5)
+    ident, cov, null = rng.random((n, n)), rng.random((n, n)), rng.random((n, n)) < 0.2
+    ident[0, 0], cov[0, 1] = 1.0, 5e-324
+
+    class RunStub:
+        configuration_id = 0
+
+    dumps = {}
+    for native in (True, False):
+        conn = rundb.connect_to_db(tmp_path / f"{native}.sqlite")
+        RunStub.configuration_id = rundb.db_configuration(conn, "sourmash-hip", "libpyani_hip", "0.1.0", kmersize=31, extra="scaled=1000").configuration_id
+        conn.commit()
+        assert rundb.ingest_matrices(conn, RunStub, hashes, hashes, ident, cov, null, native=native) == n * n
+        query = ("SELECT comparison_id, query_hash, subject_hash, configuration_id, identity, aln_length, sim_errors, cov_query, "
+                 "cov_subject, uname_system, uname_release, uname_machine FROM comparisons ORDER BY comparison_id")
+        dumps[native] = conn.execute(query).fetchall()
+        # every pair is there already: nothing is added, nothing fails
+        assert rundb.ingest_matrices(conn, RunStub, hashes[:5], hashes, ident[:5] * 0.5, cov[:5], null[:5], native=native) == 5 * n
+        assert conn.execute(query).fetchall() == dumps[native]
+        conn.close()
+    assert dumps[True] == dumps[False] and len(dumps[True]) == n * n
+    assert [r[4] for r in dumps[True][:2]] == [None if null[0, 0] else 1.0, None if null[0, 1] else ident[0, 1]]
+    # an in-memory database has no file another connection could open: the Python route serves it
+    mem = sqlite3.connect(":memory:")
+    mem.executescript(rundb.SCHEMA)
+    assert rundb.ingest_matrices_native(mem, RunStub, hashes, hashes, ident, cov, null) is None
+    assert rundb.ingest_matrices(mem, RunStub, hashes, hashes, ident, cov, null) == n * n
+    assert mem.execute("SELECT COUNT(*) FROM comparisons").fetchone()[0] == n * n
+    # failures are reported, not swallowed
+    lib = _capi.load_library()
+    arr = (C.c_char_p * 1)(b"a")
+    one = np.zeros(1)
+    status = lib.pa_sqlite_insert_comparisons(str(tmp_path / "absent" / "x.sqlite").encode(), 1, b"s", b"r", b"m", arr, 1, arr, 1,
+                                              one.ctypes.data, one.ctypes.data, np.zeros(1, np.uint8).ctypes.data, None)
+    assert status == _capi.PA_E_IO and "cannot open" in _capi.last_error()
+    (tmp_path / "empty.sqlite").write_bytes(b"")
+    status = lib.pa_sqlite_insert_comparisons(str(tmp_path / "empty.sqlite").encode(), 1, b"s", b"r", b"m", arr, 1, arr, 1,
+                                              one.ctypes.data, one.ctypes.data, np.zeros(1, np.uint8).ctypes.data, None)
+    assert status == _capi.PA_E_IO and "no such table" in _capi.last_error()
+
+
 def test_driver_rejects_duplicates_and_bad_gzip(tmp_path):
     d = tmp_path / "in"
     d.mkdir()
