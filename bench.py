@@ -132,9 +132,14 @@ def cpu_baseline(engine, arena, sk, args, n_total: int, lengths: list[int]) -> d
     import oracle
     from pyani_plus_amd.synth import arena_to_ascii, device_arena_to_host
 
-    cores = len(os.sched_getaffinity(0))
-    # enough genomes to keep every thread busy twice over, bounded (<= 512 genomes = 2.5 GB of text)
-    n_samp = args.cpu_sample_genomes or max(2, min(arena.n_genomes, max(2 * cores, 16), 512))
+    # threads that can run at once: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 CPUs to a
+    # container that is allowed 16 CPUs' worth of time; 256 busy threads there are throttled, not faster)
+    from pyani_plus_amd import _capi
+
+    visible = len(os.sched_getaffinity(0))
+    cores = max(1, min(visible, int(_capi.load_library().pa_host_cpu_budget())))
+    # enough genomes to keep every thread busy four times over, bounded (<= 512 genomes = 2.5 GB of text)
+    n_samp = args.cpu_sample_genomes or max(2, min(arena.n_genomes, max(4 * cores, 16), 512))
     sample = list(range(n_samp))
     seqs = _ascii_genomes(engine, arena, sample, lengths)
     if n_samp <= 4:  # tiny runs: also exercise the host-side unpacker
@@ -173,6 +178,7 @@ def cpu_baseline(engine, arena, sk, args, n_total: int, lengths: list[int]) -> d
         "value": n_total * n_total / est,
         "unit": "pairs/s",
         "cores": cores,
+        "cpus_visible": visible,
         "kind": "port",
         "sample": f"{n_samp} genomes ({sample_bases / 1e6:.0f} Mb) sketched + {n_pair}x{n_pair} sketch pairs+ANI with {cores} OpenMP threads "
         f"(oracle tuned scalar form); extrapolated to N={n_total}: N*{t_sketch:.4f}s + N^2*{t_pair * 1e6:.3f}us",

@@ -207,7 +207,7 @@ PA_API int pa_pair_dict_prepare(pa_ctx *ctx, const uint64_t *d_subject_hashes, u
  * pa_ani runs on the device (f64; <= 1 ulp from libm);
  * pa_ani_host uses the host libm `pow`, which reproduces every reference
  * fixture bit for bit, and is what the JSON/DB boundary uses; rows are split over
- * n_threads host threads (0 = up to 64 of the cores), and with `symmetric` != 0 (square
+ * n_threads host threads (0 = pa_host_cpu_budget(), at most 64), and with `symmetric` != 0 (square
  * block, queries and subjects are the same genomes in the same order) one pow per
  * ordered pair is computed instead of two: (I/|S|)^(1/k) of (q,s) is cov_query of (s,q). */
 PA_API int pa_ani(pa_ctx *ctx, const uint32_t *d_counts, const uint64_t *d_off, uint32_t q0, uint32_t q1,
@@ -269,7 +269,7 @@ PA_API int64_t pa_fasta_records(const uint8_t *h_text, uint64_t n_text, uint64_t
  * File i = heads[i] + "h0,h1,..." + mids[i] + md5sum + tails[i], where the hashes are
  * h_mins[h_off[i] .. h_off[i+1]) in decimal and md5sum = md5(str(ksize) + concatenated decimals), sourmash's
  * checksum of a sketch.  The three text parts come from the caller (json.dumps of everything around the
- * `mins` list and the `md5sum` value).  Files are written to <path>.tmp and renamed; n_threads 0 = all cores. */
+ * `mins` list and the `md5sum` value).  Files are written to <path>.tmp and renamed; n_threads 0 = pa_host_cpu_budget(). */
 PA_API int pa_write_sigs(uint32_t n_files, const char *const *paths, const char *const *heads, const char *const *mids,
                          const char *const *tails, uint32_t ksize, const uint64_t *h_mins, const uint64_t *h_off,
                          uint32_t n_threads);
@@ -289,6 +289,12 @@ PA_API int pa_write_comparisons_json(const char *path, const char *prefix, const
 PA_API int pa_append_comparisons_json(const char *path, const char *suffix, int file_has_rows,
                                const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
                                const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null);
+
+/* Host threads worth starting: the CPUs the process may run on, capped by the cgroup CPU quota when there is one
+ * (the reference sizes its worker pools with len(os.sched_getaffinity(0)), pyani_plus/utils.py:199-214, which
+ * counts 256 on a box whose container is allowed 16 CPUs' worth of time).  The default of every n_threads = 0
+ * argument in this header. */
+PA_API uint32_t pa_host_cpu_budget(void);
 
 /* ---- comparison rows into the run database ----
  * Replaces, for this method, the parent process's import of the column file: parse the JSON back and

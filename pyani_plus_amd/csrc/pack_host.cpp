@@ -62,6 +62,8 @@ constexpr Lut kLut;
 
 }  // namespace
 
+extern "C" uint32_t pa_host_cpu_budget(void) { return pa_cpu_budget(); }
+
 extern "C" uint64_t pa_pack_bound(uint64_t n_text_bytes) { return (n_text_bytes / 64 + 1) * 64 + 64; }
 
 // Runs of set bits of an invalid-position mask, ascending (word scan: zero words cost one compare).
@@ -222,7 +224,7 @@ extern "C" int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, 
     return PA_E_INVALID;
   }
   const double inv_k = 1.0 / (double)k;
-  uint32_t nt = n_threads ? n_threads : std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+  uint32_t nt = n_threads ? n_threads : std::min<uint32_t>(pa_cpu_budget(), 64u);
   nt = std::max<uint32_t>(1u, std::min<uint32_t>(nt, (uint32_t)(((uint64_t)nq * ns) / 8192u + 1u)));
   nt = std::min(nt, std::max(1u, nq));
   // rows are dealt in small blocks through a shared counter: NULL-heavy rows cost nothing, dense ones a pow each

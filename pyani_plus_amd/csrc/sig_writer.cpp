@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/pyani_hip.h"
+#include "host_pool.h"
 #include "md5.h"
 
 void pa_set_error(const char *fmt, ...);
@@ -56,7 +57,7 @@ extern "C" int pa_write_sigs(uint32_t n_files, const char *const *paths, const c
     pa_set_error("pa_write_sigs: null argument");
     return PA_E_INVALID;
   }
-  if (n_threads == 0) n_threads = std::thread::hardware_concurrency();
+  if (n_threads == 0) n_threads = pa_cpu_budget();
   if (n_threads == 0) n_threads = 1;
   if (n_threads > n_files) n_threads = n_files;
   std::vector<int> status(n_threads, PA_OK);

@@ -124,7 +124,7 @@ def load_fasta_files(paths, threads: int = 0, *, pinned: bool = False) -> tuple[
     paths = [str(p) for p in paths]
     n = len(paths)
     if threads <= 0:
-        threads = len(os.sched_getaffinity(0))
+        threads = int(lib.pa_host_cpu_budget())  # CPUs of the affinity mask, capped by the cgroup quota
     arr = (C.c_char_p * max(n, 1))(*[p.encode() for p in paths])
     batch = C.c_void_p()
     check(lib.pa_fasta_batch_load(arr, n, threads, C.byref(batch)), "pa_fasta_batch_load")
