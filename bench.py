@@ -89,7 +89,18 @@ def launch_ranks(args) -> int:
             subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                              stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, text=rank == 0)
         )  # fmt: skip
-    out, _ = procs[0].communicate()
+    # A rank that dies (bad device index, out of memory) leaves the others waiting in the rendezvous or in a
+    # barrier: watch all of them and, when one has failed, end the ones this process started (by handle, not by name).
+    out = None
+    while out is None:
+        try:
+            out, _ = procs[0].communicate(timeout=1.0)
+        except subprocess.TimeoutExpired:
+            if any(p.poll() not in (None, 0) for p in procs[1:]):
+                time.sleep(5.0)  # let rank 0 report the failure itself if it can
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     line = None
     for cand in reversed((out or "").splitlines()):
