@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,8 +26,12 @@
 #include "../../include/pyani_hip.h"
 #include "host_pool.h"
 #include "md5.h"
+#include "md5_mb.h"
 
 void pa_set_error(const char *fmt, ...);
+int pa_pack_fasta_records(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask, uint64_t cap_bases,
+                          uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records, uint64_t *n_invalid,
+                          std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len);
 
 namespace {
 
@@ -154,35 +159,45 @@ std::string basename_of(const std::string &p) {
   return k == std::string::npos ? p : p.substr(k + 1);
 }
 
-// One file.  `buf`/`room`: the worker's slot for the file's bytes; raw/text: its scratch vectors for files that do
-// not fit the slot and for inflated text (reused from file to file).  `out_packed`/`out_mask`/`out_cap`: the
-// file's room in the batch slab (out_cap bases, 0 = none: the file keeps vectors of its own).
-void process(const std::string &path, FileResult &r, uint8_t *buf, size_t room, std::vector<uint8_t> &raw,
-             std::vector<uint8_t> &text, uint32_t *out_packed, uint32_t *out_mask, uint64_t out_cap) {
+// Step 1 of a file: its bytes.  `buf`/`room`: the worker's slot for them; raw: scratch for a file that does not fit
+// the slot; text: where inflated text goes (kept until the file is finished).  Returns false with status/message set.
+bool acquire(const std::string &path, FileResult &r, uint8_t *buf, size_t room, std::vector<uint8_t> &raw,
+             std::vector<uint8_t> &text, const uint8_t **data_out, size_t *n_out) {
   const uint8_t *data = nullptr;
   size_t n_data = 0;
-  if (!read_file(path, buf, room, raw, &data, &n_data, r.message)) { r.status = PA_E_INVALID; return; }
+  if (!read_file(path, buf, room, raw, &data, &n_data, r.message)) { r.status = PA_E_INVALID; return false; }
   r.gz = n_data >= 2 && data[0] == 0x1f && data[1] == 0x8b;
   const std::string name = basename_of(path);
   if (r.gz && !ends_with(path, ".gz")) {
     r.status = PA_E_INVALID;
     r.message = "No .gz ending, but " + name + " is gzip compressed";
-    return;
+    return false;
   }
   if (!r.gz && ends_with(path, ".gz")) {
     r.status = PA_E_INVALID;
     r.message = "Has .gz ending, but " + name + " is NOT gzip compressed";
-    return;
+    return false;
   }
   if (r.gz) {
-    if (!gunzip(data, n_data, text, r.message)) { r.status = PA_E_INVALID; r.message = name + ": " + r.message; return; }
+    if (!gunzip(data, n_data, text, r.message)) { r.status = PA_E_INVALID; r.message = name + ": " + r.message; return false; }
     data = text.data();
     n_data = text.size();
+  } else if (data == raw.data()) {
+    text.swap(raw);  // the scratch is reused by the next file of the group: keep these bytes
+    data = text.data();
   }
   r.n_text = n_data;
-  Md5 md5;
-  md5.update(data, n_data);
-  md5.hex(r.md5);
+  *data_out = data;
+  *n_out = n_data;
+  return true;
+}
+
+// Step 2 (after the checksum): first title, 2-bit arena and record table in one pass over the text.
+// `out_packed`/`out_mask`/`out_cap`: the file's room in the batch slab (out_cap bases, 0 = none: the file keeps
+// vectors of its own).
+void finish(const std::string &path, FileResult &r, const uint8_t *data, size_t n_data, uint32_t *out_packed,
+            uint32_t *out_mask, uint64_t out_cap) {
+  const std::string name = basename_of(path);
   // first title = description (db_orm.py:836-838): first line starting with '>'
   {
     size_t i = 0;
@@ -208,13 +223,11 @@ void process(const std::string &path, FileResult &r, uint8_t *buf, size_t room, 
     packed = r.own_packed.data();
     mask = r.own_mask.data();
   }
-  const int st = pa_pack_fasta(data, n_data, packed, mask, cap, &r.n_bases, &r.n_residues, &r.n_records, &r.n_invalid);
+  const int st = pa_pack_fasta_records(data, n_data, packed, mask, cap, &r.n_bases, &r.n_residues, &r.n_records, &r.n_invalid,
+                                       &r.rec_start, &r.rec_len);
   if (st != PA_OK) { r.status = st; r.message = name + ": packing failed"; return; }
   r.packed = packed;
   r.mask = mask;
-  r.rec_start.resize(r.n_records);
-  r.rec_len.resize(r.n_records);
-  if (r.n_records) pa_fasta_records(data, n_data, r.rec_start.data(), r.rec_len.data(), r.n_records);
   if (r.n_records == 0) {
     r.status = PA_E_INVALID;
     r.message = "File " + name + " is not recognised as a FASTA record";
@@ -252,28 +265,58 @@ int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fa
   }
   uint32_t nt = threads > 0 ? (uint32_t)threads : pa_cpu_budget();
   if (nt > n) nt = n ? n : 1u;
-  const size_t read_room = (size_t)((largest + 4095) & ~4095ull);  // one read slot per worker
+  // Files are taken in groups so that their checksums can be computed side by side (md5_mb.h: sixteen messages per
+  // AVX-512 register), largest files first: the lanes of a group then have similar lengths and the long files do
+  // not end up alone at the end of the batch.  A worker holds the bytes of its whole group: one read slot per lane,
+  // the group size reduced so that the slots stay within ~2 GiB.
+  const size_t read_room = (size_t)((largest + 4095) & ~4095ull);
+  uint32_t lanes = md5mb::have_avx512() ? 16u : 1u;
+  while (lanes > 1 && (uint64_t)read_room * lanes * nt > (2ull << 30)) lanes /= 2;
+  if ((uint64_t)n < (uint64_t)lanes * nt) lanes = std::max<uint32_t>(1u, (n + nt - 1) / nt);  // few files: spread them over the workers
+  std::vector<uint32_t> order(n);
+  for (uint32_t i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return slot_cap[x] > slot_cap[y]; });
   Slab reads;
-  if (!b->packed.alloc(slot_off[n] / 4) || !b->mask.alloc(slot_off[n] / 8) || !reads.alloc(read_room * nt)) {
+  if (!b->packed.alloc(slot_off[n] / 4) || !b->mask.alloc(slot_off[n] / 8) || !reads.alloc(read_room * lanes * nt)) {
     delete b;
     pa_set_error("pa_fasta_batch_load: cannot map %llu bytes of host memory",
-                 (unsigned long long)(slot_off[n] / 4 + slot_off[n] / 8 + read_room * nt));
+                 (unsigned long long)(slot_off[n] / 4 + slot_off[n] / 8 + read_room * lanes * nt));
     return PA_E_NOMEM;
   }
   std::atomic<uint32_t> next{0};
   HostPool::get().run(nt, [&](uint32_t worker, uint32_t) {
-    std::vector<uint8_t> raw, text;
-    uint8_t *buf = read_room ? reads.p + (size_t)worker * read_room : nullptr;
+    std::vector<uint8_t> raw;
+    std::vector<std::vector<uint8_t>> text(lanes);
+    std::vector<const uint8_t *> data(lanes);
+    std::vector<size_t> n_data(lanes);
+    std::vector<uint32_t> file(lanes);
+    const std::unique_ptr<char[][33]> hex(new char[lanes][33]);
     for (;;) {
-      const uint32_t i = next.fetch_add(1);
-      if (i >= n) break;
-      try {
-        process(p[i], b->files[i], buf, read_room, raw, text,
-                reinterpret_cast<uint32_t *>(b->packed.p + slot_off[i] / 4),
-                reinterpret_cast<uint32_t *>(b->mask.p + slot_off[i] / 8), slot_cap[i]);
-      } catch (const std::exception &e) {
-        b->files[i].status = PA_E_NOMEM;
-        b->files[i].message = std::string("exception while loading ") + p[i] + ": " + e.what();
+      const uint32_t g0 = next.fetch_add(lanes);
+      if (g0 >= n) break;
+      const uint32_t g1 = std::min(n, g0 + lanes);
+      uint32_t have = 0;
+      for (uint32_t q = g0; q < g1; ++q) {
+        const uint32_t i = order[q];
+        uint8_t *buf = read_room ? reads.p + ((size_t)worker * lanes + have) * read_room : nullptr;
+        try {
+          if (acquire(p[i], b->files[i], buf, read_room, raw, text[have], &data[have], &n_data[have])) file[have++] = i;
+        } catch (const std::exception &e) {
+          b->files[i].status = PA_E_NOMEM;
+          b->files[i].message = std::string("exception while loading ") + p[i] + ": " + e.what();
+        }
+      }
+      md5mb::md5_many(data.data(), n_data.data(), have, hex.get());
+      for (uint32_t l = 0; l < have; ++l) {
+        const uint32_t i = file[l];
+        memcpy(b->files[i].md5, hex[l], 33);
+        try {
+          finish(p[i], b->files[i], data[l], n_data[l], reinterpret_cast<uint32_t *>(b->packed.p + slot_off[i] / 4),
+                 reinterpret_cast<uint32_t *>(b->mask.p + slot_off[i] / 8), slot_cap[i]);
+        } catch (const std::exception &e) {
+          b->files[i].status = PA_E_NOMEM;
+          b->files[i].message = std::string("exception while loading ") + p[i] + ": " + e.what();
+        }
       }
     }
   });

@@ -7,7 +7,10 @@
 // " \t\r\n" are dropped from sequence lines.  Residues are case-insensitive;
 // anything outside ACGT becomes an invalid position, and one invalid position
 // is written between records so that no k-mer window spans two records.
+#include <immintrin.h>
+
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <algorithm>
@@ -100,40 +103,129 @@ extern "C" uint64_t pa_max_hash(uint64_t scaled) {
   return (uint64_t)(18446744073709551616.0 / (double)scaled);
 }
 
-extern "C" int pa_pack_fasta(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask,
-                             uint64_t cap_bases, uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records,
-                             uint64_t *n_invalid) {
-  if ((!h_text && n_text) || !h_packed || !h_mask || (cap_bases & 63)) {
-    pa_set_error("pa_pack_fasta: null buffer or capacity %llu not a multiple of 64", (unsigned long long)cap_bases);
-    return PA_E_INVALID;
+namespace {
+
+// ---- runs of plain ACGT/acgt, 32 or 16 characters at a time (AVX2) -------------------------------------------
+// A chunk whose characters are all ACGT in either case becomes 2 bits per base with a handful of vector
+// instructions (compare against the four letters, combine the codes with two multiply-adds); any other chunk --
+// N runs, IUPAC codes, blanks inside a line -- goes through the per-character table below, as every chunk does
+// on a CPU without AVX2.  The appended bits are what ArenaWriter::put would have produced one base at a time.
+__attribute__((target("avx2"))) inline bool codes32(const uint8_t *p, uint64_t *bits) {
+  const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(p));
+  const __m256i u = _mm256_and_si256(v, _mm256_set1_epi8((char)0xdf));  // fold case: only a letter or letter|0x20 folds to it
+  const __m256i is_c = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('C')), is_g = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('G')),
+                is_t = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('T')), is_a = _mm256_cmpeq_epi8(u, _mm256_set1_epi8('A'));
+  const __m256i valid = _mm256_or_si256(_mm256_or_si256(is_a, is_c), _mm256_or_si256(is_g, is_t));
+  if ((uint32_t)_mm256_movemask_epi8(valid) != 0xffffffffu) return false;
+  const __m256i code = _mm256_or_si256(_mm256_or_si256(_mm256_and_si256(is_c, _mm256_set1_epi8(1)), _mm256_and_si256(is_g, _mm256_set1_epi8(2))),
+                                       _mm256_and_si256(is_t, _mm256_set1_epi8(3)));
+  const __m256i pairs = _mm256_maddubs_epi16(code, _mm256_set1_epi16(0x0401));   // c0 + 4 c1 per 16-bit lane
+  const __m256i quads = _mm256_madd_epi16(pairs, _mm256_set1_epi32(0x00100001));  // + 16 (c2 + 4 c3): one byte per 4 bases
+  const __m256i gather = _mm256_shuffle_epi8(quads, _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                                                     0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+  *bits = (uint64_t)(uint32_t)_mm256_extract_epi32(gather, 0) | ((uint64_t)(uint32_t)_mm256_extract_epi32(gather, 4) << 32);
+  return true;
+}
+__attribute__((target("avx2"))) inline bool codes16(const uint8_t *p, uint32_t *bits) {
+  const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p));
+  const __m128i u = _mm_and_si128(v, _mm_set1_epi8((char)0xdf));
+  const __m128i is_c = _mm_cmpeq_epi8(u, _mm_set1_epi8('C')), is_g = _mm_cmpeq_epi8(u, _mm_set1_epi8('G')),
+                is_t = _mm_cmpeq_epi8(u, _mm_set1_epi8('T')), is_a = _mm_cmpeq_epi8(u, _mm_set1_epi8('A'));
+  const __m128i valid = _mm_or_si128(_mm_or_si128(is_a, is_c), _mm_or_si128(is_g, is_t));
+  if (_mm_movemask_epi8(valid) != 0xffff) return false;
+  const __m128i code = _mm_or_si128(_mm_or_si128(_mm_and_si128(is_c, _mm_set1_epi8(1)), _mm_and_si128(is_g, _mm_set1_epi8(2))),
+                                    _mm_and_si128(is_t, _mm_set1_epi8(3)));
+  const __m128i pairs = _mm_maddubs_epi16(code, _mm_set1_epi16(0x0401));
+  const __m128i quads = _mm_madd_epi16(pairs, _mm_set1_epi32(0x00100001));
+  const __m128i gather = _mm_shuffle_epi8(quads, _mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1));
+  *bits = (uint32_t)_mm_cvtsi128_si32(gather);
+  return true;
+}
+
+// 32 (16) valid bases at once: the bits go where put() would have put them, the mask gets zeros
+inline void put_valid32(ArenaWriter &w, uint64_t bits) {
+  const uint32_t sh = 2u * (uint32_t)(w.pos & 15), word = (uint32_t)(w.pos >> 4);
+  w.packed[word] = w.pw | (uint32_t)(bits << sh);
+  w.packed[word + 1] = (uint32_t)(bits >> (32u - sh));
+  w.pw = sh ? (uint32_t)(bits >> (64u - sh)) : 0u;
+  w.mask[w.pos >> 5] = w.mw;  // the 32 new positions complete this mask word and leave the next one empty so far
+  w.mw = 0;
+  w.pos += 32;
+}
+inline void put_valid16(ArenaWriter &w, uint32_t bits) {
+  const uint32_t sh = 2u * (uint32_t)(w.pos & 15), word = (uint32_t)(w.pos >> 4);
+  w.packed[word] = w.pw | (bits << sh);  // sh == 0: the word is complete and pw restarts at 0
+  w.pw = sh ? bits >> (32u - sh) : 0u;
+  if ((w.pos & 31) >= 16) { w.mask[w.pos >> 5] = w.mw; w.mw = 0; }
+  w.pos += 16;
+}
+
+// the leading run of whole clean chunks of [p, e): appended; returns how many characters that was
+__attribute__((target("avx2"))) size_t clean_run_avx2(ArenaWriter &w, const uint8_t *p, const uint8_t *e) {
+  const uint8_t *const p0 = p;
+  while (e - p >= 32 && w.pos + 32 <= w.cap) {
+    uint64_t bits;
+    if (!codes32(p, &bits)) break;
+    put_valid32(w, bits);
+    p += 32;
   }
+  while (e - p >= 16 && w.pos + 16 <= w.cap) {
+    uint32_t bits;
+    if (!codes16(p, &bits)) break;
+    put_valid16(w, bits);
+    p += 16;
+  }
+  return (size_t)(p - p0);
+}
+
+// the residues of one sequence line [p, e) (no line feed inside): the per-character rules of pa_pack_fasta
+template <bool kVector>
+inline void pack_line(ArenaWriter &w, const uint8_t *p, const uint8_t *e, uint64_t &residues, uint64_t &invalid) {
+  while (p < e) {
+    if constexpr (kVector) {
+      if (e - p >= 16) {
+        const size_t n = clean_run_avx2(w, p, e);
+        residues += n;
+        p += n;
+      }
+    }
+    // up to the end of the line, or (vector form) past the next character that is not a plain base: an N run or a
+    // blank interrupts a clean stretch, after it whole chunks are tried again
+    for (; p < e; ++p) {
+      const uint8_t code = kLut.v[*p];
+      if (code < 4) { w.put(code, 0); ++residues; continue; }
+      if (code == 4) { w.put(0, 1); ++residues; ++invalid; }
+      if (kVector && e - p > 32 && kLut.v[p[1]] < 4) { ++p; break; }
+    }
+  }
+}
+
+template <bool kVector>
+int pack_fasta_impl(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask, uint64_t cap_bases,
+                    uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records, uint64_t *n_invalid,
+                    std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len) {
   ArenaWriter w{h_packed, h_mask, cap_bases};
-  uint64_t residues = 0, records = 0, invalid = 0;
-  uint64_t i = 0;
+  uint64_t residues = 0, records = 0, invalid = 0, record_first_residue = 0;
+  const uint8_t *p = h_text, *const end = h_text + n_text;
   bool in_record = false;
-  while (i < n_text) {
-    if (h_text[i] == '>') {  // title line (we are at the start of a line)
-      if (in_record) w.put(0, 1);  // separator: windows never span records
+  while (p < end) {
+    const uint8_t *nl = static_cast<const uint8_t *>(memchr(p, '\n', (size_t)(end - p)));
+    const uint8_t *e = nl ? nl : end;
+    if (*p == '>') {  // title line (we are at the start of a line)
+      if (in_record) {
+        if (rec_len) rec_len->push_back(residues - record_first_residue);
+        w.put(0, 1);  // separator: windows never span records
+      }
       in_record = true;
       ++records;
-      while (i < n_text && h_text[i] != '\n') ++i;
-      if (i < n_text) ++i;
-      continue;
+      if (rec_start) rec_start->push_back(w.pos);  // positions count the one-position separators
+      record_first_residue = residues;
+    } else if (in_record) {  // a sequence line; text before the first record is ignored
+      pack_line<kVector>(w, p, e, residues, invalid);
     }
-    // a sequence line (or junk before the first record): consume to end of line
-    if (!in_record) {
-      while (i < n_text && h_text[i] != '\n') ++i;
-      if (i < n_text) ++i;
-      continue;
-    }
-    while (i < n_text) {
-      const uint8_t ch = h_text[i++];
-      const uint8_t code = kLut.v[ch];
-      if (code < 4) { w.put(code, 0); ++residues; }
-      else if (code == 4) { w.put(0, 1); ++residues; ++invalid; }
-      else if (ch == '\n') break;
-    }
+    p = nl ? nl + 1 : end;
   }
+  if (in_record && rec_len) rec_len->push_back(residues - record_first_residue);
   w.pad64();
   if (w.overflow) {
     pa_set_error("pa_pack_fasta: arena capacity %llu bases is too small (need %llu)", (unsigned long long)cap_bases,
@@ -146,6 +238,28 @@ extern "C" int pa_pack_fasta(const uint8_t *h_text, uint64_t n_text, uint32_t *h
   if (n_records) *n_records = records;
   if (n_invalid) *n_invalid = invalid;
   return PA_OK;
+}
+
+}  // namespace
+
+// pa_pack_fasta plus the record table of pa_fasta_records from the same pass (the FASTA loader's form)
+int pa_pack_fasta_records(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask, uint64_t cap_bases,
+                          uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records, uint64_t *n_invalid,
+                          std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len) {
+  if ((!h_text && n_text) || !h_packed || !h_mask || (cap_bases & 63)) {
+    pa_set_error("pa_pack_fasta: null buffer or capacity %llu not a multiple of 64", (unsigned long long)cap_bases);
+    return PA_E_INVALID;
+  }
+  static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("PA_PACK_SCALAR") == nullptr;
+  return avx2 ? pack_fasta_impl<true>(h_text, n_text, h_packed, h_mask, cap_bases, n_bases, n_residues, n_records, n_invalid, rec_start, rec_len)
+              : pack_fasta_impl<false>(h_text, n_text, h_packed, h_mask, cap_bases, n_bases, n_residues, n_records, n_invalid, rec_start, rec_len);
+}
+
+extern "C" int pa_pack_fasta(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask,
+                             uint64_t cap_bases, uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records,
+                             uint64_t *n_invalid) {
+  return pa_pack_fasta_records(h_text, n_text, h_packed, h_mask, cap_bases, n_bases, n_residues, n_records, n_invalid,
+                               nullptr, nullptr);
 }
 
 extern "C" int64_t pa_fasta_records(const uint8_t *h_text, uint64_t n_text, uint64_t *h_rec_start,

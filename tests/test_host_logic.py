@@ -554,6 +554,106 @@ def test_threaded_fasta_loader_matches_python_reader(tmp_path):
     assert np.array_equal(arena.genome_start, ref.genome_start) and arena.residues == ref.residues
 
 
+def _pack_truth(text: bytes):
+    """FASTA text -> (packed words, mask words, residues, records, invalid, record starts, record lengths) by the
+    rules of pyani_plus/utils.py:67-90, one character at a time in Python: the independent statement the vectorised
+    packer is held to."""
+    codes, bad, rec_start, rec_len = [], [], [], []
+    residues = invalid = 0
+    in_record = False
+    for line in text.split(b"\n"):
+        if line[:1] == b">":
+            if in_record:
+                codes.append(0)
+                bad.append(1)
+            in_record = True
+            rec_start.append(len(codes))
+            rec_len.append(0)
+            continue
+        if not in_record:
+            continue
+        for ch in line:
+            if ch in b" \t\r":
+                continue
+            residues += 1
+            rec_len[-1] += 1
+            code = b"ACGT".find(bytes([ch]).upper())
+            codes.append(max(code, 0))
+            bad.append(int(code < 0))
+            invalid += int(code < 0)
+    codes.append(0)
+    bad.append(1)
+    while len(codes) % 64:
+        codes.append(0)
+        bad.append(1)
+    c = np.array(codes, dtype=np.uint64).reshape(-1, 16)
+    packed = (c << (2 * np.arange(16, dtype=np.uint64))).sum(axis=1).astype(np.uint32)
+    m = np.array(bad, dtype=np.uint64).reshape(-1, 32)
+    mask = (m << np.arange(32, dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+    return packed, mask, residues, len(rec_start), invalid, rec_start, rec_len
+
+
+def test_vector_packer_equals_the_character_rules(tmp_path):
+    """The AVX2 chunks of pa_pack_fasta (32 / 16 clean bases at a time) against a character-by-character packer, on
+    texts built to break chunking: every line length around the chunk sizes, Ns and IUPAC codes, lower case, blanks,
+    CR LF, records of all sizes, text before the first record, no final line feed."""
+    import ctypes as C
+
+    from pyani_plus_amd.engine import load_fasta_files
+
+    lib = _capi.load_library()
+    rng = np.random.default_rng(11)
+    texts = []
+    for case in range(60):
+        parts = [b"junk before the first record\n"] if case % 7 == 0 else []
+        for rec in range(int(rng.integers(1, 5))):
+            parts.append(b">rec%d some title\n" % rec)
+            for _line in range(int(rng.integers(0, 9))):
+                n = int(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 47, 48, 60, 63, 64, 65, 70, 80, 95, 96, 97, 200, 1000]))
+                seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)].copy()
+                style = case % 5
+                if style == 1 and n:  # sprinkled non-bases
+                    at = rng.integers(0, n, max(1, n // 20))
+                    seq[at] = np.frombuffer(b"NnRYKM- \t*", dtype=np.uint8)[rng.integers(0, 10, len(at))]
+                if style == 2 and n > 40:  # an N run inside a clean line
+                    a = int(rng.integers(0, n - 30))
+                    seq[a : a + int(rng.integers(1, 30))] = ord("N")
+                if style == 3:  # lower case
+                    seq = np.where(rng.random(n) < 0.5, seq | 0x20, seq).astype(np.uint8)
+                parts.append(seq.tobytes() + (b"\r\n" if style == 4 else b"\n"))
+        text = b"".join(parts)
+        if case % 3 == 0 and text.endswith(b"\n"):
+            text = text[:-1]
+        texts.append(text)
+    for text in texts:
+        cap = int(lib.pa_pack_bound(len(text)))
+        packed, mask = np.full(cap // 16, 0xDEADBEEF, dtype=np.uint32), np.full(cap // 32, 0xDEADBEEF, dtype=np.uint32)
+        nb, nres, nrec, ninv = (C.c_uint64() for _ in range(4))
+        _capi.check(lib.pa_pack_fasta(text, len(text), packed.ctypes.data, mask.ctypes.data, cap, C.byref(nb), C.byref(nres),
+                                      C.byref(nrec), C.byref(ninv)), "pa_pack_fasta")
+        t_packed, t_mask, t_res, t_rec, t_inv, t_start, t_len = _pack_truth(text)
+        assert (nb.value, nres.value, nrec.value, ninv.value) == (16 * len(t_packed), t_res, t_rec, t_inv), text[:80]
+        assert np.array_equal(packed[: len(t_packed)], t_packed) and np.array_equal(mask[: len(t_mask)], t_mask), text[:80]
+        rs, rl = np.zeros(max(t_rec, 1), dtype=np.uint64), np.zeros(max(t_rec, 1), dtype=np.uint64)
+        assert lib.pa_fasta_records(text, len(text), rs.ctypes.data, rl.ctypes.data, t_rec) == t_rec
+        assert rs[:t_rec].tolist() == t_start and rl[:t_rec].tolist() == t_len
+    # the same texts as files through the loader (checksums side by side, record tables from the packing pass)
+    paths = []
+    for i, text in enumerate(texts):
+        paths.append(tmp_path / f"t{i:02d}.fasta")
+        paths[-1].write_bytes(text)
+    from tests.helpers import md5_hex
+
+    for threads in (1, 3):
+        infos, arena = load_fasta_files(paths, threads=threads)
+        assert [i.status for i in infos] == [0] * len(texts)
+        assert [i.md5 for i in infos] == [md5_hex(t) for t in texts]
+        ref = pack_genomes(texts)
+        assert np.array_equal(arena.packed, ref.packed) and np.array_equal(arena.mask, ref.mask)
+        assert np.array_equal(arena.contig_start, ref.contig_start) and np.array_equal(arena.contig_len, ref.contig_len)
+        assert np.array_equal(arena.contig_genome, ref.contig_genome) and arena.residues == ref.residues
+
+
 @pytest.mark.parametrize("name", list(FIXTURE_SETS))
 def test_manysearch_csv_export_equals_fixture_text(name, tmp_path):
     """All 15 columns of the reference's intermediate manysearch.csv, as text, from counts + sizes."""
