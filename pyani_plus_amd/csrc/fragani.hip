@@ -146,11 +146,20 @@ constexpr int kTile = kThreads * kPPT;        // 2048 positions per workgroup, o
 constexpr int kHalo = 128;                    // the first 128 are look-back (needs w <= 64)
 constexpr int kOwn = kTile - kHalo;
 
-template <int K, bool WRITE>
+// One pass: every workgroup hashes and winnows its tile once, then learns where its minimizers go from the
+// workgroups before it -- a chained scan with look-back (each publishes first the count of its own tile, then, once it
+// knows it, the count of everything up to and including itself; a workgroup adds up published tile counts backwards
+// until it meets such a running total).  Tiles are handed out by a ticket counter, so a workgroup only ever waits for
+// workgroups that started before it.  `look` holds one 64-bit word per tile: state (0 nothing yet, 1 tile count,
+// 2 running total) in the top two bits, the count below; `scalars`: [0] ticket, [1] total, [2] a wait ran out.
+constexpr uint64_t kLookTile = 1ULL << 62, kLookTotal = 2ULL << 62;
+constexpr uint32_t kLookSpinLimit = 1u << 24;
+
+template <int K>
 __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
     const uint64_t *__restrict__ contig_start, const uint32_t *__restrict__ contig_len, uint32_t n_contigs, int w,
-    uint32_t *__restrict__ block_counts, const uint32_t *__restrict__ block_offsets, uint32_t *__restrict__ out_hash,
+    unsigned long long *__restrict__ look, uint32_t *__restrict__ scalars, uint32_t cap, uint32_t *__restrict__ out_hash,
     uint32_t *__restrict__ out_wpos, uint32_t *__restrict__ out_contig) {
   static_assert(K >= 8 && K <= 16, "both k-mer registers are 32-bit");
   constexpr int kWords = (K + 7) / 8;
@@ -159,14 +168,18 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
   __shared__ uint32_t s_h[kTile];
   __shared__ int32_t s_mp[kTile];
   __shared__ uint32_t s_scan[kThreads / 64];
+  __shared__ uint32_t s_tile, s_before;
   const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_tile = atomicAdd(&scalars[0], 1u);
 #pragma unroll
   for (int j = 0; j < kWords; ++j) {
     const uint64_t cj = (j & 1) ? kC2 : kC1;
     s_lo[j][tid] = (uint64_t)ascii_group(tid, K - 8 * j) * cj;
     s_hi[j][tid] = (uint32_t)((uint64_t)ascii_group(tid, K - 8 * j - 4) * cj);
   }
-  const int64_t tile0 = (int64_t)blockIdx.x * kOwn - kHalo;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const int64_t tile0 = (int64_t)tile * kOwn - kHalo;
   const int64_t p0 = tile0 + (int64_t)tid * kPPT;
   __syncthreads();
 
@@ -274,19 +287,51 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     if ((uint32_t)q < wave) pre += s_scan[q];
     total += s_scan[q];
   }
-  if constexpr (!WRITE) {
-    if (tid == 0) block_counts[blockIdx.x] = total;
-  } else {
-    uint32_t o = block_offsets[blockIdx.x] + pre + wex;
+  // ---- minimizers of all tiles before this one
+  if (wave == 0) {
+    uint32_t before = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(&look[0], kLookTotal | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(&look[tile], kLookTile | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t at = (int64_t)tile - 1;  // lane l looks at tile at - l
+      uint32_t spins = 0;
+      for (;;) {
+        const int64_t idx = at - (int64_t)lane;
+        const uint64_t v = idx >= 0 ? __hip_atomic_load(&look[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kLookTotal;
+        const uint32_t state = (uint32_t)(v >> 62);
+        const uint64_t totals = __ballot(state == 2u), missing = __ballot(state == 0u);
+        const uint32_t stop = totals ? (uint32_t)__builtin_ctzll(totals) : 64u;  // first lane holding a running total
+        const uint64_t needed = stop >= 63u ? ~0ULL : ((2ULL << stop) - 1ULL);
+        if (missing & needed) {  // a tile in front has not published yet
+          if (++spins > kLookSpinLimit) { if (lane == 0) scalars[2] = 1u; break; }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        before += wave_sum(lane <= stop ? (uint32_t)v : 0u);
+        if (stop < 64u) break;
+        at -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&look[tile], kLookTotal | (uint64_t)(before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) {
+      s_before = before;
+      if (tile == gridDim.x - 1) scalars[1] = before + total;
+    }
+  }
+  __syncthreads();
+  uint32_t o = s_before + pre + wex;
 #pragma unroll
-    for (int j = 0; j < kPPT; ++j) {
-      if (!((flags >> j) & 1u)) continue;
+  for (int j = 0; j < kPPT; ++j) {
+    if (!((flags >> j) & 1u)) continue;
+    if (o < cap) {  // a run that overflows the estimate is repeated with the exact size
       const int x = (int)tid * kPPT + j;
       out_hash[o] = s_h[s_mp[x]];
       out_wpos[o] = local[j] - (uint32_t)w + 1u;
       out_contig[o] = cidx[j];
-      ++o;
     }
+    ++o;
   }
 }
 
@@ -1305,29 +1350,36 @@ template <int K>
 int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                    uint32_t n_contigs, int w, uint32_t *m_out) {
   const uint32_t blocks = ceil_div_u64(arena_bases, kOwn);
-  PA_TRY(W.block_counts.reserve((uint64_t)blocks * 4));
-  PA_TRY(W.block_offsets.reserve((uint64_t)blocks * 4));
+  PA_TRY(W.block_counts.reserve((uint64_t)blocks * 8));  // the look-back words of minimizer_kernel
   PA_TRY(W.scalars.reserve(64));
-  hipLaunchKernelGGL((minimizer_kernel<K, false>), dim3(blocks), dim3(kThreads), 0, c->stream, d_packed, d_mask,
-                     arena_bases, W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
-                     W.block_counts.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                     (uint32_t *)nullptr);
-  PA_TRY(pa_exclusive_scan_u32(c, W.block_counts.as<uint32_t>(), W.block_offsets.as<uint32_t>(), blocks,
-                               W.scalars.as<uint64_t>()));
-  PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
-  PA_HIP(hipStreamSynchronize(c->stream));
-  const uint64_t m = c->h_pinned[0];
-  PA_REQUIRE(m < (1ULL << 31), "fragment ANI: %llu minimizers exceed the 31-bit index space", (unsigned long long)m);
-  PA_TRY(W.mini_hash.reserve(m * 4 + 16));
-  PA_TRY(W.mini_wpos.reserve(m * 4 + 16));
-  PA_TRY(W.mini_contig.reserve(m * 4 + 16));
-  hipLaunchKernelGGL((minimizer_kernel<K, true>), dim3(blocks), dim3(kThreads), 0, c->stream, d_packed, d_mask,
-                     arena_bases, W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
-                     (uint32_t *)nullptr, W.block_offsets.as<uint32_t>(), W.mini_hash.as<uint32_t>(),
-                     W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>());
-  PA_HIP(hipGetLastError());
-  *m_out = (uint32_t)m;
-  return PA_OK;
+  // expected density of winnowed minimizers is 2 / (w + 1); the arrays are sized a quarter above that and the run is
+  // repeated with the exact size should a low-complexity data set need more
+  uint64_t cap = (uint64_t)((double)arena_bases * 2.5 / (double)(w + 1)) + (1u << 20);
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    PA_REQUIRE(cap < (1ULL << 31), "fragment ANI: room for %llu minimizers exceeds the 31-bit index space", (unsigned long long)cap);
+    PA_TRY(W.mini_hash.reserve(cap * 4 + 16));
+    PA_TRY(W.mini_wpos.reserve(cap * 4 + 16));
+    PA_TRY(W.mini_contig.reserve(cap * 4 + 16));
+    PA_HIP(hipMemsetAsync(W.block_counts.p, 0, (uint64_t)blocks * 8, c->stream));
+    PA_HIP(hipMemsetAsync(W.scalars.p, 0, 16, c->stream));
+    hipLaunchKernelGGL((minimizer_kernel<K>), dim3(blocks), dim3(kThreads), 0, c->stream, d_packed, d_mask, arena_bases,
+                       W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
+                       W.block_counts.as<unsigned long long>(), W.scalars.as<uint32_t>(), (uint32_t)cap,
+                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>());
+    PA_HIP(hipGetLastError());
+    PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 16, hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(c->h_pinned);
+    PA_REQUIRE(h[2] == 0, "fragment ANI: the minimizer scan gave up waiting for a tile (%u tiles)", blocks);
+    const uint64_t m = h[1];
+    if (m <= cap) {
+      *m_out = (uint32_t)m;
+      return PA_OK;
+    }
+    cap = m;
+  }
+  pa_set_error("fragment ANI: minimizer count changed between two runs over the same arena");
+  return PA_E_HIP;
 }
 
 int dispatch_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
