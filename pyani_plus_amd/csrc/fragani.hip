@@ -231,7 +231,25 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
   }
   __syncthreads();
 
-  // ---- winnowing minimum (rightmost on ties) for every position that can be asked about
+  // ---- winnowing minimum (rightmost on ties) for every position that can be asked about.  A window of w >= 9
+  // positions ending at x = 8 tid + j is the thread's own positions up to x (running minimum in registers), the whole
+  // groups of eight to the left of them (one minimum per group, computed once), and the tail of the group the window
+  // starts in: about 10 LDS reads per position instead of w.
+  __shared__ uint32_t s_gh[kThreads];
+  __shared__ uint16_t s_gp[kThreads];
+  {
+    const int x7 = (int)tid * kPPT + kPPT - 1;
+    uint32_t bh = s_h[x7];
+    int bp = x7;
+#pragma unroll
+    for (int y = x7 - 1; y > x7 - kPPT; --y) {
+      const uint32_t hy = s_h[y];
+      if (hy < bh) { bh = hy; bp = y; }
+    }
+    s_gh[tid] = bh;
+    s_gp[tid] = (uint16_t)bp;
+  }
+  __syncthreads();
   uint32_t c = 0;
   bool have_c = false;
   if (p0 >= 0 && (uint64_t)p0 < arena_bases) { c = contig_of(contig_start, n_contigs, (uint64_t)p0); have_c = true; }
@@ -249,9 +267,25 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
       if (loc < contig_len[c] && loc + 1 >= (uint64_t)w && s_h[x] != kSkip) {
         uint32_t best = s_h[x];
         mp = x;
-        for (int y = x - 1; y > x - w; --y) {
-          const uint32_t hy = s_h[y];
-          if (hy < best) { best = hy; mp = y; }
+        if (w > kPPT) {
+          const int a = x - w + 1, ga = a / kPPT;  // a >= 1: x >= kHalo / 2 and w <= 64
+          for (int y = x - 1; y >= (int)tid * kPPT; --y) {  // the thread's own positions left of x
+            const uint32_t hy = s_h[y];
+            if (hy < best) { best = hy; mp = y; }
+          }
+          for (int g = (int)tid - 1; g > ga; --g) {
+            const uint32_t hg = s_gh[g];
+            if (hg < best) { best = hg; mp = s_gp[g]; }
+          }
+          for (int y = ga * kPPT + kPPT - 1; y >= a; --y) {
+            const uint32_t hy = s_h[y];
+            if (hy < best) { best = hy; mp = y; }
+          }
+        } else {
+          for (int y = x - 1; y > x - w; --y) {
+            const uint32_t hy = s_h[y];
+            if (hy < best) { best = hy; mp = y; }
+          }
         }
         local[j] = (uint32_t)loc;
         cidx[j] = c;
