@@ -149,8 +149,8 @@ def cpu_baseline(engine, arena, sk, args, n_total: int, lengths: list[int]) -> d
 
     visible = len(os.sched_getaffinity(0))
     cores = max(1, min(visible, int(_capi.load_library().pa_host_cpu_budget())))
-    # enough genomes to keep every thread busy four times over, bounded (<= 512 genomes = 2.5 GB of text)
-    n_samp = args.cpu_sample_genomes or max(2, min(arena.n_genomes, max(4 * cores, 16), 512))
+    # enough genomes to keep every thread busy eight times over (about 13 CPU-seconds with the pair block), bounded (<= 512 genomes = 2.5 GB of text)
+    n_samp = args.cpu_sample_genomes or max(2, min(arena.n_genomes, max(8 * cores, 16), 512))
     sample = list(range(n_samp))
     seqs = _ascii_genomes(engine, arena, sample, lengths)
     if n_samp <= 4:  # tiny runs: also exercise the host-side unpacker
