@@ -1389,6 +1389,7 @@ int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint3
   // expected density of winnowed minimizers is 2 / (w + 1); the arrays are sized a quarter above that and the run is
   // repeated with the exact size should a low-complexity data set need more
   uint64_t cap = (uint64_t)((double)arena_bases * 2.5 / (double)(w + 1)) + (1u << 20);
+  if (const char *v = getenv("PA_FRAGANI_MINIMIZER_ROOM")) cap = std::max<uint64_t>(1, strtoull(v, nullptr, 10));  // tests: force the repeat
   for (int attempt = 0; attempt < 2; ++attempt) {
     PA_REQUIRE(cap < (1ULL << 31), "fragment ANI: room for %llu minimizers exceeds the 31-bit index space", (unsigned long long)cap);
     PA_TRY(W.mini_hash.reserve(cap * 4 + 16));

@@ -83,6 +83,28 @@ def test_minimizers_equal_oracle(engine, k, w):
     assert ci == len(arena.contig_start)
 
 
+def test_minimizer_run_is_repeated_when_the_estimate_is_too_small(engine, monkeypatch):
+    """The single-pass minimizer kernel writes into arrays sized from the expected density 2 / (w + 1); low-complexity
+    sequence (every window of a homopolymer records a new, rightmost, position) needs more, and the run is repeated
+    with the exact size.  Forced here by giving the first run room for 100 minimizers."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(3)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    contigs = [b"A" * 5_000 + rng.choice(acgt, size=6_000).tobytes() + b"AC" * 1_500, rng.choice(acgt, size=30_000).tobytes()]
+    arena = pack_genomes([b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs))])
+    for room in ("100", None):
+        if room is None:
+            monkeypatch.delenv("PA_FRAGANI_MINIMIZER_ROOM", raising=False)
+        else:
+            monkeypatch.setenv("PA_FRAGANI_MINIMIZER_ROOM", room)
+        h, wp, ct = engine.fragani_sketch(engine.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, 16, 24)
+        for ci, contig in enumerate(contigs):
+            want_h, want_p = oracle.fragani_minimizers(contig, 16, 24)
+            assert np.array_equal(h[ct == ci], want_h) and np.array_equal(wp[ct == ci].astype(np.int32), want_p)
+        assert len(h) > 5_000  # the homopolymer alone gives one minimizer per window
+
+
 def _check_against_oracle(engine, texts, contig_lists, frag=FRAG, k=K):
     from pyani_plus_amd.engine import pack_genomes
 
