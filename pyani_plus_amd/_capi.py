@@ -105,6 +105,7 @@ SIGNATURES: dict[str, tuple] = {
         [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp],
     ),
     "pa_host_cpu_budget": (C.c_uint32, []),
+    "pa_gunzip": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _u64p, C.c_int]),
     "pa_sqlite_insert_comparisons": (
         C.c_int,
         [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp, _u64p],

@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -25,6 +26,7 @@
 
 #include "../../include/pyani_hip.h"
 #include "host_pool.h"
+#include "inflate_fast.h"
 #include "md5.h"
 #include "md5_mb.h"
 
@@ -98,8 +100,18 @@ bool read_file(const std::string &path, uint8_t *buf, size_t room, std::vector<u
   return true;
 }
 
-// multi-member gzip inflate
+// multi-member gzip inflate: the fast decoder of inflate_fast.h first (every member checked against its CRC-32 and
+// length), zlib over the same bytes whenever that reports anything unexpected
+bool gunzip_zlib(const uint8_t *raw_p, size_t raw_n, std::vector<uint8_t> &out, std::string &err);
 bool gunzip(const uint8_t *raw_p, size_t raw_n, std::vector<uint8_t> &out, std::string &err) {
+  static const bool zlib_only = [] {
+    const char *v = getenv("PA_GUNZIP");
+    return v && v[0] == 'z';
+  }();
+  if (!zlib_only && pa_inflate::gunzip_all(raw_p, raw_n, out)) return true;
+  return gunzip_zlib(raw_p, raw_n, out, err);
+}
+bool gunzip_zlib(const uint8_t *raw_p, size_t raw_n, std::vector<uint8_t> &out, std::string &err) {
   z_stream zs;
   memset(&zs, 0, sizeof(zs));
   if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "inflateInit2 failed"; return false; }
@@ -389,5 +401,34 @@ int pa_fasta_batch_copy_arena(const pa_fasta_batch *b, uint32_t *h_packed, uint3
 }
 
 void pa_fasta_batch_free(pa_fasta_batch *b) { delete b; }
+
+int pa_gunzip(const uint8_t *h_gz, uint64_t n_gz, uint8_t *h_out, uint64_t cap, uint64_t *n_out, int decoder) {
+  if ((!h_gz && n_gz) || (!h_out && cap) || !n_out || decoder < 0 || decoder > 2) {
+    pa_set_error("pa_gunzip: bad argument");
+    return PA_E_INVALID;
+  }
+  *n_out = 0;
+  std::vector<uint8_t> out;
+  std::string err;
+  bool ok;
+  try {
+    if (decoder == 1) {
+      ok = pa_inflate::gunzip_all(h_gz, n_gz, out);
+      if (!ok) err = "not accepted by the fast decoder";
+    } else if (decoder == 2) {
+      ok = gunzip_zlib(h_gz, n_gz, out, err);
+    } else {
+      ok = gunzip(h_gz, n_gz, out, err);
+    }
+  } catch (const std::exception &e) {
+    pa_set_error("pa_gunzip: %s", e.what());
+    return PA_E_NOMEM;
+  }
+  if (!ok) { pa_set_error("pa_gunzip: %s", err.c_str()); return PA_E_INVALID; }
+  *n_out = out.size();
+  if (out.size() > cap) { pa_set_error("pa_gunzip: %llu bytes needed, room for %llu", (unsigned long long)out.size(), (unsigned long long)cap); return PA_E_CAPACITY; }
+  if (!out.empty()) memcpy(h_out, out.data(), out.size());
+  return PA_OK;
+}
 
 }  // extern "C"

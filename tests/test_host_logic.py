@@ -654,6 +654,84 @@ def test_vector_packer_equals_the_character_rules(tmp_path):
         assert np.array_equal(arena.contig_genome, ref.contig_genome) and arena.residues == ref.residues
 
 
+def _pa_gunzip(data: bytes, decoder: int, cap: int | None = None):
+    import ctypes as C
+
+    lib = _capi.load_library()
+    n = C.c_uint64()
+    cap = max(64, len(data) * 1100) if cap is None else cap
+    out = np.empty(cap, dtype=np.uint8)
+    status = lib.pa_gunzip(data, len(data), out.ctypes.data, cap, C.byref(n), decoder)
+    return status, (out[: n.value].tobytes() if status == 0 else None)
+
+
+def test_own_inflate_equals_zlib():
+    """inflate_fast.h (decoder 1) against what zlib wrote: every block type and strategy zlib can be made to emit,
+    literal-only and match-heavy data, headers with names, flushes, several members, zero padding -- and damaged
+    streams, where the loader's route (decoder 0) must accept exactly what Python's gzip module accepts."""
+    import gzip
+    import io
+    import zlib
+
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def dna(n: int, width: int = 80) -> bytes:
+        seq = acgt[rng.integers(0, 4, n, dtype=np.uint8)].tobytes()
+        return b">g\n" + b"\n".join(seq[i : i + width] for i in range(0, n, width)) + b"\n"
+
+    payloads = {
+        "empty": b"", "one": b"A", "dna_small": dna(1000), "dna": dna(400_000), "dna_one_line": dna(100_000, 100_000),
+        "zeros": bytes(300_000), "random": rng.integers(0, 256, 200_000, dtype=np.uint8).tobytes(),
+        "text": b"the quick brown fox jumps over the lazy dog. " * 5000, "period3": b"abc" * 50_000,
+        "two_letters": acgt[rng.integers(0, 2, 100_000, dtype=np.uint8)].tobytes(),
+    }  # fmt: skip
+    for name, data in payloads.items():
+        for level in (0, 1, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+                comp = zlib.compressobj(level, zlib.DEFLATED, 31, 8, strategy)
+                status, out = _pa_gunzip(comp.compress(data) + comp.flush(), 1)
+                assert status == 0 and out == data, (name, level, strategy, _capi.last_error())
+        buf = io.BytesIO()
+        with gzip.GzipFile(filename="some_name.fasta", mode="wb", fileobj=buf, mtime=0) as handle:
+            handle.write(data)
+        assert _pa_gunzip(buf.getvalue(), 1) == (0, data)
+        comp = zlib.compressobj(6, zlib.DEFLATED, 31, 1)  # little memory: many dynamic blocks; flushes: empty stored blocks
+        third = len(data) // 3
+        parts = [comp.compress(data[:third]), comp.flush(zlib.Z_SYNC_FLUSH), comp.compress(data[third:]), comp.flush(zlib.Z_FULL_FLUSH), comp.flush()]
+        assert _pa_gunzip(b"".join(parts), 1) == (0, data)
+    a, b = payloads["dna_small"], payloads["text"]
+    multi = gzip.compress(a) + gzip.compress(b) + gzip.compress(b"")
+    for decoder in (0, 1, 2):
+        assert _pa_gunzip(multi, decoder) == (0, a + b)
+        assert _pa_gunzip(multi + bytes(512), decoder) == (0, a + b)  # zero padding, as Python's gzip accepts it
+        assert _pa_gunzip(multi + b"junk", decoder)[0] != 0
+    assert _pa_gunzip(multi, 0, cap=10)[0] == _capi.PA_E_CAPACITY
+    # damage: never a wrong answer; the loader's route agrees with Python's gzip module on what is readable
+    good = gzip.compress(payloads["dna"][:60_000])
+    for trial in range(150):
+        bad = bytearray(good)
+        if trial % 3 == 0:
+            bad[int(rng.integers(10, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+        elif trial % 3 == 1:
+            bad = bad[: int(rng.integers(1, len(bad)))]
+        else:
+            at = int(rng.integers(10, len(bad) - 8))
+            bad[at : at + 8] = rng.integers(0, 256, 8, dtype=np.uint8).tobytes()
+        try:
+            want = gzip.decompress(bytes(bad))
+        except Exception:  # noqa: BLE001 - zlib.error, EOFError, BadGzipFile, ...
+            want = None
+        status, out = _pa_gunzip(bytes(bad), 1)
+        assert status != 0 or out == payloads["dna"][:60_000]
+        status, out = _pa_gunzip(bytes(bad), 0)
+        assert (status == 0) == (want is not None) and out == want, trial
+    # the reference's own compressed fixtures
+    for path in sorted((GOLDEN / "bacterial_example").glob("*.gz")):
+        raw = path.read_bytes()
+        assert _pa_gunzip(raw, 1) == (0, gzip.decompress(raw))
+
+
 @pytest.mark.parametrize("name", list(FIXTURE_SETS))
 def test_manysearch_csv_export_equals_fixture_text(name, tmp_path):
     """All 15 columns of the reference's intermediate manysearch.csv, as text, from counts + sizes."""

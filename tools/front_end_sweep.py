@@ -1,6 +1,6 @@
 """Thread sweep of the FASTA front-end on synthetic files.
 
-    python tools/front_end_sweep.py [n_files=400] [length=5000000]
+    python tools/front_end_sweep.py [n_files=400] [length=5000000] [gz]
 Times load_fasta_files (read + md5 + parse + 2-bit pack + arena copy) per thread count, into pageable and into
 page-locked memory, and prints GB of FASTA text per second.
 """
@@ -18,6 +18,7 @@ from pyani_plus_amd.engine import load_fasta_files  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 length = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
+gz = len(sys.argv) > 3 and sys.argv[3] == "gz"
 rng = np.random.default_rng(7)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
@@ -25,14 +26,18 @@ with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
     paths = []
     for g in range(n):
         seq = np.roll(base, g * 997)
-        path = Path(tmp) / f"genome_{g:05d}.fasta"
-        with path.open("wb") as handle:
-            handle.write(b">genome_%d synthetic\n" % g)
-            handle.write(b"\n".join(seq[i : i + 100_000].tobytes() for i in range(0, length, 100_000)))
-            handle.write(b"\n")
+        path = Path(tmp) / (f"genome_{g:05d}.fasta" + (".gz" if gz else ""))
+        width = 80 if gz else 100_000
+        text = b">genome_%d synthetic\n" % g + b"\n".join(seq[i : i + width].tobytes() for i in range(0, length, width)) + b"\n"
+        if gz:
+            import zlib
+
+            comp = zlib.compressobj(6, zlib.DEFLATED, 31)
+            text = comp.compress(text) + comp.flush()
+        path.write_bytes(text)
         paths.append(path)
     cores = len(os.sched_getaffinity(0))
-    print(f"{n} files of {length} bases, {cores} cores", flush=True)
+    print(f"{n} files of {length} bases{' (gzip)' if gz else ''}, {cores} cores", flush=True)
     for pinned in (False, True):
         for threads in sorted({8, 16, 32, 64, 128, cores}):
             if threads > cores:
