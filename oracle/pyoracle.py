@@ -191,7 +191,7 @@ FRAGANI_OPTIONS = {"window_rule": 0, "bin_rule": 1, "l2_rule": 2, "conf": 3}
 
 
 def fragani_set_option(name: str, value: float) -> None:
-    """Switch one of the oracle's restatement choices (tools/fragani_bisect.py); process-wide."""
+    """Switch one of the oracle's restatement choices (tests/tools/fragani_bisect.py); process-wide."""
     _load_frag().orc_fragani_set_option(FRAGANI_OPTIONS[name], float(value))
 
 

@@ -7,7 +7,7 @@ reference itself at tests/snakemake/test_fastani_workflow.py:67-86):
     total fragments   exact  (= sum over contigs of floor(len / fragLen))
     kept fragments    within 1 % of the total (and within 1 for the phages)
     ANI               within 0.1 percentage points
-tools/fragani_bisect.py measures each restatement choice against the 25 rows (profiles/r02_fragani_bisect.md):
+tests/tools/fragani_bisect.py measures each restatement choice against the 25 rows (profiles/r02_fragani_bisect.md):
 with Mashmap's sketch-size list (window 24), fastANI's fragLen-20 reference buckets and Mashmap's slide over the
 reference minimizer positions the maximum deviations are 0.070 points and 0.71 %.
 """
@@ -83,7 +83,7 @@ def test_viral_rows_within_tolerance():
 )
 def test_bacterial_rows_within_tolerance(q, r):
     """Three of the 16 bacterial rows (an 83 %, an 86 % and a 99.99 % pair); all 16 are within the same bounds
-    (tools/fragani_bisect.py runs them all; the GPU test checks all 16 on the device)."""
+    (tests/tools/fragani_bisect.py runs them all; the GPU test checks all 16 on the device)."""
     rows = {(a, b): (ani, m, t) for a, b, ani, m, t in fixture_rows("bacterial_example")}
     ani, matched, total = rows[(q, r)]
     got_ani, got_m, got_t = oracle.fragani_pair(contigs_of(GOLDEN / "bacterial_example" / q), contigs_of(GOLDEN / "bacterial_example" / r), K, FRAG, 0.2)

@@ -1,6 +1,6 @@
 """Bisect the fragment-ANI oracle's restatement choices against the reference's 25 fastANI rows.
 
-    python tools/fragani_bisect.py [out.md]
+    python tests/tools/fragani_bisect.py [out.md]
 For every variant: max and mean |dANI| (percentage points) and max |d matched| / total over the 25 rows of
 tests/golden/{viral,bacterial}_example/fastANI/*.fastani (copies of the reference's fixtures, data only).
 CPU only (oracle); rows run on a process pool.
@@ -10,7 +10,7 @@ import sys
 from concurrent.futures import ProcessPoolExecutor
 from pathlib import Path
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 from tests.helpers import GOLDEN, read_fasta_bytes  # noqa: E402
 
