@@ -172,7 +172,7 @@ inline uint32_t lookup(const uint32_t *table, uint32_t table_bits, uint64_t bits
 // the symbols of one Huffman-coded block, appended to out[0 .. pos).  0 = end of block reached, -1 = failure.
 // The reader's state and the output cursor live in locals for the length of the block: byte stores may alias
 // anything, so state kept behind references would be reloaded after every literal.
-inline int decode_block(BitReader &reader, const Tables &t, std::vector<uint8_t> &out, size_t &out_pos) {
+inline int decode_block(BitReader &reader, const Tables &t, std::vector<uint8_t> &out, size_t &out_pos, size_t member_start) {
   const uint8_t *p = reader.p, *const end = reader.end;
   uint64_t bits = reader.bits;
   uint32_t n = reader.n;
@@ -247,7 +247,7 @@ inline int decode_block(BitReader &reader, const Tables &t, std::vector<uint8_t>
         const size_t offset = e_value(d) + (size_t)(bits & ((1ull << e_extra(d)) - 1ull));
         bits >>= e_extra(d);
         n -= e_extra(d);
-        if (offset > pos) goto done;
+        if (offset > pos - member_start) goto done;  // a match never reaches back past its own member
         uint8_t *dst = o + pos;
         const uint8_t *src = dst - offset;
         if (offset >= 16) {
@@ -293,7 +293,7 @@ inline int decode_block(BitReader &reader, const Tables &t, std::vector<uint8_t>
       const size_t offset = e_value(d) + (size_t)(bits & ((1ull << e_extra(d)) - 1ull));
       bits >>= e_extra(d);
       n -= e_extra(d);
-      if (offset > pos) goto done;
+      if (offset > pos - member_start) goto done;  // a match never reaches back past its own member
       for (uint32_t i = 0; i < length; ++i) o[pos + i] = o[pos + i - offset];
       pos += length;
     }
@@ -312,6 +312,7 @@ done:
 
 // raw DEFLATE stream at br -> out[0 .. pos), through the final block.  false = failure (caller falls back to zlib).
 inline bool inflate_stream(BitReader &br, std::vector<uint8_t> &out, size_t &pos, Tables &t) {
+  const size_t member_start = pos;
   static const uint8_t kOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
   for (;;) {
     if (!br.need(3)) return false;
@@ -389,7 +390,7 @@ inline bool inflate_stream(BitReader &br, std::vector<uint8_t> &out, size_t &pos
       if (!build_table(lens, n_lit, true, t.lit, kLitBits, kLitTableSize)) return false;
       pair_literals(t.lit);
       if (!build_table(lens + 288, n_dist, false, t.dist, kDistBits, kDistTableSize)) return false;
-      if (decode_block(br, t, out, pos) != 0) return false;
+      if (decode_block(br, t, out, pos, member_start) != 0) return false;
     } else {
       return false;
     }
