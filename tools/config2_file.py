@@ -1,7 +1,7 @@
 """Whole path on files at a size between BASELINE configs[0] and configs[1]: N synthetic 5 Mb genomes written
 as FASTA files, then FASTA directory -> database with N^2 comparisons through rundb.run_sourmash_hip.
 
-    python tools/config2_file.py [n_genomes=200] [length=5000000] [ingest=json|direct]
+    python tools/config2_file.py [n_genomes=200] [length=5000000] [ingest=json|direct] [reps=2] [gz]
 Prints the wall time of the run and of its parts (threaded FASTA front-end, device work, column files, SQLite, matrix cache).
 """
 import logging
@@ -21,6 +21,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 length = int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
 ingest = sys.argv[3] if len(sys.argv) > 3 else "json"
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+gz = len(sys.argv) > 5 and sys.argv[5] == "gz"  # 80-column lines, zlib level 6: the form NCBI ships
 rng = np.random.default_rng(20260802)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 roots = rng.integers(0, 4, size=(8, length), dtype=np.uint8)
@@ -34,11 +35,15 @@ with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         hit = rng.random(length) < RATES[(g // 8) % len(RATES)]
         seq[hit] = (seq[hit] + rng.integers(1, 4, size=int(hit.sum()), dtype=np.uint8)) & 3
         text = acgt[seq]
-        with (fasta / f"genome_{g:05d}.fasta").open("wb") as handle:
-            handle.write(b">genome_%d synthetic\n" % g)
-            handle.write(b"\n".join(text[i : i + 100_000].tobytes() for i in range(0, length, 100_000)))
-            handle.write(b"\n")
-    print(f"wrote {n} FASTA files ({n * length / 1e9:.2f} Gb) in {time.perf_counter() - t0:.1f} s", flush=True)
+        width = 80 if gz else 100_000
+        body = b">genome_%d synthetic\n" % g + b"\n".join(text[i : i + width].tobytes() for i in range(0, length, width)) + b"\n"
+        if gz:
+            import zlib
+
+            comp = zlib.compressobj(6, zlib.DEFLATED, 31)
+            body = comp.compress(body) + comp.flush()
+        (fasta / (f"genome_{g:05d}.fasta" + (".gz" if gz else ""))).write_bytes(body)
+    print(f"wrote {n} {'gzip ' if gz else ''}FASTA files ({n * length / 1e9:.2f} Gb) in {time.perf_counter() - t0:.1f} s", flush=True)
     for rep in range(reps):
         db = Path(tmp) / f"run{rep}.sqlite"
         t0 = time.perf_counter()
