@@ -353,26 +353,31 @@ def ingest_matrices(conn, run: Run, queries: list[str], subjects: list[str], ide
     return nq * ns
 
 
-def cache_matrices(conn, run: Run, hashes: list[str], identity, cov_query, is_null) -> dict[str, str]:
-    """``cache_comparisons`` from matrices that are already in memory (rows = query, columns = subject, both in
-    ``hashes`` order = sorted md5): same strings as the SELECT-based form, without reading 10^8 rows back."""
+def format_matrix_cache(hashes: list[str], identity, cov_query, is_null) -> dict[str, str] | None:
+    """The five ``runs.df_*`` strings from matrices in memory (rows = query, columns = subject, both in ``hashes``
+    order = sorted md5); None when they would not fit a SQLite value."""
     import pandas as pd
 
     assert hashes == sorted(hashes)
     n = len(hashes)
     if _matrix_cache_too_big(n):
-        _store_matrix_cache(conn, run, None)
-        return {}
+        return None
     ident = np.where(is_null, np.nan, identity)
     cov = np.where(is_null, np.nan, cov_query)
     nan = np.full((n, n), np.nan)
     mats = {"identity": ident, "cov_query": cov, "aln_length": nan, "sim_errors": nan, "hadamard": ident * cov}
-    out = {
+    return {
         f"df_{key}": pd.DataFrame(data=mat, index=hashes, columns=hashes, dtype=float).to_json(orient="split")
         for key, mat in mats.items()
     }
+
+
+def cache_matrices(conn, run: Run, hashes: list[str], identity, cov_query, is_null, *, formatted=None) -> dict[str, str]:
+    """``cache_comparisons`` from matrices that are already in memory: same strings as the SELECT-based form, without
+    reading 10^8 rows back.  ``formatted`` = the result of an earlier ``format_matrix_cache`` of the same matrices."""
+    out = formatted if formatted is not None else format_matrix_cache(hashes, identity, cov_query, is_null)
     _store_matrix_cache(conn, run, out)
-    return out
+    return out or {}
 
 
 def _matrix_cache_too_big(n: int) -> bool:
@@ -464,10 +469,16 @@ def _compute_direct(logger, conn, run: Run, cache_dir: Path, tmp_dir: Path, engi
     mark("pairs_and_tile_files")
     conn.execute("PRAGMA synchronous=OFF")
     conn.execute("PRAGMA cache_size=-1048576")
-    rows = ingest_matrices(conn, run, hashes, hashes, ident, cov, null)
+    # the cached matrices are formatted on a second thread while the rows go in (the native insert releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=1) as side:
+        formatting = side.submit(format_matrix_cache, hashes, ident, cov, null)
+        rows = ingest_matrices(conn, run, hashes, hashes, ident, cov, null)
+        formatted = formatting.result()
     conn.execute("PRAGMA synchronous=FULL")
     mark("insert_rows")
-    return rows, hashes, ident, cov, null
+    return rows, hashes, ident, cov, null, formatted
 
 
 def import_tile(logger: logging.Logger, conn, run: Run, tile_file: Path) -> int:
@@ -594,7 +605,10 @@ def run_sourmash_hip(  # noqa: PLR0913
     if direct is None:
         cache_comparisons(conn, run)
     else:
-        cache_matrices(conn, run, *direct[1:])
+        if direct[5] is None:
+            _store_matrix_cache(conn, run, None)
+        else:
+            cache_matrices(conn, run, *direct[1:5], formatted=direct[5])
     mark("matrix_cache")
     run.status = "Done"
     session.commit()
