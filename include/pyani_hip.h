@@ -114,7 +114,8 @@ PA_API int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_packed,
 /* ---- host side: files -> md5 + length + title + arena, on a pool of host threads ----
  * One pass per file does what the reference does in three (md5 of the decompressed bytes,
  * pyani_plus/utils.py:142-196; length and description, pyani_plus/db_orm.py:832-866; the
- * sketcher's own read, pyani_plus/methods/sourmash.py:67-83): read, gunzip, md5, parse, pack.
+ * sketcher's own read, pyani_plus/methods/sourmash.py:67-83): read, gunzip (pa_gunzip's decoder 0), md5 (sixteen
+ * files side by side where the CPU has AVX-512), parse, pack (pa_pack_fasta).  threads <= 0: pa_host_cpu_budget().
  * pa_fasta_batch_info returns the file's own status (PA_OK or a negative code with `message`,
  * e.g. "Has .gz ending, but x.fa.gz is NOT gzip compressed", db_orm.py:846-854); strings are
  * owned by the batch.  pa_fasta_batch_copy_arena concatenates the successfully loaded genomes
