@@ -111,6 +111,13 @@ PA_API int pa_pack_fasta(const uint8_t *h_text, uint64_t n_text, uint32_t *h_pac
 PA_API int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_packed, uint32_t *h_mask,
                 uint64_t cap_bases, uint64_t *n_bases, uint64_t *n_invalid);
 
+/* gzip data (one or more members, zero padding after the last accepted) -> bytes, what Python's gzip module does for
+ * the reference (pyani_plus/utils.py:178-196).  decoder 0: the library's own inflate (64-bit bit buffer, two-level
+ * tables; every member checked against its CRC-32 and length) with zlib over the same bytes on any failure -- the
+ * loader's route; 1: the library's own only; 2: zlib only.  PA_E_CAPACITY with *n_out = bytes needed when cap is
+ * too small; PA_E_INVALID for a corrupt or truncated stream. */
+PA_API int pa_gunzip(const uint8_t *h_gz, uint64_t n_gz, uint8_t *h_out, uint64_t cap, uint64_t *n_out, int decoder);
+
 /* ---- host side: files -> md5 + length + title + arena, on a pool of host threads ----
  * One pass per file does what the reference does in three (md5 of the decompressed bytes,
  * pyani_plus/utils.py:142-196; length and description, pyani_plus/db_orm.py:832-866; the
@@ -120,12 +127,6 @@ PA_API int pa_pack_seq(const uint8_t *h_seq, uint64_t n_seq, uint32_t *h_packed,
  * e.g. "Has .gz ending, but x.fa.gz is NOT gzip compressed", db_orm.py:846-854); strings are
  * owned by the batch.  pa_fasta_batch_copy_arena concatenates the successfully loaded genomes
  * (failed files occupy no space) and writes genome_start[n+1]. */
-/* gzip data (one or more members, zero padding after the last accepted) -> bytes, what Python's gzip module does for
- * the reference (pyani_plus/utils.py:178-196).  decoder 0: the library's own inflate (64-bit bit buffer, two-level
- * tables; every member checked against its CRC-32 and length) with zlib over the same bytes on any failure -- the
- * loader's route; 1: the library's own only; 2: zlib only.  PA_E_CAPACITY with *n_out = bytes needed when cap is
- * too small; PA_E_INVALID for a corrupt or truncated stream. */
-PA_API int pa_gunzip(const uint8_t *h_gz, uint64_t n_gz, uint8_t *h_out, uint64_t cap, uint64_t *n_out, int decoder);
 typedef struct pa_fasta_batch pa_fasta_batch;
 PA_API int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fasta_batch **out);
 PA_API int pa_fasta_batch_info(const pa_fasta_batch *batch, uint32_t i, char md5hex33[33], uint64_t *n_residues,
