@@ -655,6 +655,51 @@ def test_vector_packer_equals_the_character_rules(tmp_path):
         assert np.array_equal(arena.contig_genome, ref.contig_genome) and arena.residues == ref.residues
 
 
+def test_host_pool_serves_two_callers_at_once(tmp_path):
+    """The FASTA loader runs on a background thread of the batched front-end while the main thread uses the same
+    host pool (strict ANI, writers).  Two callers at once must both get correct results."""
+    import threading
+
+    from pyani_plus_amd.engine import load_fasta_files
+    from tests.helpers import md5_hex
+
+    rng = np.random.default_rng(2)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    texts = [b">g%d\n" % i + acgt[rng.integers(0, 4, 20_000)].tobytes() + b"\n" for i in range(24)]
+    paths = []
+    for i, text in enumerate(texts):
+        paths.append(tmp_path / f"g{i}.fna")
+        paths[-1].write_bytes(text)
+    counts = rng.integers(0, 50, size=(300, 300)).astype(np.uint32)
+    sizes = rng.integers(50, 5000, size=300).astype(np.uint64)
+    want = ani_host(counts, sizes, sizes, K, threads=1)
+    errors = []
+
+    def loader():
+        try:
+            for _ in range(15):
+                infos, _arena = load_fasta_files(paths, threads=4)
+                assert [i.md5 for i in infos] == [md5_hex(t) for t in texts]
+        except Exception as err:  # noqa: BLE001
+            errors.append(err)
+
+    def transform():
+        try:
+            for _ in range(60):
+                got = ani_host(counts, sizes, sizes, K, threads=4)
+                for a, b in zip(got, want):
+                    assert np.array_equal(a, b, equal_nan=True)
+        except Exception as err:  # noqa: BLE001
+            errors.append(err)
+
+    workers = [threading.Thread(target=loader), threading.Thread(target=transform)]
+    for w in workers:
+        w.start()
+    for w in workers:
+        w.join()
+    assert not errors, errors
+
+
 def _pa_gunzip(data: bytes, decoder: int, cap: int | None = None):
     import ctypes as C
 
