@@ -118,40 +118,66 @@ extern "C" int pa_sqlite_insert_comparisons(const char *database, int64_t config
   // synchronous=OFF lasts as long as this connection: the rows are re-derivable (the tile files are on disk)
   if (a.exec(db, "PRAGMA synchronous=OFF; PRAGMA cache_size=-1048576; BEGIN IMMEDIATE", nullptr, nullptr, nullptr) != kSqliteOk)
     return fail("begin");
-  sqlite3_stmt *st = nullptr;
+  // Rows go in kBlock at a time through one statement with kBlock value tuples (fewer trips through
+  // sqlite3_step / sqlite3_reset and the statement's set-up and tear-down code); the last rows of a matrix row
+  // through the one-tuple statement.  Constant columns are bound once: bindings survive sqlite3_reset.
+  constexpr uint32_t kBlock = 64, kCols = 10;  // 640 parameters: below the 999 older SQLite builds allow
+  std::string many = "INSERT OR IGNORE INTO comparisons (query_hash, subject_hash, configuration_id, identity, aln_length, "
+                     "sim_errors, cov_query, uname_system, uname_release, uname_machine) VALUES ";
+  for (uint32_t r = 0; r < kBlock; ++r) many += r ? ",(?,?,?,?,?,?,?,?,?,?)" : "(?,?,?,?,?,?,?,?,?,?)";
+  sqlite3_stmt *st = nullptr, *stm = nullptr;
   if (a.prepare_v2(db, kInsert, -1, &st, nullptr) != kSqliteOk) return fail("prepare");
-  const destructor_t kStatic = nullptr;  // SQLITE_STATIC: the strings outlive the statement
+  if (a.prepare_v2(db, many.c_str(), -1, &stm, nullptr) != kSqliteOk) { a.finalize(st); return fail("prepare (block form)"); }
+  const destructor_t kStatic = nullptr;  // SQLITE_STATIC: the strings outlive the statements
   const int before = a.total_changes(db);
   bool bad = false;
-  bad |= a.bind_int64(st, 3, configuration_id) != kSqliteOk;
-  bad |= a.bind_null(st, 5) != kSqliteOk;  // aln_length and sim_errors are never set by this method
-  bad |= a.bind_null(st, 6) != kSqliteOk;  // (pyani_plus/private_cli.py:1866-1880)
-  bad |= a.bind_text(st, 8, uname_system, -1, kStatic) != kSqliteOk;
-  bad |= a.bind_text(st, 9, uname_release, -1, kStatic) != kSqliteOk;
-  bad |= a.bind_text(st, 10, uname_machine, -1, kStatic) != kSqliteOk;
+  auto bind_constants = [&](sqlite3_stmt *s, uint32_t tuples) {
+    for (uint32_t r = 0; r < tuples; ++r) {
+      const int o = (int)(r * kCols);
+      bad |= a.bind_int64(s, o + 3, configuration_id) != kSqliteOk;
+      bad |= a.bind_null(s, o + 5) != kSqliteOk;  // aln_length and sim_errors are never set by this method
+      bad |= a.bind_null(s, o + 6) != kSqliteOk;  // (pyani_plus/private_cli.py:1866-1880)
+      bad |= a.bind_text(s, o + 8, uname_system, -1, kStatic) != kSqliteOk;
+      bad |= a.bind_text(s, o + 9, uname_release, -1, kStatic) != kSqliteOk;
+      bad |= a.bind_text(s, o + 10, uname_machine, -1, kStatic) != kSqliteOk;
+    }
+  };
+  bind_constants(st, 1);
+  bind_constants(stm, kBlock);
+  auto bind_pair = [&](sqlite3_stmt *s, int o, uint32_t sub, uint64_t cell) {
+    bad |= a.bind_text(s, o + 2, subject_hashes[sub], -1, kStatic) != kSqliteOk;
+    if (is_null[cell]) {
+      bad |= a.bind_null(s, o + 4) != kSqliteOk;
+      bad |= a.bind_null(s, o + 7) != kSqliteOk;
+    } else {
+      bad |= a.bind_double(s, o + 4, identity[cell]) != kSqliteOk;
+      bad |= a.bind_double(s, o + 7, cov_query[cell]) != kSqliteOk;
+    }
+  };
   uint64_t stepped = 0;
   for (uint32_t q = 0; q < n_queries && !bad; ++q) {
-    // bindings survive sqlite3_reset: the query hash is bound once per matrix row
-    bad |= a.bind_text(st, 1, query_hashes[q], -1, kStatic) != kSqliteOk;
     const uint64_t row = (uint64_t)q * n_subjects;
-    for (uint32_t s = 0; s < n_subjects && !bad; ++s) {
-      bad |= a.bind_text(st, 2, subject_hashes[s], -1, kStatic) != kSqliteOk;
-      if (is_null[row + s]) {
-        bad |= a.bind_null(st, 4) != kSqliteOk;
-        bad |= a.bind_null(st, 7) != kSqliteOk;
-      } else {
-        bad |= a.bind_double(st, 4, identity[row + s]) != kSqliteOk;
-        bad |= a.bind_double(st, 7, cov_query[row + s]) != kSqliteOk;
-      }
+    bad |= a.bind_text(st, 1, query_hashes[q], -1, kStatic) != kSqliteOk;
+    for (uint32_t r = 0; r < kBlock; ++r) bad |= a.bind_text(stm, (int)(r * kCols) + 1, query_hashes[q], -1, kStatic) != kSqliteOk;
+    uint32_t s = 0;
+    for (; s + kBlock <= n_subjects && !bad; s += kBlock) {
+      for (uint32_t r = 0; r < kBlock; ++r) bind_pair(stm, (int)(r * kCols), s + r, row + s + r);
+      bad |= a.step(stm) != kSqliteDone;
+      a.reset(stm);
+      stepped += kBlock;
+    }
+    for (; s < n_subjects && !bad; ++s) {
+      bind_pair(st, 0, s, row + s);
       bad |= a.step(st) != kSqliteDone;
       a.reset(st);
       ++stepped;
     }
   }
+  a.finalize(stm);
   if (bad) {
     a.finalize(st);
     char what[64];
-    snprintf(what, sizeof(what), "insert of row %llu", (unsigned long long)stepped);
+    snprintf(what, sizeof(what), "insert near row %llu", (unsigned long long)stepped);
     return fail(what);
   }
   a.finalize(st);
