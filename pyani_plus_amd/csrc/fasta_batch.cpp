@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,16 +51,64 @@ struct FileResult {
   std::vector<uint64_t> rec_start, rec_len;  // FASTA records, positions relative to the genome start
 };
 
-// Anonymous mapping, huge pages asked for.  One mapping per batch instead of two allocations per file: with
-// hundreds of threads every mmap/munmap waits for the page faults in flight on all the others and holds up new
-// ones (the address-space lock is one per process) -- measured: 400 files of 5 MB took 0.35-0.47 s on 64-256
-// threads, no faster than on 16, until the per-file allocations went away.
+// Anonymous mapping, huge pages asked for: one per batch for the packed genomes, one for their masks, one for the bytes
+// of the files being read, instead of allocations per file.  A run loads several batches of the same shape one after
+// the other and a fresh mapping costs a page fault and a zeroed huge page per 2 MB touched (2 GB per batch of 400
+// genomes), so released mappings are kept for the next batch -- at most three, at most 3 GiB, PA_HOST_SLAB_CACHE=0
+// turns it off.  (Nothing in a reused mapping is read before it is written: the packer writes every word it reports,
+// the arena copy takes only those.)
+struct SlabCache {
+  struct Item { uint8_t *p; size_t bytes; };
+  std::mutex m;
+  std::vector<Item> items;
+  static SlabCache &get() {
+    static SlabCache *c = new SlabCache();  // never destroyed: mappings die with the process
+    return *c;
+  }
+  static bool enabled() {
+    static const bool on = [] {
+      const char *v = getenv("PA_HOST_SLAB_CACHE");
+      return !(v && v[0] == '0');
+    }();
+    return on;
+  }
+  uint8_t *take(size_t n, size_t *bytes) {
+    std::lock_guard<std::mutex> lock(m);
+    size_t best = items.size();
+    for (size_t i = 0; i < items.size(); ++i)
+      if (items[i].bytes >= n && items[i].bytes <= 2 * n + (64u << 20) && (best == items.size() || items[i].bytes < items[best].bytes)) best = i;
+    if (best == items.size()) return nullptr;
+    uint8_t *p = items[best].p;
+    *bytes = items[best].bytes;
+    items.erase(items.begin() + (long)best);
+    return p;
+  }
+  void give(uint8_t *p, size_t bytes) {
+    uint8_t *drop = p;
+    size_t drop_bytes = bytes;
+    if (enabled()) {
+      std::lock_guard<std::mutex> lock(m);
+      items.push_back({p, bytes});
+      drop = nullptr;
+      size_t total = 0;
+      for (const Item &it : items) total += it.bytes;
+      if (items.size() > 3 || total > (3ull << 30)) {  // let the oldest go
+        drop = items.front().p;
+        drop_bytes = items.front().bytes;
+        items.erase(items.begin());
+      }
+    }
+    if (drop) munmap(drop, drop_bytes);
+  }
+};
+
 struct Slab {
   uint8_t *p = nullptr;
   size_t bytes = 0;
   bool alloc(size_t n) {
     release();
     if (n == 0) return true;
+    if (SlabCache::enabled() && (p = SlabCache::get().take(n, &bytes))) return true;
     void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) return false;
     madvise(m, n, MADV_HUGEPAGE);
@@ -68,7 +117,7 @@ struct Slab {
     return true;
   }
   void release() {
-    if (p) munmap(p, bytes);
+    if (p) SlabCache::get().give(p, bytes);
     p = nullptr;
     bytes = 0;
   }

@@ -69,15 +69,15 @@ extern "C" uint32_t pa_host_cpu_budget(void) { return pa_cpu_budget(); }
 
 extern "C" uint64_t pa_pack_bound(uint64_t n_text_bytes) { return (n_text_bytes / 64 + 1) * 64 + 64; }
 
-// Runs of set bits of an invalid-position mask, ascending (word scan: zero words cost one compare).
-extern "C" int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, uint64_t *h_run_start,
-                                uint64_t *h_run_len, uint64_t cap) {
-  if (!h_mask && arena_bases) return -1;
-  const uint64_t n_words = arena_bases / 32;
-  uint64_t n = 0, start = 0;
+// Runs of set bits of an invalid-position mask, ascending (word scan: zero words cost one compare).  The words are
+// scanned in chunks on the host pool (625 MB of mask per 5 Gb arena: 0.1 s on one core); a run that crosses a chunk
+// boundary comes out of both chunks and is joined when the lists are put together.
+namespace {
+void mask_runs_range(const uint32_t *h_mask, uint64_t w0, uint64_t w1, std::vector<uint64_t> &starts, std::vector<uint64_t> &lens) {
+  uint64_t start = 0;
   bool in_run = false;
-  for (uint64_t w = 0; w < n_words; ++w) {
-    uint32_t x = h_mask[w];
+  for (uint64_t w = w0; w < w1; ++w) {
+    const uint32_t x = h_mask[w];
     if (!in_run && x == 0) continue;
     if (in_run && x == 0xffffffffu) continue;
     for (uint32_t b = 0; b < 32; ++b) {
@@ -85,14 +85,43 @@ extern "C" int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, ui
       if (bit && !in_run) { in_run = true; start = w * 32 + b; }
       else if (!bit && in_run) {
         in_run = false;
-        if (n < cap && h_run_start && h_run_len) { h_run_start[n] = start; h_run_len[n] = w * 32 + b - start; }
-        ++n;
+        starts.push_back(start);
+        lens.push_back(w * 32 + b - start);
       }
     }
   }
   if (in_run) {
-    if (n < cap && h_run_start && h_run_len) { h_run_start[n] = start; h_run_len[n] = n_words * 32 - start; }
-    ++n;
+    starts.push_back(start);
+    lens.push_back(w1 * 32 - start);
+  }
+}
+}  // namespace
+
+extern "C" int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, uint64_t *h_run_start,
+                                uint64_t *h_run_len, uint64_t cap) {
+  if (!h_mask && arena_bases) return -1;
+  const uint64_t n_words = arena_bases / 32;
+  const uint32_t nt = pa_host_threads(n_words, 4u << 20, 0);
+  std::vector<std::vector<uint64_t>> starts(nt), lens(nt);
+  HostPool::get().run(nt, [&](uint32_t t, uint32_t n_workers) {
+    const uint64_t w0 = n_words * t / n_workers, w1 = n_words * (t + 1) / n_workers;
+    mask_runs_range(h_mask, w0, w1, starts[t], lens[t]);
+  });
+  uint64_t n = 0, last_end = ~0ULL;  // end of the last run emitted (to join runs across chunk boundaries)
+  uint64_t last_slot = 0;
+  for (uint32_t t = 0; t < nt; ++t) {
+    for (size_t i = 0; i < starts[t].size(); ++i) {
+      const uint64_t s0 = starts[t][i], l0 = lens[t][i];
+      if (n && s0 == last_end) {  // continues the previous run
+        if (last_slot < cap && h_run_start && h_run_len) h_run_len[last_slot] += l0;
+        last_end += l0;
+        continue;
+      }
+      if (n < cap && h_run_start && h_run_len) { h_run_start[n] = s0; h_run_len[n] = l0; }
+      last_slot = n;
+      last_end = s0 + l0;
+      ++n;
+    }
   }
   return (int64_t)n;
 }

@@ -655,6 +655,31 @@ def test_vector_packer_equals_the_character_rules(tmp_path):
         assert np.array_equal(arena.contig_genome, ref.contig_genome) and arena.residues == ref.residues
 
 
+def test_mask_runs_across_chunks():
+    """pa_mask_runs scans the mask in chunks on the host pool: runs that cross a chunk boundary (here: a run over the
+    middle of the arena, where two workers meet) come out joined, in order, with the count right when cap is small."""
+    lib = _capi.load_library()
+    bases = 150_000_000 // 64 * 64  # 4.7M mask words: two workers
+    mask = np.zeros(bases // 32, dtype=np.uint32)
+    bits = np.unpackbits(mask.view(np.uint8), bitorder="little")
+    rng = np.random.default_rng(8)
+    truth = []
+    for start in sorted(rng.integers(0, bases - 5000, 40).tolist()) + [bases // 2 - 100_000]:
+        length = int(rng.integers(1, 4000)) if start != bases // 2 - 100_000 else 300_000
+        bits[start : start + length] = 1
+    bits[-1] = 1
+    edges = np.flatnonzero(np.diff(np.concatenate([[0], bits, [0]]).astype(np.int8)))
+    truth = list(zip(edges[0::2].tolist(), (edges[1::2] - edges[0::2]).tolist()))
+    mask = np.packbits(bits, bitorder="little").view(np.uint32)
+    starts, lens = np.zeros(64, dtype=np.uint64), np.zeros(64, dtype=np.uint64)
+    n = lib.pa_mask_runs(mask.ctypes.data, bases, starts.ctypes.data, lens.ctypes.data, 64)
+    assert n == len(truth) and list(zip(starts[:n].tolist(), lens[:n].tolist())) == truth
+    assert any(s < bases // 2 < s + l for s, l in truth)  # the run over the chunk boundary
+    assert lib.pa_mask_runs(mask.ctypes.data, bases, starts.ctypes.data, lens.ctypes.data, 3) == len(truth)
+    assert list(zip(starts[:3].tolist(), lens[:3].tolist())) == truth[:3]
+    assert lib.pa_mask_runs(mask.ctypes.data, bases, None, None, 0) == len(truth)
+
+
 def test_host_pool_serves_two_callers_at_once(tmp_path):
     """The FASTA loader runs on a background thread of the batched front-end while the main thread uses the same
     host pool (strict ANI, writers).  Two callers at once must both get correct results."""
