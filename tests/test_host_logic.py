@@ -655,6 +655,38 @@ def test_vector_packer_equals_the_character_rules(tmp_path):
         assert np.array_equal(arena.contig_genome, ref.contig_genome) and arena.residues == ref.residues
 
 
+def test_packer_on_arbitrary_bytes():
+    """Property test: whatever the bytes (binary junk, '>' inside lines, lone CRs, NULs), pa_pack_fasta -- vector and
+    scalar chunks alike -- equals the character-by-character statement of the rules, and so does the record table."""
+    import ctypes as C
+
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    lib = _capi.load_library()
+    alphabet = st.sampled_from([b"A", b"C", b"G", b"T", b"a", b"c", b"g", b"t", b"N", b"n", b">", b"\n", b"\r", b" ", b"\t", b"\x00", b"-", b"X", b"\xff"])
+    runs = st.builds(lambda ch, n: ch * n, st.sampled_from([b"A", b"C", b"G", b"T", b"ACGT", b"acgtn", b"N", b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT"]), st.integers(1, 70))
+    piece = st.one_of(alphabet, runs, st.just(b"\n>title line\n"), st.binary(min_size=0, max_size=8))
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.lists(piece, min_size=0, max_size=40))
+    def check(pieces):
+        text = b"".join(pieces)
+        cap = int(lib.pa_pack_bound(len(text)))
+        packed, mask = np.full(cap // 16, 0xDEADBEEF, dtype=np.uint32), np.full(cap // 32, 0xDEADBEEF, dtype=np.uint32)
+        nb, nres, nrec, ninv = (C.c_uint64() for _ in range(4))
+        status = lib.pa_pack_fasta(text or None, len(text), packed.ctypes.data, mask.ctypes.data, cap, C.byref(nb), C.byref(nres), C.byref(nrec), C.byref(ninv))
+        assert status == 0
+        t_packed, t_mask, t_res, t_rec, t_inv, t_start, t_len = _pack_truth(text)
+        assert (nb.value, nres.value, nrec.value, ninv.value) == (16 * len(t_packed), t_res, t_rec, t_inv)
+        assert np.array_equal(packed[: len(t_packed)], t_packed) and np.array_equal(mask[: len(t_mask)], t_mask)
+        rs, rl = np.zeros(max(t_rec, 1), dtype=np.uint64), np.zeros(max(t_rec, 1), dtype=np.uint64)
+        assert lib.pa_fasta_records(text or None, len(text), rs.ctypes.data, rl.ctypes.data, t_rec) == t_rec
+        assert rs[:t_rec].tolist() == t_start and rl[:t_rec].tolist() == t_len
+
+    check()
+
+
 def test_mask_runs_across_chunks():
     """pa_mask_runs scans the mask in chunks on the host pool: runs that cross a chunk boundary (here: a run over the
     middle of the arena, where two workers meet) come out joined, in order, with the count right when cap is small."""
