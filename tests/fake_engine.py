@@ -56,3 +56,25 @@ class OracleEngine:
 
     def pair_counts(self, sk: _Sketches, q_range=None, s_range=None, algo=0):
         return _HostTensor(oracle.pair_counts(sk.sketches, q_range, s_range))
+
+
+    def fragani(self, arena: HostArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000, ref_range=None):
+        """Fragment ANI of every ordered pair through the oracle: (total[n], matched[n, n], ident_sum[n, n])."""
+        n = arena.n_genomes
+        contigs = [[] for _ in range(n)]
+        for start, length, g in zip(contig_start, contig_len, contig_genome):
+            g0 = int(arena.genome_start[int(g)])
+            text = arena_to_ascii(HostArena(arena.packed, arena.mask, arena.genome_start), int(g))
+            contigs[int(g)].append(text[int(start) - g0 : int(start) - g0 + int(length)])
+        r0, r1 = (0, n) if ref_range is None else ref_range
+        total = np.zeros(n, dtype=np.uint32)
+        matched = np.zeros((n, n), dtype=np.uint32)
+        ident_sum = np.zeros((n, n), dtype=np.float64)
+        for q in range(n):
+            for r in range(n):
+                ani, m, t = oracle.fragani_pair(contigs[q], contigs[r], k, frag_len, 0.0)
+                total[q] = t
+                if r0 <= r < r1 and m:
+                    matched[q, r] = m
+                    ident_sum[q, r] = ani * m
+        return total, matched, ident_sum
