@@ -281,6 +281,107 @@ int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const ui
                                  d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
 }
 
+// ---- k from 33 to 64 ------------------------------------------------------------------------------------------
+// sourmash hashes k-mers of any length (its own defaults are 21, 31 and 51) and the reference passes --kmersize
+// through (pyani_plus/public_cli_args.py:229, pyani_plus/methods/sourmash.py:75-76).  Beyond 32 bases a k-mer no
+// longer fits the register pair the kernel above is built around, so these sizes take a plain form of the same
+// arithmetic: one thread per window END (the window reaches back up to 63 positions, into blocks that are always
+// already there -- also when the arena arrives in chunks), both strands as 128-bit values, MurmurHash3 without tables
+// or screen.  Several times slower per window than the kernel above; same results as the oracle for every k.
+__device__ __forceinline__ uint64_t murmur3_words(const uint64_t (&w)[8], uint32_t k) {
+  uint64_t h1 = 42, h2 = 42;
+  const uint32_t nblocks = k >> 4, tail = k & 15u;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    if (i >= nblocks) break;
+    uint64_t k1 = w[2 * i] * kC1;
+    k1 = rotl64(k1, 31) * kC2;
+    h1 ^= k1;
+    h1 = rotl64(h1, 27) + h2;
+    h1 = h1 * 5 + 0x52dce729ULL;
+    uint64_t k2 = w[2 * i + 1] * kC2;
+    k2 = rotl64(k2, 33) * kC1;
+    h2 ^= k2;
+    h2 = rotl64(h2, 31) + h1;
+    h2 = h2 * 5 + 0x38495ab5ULL;
+  }
+  // the words of the tail (bytes past k are zero in w)
+  uint64_t t1 = 0, t2 = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i)
+    if (i == nblocks) { t1 = w[2 * i]; t2 = w[2 * i + 1]; }
+  if (tail > 8) h2 ^= rotl64(t2 * kC2, 33) * kC1;
+  if (tail > 0) h1 ^= rotl64(t1 * kC1, 31) * kC2;
+  h1 ^= (uint64_t)k;
+  h2 ^= (uint64_t)k;
+  h1 += h2;
+  h2 += h1;
+  h1 = fmix64(h1);
+  h2 = fmix64(h2);
+  return h1 + h2;
+}
+
+__global__ __launch_bounds__(kThreads) void kmer_hash_long_kernel(
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t pos0, uint64_t pos1, uint32_t k,
+    const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *__restrict__ cand_hash,
+    uint32_t *__restrict__ cand_genome, uint64_t cap, unsigned long long *__restrict__ count,
+    const uint64_t *__restrict__ region_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ overflow) {
+  const uint64_t e = pos0 + (uint64_t)blockIdx.x * kThreads + threadIdx.x;  // last position of the window
+  if (e >= pos1 || e + 1 < k) return;
+  const uint64_t a = e + 1 - k;  // first position
+  // the window inside the words it touches: up to three mask words and five packed words
+  const uint64_t m0 = a >> 5, w0 = a >> 4;
+  const uint32_t sh_m = (uint32_t)(a & 31u), sh_p = 2u * (uint32_t)(a & 15u);
+  unsigned __int128 bad = 0, f = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) bad |= (unsigned __int128)(m0 + i <= (e >> 5) ? mask[m0 + i] : 0u) << (32 * i);
+  bad >>= sh_m;
+  const unsigned __int128 kbits = k == 64 ? ~(unsigned __int128)0 >> 64 : (((unsigned __int128)1 << k) - 1);
+  if (bad & kbits) return;  // an invalid position inside the window (also: a record or genome boundary)
+  // five packed words cover 64 bases from any offset; the fifth only matters when the window is not word-aligned
+  {
+    unsigned __int128 lo = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo |= (unsigned __int128)(w0 + i <= (e >> 4) ? packed[w0 + i] : 0u) << (32 * i);
+    const uint32_t w4 = w0 + 4 <= (e >> 4) ? packed[w0 + 4] : 0u;
+    f = sh_p ? (lo >> sh_p) | ((unsigned __int128)w4 << (128 - sh_p)) : lo;
+  }
+  const unsigned __int128 kmask = k == 64 ? ~(unsigned __int128)0 : (((unsigned __int128)1 << (2 * k)) - 1);
+  f &= kmask;
+  // reverse complement, LSB-first like f: reverse the 2-bit groups of the 128 bits, complement, drop the unused top
+  const uint64_t f_lo = (uint64_t)f, f_hi = (uint64_t)(f >> 64);
+  auto rev_groups = [](uint64_t x) -> uint64_t {
+    x = __builtin_bitreverse64(x);
+    return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+  };
+  unsigned __int128 r = ((unsigned __int128)rev_groups(f_lo) << 64) | rev_groups(f_hi);
+  r = ~r >> (128 - 2 * k);
+  r &= kmask;
+  // the lexicographically smaller strand: MSB-first order of one strand is the complement of the LSB-first form of
+  // the other (see the kernel above), so "forward <= reverse complement" is f <= r
+  const unsigned __int128 c = f <= r ? f : r;
+  uint64_t w[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t g16 = (uint32_t)(c >> (16 * j)) & 0xffffu;
+    const int left = (int)k - 8 * j;  // bases of the k-mer from this word on
+    w[j] = u64_of(ascii_group(g16 & 0xffu, left), ascii_group(g16 >> 8, left - 4));
+  }
+  const uint64_t h = murmur3_words(w, k);
+  if (h > max_hash) return;
+  const uint32_t blk = (uint32_t)(e >> 6);
+  const uint32_t g = find_genome(genome_blk, n_genomes, blk);
+  if (region_off) {
+    region_append(cand_hash, region_off, cursor, overflow, g, h);
+  } else {
+    const unsigned long long slot = atomicAdd(count, 1ULL);
+    if (slot < cap) {
+      cand_hash[slot] = h;
+      cand_genome[slot] = g;
+    }
+  }
+}
+
 }  // namespace
 
 int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const uint64_t *d_dirty, uint64_t n_blocks64,
@@ -290,6 +391,15 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
                         hipStream_t stream) {
   PA_REQUIRE(n_blocks64 < (1ULL << 32), "arena too large: %llu blocks of 64 bases", (unsigned long long)n_blocks64);
   if (n_blocks64 <= blk0) return PA_OK;
+  if (k > 32 && k <= 64) {
+    const uint64_t pos0 = blk0 * 64, pos1 = n_blocks64 * 64;
+    hipLaunchKernelGGL(kmer_hash_long_kernel, dim3(ceil_div_u64(pos1 - pos0, kThreads)), dim3(kThreads), 0,
+                       stream ? stream : c->stream, d_packed, d_mask, pos0, pos1, k, d_genome_blk, n_genomes, max_hash,
+                       d_cand_hash, d_cand_genome, cap, reinterpret_cast<unsigned long long *>(d_count), d_region_off,
+                       d_cursor, d_overflow);
+    PA_HIP(hipGetLastError());
+    return PA_OK;
+  }
 #define PA_K_CASE(KK) \
   case KK: return launch<KK>(c, d_packed, d_mask, d_dirty, n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
   PA_REQUIRE((blk0 & 63u) == 0, "k-mer hash launch must start at a multiple of 64 blocks, not %llu", (unsigned long long)blk0);
@@ -299,7 +409,7 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
     PA_K_CASE(17) PA_K_CASE(18) PA_K_CASE(19) PA_K_CASE(20) PA_K_CASE(21) PA_K_CASE(22) PA_K_CASE(23) PA_K_CASE(24)
     PA_K_CASE(25) PA_K_CASE(26) PA_K_CASE(27) PA_K_CASE(28) PA_K_CASE(29) PA_K_CASE(30) PA_K_CASE(31) PA_K_CASE(32)
     default:
-      pa_set_error("k=%u outside [1,32]", k);
+      pa_set_error("k=%u outside [1,64]", k);
       return PA_E_INVALID;
   }
 #undef PA_K_CASE

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <cstdlib>
+
 #include "pa_internal.h"
 
 namespace {
@@ -170,7 +172,9 @@ int pa_sketch_streamed(pa_ctx *c, const uint32_t *h_packed, const uint64_t *h_ru
   PA_HIP(hipStreamSynchronize(c->stream));  // blk / region_off are stack-owned; the copy stream starts after this
 
   // 64 MB of packed bases (2.7e8 positions) per chunk: ~1.2 ms on the bus, ~0.7 ms of hashing
-  const uint64_t chunk_blocks = (64ull << 20) / 16;
+  uint64_t chunk_blocks = (64ull << 20) / 16;
+  if (const char *v = getenv("PA_STREAM_CHUNK_BLOCKS"))  // tests: small chunks, so that windows cross chunk boundaries
+    chunk_blocks = std::max<uint64_t>(64, (strtoull(v, nullptr, 10) + 63) / 64 * 64);
   std::vector<hipEvent_t> arrived;
   int status = PA_OK;
   {

@@ -205,8 +205,8 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, pr
     if not config.extra:
         log_sys_exit(logger, f"{METHOD} requires extra setting, default is scaled={SCALED}")
     scaled = parse_scaled(config.extra)
-    if not 1 <= int(config.kmersize) <= 32:
-        log_sys_exit(logger, f"{METHOD} supports k-mer sizes 1 to 32, not {config.kmersize}")
+    if not 1 <= int(config.kmersize) <= 64:
+        log_sys_exit(logger, f"{METHOD} supports k-mer sizes 1 to 64, not {config.kmersize}")
     if not Path(cache).is_dir():
         msg = f"Cache directory '{cache}' does not exist"
         raise ValueError(msg)

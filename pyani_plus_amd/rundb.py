@@ -528,8 +528,8 @@ def run_sourmash_hip(  # noqa: PLR0913
 
     logger = logger or logging.getLogger("pyani_plus_amd")
     fasta = Path(fasta)
-    if not 1 <= int(kmersize) <= 32:  # before any file is read
-        sourmash_hip.log_sys_exit(logger, f"{sourmash_hip.METHOD} supports k-mer sizes 1 to 32, not {kmersize}")
+    if not 1 <= int(kmersize) <= 64:  # before any file is read
+        sourmash_hip.log_sys_exit(logger, f"{sourmash_hip.METHOD} supports k-mer sizes 1 to 64, not {kmersize}")
     if int(scaled) < 1:
         sourmash_hip.log_sys_exit(logger, f"scaled must be a positive integer, not {scaled}")
     if ingest not in {"json", "direct"}:

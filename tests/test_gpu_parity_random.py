@@ -43,7 +43,7 @@ def _random_fasta(rng, n_records, max_len, *, lower=False, n_runs=0) -> bytes:
     return b"".join(out)
 
 
-@pytest.mark.parametrize("k", [15, 16, 21, 31, 32, 7, 20, 24, 30])
+@pytest.mark.parametrize("k", [15, 16, 21, 31, 32, 7, 20, 24, 30, 33, 51, 64])
 @pytest.mark.parametrize("scaled", [1, 7, 1000])
 def test_sketch_random_fasta_matches_oracle(engine, k, scaled):
     from pyani_plus_amd.engine import pack_genomes
@@ -69,17 +69,22 @@ def test_sketch_random_fasta_matches_oracle(engine, k, scaled):
 
 def test_sketch_every_kmer_size_matches_oracle(engine):
     """The reference hands any --kmersize to sourmash (pyani_plus/public_cli_args.py:229,
-    pyani_plus/methods/sourmash.py:75-76): every k from 1 to 32 is compiled in and equals the oracle."""
+    pyani_plus/methods/sourmash.py:75-76): every k from 1 to 32 is compiled into the tuned kernel, 33 to 64 (sourmash's
+    own third default is 51) take the plain 128-bit form; all of them equal the oracle, and beyond 64 is refused."""
     from pyani_plus_amd.engine import pack_genomes
 
     rng = np.random.default_rng(99)
     texts = [_random_fasta(rng, 2, 6000, n_runs=3), _random_fasta(rng, 1, 9000, lower=True), b">tiny\nACGTTGCA\n"]
     dev = engine.upload(pack_genomes(texts))
-    for k in range(1, 33):
+    for k in range(1, 65):
         got = engine.sketch(dev, k, 3).to_host()
         for g, text in enumerate(texts):
             want, _total = oracle.sketch_fasta_text(text, k, 3)
             assert np.array_equal(got[g], want), f"k={k} genome {g}: {len(got[g])} vs {len(want)}"
+    from pyani_plus_amd._capi import HipBackendError
+
+    with pytest.raises(HipBackendError, match="outside"):
+        engine.sketch(dev, 65, 3)
 
 
 def test_sketch_staging_overflow_and_capacity_retry(engine):
@@ -282,9 +287,9 @@ def test_degenerate_inputs_and_error_codes(engine):
     assert tuple(engine.pair_counts(empty).shape) == (0, 0)
     # unsupported k, bad ranges, bad algo -> error codes with messages, no crash
     one = pack_genomes([b"ACGT" * 100], fasta=False)
-    with pytest.raises(_capi.HipBackendError, match=r"outside \[1,32\]"):
-        engine.sketch(engine.upload(one), 33, 10)
-    with pytest.raises(_capi.HipBackendError, match=r"outside \[1,32\]"):
+    with pytest.raises(_capi.HipBackendError, match=r"outside \[1,64\]"):
+        engine.sketch(engine.upload(one), 65, 10)
+    with pytest.raises(_capi.HipBackendError, match=r"outside \[1,64\]"):
         engine.sketch(engine.upload(one), 0, 10)
     good = engine.sketch(engine.upload(one), 31, 10)
     with pytest.raises(_capi.HipBackendError, match="ranges"):
@@ -327,3 +332,21 @@ def test_streamed_sketch_equals_resident_sketch(engine):
         assert engine.torch.equal(got.hashes[: got.total], want.hashes[: want.total])
         assert engine.torch.equal(dev2.mask[: arena.mask.size], dev.mask)
         assert engine.torch.equal(dev2.packed[: arena.packed.size], dev.packed)
+
+
+@pytest.mark.parametrize("k", [31, 51, 64])
+def test_streamed_sketch_windows_across_chunk_boundaries(engine, k, monkeypatch):
+    """The hash kernel of chunk c looks back into chunk c - 1 (up to k - 1 positions, 63 for the long-k form): with
+    chunks of 64 arena blocks every 4 096th position is such a boundary."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(k)
+    texts = [_random_fasta(rng, 2, 30_000, n_runs=3), _random_fasta(rng, 1, 50_000), _random_fasta(rng, 3, 9_000, lower=True)]
+    arena = pack_genomes(texts)
+    want = engine.sketch(engine.upload(arena), k, 20).to_host()
+    monkeypatch.setenv("PA_STREAM_CHUNK_BLOCKS", "64")
+    _dev, got = engine.sketch_streamed(engine.pin_arena(arena), k, 20)
+    got = got.to_host()
+    for g, text in enumerate(texts):
+        oracle_mins, _total = oracle.sketch_fasta_text(text, k, 20)
+        assert np.array_equal(got[g], want[g]) and np.array_equal(got[g], oracle_mins), (k, g)

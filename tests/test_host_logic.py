@@ -461,8 +461,8 @@ def test_driver_rejects_duplicates_and_bad_gzip(tmp_path):
     with pytest.raises(SystemExit, match="No FASTA input genomes"):
         rundb.run_sourmash_hip(tmp_path, tmp_path / "z.sqlite", engine=OracleEngine())
     # parameters are checked before any file is read (the reference passes any --kmersize on, public_cli_args.py:229)
-    with pytest.raises(SystemExit, match="k-mer sizes 1 to 32"):
-        rundb.run_sourmash_hip(d, tmp_path / "k.sqlite", kmersize=33, engine=OracleEngine())
+    with pytest.raises(SystemExit, match="k-mer sizes 1 to 64"):
+        rundb.run_sourmash_hip(d, tmp_path / "k.sqlite", kmersize=65, engine=OracleEngine())
     with pytest.raises(SystemExit, match="ingest must be"):
         rundb.run_sourmash_hip(d, tmp_path / "k.sqlite", ingest="csv", engine=OracleEngine())
 
@@ -685,6 +685,27 @@ def test_packer_on_arbitrary_bytes():
         assert rs[:t_rec].tolist() == t_start and rl[:t_rec].tolist() == t_len
 
     check()
+
+
+def test_driver_with_a_long_kmer_size(tmp_path):
+    """--kmersize 51 (sourmash's third default; the reference passes any size on, public_cli_args.py:229) through the
+    whole host side: cache directory name, signature files with ksize 51, complete database."""
+    name = "viral_example"
+    scaled, genomes = FIXTURE_SETS[name]
+    run = rundb.run_sourmash_hip(GOLDEN / name, tmp_path / "k51.sqlite", cache=tmp_path / "cache", kmersize=51, scaled=scaled,
+                                 engine=OracleEngine(), temp=tmp_path, ingest="direct")
+    sigs = sorted((tmp_path / "cache" / f"sourmash_k=51_scaled={scaled}").glob("*.sig"))
+    assert len(sigs) == len(genomes) == len(run.fasta_hashes)
+    by_hash = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}
+    for path in sigs:
+        data = load_sig(path)
+        assert data["signatures"][0]["ksize"] == 51
+        want, _total = oracle.sketch_fasta_text(read_fasta_bytes(GOLDEN / name / by_hash[path.stem]), 51, scaled)
+        assert np.array_equal(np.array(data["signatures"][0]["mins"], dtype=np.uint64), want)
+    conn = sqlite3.connect(tmp_path / "k51.sqlite")
+    assert conn.execute("SELECT kmersize FROM configurations").fetchall() == [(51,)]
+    assert conn.execute("SELECT COUNT(*) FROM comparisons WHERE identity = 1.0 AND query_hash = subject_hash").fetchone()[0] == len(genomes)
+    conn.close()
 
 
 def test_mask_runs_across_chunks():
