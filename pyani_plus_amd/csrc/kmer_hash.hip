@@ -326,7 +326,9 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_long_kernel(
     const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *__restrict__ cand_hash,
     uint32_t *__restrict__ cand_genome, uint64_t cap, unsigned long long *__restrict__ count,
     const uint64_t *__restrict__ region_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ overflow) {
-  const uint64_t e = pos0 + (uint64_t)blockIdx.x * kThreads + threadIdx.x;  // last position of the window
+  // last position of the window.  The grid is two-dimensional: one dimension of a launch holds fewer than 2^32
+  // threads, an arena of 1 000 genomes of 5 Mb has 5 * 10^9 positions.
+  const uint64_t e = pos0 + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;
   if (e >= pos1 || e + 1 < k) return;
   const uint64_t a = e + 1 - k;  // first position
   // the window inside the words it touches: up to three mask words and five packed words
@@ -393,7 +395,10 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
   if (n_blocks64 <= blk0) return PA_OK;
   if (k > 32 && k <= 64) {
     const uint64_t pos0 = blk0 * 64, pos1 = n_blocks64 * 64;
-    hipLaunchKernelGGL(kmer_hash_long_kernel, dim3(ceil_div_u64(pos1 - pos0, kThreads)), dim3(kThreads), 0,
+    const uint64_t n_wg = (pos1 - pos0 + kThreads - 1) / kThreads;
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(n_wg, 1u << 20), gy = (uint32_t)((n_wg + gx - 1) / gx);
+    PA_REQUIRE(gy <= 65535u, "arena too large for one launch of the long k-mer kernel: %llu positions", (unsigned long long)(pos1 - pos0));
+    hipLaunchKernelGGL(kmer_hash_long_kernel, dim3(gx, gy), dim3(kThreads), 0,
                        stream ? stream : c->stream, d_packed, d_mask, pos0, pos1, k, d_genome_blk, n_genomes, max_hash,
                        d_cand_hash, d_cand_genome, cap, reinterpret_cast<unsigned long long *>(d_count), d_region_off,
                        d_cursor, d_overflow);

@@ -235,6 +235,24 @@ def test_full_size_properties_baseline_config(engine):
     assert np.array_equal(c[0:1000:25, 0:1000:25], oracle.pair_counts(block, threads=8))
 
 
+def test_full_size_long_kmer(engine):
+    """k = 51 over the full 5 * 10^9 positions of BASELINE configs[1] (more threads than one grid dimension holds):
+    sketch sizes ~ L / scaled everywhere, sampled genomes equal the oracle, the last genome included."""
+    from pyani_plus_amd.synth import device_arena_to_host, synth_arena_torch
+
+    n, length, k, scaled = 1000, 5_000_000, 51, 1000
+    arena = synth_arena_torch(engine, n, length)
+    sk = engine.sketch(arena, k, scaled)
+    off = sk.off.cpu().numpy()
+    sizes = np.diff(off)
+    assert sizes.min() > 4500 and sizes.max() < 5500
+    flat = sk.hashes[: sk.total].cpu().numpy().view(np.uint64)
+    sample = [0, 500, 999]
+    host = device_arena_to_host(arena, sample, length)
+    for i, g in enumerate(sample):
+        assert np.array_equal(flat[off[g] : off[g + 1]], oracle.sketch_seq(arena_to_ascii(host, i), k, scaled))
+
+
 def test_mixed_length_set_config5_style(engine):
     """BASELINE configs[4] shape at reduced count: log-uniform lengths 100 kb - 10 Mb, cost-balanced shards."""
     from pyani_plus_amd.distributed import shard_bounds_by_cost
