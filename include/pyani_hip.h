@@ -253,7 +253,7 @@ PA_API int pa_ani_mash(pa_ctx *ctx, const uint32_t *d_common, const uint32_t *d_
  * (pyani_plus/methods/fastani.py:98-120 parses exactly these three numbers).
  * Only the reference genomes [ref0, ref1) are mapped against (columns outside stay 0): the reference's worker is
  * called once per subject column (pyani_plus/private_cli.py:976-1063), and a column costs one column's mappings.
- * Algorithm and its tolerance-only parity: oracle/fragani_oracle.c.  k in {12,14,15,16}; fragLen in
+ * Algorithm and its tolerance-only parity: oracle/fragani_oracle.c.  k from 8 to 16 (fastANI itself stops at 16); fragLen in
  * [100, 65535]; contigs listed genome by genome, at most 65535 per genome and 2^20-1 in all; at most 2^20-1
  * fragments per genome.  The workspace (about 12 GB for 1000 x 5 Mb genomes) stays in the context. */
 PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,

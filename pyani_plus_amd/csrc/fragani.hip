@@ -1420,12 +1420,17 @@ int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint3
 int dispatch_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                         uint32_t n_contigs, uint32_t k, int w, uint32_t *m_out) {
   switch (k) {
+    case 8: return run_minimizers<8>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
+    case 9: return run_minimizers<9>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
+    case 10: return run_minimizers<10>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
+    case 11: return run_minimizers<11>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
     case 12: return run_minimizers<12>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
+    case 13: return run_minimizers<13>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
     case 14: return run_minimizers<14>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
     case 15: return run_minimizers<15>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
     case 16: return run_minimizers<16>(c, W, d_packed, d_mask, arena_bases, n_contigs, w, m_out);
     default:
-      pa_set_error("fragment ANI: k=%u is not compiled in (supported: 12, 14, 15, 16)", k);
+      pa_set_error("fragment ANI: k=%u outside [8,16] (fastANI itself stops at 16)", k);
       return PA_E_INVALID;
   }
 }

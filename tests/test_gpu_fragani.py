@@ -63,7 +63,7 @@ def test_parameters_match_oracle(engine):
         assert lib.pa_fragani_identity(shared, s, 16) == oracle.fragani_identity(shared, s, 16)
 
 
-@pytest.mark.parametrize("k,w", [(16, 23), (15, 19), (16, 5), (12, 64)])
+@pytest.mark.parametrize("k,w", [(16, 23), (15, 19), (16, 5), (12, 64), (13, 24), (8, 31), (11, 9)])
 def test_minimizers_equal_oracle(engine, k, w):
     from pyani_plus_amd.engine import pack_genomes
 
