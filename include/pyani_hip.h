@@ -123,6 +123,8 @@ PA_API int pa_gunzip(const uint8_t *h_gz, uint64_t n_gz, uint8_t *h_out, uint64_
  * pyani_plus/utils.py:142-196; length and description, pyani_plus/db_orm.py:832-866; the
  * sketcher's own read, pyani_plus/methods/sourmash.py:67-83): read, gunzip (pa_gunzip's decoder 0), md5 (sixteen
  * files side by side where the CPU has AVX-512), parse, pack (pa_pack_fasta).  threads <= 0: pa_host_cpu_budget().
+ * The scratch mappings of a batch (up to three, at most 3 GiB) are kept for the next call; the environment variable
+ * PA_HOST_SLAB_CACHE=0 returns them to the system at once.
  * pa_fasta_batch_info returns the file's own status (PA_OK or a negative code with `message`,
  * e.g. "Has .gz ending, but x.fa.gz is NOT gzip compressed", db_orm.py:846-854); strings are
  * owned by the batch.  pa_fasta_batch_copy_arena concatenates the successfully loaded genomes
