@@ -93,8 +93,10 @@ def sketch_seq(seq: bytes, k: int, scaled: int) -> np.ndarray:
 
 
 def sketch_many(seqs: list[bytes] | list[np.ndarray], k: int, scaled: int, threads: int = 1, fast: bool = False) -> list[np.ndarray]:
-    """Sketch bare residue strings, one OpenMP task each (fast=True: the tuned scalar form)."""
+    """Sketch bare residue strings, one OpenMP task each (fast=True: the tuned scalar form, which holds a k-mer in one
+    64-bit word: k above 32 takes the plain form whatever ``fast`` says)."""
     lib = _load()
+    fast = fast and k <= 32
     lens = np.array([len(s) for s in seqs], dtype=np.uint64)
     off = np.zeros(len(seqs) + 1, dtype=np.uint64)
     np.cumsum(lens, out=off[1:])
