@@ -540,7 +540,9 @@ def run_rank(args) -> None:
     # passes of tools/pmc_passes.sh (profiles/hash_counters.json), and are labelled as such
     counters = None
     cfile = ROOT / "profiles" / "hash_counters.json"
-    if cfile.is_file():
+    # ... of the profiled workload only: kmer_hash_kernel<31>, scaled mode, 1 000 genomes of 5 Mb per launch
+    profiled = args.kmer == 31 and not bottom and not args.mixed_lengths and args.length == 5_000_000 and (g1 - g0) == 1000
+    if profiled and cfile.is_file():
         try:
             counters = json.loads(cfile.read_text())
         except Exception:
@@ -566,7 +568,7 @@ def run_rank(args) -> None:
     if rank == 0:
         windows = max(1.0, sum(lengths[g0:g1]) / 64.0)  # wave-steps of one launch: one window per lane
         clock_ghz = (counters or {}).get("effective_clock_ghz")
-        valu = {
+        valu = None if args.kmer != 31 or bottom else {  # the instruction mix below is that of kmer_hash_kernel<31>
             "instr_per_window_static": 92.5,
             "model_cycles_per_wave_step": 24.6875 * 2.6 + 67.8125 * 4.35,
             "issue_cost_cycles": {"plain_vop2_add_logic": 2.6, "everything_else": 4.35, "source": "profiles/r02_ubench_valu_gfx950.txt"},
@@ -574,11 +576,11 @@ def run_rank(args) -> None:
             "note": "model = static instruction mix x measured per-instruction issue costs; measured/model near 1 means the "
             "kernel runs at the VALU issue limit of its instruction stream",
         }
-        if clock_ghz:
+        if valu is not None and clock_ghz:
             valu["clock_ghz_measured"] = clock_ghz
             valu["clock_source"] = (counters or {}).get("clock_source")
             valu["measured_cycles_per_wave_step"] = per_launch_s * clock_ghz * 1e9 * SIMDS / windows
-        if counters and counters.get("valu_busy_pct") is not None:
+        if valu is not None and counters and counters.get("valu_busy_pct") is not None:
             valu["valu_busy_pct_from_counters"] = counters["valu_busy_pct"]
             valu["counters"] = counters.get("sq")
         result = {
@@ -617,14 +619,14 @@ def run_rank(args) -> None:
             "rccl_ranks": (dist.get_world_size() if dist_path else 0),
             "collective_backend": (backend if dist_path else None),
             "roofline": {
-                "kernel": f"kmer_hash_kernel<{args.kmer}>",
+                "kernel": f"kmer_hash_kernel<{args.kmer}>" if args.kmer <= 32 else f"kmer_hash_long_kernel (k={args.kmer})",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": (counters or {}).get("hbm_bytes_per_launch"),
-                "traffic_source": (counters or {}).get("traffic_source", None),
+                "traffic_source": (counters or {}).get("traffic_source", None if profiled else "no counter passes committed for this workload"),
                 "measured_copy_gbs": copy_gbs,
                 "frac_of_measured_copy": achieved / copy_gbs if copy_gbs else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
