@@ -284,93 +284,124 @@ int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const ui
 // ---- k from 33 to 64 ------------------------------------------------------------------------------------------
 // sourmash hashes k-mers of any length (its own defaults are 21, 31 and 51) and the reference passes --kmersize
 // through (pyani_plus/public_cli_args.py:229, pyani_plus/methods/sourmash.py:75-76).  Beyond 32 bases a k-mer no
-// longer fits the register pair the kernel above is built around, so these sizes take a plain form of the same
-// arithmetic: one thread per window END (the window reaches back up to 63 positions, into blocks that are always
-// already there -- also when the arena arrives in chunks), both strands as 128-bit values, MurmurHash3 without tables
-// or screen.  Several times slower per window than the kernel above; same results as the oracle for every k.
-__device__ __forceinline__ uint64_t murmur3_words(const uint64_t (&w)[8], uint32_t k) {
+// longer fits the register pair the kernel above is built around, so these sizes take a simpler decomposition of the
+// same arithmetic: one thread per window END (the window reaches back up to 63 positions, into blocks that are always
+// already there -- also when the arena arrives in chunks), both strands as four 32-bit words, the first multiply
+// of each of the up to eight murmur words from the same kind of LDS tables as above, the high-word screen before
+// the last multiply.  Same results as the oracle for every k.
+__device__ __forceinline__ uint32_t rev_groups32(uint32_t x) {  // the sixteen 2-bit groups of a word in reverse order
+  x = __builtin_bitreverse32(x);
+  return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+
+// everything of MurmurHash3_x64_128 between the first multiply of every word (P[j], from the tables) and the last
+// multiply of the two fmix64: U and V as in murmur3_pre_last_mul, for a run-time k (uniform over the launch)
+__device__ __forceinline__ void murmur3_pre_last_mul_rt(const uint64_t (&P)[8], uint32_t k, uint64_t &U, uint64_t &V) {
   uint64_t h1 = 42, h2 = 42;
   const uint32_t nblocks = k >> 4, tail = k & 15u;
 #pragma unroll
   for (uint32_t i = 0; i < 4; ++i) {
     if (i >= nblocks) break;
-    uint64_t k1 = w[2 * i] * kC1;
-    k1 = rotl64(k1, 31) * kC2;
-    h1 ^= k1;
+    h1 ^= rotl64(P[2 * i], 31) * kC2;
     h1 = rotl64(h1, 27) + h2;
-    h1 = h1 * 5 + 0x52dce729ULL;
-    uint64_t k2 = w[2 * i + 1] * kC2;
-    k2 = rotl64(k2, 33) * kC1;
-    h2 ^= k2;
+    h1 = times5_plus(h1, 0x52dce729ULL);
+    h2 ^= rotl64(P[2 * i + 1], 33) * kC1;
     h2 = rotl64(h2, 31) + h1;
-    h2 = h2 * 5 + 0x38495ab5ULL;
+    h2 = times5_plus(h2, 0x38495ab5ULL);
   }
-  // the words of the tail (bytes past k are zero in w)
   uint64_t t1 = 0, t2 = 0;
 #pragma unroll
   for (uint32_t i = 0; i < 4; ++i)
-    if (i == nblocks) { t1 = w[2 * i]; t2 = w[2 * i + 1]; }
-  if (tail > 8) h2 ^= rotl64(t2 * kC2, 33) * kC1;
-  if (tail > 0) h1 ^= rotl64(t1 * kC1, 31) * kC2;
+    if (i == nblocks) { t1 = P[2 * i]; t2 = P[2 * i + 1]; }
+  if (tail > 8) h2 ^= rotl64(t2, 33) * kC1;
+  if (tail > 0) h1 ^= rotl64(t1, 31) * kC2;
   h1 ^= (uint64_t)k;
   h2 ^= (uint64_t)k;
   h1 += h2;
   h2 += h1;
-  h1 = fmix64(h1);
-  h2 = fmix64(h2);
-  return h1 + h2;
+  h1 ^= h1 >> 33; h1 *= kF1; h1 ^= h1 >> 33;
+  h2 ^= h2 >> 33; h2 *= kF1; h2 ^= h2 >> 33;
+  U = h1;
+  V = h2;
 }
 
+constexpr int kLongIter = 32;  // window ends per thread of kmer_hash_long_kernel
 __global__ __launch_bounds__(kThreads) void kmer_hash_long_kernel(
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t pos0, uint64_t pos1, uint32_t k,
     const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash, uint64_t *__restrict__ cand_hash,
     uint32_t *__restrict__ cand_genome, uint64_t cap, unsigned long long *__restrict__ count,
     const uint64_t *__restrict__ region_off, uint32_t *__restrict__ cursor, uint32_t *__restrict__ overflow) {
-  // last position of the window.  The grid is two-dimensional: one dimension of a launch holds fewer than 2^32
-  // threads, an arena of 1 000 genomes of 5 Mb has 5 * 10^9 positions.
-  const uint64_t e = pos0 + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x;
-  if (e >= pos1 || e + 1 < k) return;
+  __shared__ uint64_t s_lo[8][256];
+  __shared__ uint32_t s_hi[8][256];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n_words = (k + 7u) >> 3;
+  for (uint32_t j = 0; j < n_words; ++j) {  // word j of the k-mer: bases 8j .. 8j+7, the last one partial
+    const uint64_t cj = (j & 1u) ? kC2 : kC1;
+    s_lo[j][tid] = (uint64_t)ascii_group(tid, (int)k - 8 * (int)j) * cj;
+    s_hi[j][tid] = (uint32_t)((uint64_t)ascii_group(tid, (int)k - 8 * (int)j - 4) * cj);
+  }
+  __syncthreads();
+  // A workgroup takes kLongIter * 256 consecutive window ends, 256 at a time (the tables above cost as much as hashing
+  // a window: they have to serve many).  The grid is two-dimensional: an arena of 1 000 genomes of 5 Mb has 5 * 10^9
+  // positions, more than one grid dimension is sure to hold.
+  const uint64_t wg_first = pos0 + ((uint64_t)blockIdx.y * gridDim.x + blockIdx.x) * (uint64_t)(kThreads * kLongIter);
+#pragma unroll 1
+  for (int it = 0; it < kLongIter; ++it) {
+  const uint64_t e = wg_first + (uint64_t)it * kThreads + tid;  // last position of the window
+  if (e >= pos1 || e + 1 < k) continue;
   const uint64_t a = e + 1 - k;  // first position
-  // the window inside the words it touches: up to three mask words and five packed words
-  const uint64_t m0 = a >> 5, w0 = a >> 4;
-  const uint32_t sh_m = (uint32_t)(a & 31u), sh_p = 2u * (uint32_t)(a & 15u);
-  unsigned __int128 bad = 0, f = 0;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) bad |= (unsigned __int128)(m0 + i <= (e >> 5) ? mask[m0 + i] : 0u) << (32 * i);
-  bad >>= sh_m;
-  const unsigned __int128 kbits = k == 64 ? ~(unsigned __int128)0 >> 64 : (((unsigned __int128)1 << k) - 1);
-  if (bad & kbits) return;  // an invalid position inside the window (also: a record or genome boundary)
-  // five packed words cover 64 bases from any offset; the fifth only matters when the window is not word-aligned
+  // ---- usable?  the k mask bits from position a on: up to three mask words
   {
-    unsigned __int128 lo = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lo |= (unsigned __int128)(w0 + i <= (e >> 4) ? packed[w0 + i] : 0u) << (32 * i);
-    const uint32_t w4 = w0 + 4 <= (e >> 4) ? packed[w0 + 4] : 0u;
-    f = sh_p ? (lo >> sh_p) | ((unsigned __int128)w4 << (128 - sh_p)) : lo;
+    const uint64_t m0 = a >> 5, m_last = e >> 5;
+    const uint32_t sm = (uint32_t)(a & 31u);
+    const uint32_t w0 = mask[m0], w1 = m0 + 1 <= m_last ? mask[m0 + 1] : 0u, w2 = m0 + 2 <= m_last ? mask[m0 + 2] : 0u;
+    const uint32_t b0 = alignbit(w1, w0, sm), b1 = alignbit(w2, w1, sm);  // a shift of 0 returns the low operand
+    const uint32_t top = k == 64 ? 0xffffffffu : ((1u << (k - 32u)) - 1u);  // k is 33 .. 64 here
+    if (b0 | (b1 & top)) continue;  // an invalid position inside the window (also: a record or genome boundary)
   }
-  const unsigned __int128 kmask = k == 64 ? ~(unsigned __int128)0 : (((unsigned __int128)1 << (2 * k)) - 1);
-  f &= kmask;
-  // reverse complement, LSB-first like f: reverse the 2-bit groups of the 128 bits, complement, drop the unused top
-  const uint64_t f_lo = (uint64_t)f, f_hi = (uint64_t)(f >> 64);
-  auto rev_groups = [](uint64_t x) -> uint64_t {
-    x = __builtin_bitreverse64(x);
-    return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
-  };
-  unsigned __int128 r = ((unsigned __int128)rev_groups(f_lo) << 64) | rev_groups(f_hi);
-  r = ~r >> (128 - 2 * k);
-  r &= kmask;
-  // the lexicographically smaller strand: MSB-first order of one strand is the complement of the LSB-first form of
-  // the other (see the kernel above), so "forward <= reverse complement" is f <= r
-  const unsigned __int128 c = f <= r ? f : r;
-  uint64_t w[8];
+  // ---- the window as four words, base j at bits 2j (the order murmur wants), and its reverse complement
+  uint32_t F[4], R[4];
+  {
+    const uint64_t p0 = a >> 4, p_last = e >> 4;
+    const uint32_t sp = 2u * (uint32_t)(a & 15u);
+    uint32_t w[5];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const uint32_t g16 = (uint32_t)(c >> (16 * j)) & 0xffffu;
-    const int left = (int)k - 8 * j;  // bases of the k-mer from this word on
-    w[j] = u64_of(ascii_group(g16 & 0xffu, left), ascii_group(g16 >> 8, left - 4));
+    for (int i = 0; i < 5; ++i) w[i] = p0 + i <= p_last ? packed[p0 + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) F[i] = alignbit(w[i + 1], w[i], sp);
+    const uint32_t used = 2u * k - 64u;  // bits of the upper two words that belong to the k-mer (2 .. 64)
+    if (used < 32u) { F[2] &= (1u << used) - 1u; F[3] = 0u; }
+    else if (used < 64u) F[3] &= (1u << (used - 32u)) - 1u;
+    // complement of the group-reversed window, moved down by the 128 - 2k bits the reversal left empty at the bottom
+    const uint32_t C[6] = {~rev_groups32(F[3]), ~rev_groups32(F[2]), ~rev_groups32(F[1]), ~rev_groups32(F[0]), 0u, 0u};
+    const uint32_t s = 128u - 2u * k, ws = s >> 5, bs = s & 31u;  // 0 .. 62: at most one whole word
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R[i] = ws ? alignbit(C[i + 2], C[i + 1], bs) : alignbit(C[i + 1], C[i], bs);
+    if (used < 32u) { R[2] &= (1u << used) - 1u; R[3] = 0u; }
+    else if (used < 64u) R[3] &= (1u << (used - 32u)) - 1u;
   }
-  const uint64_t h = murmur3_words(w, k);
-  if (h > max_hash) return;
+  // ---- the lexicographically smaller strand: "forward <= reverse complement" is F <= R as 128-bit numbers
+  // (MSB-first order of one strand is the complement of the LSB-first form of the other, see the kernel above)
+  const uint64_t f_hi = u64_of(F[2], F[3]), f_lo = u64_of(F[0], F[1]), r_hi = u64_of(R[2], R[3]), r_lo = u64_of(R[0], R[1]);
+  const bool fwd = f_hi < r_hi || (f_hi == r_hi && f_lo <= r_lo);
+  uint32_t c[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = fwd ? F[i] : R[i];
+  uint64_t P[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    if (j >= n_words) break;
+    const uint32_t src = c[j >> 1], glo = (src >> (16u * (j & 1u))) & 0xffu, ghi = (src >> (16u * (j & 1u) + 8u)) & 0xffu;
+    const uint64_t lo = s_lo[j][glo];
+    P[j] = u64_of((uint32_t)lo, (uint32_t)(lo >> 32) + s_hi[j][ghi]);
+  }
+  uint64_t U, V;
+  murmur3_pre_last_mul_rt(P, k, U, V);
+  const uint32_t max_hi = (uint32_t)(max_hash >> 32);
+  if (max_hi != 0xffffffffu && last_mul_high_sum_plus1(U, V) > max_hi + 1u) continue;  // the screen of the kernel above
+  const uint64_t X = U * kF2, Y = V * kF2;
+  const uint64_t h = (X ^ (X >> 33)) + (Y ^ (Y >> 33));
+  if (h > max_hash) continue;
   const uint32_t blk = (uint32_t)(e >> 6);
   const uint32_t g = find_genome(genome_blk, n_genomes, blk);
   if (region_off) {
@@ -382,6 +413,7 @@ __global__ __launch_bounds__(kThreads) void kmer_hash_long_kernel(
       cand_genome[slot] = g;
     }
   }
+  }  // window ends of this workgroup
 }
 
 }  // namespace
@@ -395,7 +427,8 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
   if (n_blocks64 <= blk0) return PA_OK;
   if (k > 32 && k <= 64) {
     const uint64_t pos0 = blk0 * 64, pos1 = n_blocks64 * 64;
-    const uint64_t n_wg = (pos1 - pos0 + kThreads - 1) / kThreads;
+    const uint64_t per_wg = (uint64_t)kThreads * kLongIter;
+    const uint64_t n_wg = (pos1 - pos0 + per_wg - 1) / per_wg;
     const uint32_t gx = (uint32_t)std::min<uint64_t>(n_wg, 1u << 20), gy = (uint32_t)((n_wg + gx - 1) / gx);
     PA_REQUIRE(gy <= 65535u, "arena too large for one launch of the long k-mer kernel: %llu positions", (unsigned long long)(pos1 - pos0));
     hipLaunchKernelGGL(kmer_hash_long_kernel, dim3(gx, gy), dim3(kThreads), 0,
