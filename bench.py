@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive passes (keeps a rocprof kernel trace to the timed steps' launches)")
     ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other BASELINE configs")
-    ap.add_argument("--also", default="bottom,mixed,n10000,fragani", help="comma list of the extra runs at N=1")
+    ap.add_argument("--also", default="bottom,k51,mixed,n10000,fragani", help="comma list of the extra runs at N=1")
     ap.add_argument("--also-fragani-genomes", type=int, default=1000)
     ap.add_argument("--also-n", type=int, default=10000)
     return ap.parse_args(argv)
@@ -254,6 +254,39 @@ def also_bottom(engine, arena, args, n_total, lengths) -> dict:
         "workload": f"{n_total} synthetic {args.length / 1e6:g} Mb genomes, k={args.kmer} bottom-m={m} MinHash + NxN Mash-Jaccard ANI (BASELINE configs[1] as worded)",
         "ms_per_step": sec * 1e3, "pairs_per_s": n_total * n_total / sec, "steps": 3,
         "parity": f"unpinned mode (the reference never uses num>0); sketches of 3 genomes and a {nb}x{nb} common/denominator block equal the oracle's Mash restatement",
+    }
+
+
+def also_long_kmer(engine, arena, args, n_total, lengths) -> dict:
+    """The headline workload at k = 51, sourmash's third default size (the reference passes any --kmersize on,
+    pyani_plus/public_cli_args.py:229): k above 32 takes kmer_hash_long_kernel."""
+    import oracle
+
+    torch = engine.torch
+    k = 51
+
+    def step():
+        sk = engine.sketch(arena, k, args.scaled)
+        counts = engine.pair_counts(sk)
+        return sk, counts, engine.ani(counts, sk, k)
+
+    sec, (sk, counts, ani) = _time_steps(torch, step, 3)
+    del ani
+    sample = [0, n_total // 2, n_total - 1]
+    seqs = _ascii_genomes(engine, arena, sample, lengths)
+    off = sk.offsets_host().astype(np.int64)
+    mine = []
+    for g, seq in zip(sample, seqs):
+        mine.append(sk.hashes[int(off[g]) : int(off[g + 1])].cpu().numpy().view(np.uint64))
+        if not np.array_equal(mine[-1], oracle.sketch_seq(seq.tobytes(), k, args.scaled)):
+            raise SystemExit(f"PARITY FAILURE (k={k}): sketch of genome {g} differs from the oracle")
+    block = counts[sample][:, sample].cpu().numpy().view(np.uint32)
+    if not np.array_equal(block, oracle.pair_counts(mine)):
+        raise SystemExit(f"PARITY FAILURE (k={k}): the sampled 3x3 count block differs from the oracle")
+    return {
+        "workload": f"{n_total} synthetic {args.length / 1e6:g} Mb genomes, k={k} scaled={args.scaled} sketch + NxN ANI on one GPU",
+        "ms_per_step": sec * 1e3, "pairs_per_s": n_total * n_total / sec, "steps": 3,
+        "parity": "sketches of the first, middle and last genome and their 3x3 count block equal the oracle",
     }
 
 
@@ -776,6 +809,8 @@ def run_rank(args) -> None:
             # order: the runs that reuse the resident arena first, then the ones that build their own
             if "bottom" in wanted:
                 extra("bottom_m", also_bottom, engine, arena, args, n_total, lengths)
+            if "k51" in wanted:
+                extra("long_kmer_k51", also_long_kmer, engine, arena, args, n_total, lengths)
             if "fragani" in wanted:
                 extra("fragment_ani", also_fragani, engine, arena, args, n_total, lengths)
             engine.prof_enable(False)
