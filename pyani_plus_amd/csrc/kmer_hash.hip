@@ -281,7 +281,184 @@ int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const ui
                                  d_cand_genome, cap, d_count, d_region_off, d_cursor, d_overflow, blk0, stream);
 }
 
-// ---- k from 33 to 64 ------------------------------------------------------------------------------------------
+// ---- k from 33 to 64, sixty-four windows per thread --------------------------------------------------------------
+// The structure of kmer_hash_kernel carried over to k-mers of up to 128 bits: one thread per 64-position block with a
+// 64-position look-back (the whole previous block), the forward stream and the reverse-complement stream as ten dwords
+// each, windows taken column by column (seven funnel shifts per stream serve the four windows e = i, i + 16, i + 32,
+// i + 48), the canonical strand from a 128-bit compare whose three lane masks are combined on the scalar unit, up to
+// eight first products from the LDS tables, the high-word screen.  Validity: the invalid-position bitset of the 128
+// positions is dilated by K; a block is skipped as clean only if neither its own dirty bit nor the previous block's is
+// set (the bitmap's "or the 32 positions before" reaches back 96 positions that way, the windows 63).
+template <int K>
+__global__ __launch_bounds__(kThreads) void kmer_hash_wide_kernel(
+    const uint4 *__restrict__ packed, const uint2 *__restrict__ mask, const uint64_t *__restrict__ dirty, uint32_t n_blocks64,
+    const uint32_t *__restrict__ genome_blk, uint32_t n_genomes, uint64_t max_hash,
+    uint64_t *__restrict__ cand_hash, uint32_t *__restrict__ cand_genome, uint64_t cap,
+    unsigned long long *__restrict__ count, const uint64_t *__restrict__ region_off, uint32_t *__restrict__ cursor,
+    uint32_t *__restrict__ overflow, uint32_t blk0) {
+  static_assert(K >= 33 && K <= 64, "k-mers of 65 to 128 bits");
+  __shared__ uint64_t s_hash[kStageCap];
+  __shared__ uint32_t s_blk[kStageCap];
+  __shared__ uint32_t s_n;
+  __shared__ unsigned long long s_base;
+  constexpr int kWords = (K + 7) / 8;
+  __shared__ uint64_t s_lo[kWords][256];
+  __shared__ uint32_t s_hi[kWords][256];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t max_hi = (uint32_t)(max_hash >> 32);
+  const bool take_all = max_hi == 0xffffffffu;
+  const uint32_t screen_hi = max_hi + 1u;
+  if (tid == 0) s_n = 0;
+#pragma unroll
+  for (int j = 0; j < kWords; ++j) {
+    const uint64_t cj = (j & 1) ? kC2 : kC1;
+    s_lo[j][tid] = (uint64_t)ascii_group(tid, K - 8 * j) * cj;
+    s_hi[j][tid] = (uint32_t)((uint64_t)ascii_group(tid, K - 8 * j - 4) * cj);
+  }
+  __syncthreads();
+
+  const uint32_t t = blk0 + blockIdx.x * kThreads + tid;
+  if (t < n_blocks64) {
+    const uint4 cur = packed[t];
+    const uint4 prev = t > 0 ? packed[t - 1] : make_uint4(0u, 0u, 0u, 0u);
+    // ---- which windows are usable (bit i of d0..d3 <-> position i - 64)
+    uint32_t d2 = 0u, d3 = 0u;
+    const uint32_t wave_blk = __builtin_amdgcn_readfirstlane(t & ~63u);
+    const uint64_t dirty_word = dirty[wave_blk >> 6];
+    const uint64_t before = wave_blk ? dirty[(wave_blk >> 6) - 1] >> 63 : 1ull;  // the block before this wave's first
+    const uint64_t dirty_or_prev = dirty_word | (dirty_word << 1) | before;
+    if ((dirty_or_prev >> (t & 63u)) & 1ull) {
+      const uint2 m = mask[t];
+      uint32_t d0 = 0xffffffffu, d1 = 0xffffffffu;
+      if (t > 0) { const uint2 mp = mask[t - 1]; d0 = mp.x; d1 = mp.y; }
+      d2 = m.x;
+      d3 = m.y;
+#pragma unroll
+      for (int c = 1; c <= 16; c *= 2) {  // OR of the bitset with itself moved up by 1, 2, 4, 8, 16: width 32
+        d3 |= alignbit(d3, d2, 32 - c);
+        d2 |= alignbit(d2, d1, 32 - c);
+        d1 |= alignbit(d1, d0, 32 - c);
+        d0 |= d0 << c;
+      }
+      if constexpr (K == 64) {  // width 64: one whole word further
+        d3 |= d2; d2 |= d1; d1 |= d0;
+      } else {
+        constexpr int r = K - 32;  // 1 .. 31: the remaining width
+        d3 |= alignbit(d3, d2, 32 - r);
+        d2 |= alignbit(d2, d1, 32 - r);
+        d1 |= alignbit(d1, d0, 32 - r);
+      }
+    }
+    const uint32_t bad[2] = {d2, d3};
+    if ((d2 & d3) != 0xffffffffu) {
+      constexpr uint32_t kMask2 = (2 * K - 64 >= 32) ? 0xffffffffu : ((1u << (2 * K - 64)) - 1u);
+      constexpr uint32_t kMask3 = (2 * K - 96 >= 32) ? 0xffffffffu : (2 * K - 96 <= 0 ? 0u : ((1u << ((2 * K - 96) & 31)) - 1u));
+      const uint32_t fw[10] = {prev.x, prev.y, prev.z, prev.w, cur.x, cur.y, cur.z, cur.w, 0u, 0u};
+      uint32_t rw[10];
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        const uint32_t x = __builtin_bitreverse32(fw[9 - j]);
+        rw[j] = ~(((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1));
+      }
+      auto columns = [&](auto base_tag, int i_begin, int i_end) {
+        constexpr int kBase = decltype(base_tag)::value;
+#pragma unroll 1
+        for (int i = i_begin; i < i_end; ++i) {
+          constexpr int kOff = 65 - K;
+          const uint32_t fo = 2u * (uint32_t)((i + kOff) & 15), ro = 30u - 2u * (uint32_t)i;
+          uint32_t A[7], B[7];
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            A[j] = alignbit(fw[kBase + j + 1], fw[kBase + j], fo);  // kBase <= 2: index <= 9
+            B[j] = alignbit(rw[j + 3], rw[j + 2], ro);
+          }
+#pragma unroll
+          for (int wi = 0; wi < 4; ++wi) {
+            const uint32_t f0 = A[wi], f1 = A[wi + 1], f2 = A[wi + 2] & kMask2, f3 = A[wi + 3] & kMask3;
+            const uint32_t r0 = B[3 - wi], r1 = B[4 - wi], r2 = B[5 - wi] & kMask2, r3 = B[6 - wi] & kMask3;
+            // forward <= reverse complement as 128-bit numbers: three 64-bit compares into lane masks, combined on the
+            // scalar unit, then four selects reading the SGPR pair (see the kernel above for why not VCC)
+            const uint64_t lt_hi = __builtin_amdgcn_uicmpl(u64_of(f2, f3), u64_of(r2, r3), 36 /* ICMP_ULT */);
+            const uint64_t eq_hi = __builtin_amdgcn_uicmpl(u64_of(f2, f3), u64_of(r2, r3), 32 /* ICMP_EQ */);
+            const uint64_t le_lo = __builtin_amdgcn_uicmpl(u64_of(f0, f1), u64_of(r0, r1), 37 /* ICMP_ULE */);
+            const uint64_t fwd = lt_hi | (eq_hi & le_lo);
+            uint32_t c0, c1, c2, c3;
+            asm("s_nop 1\n\tv_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(c0) : "v"(r0), "v"(f0), "s"(fwd));
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(c1) : "v"(r1), "v"(f1), "s"(fwd), "v"(c0));
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(c2) : "v"(r2), "v"(f2), "s"(fwd), "v"(c1));
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(c3) : "v"(r3), "v"(f3), "s"(fwd), "v"(c2));
+            const uint32_t cw[4] = {c0, c1, c2, c3};
+            uint64_t P[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < kWords; ++j) {
+              const uint32_t src = cw[j >> 1];
+              const uint32_t glo = (src >> (16 * (j & 1))) & 0xffu, ghi = (src >> (16 * (j & 1) + 8)) & 0xffu;
+              const uint64_t lo = s_lo[j][glo];
+              P[j] = u64_of((uint32_t)lo, (uint32_t)(lo >> 32) + s_hi[j][ghi]);
+            }
+            uint64_t U, V;
+            murmur3_pre_last_mul<K>(P, U, V);
+            if (take_all || last_mul_high_sum_plus1(U, V) <= screen_hi) {
+              const uint64_t X = U * kF2, Y = V * kF2;
+              const uint64_t h = (X ^ (X >> 33)) + (Y ^ (Y >> 33));
+              if (h > max_hash || ((bad[wi >> 1] >> (16 * (wi & 1) + i)) & 1u)) continue;
+              const uint32_t slot = atomicAdd(&s_n, 1u);
+              if (slot < kStageCap) {
+                s_hash[slot] = h;
+                s_blk[slot] = t;
+              } else if (region_off) {
+                region_append(cand_hash, region_off, cursor, overflow, find_genome(genome_blk, n_genomes, t), h);
+              } else {
+                const unsigned long long g = atomicAdd(count, 1ULL);
+                if (g < cap) {
+                  cand_hash[g] = h;
+                  cand_genome[g] = find_genome(genome_blk, n_genomes, t);
+                }
+              }
+            }
+          }
+        }
+      };
+      constexpr int kOff0 = 65 - K, kSplit = (kOff0 & 15) ? 16 - (kOff0 & 15) : 16;
+      columns(std::integral_constant<int, (kOff0 >> 4)>{}, 0, kSplit);
+      if constexpr (kSplit < 16) columns(std::integral_constant<int, (kOff0 >> 4) + 1>{}, kSplit, 16);
+    }
+  }
+  __syncthreads();
+  const uint32_t n = min(s_n, kStageCap);
+  if (n == 0) return;
+  if (region_off) {
+    const uint32_t b0 = blk0 + blockIdx.x * kThreads;
+    const uint32_t b1 = min(b0 + (uint32_t)kThreads, n_blocks64) - 1u;
+    const uint32_t g0 = find_genome(genome_blk, n_genomes, b0);
+    if (genome_blk[g0 + 1] > b1) {
+      if (tid == 0) s_base = atomicAdd(&cursor[g0], n);
+      __syncthreads();
+      const uint64_t room = region_off[g0 + 1] - region_off[g0];
+      uint64_t *__restrict__ dst = cand_hash + region_off[g0];
+      for (uint32_t i = tid; i < n; i += kThreads) {
+        const uint64_t slot = s_base + i;
+        if (slot < room) dst[slot] = s_hash[i]; else *overflow = 1u;
+      }
+    } else {
+      for (uint32_t i = tid; i < n; i += kThreads)
+        region_append(cand_hash, region_off, cursor, overflow, find_genome(genome_blk, n_genomes, s_blk[i]), s_hash[i]);
+    }
+    return;
+  }
+  if (tid == 0) s_base = atomicAdd(count, (unsigned long long)n);
+  __syncthreads();
+  const unsigned long long base = s_base;
+  for (uint32_t i = tid; i < n; i += kThreads) {
+    const unsigned long long g = base + i;
+    if (g < cap) {
+      cand_hash[g] = s_hash[i];
+      cand_genome[g] = find_genome(genome_blk, n_genomes, s_blk[i]);
+    }
+  }
+}
+
+// ---- k from 33 to 64, one window per thread-step (PA_KMER_LONG=plain: the cross-check of the kernel above) ---------
 // sourmash hashes k-mers of any length (its own defaults are 21, 31 and 51) and the reference passes --kmersize
 // through (pyani_plus/public_cli_args.py:229, pyani_plus/methods/sourmash.py:75-76).  Beyond 32 bases a k-mer no
 // longer fits the register pair the kernel above is built around, so these sizes take a simpler decomposition of the
@@ -425,6 +602,30 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
                         hipStream_t stream) {
   PA_REQUIRE(n_blocks64 < (1ULL << 32), "arena too large: %llu blocks of 64 bases", (unsigned long long)n_blocks64);
   if (n_blocks64 <= blk0) return PA_OK;
+  const char *long_form = getenv("PA_KMER_LONG");  // "plain": the one-window-per-step form (cross-check, read per launch)
+  const bool long_plain = long_form && long_form[0] == 'p';
+  if (k > 32 && k <= 64 && !long_plain) {
+    PA_REQUIRE((blk0 & 63u) == 0, "k-mer hash launch must start at a multiple of 64 blocks, not %llu", (unsigned long long)blk0);
+    const uint32_t grid = ceil_div_u64(n_blocks64 - blk0, kThreads);
+#define PA_WIDE_CASE(KK)                                                                                                   \
+  case KK:                                                                                                                 \
+    hipLaunchKernelGGL((kmer_hash_wide_kernel<KK>), dim3(grid), dim3(kThreads), 0, stream ? stream : c->stream,            \
+                       reinterpret_cast<const uint4 *>(d_packed), reinterpret_cast<const uint2 *>(d_mask), d_dirty,        \
+                       (uint32_t)n_blocks64, d_genome_blk, n_genomes, max_hash, d_cand_hash, d_cand_genome, cap,           \
+                       reinterpret_cast<unsigned long long *>(d_count), d_region_off, d_cursor, d_overflow, (uint32_t)blk0); \
+    break;
+    switch (k) {
+      PA_WIDE_CASE(33) PA_WIDE_CASE(34) PA_WIDE_CASE(35) PA_WIDE_CASE(36) PA_WIDE_CASE(37) PA_WIDE_CASE(38) PA_WIDE_CASE(39)
+      PA_WIDE_CASE(40) PA_WIDE_CASE(41) PA_WIDE_CASE(42) PA_WIDE_CASE(43) PA_WIDE_CASE(44) PA_WIDE_CASE(45) PA_WIDE_CASE(46)
+      PA_WIDE_CASE(47) PA_WIDE_CASE(48) PA_WIDE_CASE(49) PA_WIDE_CASE(50) PA_WIDE_CASE(51) PA_WIDE_CASE(52) PA_WIDE_CASE(53)
+      PA_WIDE_CASE(54) PA_WIDE_CASE(55) PA_WIDE_CASE(56) PA_WIDE_CASE(57) PA_WIDE_CASE(58) PA_WIDE_CASE(59) PA_WIDE_CASE(60)
+      PA_WIDE_CASE(61) PA_WIDE_CASE(62) PA_WIDE_CASE(63) PA_WIDE_CASE(64)
+      default: break;
+    }
+#undef PA_WIDE_CASE
+    PA_HIP(hipGetLastError());
+    return PA_OK;
+  }
   if (k > 32 && k <= 64) {
     const uint64_t pos0 = blk0 * 64, pos1 = n_blocks64 * 64;
     const uint64_t per_wg = (uint64_t)kThreads * kLongIter;

@@ -68,8 +68,9 @@ constexpr uint64_t kF1 = 0xff51afd7ed558ccdULL, kF2 = 0xc4ceb9fe1a85ec53ULL;  //
 // which is what the FracMinHash screen of kmer_hash.hip tests before anything else of the last step is computed.
 // (The 64-bit multiplies are left to hipcc: v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3_u32.  A hand-written
 // chain of three v_mad_u64_u32 + one add was measured at the same speed.)
-template <int K>
-__device__ __forceinline__ void murmur3_pre_last_mul(const uint64_t (&P)[4], uint64_t &U, uint64_t &V) {
+template <int K, int N>
+__device__ __forceinline__ void murmur3_pre_last_mul(const uint64_t (&P)[N], uint64_t &U, uint64_t &V) {
+  static_assert(N >= (K + 7) / 8, "one first product per 8-byte word of the k-mer");
   uint64_t h1 = 42, h2 = 42;
   constexpr int nblocks = K / 16;
   constexpr int tail = K % 16;
@@ -105,10 +106,10 @@ __device__ __forceinline__ uint32_t last_mul_high_sum_plus1(uint64_t U, uint64_t
   return (__umulhi(u0, c0) + __umulhi(v0, c0) + 1u) + ((u0 + v0) * c1 + (u1 + v1) * c0);
 }
 
-template <int K>
-__device__ __forceinline__ uint64_t murmur3_from_products(const uint64_t (&P)[4]) {
+template <int K, int N>
+__device__ __forceinline__ uint64_t murmur3_from_products(const uint64_t (&P)[N]) {
   uint64_t U, V;
-  murmur3_pre_last_mul<K>(P, U, V);
+  murmur3_pre_last_mul<K, N>(P, U, V);
   const uint64_t X = U * kF2, Y = V * kF2;
   return (X ^ (X >> 33)) + (Y ^ (Y >> 33));
 }

@@ -235,6 +235,27 @@ def test_full_size_properties_baseline_config(engine):
     assert np.array_equal(c[0:1000:25, 0:1000:25], oracle.pair_counts(block, threads=8))
 
 
+@pytest.mark.parametrize("k", [33, 34, 47, 48, 49, 51, 63, 64])
+def test_two_forms_of_the_long_kmer_kernel_agree(engine, k, monkeypatch):
+    """k above 32 has two independent kernels: 64 windows per thread (streams, column order, 128-bit compare on lane
+    masks) and one window per thread-step (PA_KMER_LONG=plain).  Same sketches, Ns, lower case, records and all; both
+    equal the oracle."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(3 * k)
+    texts = [_random_fasta(rng, 3, 20_000, n_runs=5), _random_fasta(rng, 1, 70_000, n_runs=2), _random_fasta(rng, 2, 9_000, lower=True),
+             b">short\n" + b"ACGT" * 12 + b"\n", b">exact\n" + rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=64 * 40).tobytes() + b"\n"]
+    dev = engine.upload(pack_genomes(texts))
+    for scaled in (1, 50):
+        monkeypatch.delenv("PA_KMER_LONG", raising=False)
+        wide = engine.sketch(dev, k, scaled).to_host()
+        monkeypatch.setenv("PA_KMER_LONG", "plain")
+        plain = engine.sketch(dev, k, scaled).to_host()
+        for g, text in enumerate(texts):
+            want, _total = oracle.sketch_fasta_text(text, k, scaled)
+            assert np.array_equal(wide[g], want) and np.array_equal(plain[g], want), (k, scaled, g, len(wide[g]), len(plain[g]), len(want))
+
+
 def test_full_size_long_kmer(engine):
     """k = 51 over the full 5 * 10^9 positions of BASELINE configs[1] (more threads than one grid dimension holds):
     sketch sizes ~ L / scaled everywhere, sampled genomes equal the oracle, the last genome included."""
