@@ -162,7 +162,8 @@ PA_API int pa_arena_dirty(pa_ctx *ctx, const uint32_t *d_mask, uint64_t arena_ba
  * ascending; last entry = arena_bases).
  * For every window of k valid bases inside one record: canonical k-mer ->
  * MurmurHash3_x64_128(seed 42).h1; kept when <= max_hash.  k from 1 to 64 (the reference hands any --kmersize to
- * sourmash, pyani_plus/public_cli_args.py:229; sourmash's third default is 51; 33..64 run the 128-bit form of the kernel); PA_E_INVALID beyond.
+ * sourmash, pyani_plus/public_cli_args.py:229, and sourmash's third default is 51; 33 to 64 run the 128-bit form of
+ * the kernel); PA_E_INVALID beyond.
  * Outputs (device): d_hashes[cap_hashes] genome-major ascending duplicate-free,
  * d_off[n_genomes+1] CSR offsets.  *h_total = total hashes.  If the total
  * exceeds cap_hashes the call returns PA_E_CAPACITY with *h_total = required
