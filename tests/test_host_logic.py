@@ -708,6 +708,20 @@ def test_driver_with_a_long_kmer_size(tmp_path):
     conn.close()
 
 
+def test_host_native_code_under_sanitizers():
+    """AddressSanitizer + UBSan over the host-side native code (no sanitizer runs exist on the GPU pool): the inflate
+    decoder on thousands of damaged streams in exact-size heap buffers, the AVX2 packer against the scalar one on
+    random texts, sixteen-lane md5 against the one-message form."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    done = subprocess.run(["bash", str(ROOT / "tests" / "tools" / "sanitize" / "run.sh"), "2000"], capture_output=True, text=True, timeout=900)
+    assert done.returncode == 0 and "sanitizer runs clean" in done.stdout, done.stdout[-2000:] + done.stderr[-2000:]
+    assert "ACCEPTED WRONG DATA" not in done.stdout and "MISMATCH" not in done.stdout
+
+
 def test_mask_runs_across_chunks():
     """pa_mask_runs scans the mask in chunks on the host pool: runs that cross a chunk boundary (here: a run over the
     middle of the arena, where two workers meet) come out joined, in order, with the count right when cap is small."""
