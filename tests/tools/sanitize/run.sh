@@ -1,5 +1,6 @@
 #!/bin/bash
-# Host-side native code under AddressSanitizer + UBSan (the GPU pool has no sanitizer runs; this is the CPU build).
+# Host-side native code under AddressSanitizer + UBSan, and the shared host pool under ThreadSanitizer (the GPU pool
+# has no sanitizer runs; this is the CPU build).
 #   bash tests/tools/sanitize/run.sh [trials]
 set -eu
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -11,6 +12,7 @@ FLAGS="-O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -f
 g++ $FLAGS -o "$OUT/inflate_fuzz" "$HERE/inflate_fuzz.cpp" -lz
 g++ $FLAGS -I"$ROOT/include" -o "$OUT/pack_fuzz" "$HERE/pack_fuzz.cpp" -lpthread
 g++ $FLAGS -o "$OUT/md5_lanes" "$HERE/md5_lanes.cpp"
+g++ -O1 -g -std=c++17 -fsanitize=thread -o "$OUT/pool_race" "$HERE/pool_race.cpp" -lpthread
 python3 - "$OUT" <<'PY'
 import gzip, sys, numpy as np
 out = sys.argv[1]
@@ -24,5 +26,6 @@ PY
 "$OUT/inflate_fuzz" "$OUT/text.gz" 2 "$TRIALS"
 "$OUT/pack_fuzz" "$TRIALS"
 "$OUT/md5_lanes" | head -2
+"$OUT/pool_race" 1000
 rm -rf "$OUT"
 echo "sanitizer runs clean"
