@@ -157,3 +157,32 @@ def test_batched_front_end_with_prefetch_and_direct_ingest_on_gpu(tmp_path):
     # the signature files written by both runs are the same bytes apart from the cache directory in no field
     for sig_file in (tmp_path / "c1" / f"sourmash_k={K}_scaled={scaled}").glob("*.sig"):
         assert sig_file.read_bytes() == (tmp_path / "c2" / sig_file.parent.name / sig_file.name).read_bytes()
+
+
+@pytest.mark.parametrize("kmersize", [21, 51])
+def test_run_driver_at_other_kmer_sizes_equals_the_oracle_backed_run(kmersize, tmp_path):
+    """sourmash's other default sizes through the whole driver on the device (k = 51 takes the 128-bit kernel): the
+    same signature files and the same comparison rows, bit for bit, as the oracle-backed engine produces."""
+    from tests.fake_engine import OracleEngine
+
+    name = "bacterial_example"
+    scaled, genomes = FIXTURE_SETS[name]
+    rundb.run_sourmash_hip(GOLDEN / name, tmp_path / "hip.sqlite", cache=tmp_path / "c_hip", kmersize=kmersize, scaled=scaled, temp=tmp_path,
+                           ingest="direct")
+    rundb.run_sourmash_hip(GOLDEN / name, tmp_path / "cpu.sqlite", cache=tmp_path / "c_cpu", kmersize=kmersize, scaled=scaled, temp=tmp_path,
+                           ingest="direct", engine=OracleEngine())
+    sig_dir = f"sourmash_k={kmersize}_scaled={scaled}"
+    sigs = sorted(p.name for p in (tmp_path / "c_hip" / sig_dir).glob("*.sig"))
+    assert len(sigs) == len(genomes) and sigs == sorted(p.name for p in (tmp_path / "c_cpu" / sig_dir).glob("*.sig"))
+    for sig_name in sigs:
+        assert (tmp_path / "c_hip" / sig_dir / sig_name).read_bytes() == (tmp_path / "c_cpu" / sig_dir / sig_name).read_bytes()
+
+    def rows(db):
+        conn = sqlite3.connect(db)
+        out = conn.execute("SELECT query_hash, subject_hash, identity, cov_query FROM comparisons ORDER BY 1, 2").fetchall()
+        conn.close()
+        return out
+
+    hip_rows = rows(tmp_path / "hip.sqlite")
+    assert hip_rows == rows(tmp_path / "cpu.sqlite") and len(hip_rows) == len(genomes) ** 2
+    assert all(r[2] == 1.0 for r in hip_rows if r[0] == r[1])
