@@ -17,7 +17,8 @@ Workloads (BASELINE.json configs): N=1 -> configs[1] "1 000 synthetic 5 Mb genom
 scaled=1000"; N=8 -> configs[2] "10 000 genomes tiled across 8 MI355X"; N=2/4 use the same
 1 250 genomes per GPU as configs[2].  Rank 0 prints ONE JSON line.  At N=1 the line also carries,
 under "also", short runs of the other BASELINE configs (bottom-m mode, 10 000 genomes on one GPU,
-the mixed-length set, fastANI-style fragment ANI), each with its own parity check.
+the mixed-length set, fastANI-style fragment ANI) and of the headline workload at k = 51, each with its
+own parity check.
 """
 
 from __future__ import annotations
