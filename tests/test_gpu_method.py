@@ -186,3 +186,23 @@ def test_run_driver_at_other_kmer_sizes_equals_the_oracle_backed_run(kmersize, t
     hip_rows = rows(tmp_path / "hip.sqlite")
     assert hip_rows == rows(tmp_path / "cpu.sqlite") and len(hip_rows) == len(genomes) ** 2
     assert all(r[2] == 1.0 for r in hip_rows if r[0] == r[1])
+
+
+def test_integration_md_ctypes_snippet_runs(tmp_path, monkeypatch):
+    """The minimal ctypes binding printed in INTEGRATION.md, executed as it stands: it has to keep up with the ABI."""
+    import re
+
+    import numpy as np
+
+    import oracle
+
+    root = Path(__file__).resolve().parent.parent
+    text = (root / "INTEGRATION.md").read_text()
+    code = re.search(r"```python\n(import ctypes as C\n.*?)```", text, flags=re.S).group(1)
+    code = code.replace('"pyani_plus_amd/_lib/libpyani_hip.so"', repr(str(root / "pyani_plus_amd" / "_lib" / "libpyani_hip.so")))
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[np.random.default_rng(1).integers(0, 4, 300_000)].tobytes()
+    (tmp_path / "genome.fasta").write_bytes(b">g\n" + seq + b"\n")
+    monkeypatch.chdir(tmp_path)
+    scope: dict = {}
+    exec(code, scope)  # noqa: S102 - the document's own example
+    assert np.array_equal(np.array(list(scope["mins"]), dtype=np.uint64), oracle.sketch_seq(seq, 31, 1000))
