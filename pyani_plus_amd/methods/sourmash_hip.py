@@ -179,7 +179,7 @@ def sketch_fasta_batches(logger: logging.Logger, paths: list[Path], *, kmersize:
                 continue
             if eng is None:
                 eng = get_engine()
-            if streamed:
+            if streamed and hasattr(eng, "sketch_streamed"):
                 _dev, sk = eng.sketch_streamed(eng.pin_arena(arena), kmersize, scaled, max_hash=max_hash)
             else:
                 sk = eng.sketch(eng.upload(arena), kmersize, scaled, max_hash=max_hash)

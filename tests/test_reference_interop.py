@@ -266,3 +266,24 @@ def test_reference_orm_reads_a_database_written_here(reference, ingest, tmp_path
         assert (run.df_identity, run.df_cov_query, run.df_aln_length, run.df_sim_errors, run.df_hadamard) == before
         genome = run.fasta_hashes[0].genome
         assert genome.length > 0 and genome.description
+
+
+@pytest.mark.parametrize("name", ["viral_example", "bad_alignments"])
+def test_reference_worker_commands_with_the_integration_edits(reference, name, tmp_path):
+    """The edits of INTEGRATION.md applied to a scratch copy of the reference (outside this repository), then the
+    reference's own `prepare-genomes` and `compute-column --subject 0` commands run the method: module found by name,
+    tool version checked, all-columns mode accepted, column file imported, run complete, matrices as the reference's."""
+    import subprocess
+
+    scaled, genomes = FIXTURE_SETS[name]
+    root = Path(__file__).resolve().parent.parent
+    done = subprocess.run([sys.executable, str(root / "tests" / "tools" / "patched_reference_worker.py"), str(tmp_path), str(GOLDEN / name), str(scaled)],
+                          capture_output=True, text=True, timeout=600, cwd=root)
+    assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
+    result = json.loads(done.stdout.strip().splitlines()[-1])
+    n = len(genomes)
+    assert result["compute_column"] == 0 and result["comparisons"] == n * n and result["genomes"] == n == result["signatures"]
+    assert (result["method"], result["program"]) == ("sourmash-hip", "libpyani_hip")
+    boundary = json.loads((GOLDEN / name / "boundary.json").read_text())
+    for key in ("df_identity", "df_cov_query", "df_hadamard"):
+        assert result[key] == boundary[key], key
