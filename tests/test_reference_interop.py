@@ -277,8 +277,9 @@ def test_reference_worker_commands_with_the_integration_edits(reference, name, t
 
     scaled, genomes = FIXTURE_SETS[name]
     root = Path(__file__).resolve().parent.parent
-    done = subprocess.run([sys.executable, str(root / "tests" / "tools" / "patched_reference_worker.py"), str(tmp_path), str(GOLDEN / name), str(scaled)],
-                          capture_output=True, text=True, timeout=600, cwd=root)
+    with_fastani = ["fastani"] if name == "viral_example" else []  # the reference has fastANI matrices for this set
+    done = subprocess.run([sys.executable, str(root / "tests" / "tools" / "patched_reference_worker.py"), str(tmp_path), str(GOLDEN / name), str(scaled),
+                           *with_fastani], capture_output=True, text=True, timeout=600, cwd=root)
     assert done.returncode == 0, done.stdout[-3000:] + done.stderr[-3000:]
     result = json.loads(done.stdout.strip().splitlines()[-1])
     n = len(genomes)
@@ -287,3 +288,18 @@ def test_reference_worker_commands_with_the_integration_edits(reference, name, t
     boundary = json.loads((GOLDEN / name / "boundary.json").read_text())
     for key in ("df_identity", "df_cov_query", "df_hadamard"):
         assert result[key] == boundary[key], key
+    if with_fastani:
+        # fastANI-hip, one `compute-column --subject <column>` call per subject as the unpatched scheduler issues them
+        import io
+
+        import pandas as pd
+
+        from tests.test_fragani_oracle import ANI_TOL
+
+        fast = result["fastani"]
+        assert fast["codes"] == [0] * n and fast["comparisons"] == n * n
+        identity = pd.read_json(io.StringIO(fast["df_identity"]), orient="split", dtype=float)
+        labels, want = load_matrix_tsv(GOLDEN / name / "matrices" / "fastANI_identity.tsv")
+        by_hash = {g["genome_hash"]: _stem(g["fasta_filename"]) for g in boundary["genomes"]}
+        order = [labels.index(by_hash[h]) for h in identity.index]
+        np.testing.assert_allclose(identity.to_numpy(dtype=float), want[np.ix_(order, order)], rtol=0, atol=ANI_TOL / 100 + 1e-12, equal_nan=True)
