@@ -302,7 +302,12 @@ def iter_sourmash_tiles(  # noqa: PLR0913
             log_sys_exit(logger, f"Missing sourmash signature file '{sig_file}'")
         mins = _recall_sketch(sig_file, kmersize, max_hash)
         if mins is None:
-            mins, _ = sig.read_sig(sig_file, ksize=kmersize, max_hash=max_hash)
+            try:
+                mins, _ = sig.read_sig(sig_file, ksize=kmersize, max_hash=max_hash)
+            except (ValueError, OSError, KeyError, TypeError) as err:
+                # a damaged or foreign file in the cache ends the worker the way a failing `sourmash sig collect`
+                # does in the reference (pyani_plus/methods/sourmash.py:170-183 through utils.check_output)
+                log_sys_exit(logger, f"Unreadable sourmash signature file '{sig_file}': {err}")
         sketches.append(mins)
     nq = len(queries)
     sizes = np.array([len(s) for s in sketches], dtype=np.uint64)

@@ -687,6 +687,26 @@ def test_packer_on_arbitrary_bytes():
     check()
 
 
+def test_damaged_signature_in_the_cache_ends_the_worker(tmp_path):
+    """A truncated, foreign or wrong-k `.sig` in the cache: the worker exits through log_sys_exit naming the file, as
+    the reference's `sourmash sig collect` step would (methods/sourmash.py:170-183), instead of a raw traceback."""
+    name = "viral_example"
+    scaled, genomes = FIXTURE_SETS[name]
+    run = rundb.run_sourmash_hip(GOLDEN / name, tmp_path / "ok.sqlite", cache=tmp_path / "cache", scaled=scaled, engine=OracleEngine(), temp=tmp_path)
+    sig_dir = tmp_path / "cache" / f"sourmash_k=31_scaled={scaled}"
+    victim = sorted(sig_dir.glob("*.sig"))[0]
+    good = victim.read_bytes()
+    hashes = {a.genome_hash: 1000 for a in run.fasta_hashes}
+    other_k = json.loads(good)
+    other_k[0]["signatures"][0]["ksize"] = 21
+    for damage in (good[: len(good) // 2], b"not json at all", b"[]", json.dumps(other_k).encode()):
+        victim.write_bytes(damage)
+        with pytest.raises(SystemExit, match="Unreadable sourmash signature file"):
+            sourmash_hip.compute_sourmash_hip(LOGGER, tmp_path, _Session(), run, tmp_path / "x.json", GOLDEN / name, {}, {}, hashes, "",
+                                              cache=tmp_path / "cache", engine=OracleEngine())
+    victim.write_bytes(good)
+
+
 def test_driver_with_a_long_kmer_size(tmp_path):
     """--kmersize 51 (sourmash's third default; the reference passes any size on, public_cli_args.py:229) through the
     whole host side: cache directory name, signature files with ksize 51, complete database."""
