@@ -158,6 +158,8 @@ def compute_fastani_hip(  # noqa: PLR0913
         session.commit()
     except HipBackendError as err:
         backend_failure(logger, f"{METHOD} comparison", err)
+    except ValueError as err:  # an input file that does not load: what a failing fastANI process is to the reference
+        log_sys_exit(logger, f"{METHOD} comparison failed: {err}")
     try:
         wire.export_json_db_entries(logger, json_filename, configuration, db_entries)
     except Exception:  # pragma: no cover

@@ -687,6 +687,25 @@ def test_packer_on_arbitrary_bytes():
     check()
 
 
+def test_fastani_worker_with_an_unreadable_input_ends_through_log_sys_exit(tmp_path):
+    """A FASTA file that has gone missing (or is not FASTA) ends the fastANI-hip worker with a message naming it -- what a
+    failing fastANI process is to the reference (private_cli.py:1044-1063 through utils.check_output)."""
+    from pyani_plus_amd.methods import fastani_hip
+
+    name = "viral_example"
+    _scaled, genomes = FIXTURE_SETS[name]
+    run = _make_run(GOLDEN / name, genomes, 300, method=fastani_hip.METHOD)
+    tool = fastani_hip.get_fastani_hip()
+    run.configuration.program, run.configuration.version = tool.exe_path.stem, tool.version
+    run.configuration.fragsize, run.configuration.kmersize, run.configuration.minmatch = 3000, 16, 0.2
+    hash_to_filename = {h: f for f, h in genomes.items()}
+    first = sorted(hash_to_filename)[0]
+    hash_to_filename[first] = "gone.fasta"
+    with pytest.raises(SystemExit, match="fastANI-hip comparison failed: .*gone.fasta"):
+        fastani_hip.compute_fastani_hip(LOGGER, tmp_path, _Session(), run, tmp_path / "f.json", GOLDEN / name, hash_to_filename, {},
+                                        {h: 1000 for h in hash_to_filename}, "", engine=OracleEngine())
+
+
 def test_damaged_signature_in_the_cache_ends_the_worker(tmp_path):
     """A truncated, foreign or wrong-k `.sig` in the cache: the worker exits through log_sys_exit naming the file, as
     the reference's `sourmash sig collect` step would (methods/sourmash.py:170-183), instead of a raw traceback."""
