@@ -823,7 +823,11 @@ __global__ __launch_bounds__(kThreads) void segments_from_list_kernel(const uint
   seg_nh[i] = seg_start[seg + 1] - seg_start[seg];
 }
 
-constexpr uint32_t kRefCap = 512;    // reference minimizers of one stretch (the windows of up to 64 starts) held in LDS
+// Reference minimizers of one stretch (the windows of up to 64 starts) held in LDS: a compile-time parameter of the
+// mapping kernel, chosen per call from the expected minimizers per window (map_ref_cap) -- 320 for fastANI's defaults
+// (237 per window): with 512 the per-lane arrays cost registers and waves (1.04 s against 0.99 s for the 1 000-genome
+// run), with 256 most windows no longer fit and take the cooperative path (2.9 s).
+constexpr uint32_t kRefCapMax = 512;
 // LDS of one segment's wave, carved from dynamic shared memory so that the query-hash arrays are only as
 // long as the longest fragment sketch of the batch (s_cap): ~8 KB per wave instead of 17 KB, which is what
 // sets how many of these latency-bound waves a CU keeps in flight.
@@ -839,10 +843,10 @@ struct EvalShared {
                        //   14-23 rank among the query hashes, 24 the hash is one of them
   uint16_t *xe16;      // [64] per lane: where its window ends inside the stretch
 };
-__host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap) {
-  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + kRefCap * 2u + (kRefCap + 4u) * 4u + 128u;
+__host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
+  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + ref_cap * 2u + (ref_cap + 4u) * 4u + 128u;
 }
-__device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap) {
+__device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap, uint32_t kRefCap) {
   EvalShared sh;
   sh.qh = base;
   sh.cnt = sh.qh + s_cap;
@@ -864,7 +868,8 @@ __device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t i
 }
 
 // one wave per (fragment, reference genome) segment
-__global__ __launch_bounds__(64, 5) void map_segments_kernel(
+template <uint32_t kRefCap>
+__global__ __launch_bounds__(64, 6) void map_segments_kernel(
     uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_a0,
     const uint32_t *__restrict__ seg_nh, uint32_t n_segs, bool presorted, const uint32_t *__restrict__ contig_genome,
     const uint32_t *__restrict__ genome_first_contig, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
@@ -876,7 +881,7 @@ __global__ __launch_bounds__(64, 5) void map_segments_kernel(
     const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride, unsigned long long *__restrict__ table,
     uint32_t *__restrict__ run_g, uint32_t s_cap, uint32_t hit_cap) {
   extern __shared__ uint32_t eval_lds[];
-  const EvalShared sh = eval_carve(eval_lds, s_cap, hit_cap);
+  const EvalShared sh = eval_carve(eval_lds, s_cap, hit_cap, kRefCap);
   const uint32_t lane = threadIdx.x;
   (void)run_g;
   (void)vals;
@@ -1794,17 +1799,27 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
       }
       prof.reset();
       prof.emplace(c, PA_PROF_FRAG_MAP);
+      // stretch capacity: the expected minimizers of one window (density 2 / (w + 1)) plus a third, in steps of 64
+      const uint32_t per_window = (uint32_t)(2.0 * count_windows / (w + 1.0));
+      const uint32_t ref_cap = std::min<uint32_t>(kRefCapMax, std::max<uint32_t>(256u, (per_window * 4u / 3u + 63u) / 64u * 64u));
       auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap) {
         if (count == 0) return;
-        hipLaunchKernelGGL(map_segments_kernel, dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap), c->stream, hk[hw],
-                           hv[hw], list_a0, list_nh, count, presorted,
-                           W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(), W.q_hash.as<uint32_t>(),
-                           W.q_s.as<uint32_t>(), W.frag_genome_local.as<uint32_t>(), frag_len, count_windows,
-                           W.tab_min_hits.as<uint32_t>(), W.tab_min_shared.as<uint32_t>(),
-                           W.contig_mini_off.as<uint32_t>(), W.contig_bucket_off.as<uint32_t>(),
-                           W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(),
-                           W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), total_bins,
-                           W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap);
+#define PA_MAP_CASE(CAP)                                                                                                  \
+  case CAP:                                                                                                               \
+    hipLaunchKernelGGL((map_segments_kernel<CAP>), dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap, CAP), c->stream,  \
+                       hk[hw], hv[hw], list_a0, list_nh, count, presorted, W.contig_genome.as<uint32_t>(),                 \
+                       W.genome_first_contig.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_s.as<uint32_t>(),                \
+                       W.frag_genome_local.as<uint32_t>(), frag_len, count_windows, W.tab_min_hits.as<uint32_t>(),         \
+                       W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),                                  \
+                       W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),      \
+                       W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), total_bins, \
+                       W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap);                          \
+    break;
+        switch (ref_cap) {
+          PA_MAP_CASE(256) PA_MAP_CASE(320) PA_MAP_CASE(384) PA_MAP_CASE(448)
+          default: PA_MAP_CASE(512)
+        }
+#undef PA_MAP_CASE
       };
       if (use_buckets) {
         if (n_keep) {
