@@ -1608,8 +1608,12 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   }
 
   // ---- batches of query genomes
-  const uint32_t kMaxBatchFrags = 1u << 16;
-  const uint64_t kMaxTableBytes = 1ULL << 30;
+  // Query genomes go through in batches of up to 2^17 fragments (13 batches for 1 000 genomes of 5 Mb: 1.46 s against
+  // 1.48 s with 2^16).  A batch whose seed hits do not fit 31-bit indices is halved and started again.
+  uint32_t batch_frags = 1u << 17;
+  uint64_t hit_limit = 1ULL << 31;
+  if (const char *v = getenv("PA_FRAGANI_BATCH_HITS")) hit_limit = std::max<uint64_t>(1, strtoull(v, nullptr, 10));  // tests: force the halving
+  const uint64_t kMaxTableBytes = 1ULL << 31;
   PA_TRY(W.scalars.reserve(64));
   uint32_t *d_overflow = W.scalars.as<uint32_t>() + 8;
   uint32_t *d_max_hits = W.scalars.as<uint32_t>() + 12;  // most seed hits of one fragment in the batch
@@ -1643,7 +1647,7 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   prof.reset();
   for (uint32_t g0 = 0; g0 < n_genomes;) {
     uint32_t g1 = g0 + 1;
-    while (g1 < n_genomes && genome_frag_off[g1 + 1] - genome_frag_off[g0] <= kMaxBatchFrags &&
+    while (g1 < n_genomes && genome_frag_off[g1 + 1] - genome_frag_off[g0] <= batch_frags &&
            (uint64_t)(g1 + 1 - g0) * total_bins * 8 <= kMaxTableBytes)
       ++g1;
     const uint32_t f0 = genome_frag_off[g0], nf = genome_frag_off[g1] - f0, nq = g1 - g0;
@@ -1677,8 +1681,13 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
     const uint64_t n_hits = c->h_pinned[0];
     const uint32_t max_hits = (uint32_t)c->h_pinned[1];
     const uint32_t s_cap = std::min<uint32_t>(kQMax, (((uint32_t)(c->h_pinned[1] >> 32) + 63u) / 64u) * 64u);
-    PA_REQUIRE(n_hits < (1ULL << 31), "pa_fragani: %llu seed hits in one batch (limit 2^31); highly repetitive input",
-               (unsigned long long)n_hits);
+    if (n_hits >= hit_limit && nq > 1) {  // closely related or repetitive genomes: fewer query genomes per batch
+      batch_frags = std::max<uint32_t>(1u, std::min(batch_frags, nf) / 2u);
+      prof.reset();
+      continue;  // the same g0 again
+    }
+    PA_REQUIRE(n_hits < (1ULL << 31), "pa_fragani: %llu seed hits for the fragments of genome %u alone (limit 2^31); highly "
+               "repetitive input", (unsigned long long)n_hits, g0);
     PA_TRY(W.table.reserve((uint64_t)nq * total_bins * 8));
     PA_HIP(hipMemsetAsync(W.table.p, 0, (uint64_t)nq * total_bins * 8, c->stream));
     if (n_hits) {

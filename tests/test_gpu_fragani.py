@@ -130,6 +130,17 @@ def test_pairs_equal_oracle_on_random_genomes(engine):
     _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
 
 
+def test_batches_are_halved_when_the_seed_hits_outgrow_their_indices(engine, monkeypatch):
+    """A batch of query genomes whose seed hits pass 2^31 is halved and started again; forced here with a limit of a few
+    thousand hits, down to one query genome per batch.  Same integers as the one-batch run and as the oracle."""
+    texts, contig_lists = _random_genomes(31)
+    one_batch = _check_against_oracle(engine, texts, contig_lists)
+    monkeypatch.setenv("PA_FRAGANI_BATCH_HITS", "3000")
+    halved = _check_against_oracle(engine, texts, contig_lists)
+    for a, b in zip(one_batch, halved):
+        assert np.array_equal(a, b)
+
+
 def test_repeat_families_take_the_long_segment_paths(engine):
     """Tandem repeats give (fragment, genome) segments of thousands of seed hits: more than the mapping wave
     stages in LDS (512: sorted by frag_sort_kernel, read in place) and, for the 60-copy genome, more than one
