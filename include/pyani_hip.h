@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 2
+#define PA_ABI_VERSION 3
 
 /* every entry point below is exported with default visibility */
 #define PA_API __attribute__((visibility("default")))
@@ -194,7 +194,10 @@ PA_API int pa_sketch_streamed(pa_ctx *ctx, const uint32_t *h_packed, const uint6
 /* ---- pairs: CSR sketches -> intersection counts ----
  * d_hashes/d_off describe n sketches (any source: pa_sketch, a `.sig` cache,
  * an all-gather).  Computes d_counts[(q-q0)*(s1-s0) + (s-s0)] = |S_q n S_s| for
- * q in [q0,q1), s in [s0,s1).  algo: PA_PAIRS_AUTO, or force one kernel. */
+ * q in [q0,q1), s in [s0,s1).  algo: PA_PAIRS_AUTO, or force one kernel.
+ * With the default algorithm an all-vs-all call (q range == s range) over more than one subject tile of 2048
+ * columns evaluates only the tile pairs on and above the diagonal and mirrors the rest (|A n B| = |B n A|);
+ * the environment variable PA_PAIRS_SYMMETRIC=0 evaluates every tile pair instead. */
 #define PA_PAIRS_AUTO 0        /* = PA_PAIRS_BITROW_HASH */
 #define PA_PAIRS_BITROW 1      /* dictionary by radix sort + bit-row column sums */
 #define PA_PAIRS_MERGE 2       /* per-pair merge-path intersection */
@@ -210,7 +213,9 @@ PA_API int pa_pair_counts_ex(pa_ctx *ctx, const uint64_t *d_hashes, const uint64
  * sketches, contiguous in device memory) while the sketch all-gather is still in flight -- the exchange that
  * replaces the `.sig` file lists handed to `sourmash sig collect` (pyani_plus/methods/sourmash.py:162-183).
  * The next pa_pair_counts(_ex) with the default algorithm must cover a single subject tile (<= 2048 columns)
- * holding exactly these postings; it then skips its own insert.  Any other pair call drops the preparation. */
+ * holding exactly these postings -- the same hashes, wherever they now live: the call compares a fingerprint of the
+ * tile's postings with the one taken here and fails with PA_E_INVALID on a mismatch -- and then skips its own
+ * insert.  Any other pair call drops the preparation. */
 PA_API int pa_pair_dict_prepare(pa_ctx *ctx, const uint64_t *d_subject_hashes, uint64_t n_postings);
 
 /* ---- counts -> ANI ----
@@ -262,6 +267,19 @@ PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
                const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
                uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t ref0, uint32_t ref1,
                uint32_t *h_total_frags, uint32_t *h_matched, double *h_ident_sum);
+/* The same with a query range: only the genomes [qry0, qry1) are mapped (rows outside are left untouched), which is
+ * how the reference's worker feeds fastANI -- batches of at most 500 queries per process, the column file rewritten
+ * after each (pyani_plus/private_cli.py:1029-1101) -- so that an interrupted worker keeps the finished batches.
+ * flags: PA_FRAGANI_REUSE_INDEX = the arena, contigs, k and fragLen are exactly those of the previous pa_fragani(_ex)
+ * call on this context and the reference index it built (minimizers, dictionary, postings: about a tenth of a run)
+ * is taken over instead of being rebuilt; PA_E_INVALID when there is no such call.  fastANI itself rebuilds the
+ * reference's index in every process. */
+#define PA_FRAGANI_REUSE_INDEX 1u
+PA_API int pa_fragani_ex(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                  const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
+                  uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t qry0, uint32_t qry1,
+                  uint32_t ref0, uint32_t ref1, uint32_t flags, uint32_t *h_total_frags, uint32_t *h_matched,
+                  double *h_ident_sum);
 /* stage 1 alone (testing): the winnowed minimizers of every contig, in arena order */
 PA_API int pa_fragani_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                       const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
@@ -285,6 +303,28 @@ PA_API int64_t pa_fasta_records(const uint8_t *h_text, uint64_t n_text, uint64_t
 PA_API int pa_write_sigs(uint32_t n_files, const char *const *paths, const char *const *heads, const char *const *mids,
                          const char *const *tails, uint32_t ksize, const uint64_t *h_mins, const uint64_t *h_off,
                          uint32_t n_threads);
+
+/* ---- bulk reader of sourmash-format `.sig` files ----
+ * Replaces what `sourmash sig collect` + `manysearch` do with the N cached signatures of a column worker
+ * (pyani_plus/methods/sourmash.py:160-200): open, JSON-parse and validate every file.  The n files are read on
+ * n_threads host threads (0 = pa_host_cpu_budget()).  Per file (pa_sig_batch_info returns its status):
+ *   PA_OK             one DNA sketch with this ksize and max_hash, num = 0; its hashes (ascending, duplicate-free)
+ *                     are in the batch, and the file's own `md5sum` -- md5(str(ksize) + the decimals, concatenated)
+ *                     -- matched them;
+ *   PA_SIG_UNHANDLED  a readable signature file in another layout (several sketches, another k, protein, ...):
+ *                     the caller parses it with a general JSON reader;
+ *   PA_E_IO / PA_E_INVALID  unreadable or damaged (truncated list, non-numeric entry, checksum mismatch); `message`
+ *                     says what, and the worker ends the way a failing `sourmash sig collect` ends the reference's
+ *                     (pyani_plus/utils.py:262-283).
+ * pa_sig_batch_copy writes the hashes of the PA_OK files back to back into h_mins and their CSR offsets into
+ * h_off[n+1] (files with another status occupy no room); n_mins of pa_sig_batch_info sizes the buffer. */
+#define PA_SIG_UNHANDLED 1
+typedef struct pa_sig_batch pa_sig_batch;
+PA_API int pa_read_sigs(const char *const *paths, uint32_t n, uint32_t ksize, uint64_t max_hash, uint32_t n_threads,
+                        pa_sig_batch **out);
+PA_API int pa_sig_batch_info(const pa_sig_batch *batch, uint32_t i, uint64_t *n_mins, const char **message);
+PA_API int pa_sig_batch_copy(const pa_sig_batch *batch, uint64_t *h_mins, uint64_t *h_off);
+PA_API void pa_sig_batch_free(pa_sig_batch *batch);
 
 /* ---- bulk writer of the reference's JSON column file (pyani_plus/private_cli.py:454-504) ----
  * Writes prefix + rows + suffix, rows byte-identical to json.dumps of

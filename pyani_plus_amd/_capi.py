@@ -15,10 +15,12 @@ from pathlib import Path
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "_lib" / "libpyani_hip.so"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PA_OK = 0
 PA_E_CAPACITY = -4
 PA_E_IO = -6
+PA_SIG_UNHANDLED = 1
+PA_FRAGANI_REUSE_INDEX = 1
 PA_PAIRS_AUTO, PA_PAIRS_BITROW, PA_PAIRS_MERGE, PA_PAIRS_BITROW_HASH = 0, 1, 2, 3
 PA_ALIGN_BASES = 64
 PROF_PHASES = {"kmer_hash": 0, "sketch_sort": 1, "pair_dict": 2, "pair_count": 3, "ani": 4, "frag_index": 5, "frag_seed": 6, "frag_map": 7}
@@ -63,6 +65,10 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [_vp, _vp, _vp, _vp, C.c_uint64, _u64p, C.c_uint32, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp, _u64p],
     ),
+    "pa_read_sigs": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(_vp)]),
+    "pa_sig_batch_info": (C.c_int, [_vp, C.c_uint32, _u64p, C.POINTER(C.c_char_p)]),
+    "pa_sig_batch_copy": (C.c_int, [_vp, _vp, _vp]),
+    "pa_sig_batch_free": (None, [_vp]),
     "pa_write_sigs": (C.c_int, [C.c_uint32, _vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32]),
     "pa_mask_runs": (C.c_int64, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
     "pa_mask_from_runs": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_uint64]),
@@ -88,6 +94,11 @@ SIGNATURES: dict[str, tuple] = {
     "pa_pair_mash": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp]),
     "pa_ani_mash": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, _vp]),
     "pa_fragani": (C.c_int, [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "pa_fragani_ex": (
+        C.c_int,
+        [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+         C.c_uint32, C.c_uint32, _vp, _vp, _vp],
+    ),
     "pa_fragani_sketch": (
         C.c_int,
         [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_uint64, _u64p],

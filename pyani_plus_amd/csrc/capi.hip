@@ -88,7 +88,7 @@ void pa_ctx_destroy(pa_ctx *c) {
   (void)hipStreamSynchronize(c->stream);
   DevBuf *bufs[] = {&c->cand_keys[0], &c->cand_keys[1], &c->cand_vals[0], &c->cand_vals[1], &c->genome_blk,
                     &c->counters, &c->hist, &c->flags, &c->scan_tmp, &c->region_off, &c->region_cursor, &c->dirty, &c->dict_keys[0], &c->dict_keys[1],
-                    &c->dict_vals[0], &c->dict_vals[1], &c->ids, &c->post_genome, &c->bitrows};
+                    &c->dict_vals[0], &c->dict_vals[1], &c->ids, &c->post_genome, &c->bitrows, &c->dict_scalars};
   for (DevBuf *b : bufs) b->release();
   pa_fragani_release(c);
   for (auto &ph : c->prof)

@@ -302,13 +302,7 @@ struct pa_fasta_batch {
   Slab packed, mask;
 };
 
-extern "C" {
-
-int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fasta_batch **out) {
-  if (!out || (n && !paths)) { pa_set_error("pa_fasta_batch_load: null argument"); return PA_E_INVALID; }
-  *out = nullptr;
-  pa_fasta_batch *b = new (std::nothrow) pa_fasta_batch();
-  if (!b) { pa_set_error("out of host memory"); return PA_E_NOMEM; }
+static int fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fasta_batch *b, pa_fasta_batch **out) {
   b->files.resize(n);
   std::vector<std::string> p(n);
   for (uint32_t i = 0; i < n; ++i) p[i] = paths[i] ? paths[i] : "";
@@ -339,7 +333,6 @@ int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fa
   std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return slot_cap[x] > slot_cap[y]; });
   Slab reads;
   if (!b->packed.alloc(slot_off[n] / 4) || !b->mask.alloc(slot_off[n] / 8) || !reads.alloc(read_room * lanes * nt)) {
-    delete b;
     pa_set_error("pa_fasta_batch_load: cannot map %llu bytes of host memory",
                  (unsigned long long)(slot_off[n] / 4 + slot_off[n] / 8 + read_room * lanes * nt));
     return PA_E_NOMEM;
@@ -383,6 +376,19 @@ int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fa
   });
   *out = b;
   return PA_OK;
+}
+
+extern "C" {
+
+int pa_fasta_batch_load(const char *const *paths, uint32_t n, int threads, pa_fasta_batch **out) {
+  if (!out || (n && !paths)) { pa_set_error("pa_fasta_batch_load: null argument"); return PA_E_INVALID; }
+  *out = nullptr;
+  pa_fasta_batch *b = new (std::nothrow) pa_fasta_batch();
+  if (!b) { pa_set_error("out of host memory"); return PA_E_NOMEM; }
+  // an allocation that fails on the calling thread or on a pool thread comes back as PA_E_NOMEM, never as std::terminate
+  const int st = pa_host_guard("pa_fasta_batch_load", pa_set_error, [&] { return fasta_batch_load(paths, n, threads, b, out); });
+  if (st != PA_OK) { *out = nullptr; delete b; }
+  return st;
 }
 
 int pa_fasta_batch_info(const pa_fasta_batch *b, uint32_t i, char md5hex33[33], uint64_t *n_residues,
@@ -436,17 +442,19 @@ int pa_fasta_batch_copy_arena(const pa_fasta_batch *b, uint32_t *h_packed, uint3
   // the genomes land in disjoint ranges: copy them on the host pool (2 GB at N = 1000 is 0.25 s on one core)
   const size_t n = b->files.size();
   std::atomic<size_t> next{0};
-  HostPool::get().run(pa_host_threads(pos, 32u << 20, 0), [&](uint32_t, uint32_t) {
-    for (;;) {
-      const size_t i = next.fetch_add(1);
-      if (i >= n) break;
-      const FileResult &r = b->files[i];
-      if (r.status != PA_OK || !r.n_bases) continue;
-      memcpy(h_packed + h_genome_start[i] / 16, r.packed, r.n_bases / 4);
-      memcpy(h_mask + h_genome_start[i] / 32, r.mask, r.n_bases / 8);
-    }
+  return pa_host_guard("pa_fasta_batch_copy_arena", pa_set_error, [&] {
+    HostPool::get().run(pa_host_threads(pos, 32u << 20, 0), [&](uint32_t, uint32_t) {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n) break;
+        const FileResult &r = b->files[i];
+        if (r.status != PA_OK || !r.n_bases) continue;
+        memcpy(h_packed + h_genome_start[i] / 16, r.packed, r.n_bases / 4);
+        memcpy(h_mask + h_genome_start[i] / 32, r.mask, r.n_bases / 8);
+      }
+    });
+    return (int)PA_OK;
   });
-  return PA_OK;
 }
 
 void pa_fasta_batch_free(pa_fasta_batch *b) { delete b; }

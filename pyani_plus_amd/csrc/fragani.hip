@@ -1367,6 +1367,12 @@ struct FragWork {
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
       contig_bucket_off, bucket_first;
+  // the reference index (stages 1 and 2) of the last pa_fragani(_ex) call, for PA_FRAGANI_REUSE_INDEX
+  bool index_valid = false;
+  const void *index_packed = nullptr;
+  uint64_t index_arena_bases = 0;
+  uint32_t index_contigs = 0, index_genomes = 0, index_k = 0, index_frag_len = 0, index_m = 0, index_ids = 0;
+  int index_which = 0;
   ~FragWork() {
     DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
                      &mini_contig, &contig_mini_off, &keys[0], &keys[1], &vals[0], &vals[1], &flags, &mini_id,
@@ -1492,6 +1498,7 @@ int pa_fragani_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mas
   PA_REQUIRE(window >= 1 && window <= 64, "pa_fragani_sketch: window %u outside [1,64]", window);
   PA_HIP(hipSetDevice(c->device));
   FragWork &W = frag_work(c);
+  W.index_valid = false;  // the minimizer arrays are about to be overwritten
   PA_TRY(stage_contigs(c, W, h_contig_start, h_contig_len, h_contig_genome, n_contigs, n_genomes, arena_bases));
   uint32_t m = 0;
   PA_TRY(dispatch_minimizers(c, W, d_packed, d_mask, arena_bases, n_contigs, k, (int)window, &m));
@@ -1510,8 +1517,19 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
                uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t ref0, uint32_t ref1,
                uint32_t *h_total_frags, uint32_t *h_matched, double *h_ident_sum) {
+  return pa_fragani_ex(c, d_packed, d_mask, arena_bases, h_contig_start, h_contig_len, h_contig_genome, n_contigs,
+                       n_genomes, k, frag_len, 0, n_genomes, ref0, ref1, 0, h_total_frags, h_matched, h_ident_sum);
+}
+
+int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                  const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
+                  uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t qry0, uint32_t qry1,
+                  uint32_t ref0, uint32_t ref1, uint32_t flags, uint32_t *h_total_frags, uint32_t *h_matched,
+                  double *h_ident_sum) {
   PA_REQUIRE(c && d_packed && d_mask && h_total_frags && h_matched && h_ident_sum, "pa_fragani: null argument");
   PA_REQUIRE(ref0 <= ref1 && ref1 <= n_genomes, "pa_fragani: reference range [%u,%u) outside [0,%u)", ref0, ref1, n_genomes);
+  PA_REQUIRE(qry0 <= qry1 && qry1 <= n_genomes, "pa_fragani: query range [%u,%u) outside [0,%u)", qry0, qry1, n_genomes);
+  PA_REQUIRE((flags & ~(uint32_t)PA_FRAGANI_REUSE_INDEX) == 0, "pa_fragani: unknown flags 0x%x", flags);
   PA_REQUIRE(frag_len >= 100 && frag_len <= 0xffffu, "pa_fragani: fragLen %u outside [100, 65535]", frag_len);
   PA_HIP(hipSetDevice(c->device));
   const int w = window_size_for((int)k, (int)frag_len);
@@ -1523,15 +1541,24 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
 
   // ---- 1. minimizers of every contig
   std::optional<ProfScope> prof;  // phases timed for bench.py: index build, seeding, mapping
+  const bool reuse = (flags & PA_FRAGANI_REUSE_INDEX) != 0;
+  if (reuse) {
+    PA_REQUIRE(W.index_valid && W.index_packed == (const void *)d_packed && W.index_arena_bases == arena_bases &&
+                   W.index_contigs == n_contigs && W.index_genomes == n_genomes && W.index_k == k && W.index_frag_len == frag_len,
+               "pa_fragani: PA_FRAGANI_REUSE_INDEX without a preceding call on the same arena, contigs, k and fragLen");
+  }
+  W.index_valid = false;  // until this call has passed stage 2 (or taken it over)
   prof.emplace(c, PA_PROF_FRAG_INDEX);
-  uint32_t m = 0;
+  uint32_t m = reuse ? W.index_m : 0;
+  if (!reuse) {
   PA_TRY(dispatch_minimizers(c, W, d_packed, d_mask, arena_bases, n_contigs, k, w, &m));
   PA_TRY(W.contig_mini_off.reserve((uint64_t)(n_contigs + 2) * 4));
   hipLaunchKernelGGL(contig_offsets_kernel, dim3(ceil_div_u64(n_contigs + 1, kThreads)), dim3(kThreads), 0, c->stream,
                      W.mini_contig.as<uint32_t>(), m, n_contigs, W.contig_mini_off.as<uint32_t>());
+  }
 
   // ---- per-contig bucket index over window ids
-  {
+  if (!reuse) {
     std::vector<uint32_t> cbo(n_contigs + 1, 0);
     for (uint32_t ci = 0; ci < n_contigs; ++ci) cbo[ci + 1] = cbo[ci] + (h_contig_len[ci] >> kBucketShift) + 2;
     PA_REQUIRE((uint64_t)cbo[n_contigs] < (1ULL << 31), "pa_fragani: bucket index too large");
@@ -1564,8 +1591,18 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   }
   const uint64_t total_bins = contig_bin_off[n_contigs];
   const uint32_t n_frags = (uint32_t)frag_contig.size();
-  for (uint64_t i = 0; i < (uint64_t)n_genomes * n_genomes; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
-  if (m == 0 || n_frags == 0) { prof.reset(); PA_HIP(hipStreamSynchronize(c->stream)); return PA_OK; }
+  for (uint64_t i = (uint64_t)qry0 * n_genomes; i < (uint64_t)qry1 * n_genomes; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
+  auto remember_index = [&](int which_buf) {
+    W.index_packed = d_packed; W.index_arena_bases = arena_bases; W.index_contigs = n_contigs; W.index_genomes = n_genomes;
+    W.index_k = k; W.index_frag_len = frag_len; W.index_m = m; W.index_which = which_buf;
+    W.index_valid = true;
+  };
+  if (m == 0 || n_frags == 0) {  // nothing to map (and nothing a later call could not take over)
+    prof.reset();
+    PA_HIP(hipStreamSynchronize(c->stream));
+    if (m == 0) remember_index(0);
+    return PA_OK;
+  }
 
   // ---- 2. dictionary of minimizer hashes: ids, postings, same-hash links
   for (int b = 0; b < 2; ++b) { PA_TRY(W.keys[b].reserve((uint64_t)m * 8)); PA_TRY(W.vals[b].reserve((uint64_t)m * 4)); }
@@ -1575,22 +1612,27 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   PA_TRY(W.post_cw.reserve((uint64_t)m * 8));
   uint64_t *keys[2] = {W.keys[0].as<uint64_t>(), W.keys[1].as<uint64_t>()};
   uint32_t *vals[2] = {W.vals[0].as<uint32_t>(), W.vals[1].as<uint32_t>()};
-  const uint32_t gm = ceil_div_u64(m, kThreads);
-  hipLaunchKernelGGL(mini_keys_kernel, dim3(gm), dim3(kThreads), 0, c->stream, W.mini_hash.as<uint32_t>(), m, keys[0], vals[0]);
-  int which = 0;
-  PA_TRY(pa_radix_sort_pairs(c, keys, vals, m, 0, 32, false, &which));
-  uint32_t *d_flags = W.flags.as<uint32_t>(), *d_pos = d_flags + m;
-  hipLaunchKernelGGL(key_heads_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], m, d_flags);
-  PA_TRY(pa_exclusive_scan_u32(c, d_flags, d_pos, m, W.scalars.as<uint64_t>()));
-  PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
-  PA_HIP(hipStreamSynchronize(c->stream));
-  const uint32_t n_ids = (uint32_t)c->h_pinned[0];
-  PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
-  hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
-                     n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
-                     W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
-                     W.post_cw.as<uint64_t>());
+  int which = reuse ? W.index_which : 0;
+  if (!reuse) {
+    const uint32_t gm = ceil_div_u64(m, kThreads);
+    hipLaunchKernelGGL(mini_keys_kernel, dim3(gm), dim3(kThreads), 0, c->stream, W.mini_hash.as<uint32_t>(), m, keys[0], vals[0]);
+    PA_TRY(pa_radix_sort_pairs(c, keys, vals, m, 0, 32, false, &which));
+    uint32_t *d_flags = W.flags.as<uint32_t>(), *d_pos = d_flags + m;
+    hipLaunchKernelGGL(key_heads_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], m, d_flags);
+    PA_TRY(pa_exclusive_scan_u32(c, d_flags, d_pos, m, W.scalars.as<uint64_t>()));
+    PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t n_ids = (uint32_t)c->h_pinned[0];
+    PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
+    hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
+                       n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
+                       W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
+                       W.post_cw.as<uint64_t>());
+    W.index_ids = n_ids;
+  }
   const uint32_t *d_sorted_idx = vals[which];
+  // the index (minimizers, bucket index, dictionary, postings) is complete: a later call may take it over
+  remember_index(which);
 
   // ---- tables indexed by sketch size
   {
@@ -1645,9 +1687,9 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
   const bool use_buckets = !force_sorted && (uint64_t)kBucketWaves * n_genomes * 4u <= 128u * 1024u;
   PA_HIP(hipMemsetAsync(d_overflow, 0, 8, c->stream));
   prof.reset();
-  for (uint32_t g0 = 0; g0 < n_genomes;) {
+  for (uint32_t g0 = qry0; g0 < qry1;) {
     uint32_t g1 = g0 + 1;
-    while (g1 < n_genomes && genome_frag_off[g1 + 1] - genome_frag_off[g0] <= batch_frags &&
+    while (g1 < qry1 && genome_frag_off[g1 + 1] - genome_frag_off[g0] <= batch_frags &&
            (uint64_t)(g1 + 1 - g0) * total_bins * 8 <= kMaxTableBytes)
       ++g1;
     const uint32_t f0 = genome_frag_off[g0], nf = genome_frag_off[g1] - f0, nq = g1 - g0;

@@ -6,10 +6,12 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -36,18 +38,29 @@ class HostPool {
   template <typename F>
   void run(uint32_t n_workers, F &&fn) {
     if (n_workers <= 1) { fn(0u, 1u); return; }
+    std::exception_ptr first_error;
+    std::mutex error_guard;
+    auto guarded = [&](uint32_t id, uint32_t n) {
+      try {
+        fn(id, n);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(error_guard);
+        if (!first_error) first_error = std::current_exception();
+      }
+    };
     // One job at a time.  A second caller (the FASTA loader works on a background thread while the main thread
     // formats signatures or matrices) does not queue behind the first: it runs its job on threads of its own.
     std::unique_lock<std::mutex> busy(busy_, std::try_to_lock);
     if (!busy.owns_lock()) {
       std::vector<std::thread> own;
       own.reserve(n_workers - 1);
-      for (uint32_t t = 1; t < n_workers; ++t) own.emplace_back([&fn, t, n_workers] { fn(t, n_workers); });
-      fn(0u, n_workers);
+      for (uint32_t t = 1; t < n_workers; ++t) own.emplace_back([&guarded, t, n_workers] { guarded(t, n_workers); });
+      guarded(0u, n_workers);
       for (auto &t : own) t.join();
+      if (first_error) std::rethrow_exception(first_error);
       return;
     }
-    std::function<void(uint32_t, uint32_t)> job = fn;
+    std::function<void(uint32_t, uint32_t)> job = guarded;
     {
       std::unique_lock<std::mutex> lock(m_);
       while (threads_ < n_workers - 1) {
@@ -60,10 +73,13 @@ class HostPool {
       ++generation_;
     }
     wake_.notify_all();
-    fn(0u, n_workers);
-    std::unique_lock<std::mutex> lock(m_);
-    done_.wait(lock, [this] { return pending_ == 0; });
-    job_ = nullptr;
+    guarded(0u, n_workers);
+    {
+      std::unique_lock<std::mutex> lock(m_);
+      done_.wait(lock, [this] { return pending_ == 0; });
+      job_ = nullptr;
+    }
+    if (first_error) std::rethrow_exception(first_error);
   }
 
  private:
@@ -133,4 +149,24 @@ inline uint32_t pa_host_threads(uint64_t items, uint64_t grain, uint32_t request
   const uint64_t by_work = items / (grain ? grain : 1) + 1;
   if (by_work < nt) nt = (uint32_t)by_work;
   return nt ? nt : 1u;
+}
+
+
+// Body of an extern "C" entry point that runs host-pool jobs or allocates: C++ exceptions never cross the C ABI.
+// `set_error` is pa_set_error (declared by the including file); returns the body's status, -3 (PA_E_NOMEM) for
+// std::bad_alloc, -1 (PA_E_INVALID) for anything else.
+template <typename Body, typename SetError>
+inline int pa_host_guard(const char *what, SetError &&set_error, Body &&body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    set_error("%s: out of host memory", what);
+    return -3;
+  } catch (const std::exception &e) {
+    set_error("%s: %s", what, e.what());
+    return -1;
+  } catch (...) {
+    set_error("%s: unknown C++ exception", what);
+    return -1;
+  }
 }

@@ -126,10 +126,10 @@ bool write_block(FILE *f, bool first, const char *const *q_hashes, uint32_t nq, 
 
 }  // namespace
 
-extern "C" int pa_write_comparisons_json(const char *path, const char *prefix, const char *suffix,
-                                         const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
-                                         uint32_t ns, const double *identity, const double *cov_query,
-                                         const uint8_t *is_null) {
+static int write_comparisons_json(const char *path, const char *prefix, const char *suffix,
+                                  const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
+                                  uint32_t ns, const double *identity, const double *cov_query,
+                                  const uint8_t *is_null) {
   if (!path || !prefix || !suffix || (nq && !q_hashes) || (ns && !s_hashes) || ((uint64_t)nq * ns && (!identity || !cov_query || !is_null))) {
     pa_set_error("pa_write_comparisons_json: null argument");
     return PA_E_INVALID;
@@ -137,7 +137,9 @@ extern "C" int pa_write_comparisons_json(const char *path, const char *prefix, c
   FILE *f = fopen(path, "wb");
   if (!f) { pa_set_error("cannot open %s for writing", path); return PA_E_INVALID; }
   bool ok = fwrite(prefix, 1, strlen(prefix), f) == strlen(prefix);
-  ok = ok && write_block(f, true, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+  try {
+    ok = ok && write_block(f, true, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+  } catch (...) { fclose(f); throw; }
   ok = ok && fwrite(suffix, 1, strlen(suffix), f) == strlen(suffix);
   ok = (fclose(f) == 0) && ok;
   if (!ok) { pa_set_error("short write to %s", path); return PA_E_INVALID; }
@@ -148,10 +150,10 @@ extern "C" int pa_write_comparisons_json(const char *path, const char *prefix, c
 // worker leaves the completed comparisons behind, pyani_plus/private_cli.py:1863-1894): the file written by
 // pa_write_comparisons_json ends with `suffix`; this call moves the suffix back by one block of rows, so the
 // file is a complete JSON document after every call and no row is ever formatted twice.
-extern "C" int pa_append_comparisons_json(const char *path, const char *suffix, int file_has_rows,
-                                          const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
-                                          uint32_t ns, const double *identity, const double *cov_query,
-                                          const uint8_t *is_null) {
+static int append_comparisons_json(const char *path, const char *suffix, int file_has_rows,
+                                   const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
+                                   uint32_t ns, const double *identity, const double *cov_query,
+                                   const uint8_t *is_null) {
   if (!path || !suffix || (nq && !q_hashes) || (ns && !s_hashes) || ((uint64_t)nq * ns && (!identity || !cov_query || !is_null))) {
     pa_set_error("pa_append_comparisons_json: null argument");
     return PA_E_INVALID;
@@ -163,9 +165,30 @@ extern "C" int pa_append_comparisons_json(const char *path, const char *suffix, 
   bool ok = fseeko(f, -(off_t)ls, SEEK_END) == 0 && fread(tail.data(), 1, ls, f) == ls && memcmp(tail.data(), suffix, ls) == 0;
   if (!ok) { fclose(f); pa_set_error("%s does not end with the expected JSON suffix", path); return PA_E_INVALID; }
   ok = fseeko(f, -(off_t)ls, SEEK_END) == 0;
-  ok = ok && write_block(f, !file_has_rows, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+  try {
+    ok = ok && write_block(f, !file_has_rows, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+  } catch (...) { fclose(f); throw; }
   ok = ok && fwrite(suffix, 1, ls, f) == ls;
   ok = (fclose(f) == 0) && ok;
   if (!ok) { pa_set_error("short write to %s", path); return PA_E_INVALID; }
   return PA_OK;
+}
+
+// C++ exceptions (std::bad_alloc from a formatting buffer, on the caller's or a pool thread) never cross the C ABI
+extern "C" int pa_write_comparisons_json(const char *path, const char *prefix, const char *suffix,
+                                         const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
+                                         uint32_t ns, const double *identity, const double *cov_query,
+                                         const uint8_t *is_null) {
+  return pa_host_guard("pa_write_comparisons_json", pa_set_error, [&] {
+    return write_comparisons_json(path, prefix, suffix, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+  });
+}
+
+extern "C" int pa_append_comparisons_json(const char *path, const char *suffix, int file_has_rows,
+                                          const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
+                                          uint32_t ns, const double *identity, const double *cov_query,
+                                          const uint8_t *is_null) {
+  return pa_host_guard("pa_append_comparisons_json", pa_set_error, [&] {
+    return append_comparisons_json(path, suffix, file_has_rows, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+  });
 }

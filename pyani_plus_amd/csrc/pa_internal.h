@@ -92,6 +92,9 @@ struct pa_ctx {
   bool dict_prepared = false;
   uint64_t dict_prepared_postings = 0;
   uint32_t dict_prepared_cap = 0;
+  // scalars of the hash dictionary, touched by no other phase: [0] id counter, [1] id of the key ~0 (u32 each);
+  // u64 [1..2] fingerprint of the postings a prepared dictionary was built from, [3..4] of the tile that consumes it
+  DevBuf dict_scalars;
   hipStream_t copy_stream = nullptr;  // uploads of pa_sketch_streamed, created on first use
   void *frag_work = nullptr;  // fragment-ANI workspace (fragani.hip), created on first use
   // pinned host scalars

@@ -97,8 +97,8 @@ void mask_runs_range(const uint32_t *h_mask, uint64_t w0, uint64_t w1, std::vect
 }
 }  // namespace
 
-extern "C" int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, uint64_t *h_run_start,
-                                uint64_t *h_run_len, uint64_t cap) {
+static int64_t mask_runs_impl(const uint32_t *h_mask, uint64_t arena_bases, uint64_t *h_run_start,
+                             uint64_t *h_run_len, uint64_t cap) {
   if (!h_mask && arena_bases) return -1;
   const uint64_t n_words = arena_bases / 32;
   const uint32_t nt = pa_host_threads(n_words, 4u << 20, 0);
@@ -124,6 +124,16 @@ extern "C" int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, ui
     }
   }
   return (int64_t)n;
+}
+
+extern "C" int64_t pa_mask_runs(const uint32_t *h_mask, uint64_t arena_bases, uint64_t *h_run_start,
+                                uint64_t *h_run_len, uint64_t cap) {
+  int64_t n = -1;
+  const int st = pa_host_guard("pa_mask_runs", pa_set_error, [&] {
+    n = mask_runs_impl(h_mask, arena_bases, h_run_start, h_run_len, cap);
+    return 0;
+  });
+  return st == 0 ? n : -1;  // a negative count is this entry point's failure value
 }
 
 extern "C" uint64_t pa_max_hash(uint64_t scaled) {
@@ -414,8 +424,10 @@ extern "C" int pa_ani_host(const uint32_t *h_counts, const uint64_t *h_q_sizes, 
           }
     }
   };
-  HostPool &pool = HostPool::get();
-  pool.run(nt, pass1);
-  if (symmetric) pool.run(std::min<uint32_t>(nt, (nq + 63u) / 64u), pass2);
-  return PA_OK;
+  return pa_host_guard("pa_ani_host", pa_set_error, [&] {
+    HostPool &pool = HostPool::get();
+    pool.run(nt, pass1);
+    if (symmetric) pool.run(std::min<uint32_t>(nt, (nq + 63u) / 64u), pass2);
+    return (int)PA_OK;
+  });
 }

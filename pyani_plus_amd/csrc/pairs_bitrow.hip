@@ -18,6 +18,7 @@
 // The per-ordered-pair cost drops from O(|Q|+|S|) merge steps to
 // O(|Q|/32) word operations; the result is the exact integer |Q n S|.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "pa_internal.h"
@@ -269,6 +270,45 @@ __global__ __launch_bounds__(kThreads) void table_lookup_kernel(
   }
 }
 
+// Order-free fingerprint of a run of postings: (sum, sum of squares-ish mix) over the hashes, two 64-bit words.
+// A prepared dictionary is only valid for the subject tile whose postings it was built from; the two runs live in
+// different buffers (the rank's own sketches before the all-gather, the gathered CSR after), so they are compared
+// by content.
+__global__ __launch_bounds__(kThreads) void postings_fingerprint_kernel(const uint64_t *__restrict__ hashes, uint64_t n,
+                                                                        unsigned long long *__restrict__ out) {
+  uint64_t a = 0, b = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kThreads) {
+    const uint64_t h = hashes[i];
+    a += h;
+    b += (h ^ (h >> 29)) * 0x9E3779B97F4A7C15ULL;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(&out[0], (unsigned long long)a);
+    atomicAdd(&out[1], (unsigned long long)b);
+  }
+}
+
+// All-vs-all over more than one subject tile: |A n B| = |B n A|, so tile j only evaluates the queries of tiles
+// i <= j and the blocks below the tile diagonal are the transposes of the ones above.  32 x 32 pieces through LDS
+// so that both the read and the write are coalesced; tile edges are multiples of 32, so a piece never straddles one.
+__global__ __launch_bounds__(256) void mirror_lower_kernel(uint32_t *__restrict__ counts, uint32_t n, uint32_t tile) {
+  __shared__ uint32_t s_t[32][33];
+  const uint32_t r0 = blockIdx.y * 32u, c0 = blockIdx.x * 32u;  // destination piece: rows r0.., columns c0..
+  if (r0 / tile <= c0 / tile) return;                             // on or above the tile diagonal: computed directly
+  const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5;   // 32 x 8 threads
+  for (uint32_t y = ty; y < 32u; y += 8u) {
+    const uint32_t sr = c0 + y, sc = r0 + tx;  // source element (sr, sc) = transpose position
+    s_t[y][tx] = (sr < n && sc < n) ? counts[(uint64_t)sr * n + sc] : 0u;
+  }
+  __syncthreads();
+  for (uint32_t y = ty; y < 32u; y += 8u) {
+    const uint32_t dr = r0 + y, dc = c0 + tx;
+    if (dr < n && dc < n) counts[(uint64_t)dr * n + dc] = s_t[tx][y];
+  }
+}
+
 template <int TPR>
 void launch_row_sum(pa_ctx *c, uint32_t nq, const uint32_t *ids, const uint64_t *off, uint32_t q0,
                     const uint32_t *rows, uint32_t tile_cols, uint32_t *counts, uint32_t ns, uint32_t col0) {
@@ -383,7 +423,8 @@ static int dict_insert(pa_ctx *c, const uint64_t *d_postings, uint64_t n_post, u
   const uint64_t cap64 = n_post + n_post / 2 + 1024;  // load <= 2/3
   PA_REQUIRE(cap64 < (1ULL << 32), "pair phase: tile with %llu subject postings is too large for the hash dictionary",
              (unsigned long long)n_post);
-  uint32_t *d_counter = reinterpret_cast<uint32_t *>(c->counters.as<uint64_t>() + 4);  // [0] counter, [1] special id
+  PA_TRY(c->dict_scalars.reserve(64));
+  uint32_t *d_counter = c->dict_scalars.as<uint32_t>();  // [0] counter, [1] special id
   PA_TRY(c->dict_keys[0].reserve(cap64 * sizeof(DictEntry)));
   PA_HIP(hipMemsetAsync(c->dict_keys[0].p, 0xff, cap64 * sizeof(DictEntry), c->stream));
   PA_HIP(hipMemsetAsync(d_counter, 0, 4, c->stream));
@@ -406,6 +447,13 @@ int pa_pair_dict_prepare_impl(pa_ctx *c, const uint64_t *d_subject_hashes, uint6
   c->dict_prepared = false;
   uint32_t cap = 0;
   PA_TRY(dict_insert(c, d_subject_hashes, n_postings, &cap));
+  // what the dictionary was built from, for the call that consumes it
+  unsigned long long *d_fp = c->dict_scalars.as<unsigned long long>() + 1;
+  PA_HIP(hipMemsetAsync(d_fp, 0, 16, c->stream));
+  if (n_postings)
+    hipLaunchKernelGGL(postings_fingerprint_kernel, dim3(std::min<uint32_t>(1024u, ceil_div_u64(n_postings, kThreads))),
+                       dim3(kThreads), 0, c->stream, d_subject_hashes, n_postings, d_fp);
+  PA_HIP(hipGetLastError());
   c->dict_prepared = true;
   c->dict_prepared_postings = n_postings;
   c->dict_prepared_cap = cap;
@@ -435,16 +483,21 @@ int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_
     h_off = h_off_own.data();
   }
   PA_TRY(c->ids.reserve(total * sizeof(uint32_t)));
+  PA_TRY(c->dict_scalars.reserve(64));
   uint32_t *d_ids = c->ids.as<uint32_t>();
-  uint32_t *d_counter = reinterpret_cast<uint32_t *>(c->counters.as<uint64_t>() + 4);  // [0] counter, [1] special id
+  uint32_t *d_counter = c->dict_scalars.as<uint32_t>();  // [0] counter, [1] special id
   PA_REQUIRE(!prepared || ns <= kMaxTileSubjects, "pair phase: a prepared dictionary serves one tile of at most %u subjects",
              kMaxTileSubjects);
+  // all-vs-all over several subject tiles: tile j takes the queries of tiles i <= j only, the rest is mirrored
+  static const bool symmetry_off = [] { const char *v = getenv("PA_PAIRS_SYMMETRIC"); return v && v[0] == '0'; }();
+  const bool symmetric = !symmetry_off && q0 == s0 && q1 == s1 && ns > kMaxTileSubjects;
   for (uint32_t t0 = s0; t0 < s1; t0 += kMaxTileSubjects) {
     const uint32_t t1 = (s1 - t0 > kMaxTileSubjects) ? t0 + kMaxTileSubjects : s1;
     const uint32_t cols = t1 - t0;
     const int tpr = (int)((cols + 127u) / 128u);  // threads per row: row width = tpr*128 columns
     const uint32_t w32 = (uint32_t)tpr * 4u;
-    const uint64_t pt0 = h_off[t0], pt1 = h_off[t1], pq0 = h_off[q0], pq1 = h_off[q1];
+    const uint32_t tq1 = symmetric ? t1 : q1;  // last query (exclusive) this tile evaluates
+    const uint64_t pt0 = h_off[t0], pt1 = h_off[t1], pq0 = h_off[q0], pq1 = h_off[tq1];
     uint32_t cap = 0;
     {
       ProfScope prof(c, PA_PROF_PAIR_DICT);
@@ -452,12 +505,34 @@ int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_
         PA_REQUIRE(c->dict_prepared_postings == pt1 - pt0,
                    "pair phase: the prepared dictionary holds %llu postings, the subject tile has %llu",
                    (unsigned long long)c->dict_prepared_postings, (unsigned long long)(pt1 - pt0));
+        // same number of postings is not the same postings: compare the fingerprints (one small copy and a wait;
+        // the lookups below are then enqueued a few microseconds later than they could have been)
+        unsigned long long *d_fp = c->dict_scalars.as<unsigned long long>() + 1;
+        PA_HIP(hipMemsetAsync(d_fp + 2, 0, 16, c->stream));
+        if (pt1 > pt0)
+          hipLaunchKernelGGL(postings_fingerprint_kernel, dim3(std::min<uint32_t>(1024u, ceil_div_u64(pt1 - pt0, kThreads))),
+                             dim3(kThreads), 0, c->stream, d_hashes + pt0, pt1 - pt0, d_fp + 2);
+        PA_HIP(hipMemcpyAsync(c->h_pinned, d_fp, 32, hipMemcpyDeviceToHost, c->stream));
+        PA_HIP(hipStreamSynchronize(c->stream));
+        PA_REQUIRE(c->h_pinned[0] == c->h_pinned[2] && c->h_pinned[1] == c->h_pinned[3],
+                   "pair phase: the prepared dictionary was built from other postings than the subject tile's "
+                   "(same count, %llu, different content)", (unsigned long long)(pt1 - pt0));
         cap = c->dict_prepared_cap;
       } else {
         PA_TRY(dict_insert(c, d_hashes + pt0, pt1 - pt0, &cap));
       }
-      // rows: one per distinct subject hash, at most one per subject posting; zeroed up to the device-side count
-      const uint64_t row_bound = (pt1 - pt0) ? (pt1 - pt0) : 1;
+      // rows: one per distinct subject hash, at most one per subject posting; zeroed up to the device-side count.
+      // The speculative bound (no wait for the count) is only taken while it stays moderate: beyond kRowBoundBytes
+      // the count comes to the host and the table is sized by it, as unrelated genomes share few hashes but related
+      // ones (or a small `scaled`) would otherwise reserve tens of GB that never shrink.
+      constexpr uint64_t kRowBoundBytes = 4ULL << 30;
+      uint64_t row_bound = (pt1 - pt0) ? (pt1 - pt0) : 1;
+      if (row_bound * w32 * sizeof(uint32_t) > kRowBoundBytes && row_bound * w32 * sizeof(uint32_t) > c->bitrows.bytes) {
+        PA_HIP(hipMemcpyAsync(c->h_pinned, d_counter, 8, hipMemcpyDeviceToHost, c->stream));
+        PA_HIP(hipStreamSynchronize(c->stream));
+        const uint64_t distinct = (uint32_t)c->h_pinned[0];  // ids drawn so far, the one of the key ~0 included
+        row_bound = std::max<uint64_t>(1, std::min<uint64_t>(row_bound, distinct));
+      }
       PA_TRY(c->bitrows.reserve(row_bound * w32 * sizeof(uint32_t)));
       hipLaunchKernelGGL(zero_rows_kernel, dim3(ceil_div_u64(row_bound * w32 / 4u, kThreads)), dim3(kThreads), 0,
                          c->stream, c->bitrows.as<uint4>(), d_counter, w32);
@@ -484,8 +559,15 @@ int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_
     {
       ProfScope prof(c, PA_PROF_PAIR_COUNT);
       const uint32_t *rows = c->bitrows.as<uint32_t>();
-      PA_TRY(dispatch_row_sum(c, tpr, nq, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0));
+      PA_TRY(dispatch_row_sum(c, tpr, tq1 - q0, d_ids, d_off, q0, rows, cols, d_counts, ns, t0 - s0));
     }
+    PA_HIP(hipGetLastError());
+  }
+  if (symmetric) {
+    ProfScope prof(c, PA_PROF_PAIR_COUNT);
+    static_assert(kMaxTileSubjects % 32u == 0, "mirror pieces must not straddle a tile edge");
+    const uint32_t g = (ns + 31u) / 32u;
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(g, g), dim3(256), 0, c->stream, d_counts, ns, kMaxTileSubjects);
     PA_HIP(hipGetLastError());
   }
   return PA_OK;

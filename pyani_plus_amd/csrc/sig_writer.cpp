@@ -60,21 +60,20 @@ extern "C" int pa_write_sigs(uint32_t n_files, const char *const *paths, const c
   if (n_threads == 0) n_threads = pa_cpu_budget();
   if (n_threads == 0) n_threads = 1;
   if (n_threads > n_files) n_threads = n_files;
-  std::vector<int> status(n_threads, PA_OK);
-  std::vector<uint32_t> failed(n_threads, 0);
-  std::vector<std::thread> pool;
-  for (uint32_t t = 0; t < n_threads; ++t)
-    pool.emplace_back([&, t] {
+  return pa_host_guard("pa_write_sigs", pa_set_error, [&] {
+    std::vector<int> status(n_threads, PA_OK);
+    std::vector<uint32_t> failed(n_threads, 0);
+    HostPool::get().run(n_threads, [&](uint32_t t, uint32_t) {  // a throwing worker (out of memory) surfaces in run()
       for (uint32_t i = t; i < n_files; i += n_threads) {
         const int st = write_one(paths[i], heads[i], mids[i], tails[i], ksize, h_mins + h_off[i], h_off[i + 1] - h_off[i]);
         if (st != PA_OK && status[t] == PA_OK) { status[t] = st; failed[t] = i; }
       }
     });
-  for (auto &th : pool) th.join();
-  for (uint32_t t = 0; t < n_threads; ++t)
-    if (status[t] != PA_OK) {
-      pa_set_error("pa_write_sigs: could not write %s", paths[failed[t]]);
-      return status[t];
-    }
-  return PA_OK;
+    for (uint32_t t = 0; t < n_threads; ++t)
+      if (status[t] != PA_OK) {
+        pa_set_error("pa_write_sigs: could not write %s", paths[failed[t]]);
+        return status[t];
+      }
+    return (int)PA_OK;
+  });
 }

@@ -14,6 +14,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -99,7 +100,8 @@ extern "C" int pa_sqlite_insert_comparisons(const char *database, int64_t config
   }
   const Api &a = api();
   if (!a.ok) {
-    pa_set_error("pa_sqlite_insert_comparisons: libsqlite3.so.0 could not be loaded (%s)", a.handle ? "missing symbol" : dlerror());
+    const char *why = a.handle ? "missing symbol" : dlerror();  // dlerror() may hold nothing by now
+    pa_set_error("pa_sqlite_insert_comparisons: libsqlite3.so.0 could not be loaded (%s)", why ? why : "no loader message");
     return PA_E_IO;
   }
   sqlite3 *db = nullptr;
@@ -115,8 +117,14 @@ extern "C" int pa_sqlite_insert_comparisons(const char *database, int64_t config
     return PA_E_IO;
   };
   a.busy_timeout(db, 30000);
-  // synchronous=OFF lasts as long as this connection: the rows are re-derivable (the tile files are on disk)
-  if (a.exec(db, "PRAGMA synchronous=OFF; PRAGMA cache_size=-1048576; BEGIN IMMEDIATE", nullptr, nullptr, nullptr) != kSqliteOk)
+  // synchronous=NORMAL (not OFF): the database is the user's persistent multi-run file, and with OFF a crash of the
+  // machine during the commit can corrupt all of it, other runs' rows included.  The insert is one transaction, so
+  // NORMAL costs a handful of fsyncs at commit time.  PA_SQLITE_SYNCHRONOUS=OFF opts into the faster, riskier form.
+  const char *sync_env = getenv("PA_SQLITE_SYNCHRONOUS");
+  const bool sync_off = sync_env && (sync_env[0] == 'O' || sync_env[0] == 'o' || sync_env[0] == '0');
+  if (a.exec(db, sync_off ? "PRAGMA synchronous=OFF; PRAGMA cache_size=-1048576; BEGIN IMMEDIATE"
+                          : "PRAGMA synchronous=NORMAL; PRAGMA cache_size=-1048576; BEGIN IMMEDIATE",
+             nullptr, nullptr, nullptr) != kSqliteOk)
     return fail("begin");
   // Rows go in kBlock at a time through one statement with kBlock value tuples (fewer trips through
   // sqlite3_step / sqlite3_reset and the statement's set-up and tear-down code); the last rows of a matrix row

@@ -116,13 +116,12 @@ def sharded_pair_step(engine, torch, dist, sk_local, shard_sizes: list[int], q_r
     one subject tile, the dictionary of the tile is built from ``sk_local`` while the payload is in flight.
     With ``backend != "nccl"`` the collectives run on host copies (plumbing check on boxes with fewer GPUs
     than ranks).  Returns (all sketches as DeviceSketches, counts tensor [nq, ns])."""
-    from .engine import DeviceSketches
-
     rank = dist.get_rank(group)
     own0 = sum(shard_sizes[:rank])
     own = (own0, own0 + shard_sizes[rank])
     n_total = sum(shard_sizes)
-    can_overlap = overlap and tuple(s_range) == own and 0 < shard_sizes[rank] <= 2048 and sk_local.total > 0
+    can_overlap = (overlap and tuple(s_range) == own and 0 < shard_sizes[rank] <= 2048 and sk_local.total > 0
+                   and hasattr(engine, "pair_dict_prepare"))
     hook = (lambda: engine.pair_dict_prepare(sk_local.hashes, sk_local.total)) if can_overlap else None
     sizes = sk_local.off[1:] - sk_local.off[:-1]
     if backend == "nccl":
@@ -131,7 +130,9 @@ def sharded_pair_step(engine, torch, dist, sk_local, shard_sizes: list[int], q_r
         hashes, off, off_host = allgather_sketches(
             torch, dist, sk_local.hashes[: max(1, sk_local.total)].cpu(), sizes.cpu(), shard_sizes, group, while_in_flight=hook
         )
-        hashes, off = hashes.to(engine.device), off.to(engine.device)
-    sk = DeviceSketches(hashes, off, n_total, int(off_host[-1]), off_host)
+    sk = engine.sketches_from_gathered(hashes, off, off_host)
+    assert sk.n == n_total
+    if s_range[0] == s_range[1] or q_range[0] == q_range[1]:  # a rank without columns (fewer genomes than ranks)
+        return sk, None
     counts = engine.pair_counts(sk, tuple(q_range), tuple(s_range))
     return sk, counts

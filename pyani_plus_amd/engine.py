@@ -314,6 +314,12 @@ class HipEngine:
             np.ascontiguousarray(off.astype(np.uint64)),
         )
 
+    def sketches_from_gathered(self, hashes, off, off_host: np.ndarray) -> DeviceSketches:
+        """The CSR an all-gather delivered (``distributed.allgather_sketches``: tensors on this device, or on the host
+        when the collective ran there) as ``DeviceSketches``."""
+        hashes, off = hashes.to(self.device), off.to(self.device)
+        return DeviceSketches(hashes, off, len(off_host) - 1, int(off_host[-1]), np.ascontiguousarray(off_host, dtype=np.uint64))
+
     def arena_dirty(self, arena: DeviceArena):
         """The arena's dirty-block bitmap (``pa_arena_dirty``), built on first use and kept with the arena."""
         if arena.dirty is None:
@@ -461,22 +467,33 @@ class HipEngine:
         return out
 
     # -- fastANI-style fragment ANI (BASELINE configs[3])
-    def fragani(self, arena: DeviceArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000, ref_range=None):
+    def fragani(self, arena: DeviceArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000, ref_range=None,
+                query_range=None, reuse_index: bool = False, out=None):
         """All ordered genome pairs: (total_frags[n], matched[n, n], ident_sum[n, n]) as numpy arrays;
         ANI(q, r) = ident_sum / matched (percent), rows = query.  ``ref_range`` = (r0, r1) maps the queries against
-        those reference genomes only (the other columns stay 0)."""
+        those reference genomes only (the other columns stay 0); ``query_range`` = (q0, q1) maps those query genomes
+        only and leaves the other rows of ``out`` = (total, matched, ident_sum) as they are; ``reuse_index``: the
+        previous call was on this very arena with the same k and fragment length, take over its reference index."""
         n = arena.n_genomes
         r0, r1 = ref_range if ref_range is not None else (0, n)
+        q0, q1 = query_range if query_range is not None else (0, n)
         cs = np.ascontiguousarray(contig_start, dtype=np.uint64)
         cl = np.ascontiguousarray(contig_len, dtype=np.uint32)
         cg = np.ascontiguousarray(contig_genome, dtype=np.uint32)
-        total = np.zeros(n, dtype=np.uint32)
-        matched = np.zeros((n, n), dtype=np.uint32)
-        ident_sum = np.zeros((n, n), dtype=np.float64)
+        if out is None:
+            total = np.zeros(n, dtype=np.uint32)
+            matched = np.zeros((n, n), dtype=np.uint32)
+            ident_sum = np.zeros((n, n), dtype=np.float64)
+        else:
+            total, matched, ident_sum = out
+            assert total.shape == (n,) and matched.shape == (n, n) == ident_sum.shape
+            assert total.dtype == np.uint32 and matched.dtype == np.uint32 and ident_sum.dtype == np.float64
+            assert matched.flags.c_contiguous and ident_sum.flags.c_contiguous
         check(
-            self.lib.pa_fragani(
+            self.lib.pa_fragani_ex(
                 self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,
-                cg.ctypes.data, len(cs), n, k, frag_len, int(r0), int(r1), total.ctypes.data, matched.ctypes.data, ident_sum.ctypes.data,
+                cg.ctypes.data, len(cs), n, k, frag_len, int(q0), int(q1), int(r0), int(r1),
+                _capi.PA_FRAGANI_REUSE_INDEX if reuse_index else 0, total.ctypes.data, matched.ctypes.data, ident_sum.ctypes.data,
             ),  # fmt: skip
             "pa_fragani",
         )

@@ -66,21 +66,45 @@ def is_reported(matches: int, frags: int, fragsize: int, minmatch: float, len_qu
     return frags > 0 and matches > 0 and matches * fragsize >= minmatch * min(len_query, len_subject)
 
 
-def fragment_ani_matrices(fasta_files: list[Path], *, kmersize: int, fragsize: int, engine=None, ref_range=None):
-    """(total_frags[n], matched[n, n], ani_percent[n, n], mappable_length[n]) for the given FASTA files, rows = query."""
+QUERY_BATCH = 500  # query genomes per device call and per rewrite of the column file (private_cli.py:1029)
+
+
+def load_genomes_for_fragani(fasta_files: list[Path], engine):
+    """FASTA files -> (host arena, device arena); a file that does not load raises ``ValueError`` with the loader's message."""
     from ..engine import load_fasta_files
 
     infos, arena = load_fasta_files(fasta_files)
     for info in infos:
         if info.status != 0:
             raise ValueError(info.message)
+    return arena, engine.upload(arena)
+
+
+def fragment_ani_matrices(fasta_files: list[Path], *, kmersize: int, fragsize: int, engine=None, ref_range=None):
+    """(total_frags[n], matched[n, n], ani_percent[n, n], mappable_length[n]) for the given FASTA files, rows = query."""
     eng = engine or get_engine()
-    total, matched, ident_sum = eng.fragani(
-        eng.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize, ref_range=ref_range
-    )
+    arena, dev = load_genomes_for_fragani(fasta_files, eng)
+    total, matched, ident_sum = eng.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize, ref_range=ref_range)
     with np.errstate(invalid="ignore", divide="ignore"):
         ani = np.where(matched > 0, ident_sum / np.maximum(matched, 1), np.nan)
     return total, matched, ani, mappable_lengths(arena.contig_len, arena.contig_genome, arena.n_genomes, fragsize)
+
+
+def comparison_entry(q: str, s: str, frags: int, matches: int, ani_percent: float, fragsize: int, minmatch: float, len_q: int,
+                     len_s: int, constants: dict) -> dict:
+    """One comparison as the reference's worker records it (private_cli.py:1066-1098): None everywhere when fastANI
+    would print no line for the pair."""
+    reported = is_reported(matches, frags, fragsize, minmatch, len_q, len_s)
+    return {
+        "query_hash": q,
+        "subject_hash": s,
+        "identity": fastani_print_round(float(ani_percent)) / 100.0 if reported else None,
+        # proxy values, private_cli.py:1072-1080
+        "aln_length": round(fragsize * matches) if reported else None,
+        "sim_errors": frags - matches if reported else None,
+        "cov_query": matches / frags if reported else None,
+        **constants,
+    }
 
 
 def compute_fastani_hip(  # noqa: PLR0913
@@ -97,12 +121,19 @@ def compute_fastani_hip(  # noqa: PLR0913
     *,
     cache: Path = Path(),  # noqa: ARG001
     engine=None,
+    subject_range: tuple[int, int] | None = None,
+    query_batch: int = QUERY_BATCH,
 ) -> int:
     """Run many-vs-subject (all-vs-all when ``subject_hash == ""``) and log the column(s) to JSON.
 
     A single subject column maps the queries against that one reference genome only (``ref_range``), as one
-    ``fastANI -r subject`` process does.  Library failures end the worker through ``log_sys_exit`` like a failing
-    tool (pyani_plus/utils.py:262-283); a failing save returns 2."""
+    ``fastANI -r subject`` process does; ``subject_range`` = (c0, c1) with ``subject_hash == ""`` takes the columns
+    c0 .. c1-1 of the sorted genomes (one rank's share of a multi-GPU run, ``rundb.run_fastani_hip``).
+    The queries go through in batches of ``query_batch`` genomes -- the reference's 500 (private_cli.py:1029-1033) --
+    and the column file is rewritten after each, so an interrupt keeps the finished batches
+    (private_cli.py:1101-1110); the reference index is built once and taken over by the later batches.
+    Library failures end the worker through ``log_sys_exit`` like a failing tool (pyani_plus/utils.py:262-283); a
+    failing save returns 2."""
     from .._capi import HipBackendError
     from .sourmash_hip import backend_failure
 
@@ -122,37 +153,46 @@ def compute_fastani_hip(  # noqa: PLR0913
         log_sys_exit(logger, f"{METHOD} run-id {run.run_id} is missing minmatch parameter")
 
     queries = sorted(query_hashes)
-    subjects = [subject_hash] if subject_hash else queries
+    if subject_hash:
+        subjects = [subject_hash]
+    elif subject_range is not None:
+        subjects = sorted(hash_to_filename)[subject_range[0] : subject_range[1]]
+    else:
+        subjects = queries
     genomes = sorted(set(queries) | set(subjects))
     index = {h: i for i, h in enumerate(genomes)}
-    ref_range = (index[subject_hash], index[subject_hash] + 1) if subject_hash else None
+    sub_idx = [index[s] for s in subjects]
+    contiguous = bool(sub_idx) and sub_idx == list(range(sub_idx[0], sub_idx[0] + len(sub_idx)))
+    ref_range = (sub_idx[0], sub_idx[0] + len(sub_idx)) if contiguous else None
+    constants = {"configuration_id": config_id, "uname_system": uname.system, "uname_release": uname.release, "uname_machine": uname.machine}
     db_entries: list[dict] = []
     try:
-        total, matched, ani, lengths = fragment_ani_matrices(
-            [Path(fasta_dir) / hash_to_filename[h] for h in genomes], kmersize=kmersize, fragsize=fragsize, engine=engine, ref_range=ref_range
-        )
-        for q in queries:
-            qi = index[q]
-            for s in subjects:
-                si = index[s]
-                frags, matches = int(total[qi]), int(matched[qi, si])
-                reported = is_reported(matches, frags, fragsize, minmatch, int(lengths[qi]), int(lengths[si]))  # fastANI prints a line
-                db_entries.append(
-                    {
-                        "query_hash": q,
-                        "subject_hash": s,
-                        "identity": fastani_print_round(float(ani[qi, si])) / 100.0 if reported else None,
-                        # proxy values, private_cli.py:1072-1080
-                        "aln_length": round(fragsize * matches) if reported else None,
-                        "sim_errors": frags - matches if reported else None,
-                        "cov_query": matches / frags if reported else None,
-                        "configuration_id": config_id,
-                        "uname_system": uname.system,
-                        "uname_release": uname.release,
-                        "uname_machine": uname.machine,
-                    }
-                )
-    except KeyboardInterrupt:  # pragma: no cover
+        if engine is None:
+            # one process per subject column in the reference's flow: PYANI_HIP_DEVICE=spread deals the columns over the GPUs
+            column = sorted(hash_to_filename).index(subject_hash) + 1 if subject_hash in hash_to_filename else 0
+            engine = get_engine(spread_key=column)
+        arena, dev = load_genomes_for_fragani([Path(fasta_dir) / hash_to_filename[h] for h in genomes], engine)
+        lengths = mappable_lengths(arena.contig_len, arena.contig_genome, arena.n_genomes, fragsize)
+        n = arena.n_genomes
+        out = (np.zeros(n, dtype=np.uint32), np.zeros((n, n), dtype=np.uint32), np.zeros((n, n), dtype=np.float64))
+        query_idx = [index[q] for q in queries]
+        # batches of consecutive genome indices that hold at most `query_batch` queries each
+        batches: list[list[int]] = [query_idx[i : i + max(1, int(query_batch))] for i in range(0, len(query_idx), max(1, int(query_batch)))]
+        for b, batch in enumerate(batches):
+            total, matched, ident_sum = engine.fragani(
+                dev, arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize, ref_range=ref_range,
+                query_range=(batch[0], batch[-1] + 1), reuse_index=b > 0, out=out,
+            )  # fmt: skip
+            for qi in batch:
+                q = genomes[qi]
+                frags = int(total[qi])
+                for s, si in zip(subjects, sub_idx):
+                    matches = int(matched[qi, si])
+                    ani = ident_sum[qi, si] / matches if matches else float("nan")
+                    db_entries.append(comparison_entry(q, s, frags, matches, ani, fragsize, minmatch, int(lengths[qi]), int(lengths[si]), constants))
+            if b + 1 < len(batches):
+                wire.export_json_db_entries(logger, json_filename, configuration, db_entries)
+    except KeyboardInterrupt:
         logger.error("Interrupted with %d completed %s comparisons", len(db_entries), METHOD)  # noqa: TRY400
         run.status = "Worker interrupted"
         session.commit()

@@ -93,15 +93,50 @@ def sig_cache_dir(cache: Path, kmersize: int, extra: str) -> Path:
 
 
 _ENGINE = None
+DEVICE_ENV = "PYANI_HIP_DEVICE"
 
 
-def get_engine(device: int = 0):
-    """Process-wide HipEngine (created on first use; raises HipBackendError without a GPU)."""
+def resolve_device(spread_key: int | None = None) -> int:
+    """Which GPU this process computes on.
+
+    The reference's column workers are separate processes (pyani_plus/private_cli.py:853-861, one per subject column
+    except for sourmash, pyani_plus/public_cli.py:232-261), so a node with several GPUs is used by giving each
+    process its own device and nothing else:
+
+    * ``PYANI_HIP_DEVICE=<index>`` -- that device;
+    * ``PYANI_HIP_DEVICE=spread`` -- ``spread_key`` modulo the number of devices, where the worker passes the number
+      of its subject column: the per-column processes of one run then cover the GPUs round-robin;
+    * unset -- ``LOCAL_RANK`` (ranks started by ``pyani_plus_amd.launch`` or ``torch.distributed.run``) modulo the
+      number of devices, else device 0.
+
+    Counting devices does not initialise the GPU; an index beyond the last device is an error of the caller's
+    environment and is reported by ``HipEngine``."""
+    import os
+
+    want = os.environ.get(DEVICE_ENV, "").strip().lower()
+    if want and want not in {"auto", "spread"}:
+        try:
+            return int(want)
+        except ValueError:
+            msg = f"{DEVICE_ENV} must be a device index, 'spread' or 'auto', not {want!r}"
+            raise ValueError(msg) from None
+    import torch
+
+    n_dev = max(1, torch.cuda.device_count())
+    if want == "spread" and spread_key is not None:
+        return int(spread_key) % n_dev
+    local_rank = os.environ.get("LOCAL_RANK", "")
+    return int(local_rank) % n_dev if local_rank.isdigit() else 0
+
+
+def get_engine(device: int | None = None, *, spread_key: int | None = None):
+    """Process-wide HipEngine (created on first use; raises HipBackendError without a GPU).  ``device`` None: the
+    device ``resolve_device`` names (environment; 0 by default)."""
     global _ENGINE
     if _ENGINE is None:
         from ..engine import HipEngine
 
-        _ENGINE = HipEngine(device)
+        _ENGINE = HipEngine(resolve_device(spread_key) if device is None else device)
     return _ENGINE
 
 
@@ -266,6 +301,42 @@ def prepare_genomes(logger: logging.Logger, run, cache: Path, *, engine=None, pr
 DEVICE_TILE_COLUMNS = 2048  # subject columns evaluated (and flushed to the column file) per device call
 
 
+def check_self_comparisons(queries: list[str], subjects: list[str], ident, null) -> None:
+    """The reference refuses a self-comparison that is not exactly one (pyani_plus/methods/sourmash.py:119-127)."""
+    sub_pos = {s: i for i, s in enumerate(subjects)}
+    for qi, q in enumerate(queries):
+        si = sub_pos.get(q)
+        if si is not None and not null[qi, si] and ident[qi, si] != 1.0:
+            msg = f"Expected {METHOD} {q} vs self to be one, not {ident[qi, si]!r}"
+            raise ValueError(msg)
+
+
+def read_cached_sketches(logger: logging.Logger, sig_files: list[Path], kmersize: int, max_hash: int) -> list[np.ndarray]:
+    """The sketches of the given signature files: from this process's own writes where they are still current,
+    otherwise through the native threaded reader (``sig.read_sigs``) -- the step `sourmash sig collect` +
+    `manysearch`'s own loading are in the reference (pyani_plus/methods/sourmash.py:160-200), where prepare and
+    compute are separate processes and every file is parsed again.  A missing, damaged or foreign file ends the
+    worker the way a failing `sourmash sig collect` does there (through utils.check_output -> log_sys_exit)."""
+    sketches: list = [None] * len(sig_files)
+    todo = []
+    for i, sig_file in enumerate(sig_files):
+        if not sig_file.is_file():
+            log_sys_exit(logger, f"Missing sourmash signature file '{sig_file}'")
+        sketches[i] = _recall_sketch(sig_file, kmersize, max_hash)
+        if sketches[i] is None:
+            todo.append(i)
+    if todo:
+        try:
+            loaded = sig.read_sigs([sig_files[i] for i in todo], ksize=kmersize, max_hash=max_hash)
+        except (ValueError, OSError, KeyError, TypeError) as err:
+            log_sys_exit(logger, f"Unreadable sourmash signature file: {err}")
+        except _capi.HipBackendError as err:
+            backend_failure(logger, f"{METHOD} signature loading", err)
+        for i, mins in zip(todo, loaded):
+            sketches[i] = mins
+    return sketches
+
+
 def iter_sourmash_tiles(  # noqa: PLR0913
     logger: logging.Logger,
     subject_hashes,
@@ -295,20 +366,7 @@ def iter_sourmash_tiles(  # noqa: PLR0913
     order = queries + extra_subjects  # CSR order: queries first, then subjects not among them
     index = {h: i for i, h in enumerate(order)}
     max_hash = max_hash_for_scaled(scaled)
-    sketches = []
-    for genome_hash in order:
-        sig_file = cache / f"{genome_hash}.sig"
-        if not sig_file.is_file():
-            log_sys_exit(logger, f"Missing sourmash signature file '{sig_file}'")
-        mins = _recall_sketch(sig_file, kmersize, max_hash)
-        if mins is None:
-            try:
-                mins, _ = sig.read_sig(sig_file, ksize=kmersize, max_hash=max_hash)
-            except (ValueError, OSError, KeyError, TypeError) as err:
-                # a damaged or foreign file in the cache ends the worker the way a failing `sourmash sig collect`
-                # does in the reference (pyani_plus/methods/sourmash.py:170-183 through utils.check_output)
-                log_sys_exit(logger, f"Unreadable sourmash signature file '{sig_file}': {err}")
-        sketches.append(mins)
+    sketches = read_cached_sketches(logger, [cache / f"{genome_hash}.sig" for genome_hash in order], kmersize, max_hash)
     nq = len(queries)
     sizes = np.array([len(s) for s in sketches], dtype=np.uint64)
     eng = engine or get_engine()
@@ -325,13 +383,7 @@ def iter_sourmash_tiles(  # noqa: PLR0913
         counts = np.ascontiguousarray(counts[:, sub_idx - lo])
         square = len(tile) == nq and tile == queries  # one tile, all-vs-all: one pow per ordered pair
         ident, cov, null = ani_host(counts, sizes[:nq], sizes[sub_idx], kmersize, symmetric=square)
-        # the reference refuses a self-comparison that is not exactly one (sourmash.py:119-127)
-        sub_pos = {s: i for i, s in enumerate(tile)}
-        for qi, q in enumerate(queries):
-            si = sub_pos.get(q)
-            if si is not None and not null[qi, si] and ident[qi, si] != 1.0:
-                msg = f"Expected {METHOD} {q} vs self to be one, not {ident[qi, si]!r}"
-                raise ValueError(msg)
+        check_self_comparisons(queries, tile, ident, null)
         yield queries, tile, cov, ident, null
 
 

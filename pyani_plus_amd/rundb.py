@@ -442,23 +442,25 @@ def cache_comparisons(conn, run: Run) -> dict[str, str]:
     return out
 
 
-def _compute_direct(logger, conn, run: Run, cache_dir: Path, tmp_dir: Path, engine, mark):
-    """Subject tiles -> binary column files + matrices in host memory -> rows inserted in index order."""
+def _compute_direct(logger, conn, run: Run, cache_dir: Path, tmp_dir: Path, engine, mark, *, subjects: list[str] | None = None):
+    """Subject tiles -> binary column files + matrices in host memory -> rows inserted in index order.
+    ``subjects``: only these subject columns (resuming a partial run); the matrices then hold those columns."""
     config = run.configuration
     hashes = sorted(a.genome_hash for a in run.fasta_hashes)
-    n = len(hashes)
-    ident = np.empty((n, n), dtype=np.float64)
-    cov = np.empty((n, n), dtype=np.float64)
-    null = np.empty((n, n), dtype=bool)
+    cols = hashes if subjects is None else sorted(subjects)
+    n, nc = len(hashes), len(cols)
+    ident = np.empty((n, nc), dtype=np.float64)
+    cov = np.empty((n, nc), dtype=np.float64)
+    null = np.empty((n, nc), dtype=bool)
     sig_cache = sourmash_hip.sig_cache_dir(cache_dir, config.kmersize, config.extra)
     col = 0
     try:
         for t, (queries, tile, t_cov, t_ident, t_null) in enumerate(
             sourmash_hip.iter_sourmash_tiles(
-                logger, hashes, hashes, sig_cache, kmersize=config.kmersize, scaled=sourmash_hip.parse_scaled(config.extra), engine=engine
+                logger, cols, hashes, sig_cache, kmersize=config.kmersize, scaled=sourmash_hip.parse_scaled(config.extra), engine=engine
             )
         ):
-            assert queries == hashes and tile == hashes[col : col + len(tile)]
+            assert queries == hashes and tile == cols[col : col + len(tile)]
             wire.save_tile(tmp_dir / f"{sourmash_hip.METHOD}.run_{run.run_id}.tile_{t}.npz", config, queries, tile, t_ident, t_cov, t_null)
             ident[:, col : col + len(tile)] = t_ident
             cov[:, col : col + len(tile)] = t_cov
@@ -467,18 +469,28 @@ def _compute_direct(logger, conn, run: Run, cache_dir: Path, tmp_dir: Path, engi
     except HipBackendError as err:
         sourmash_hip.backend_failure(logger, f"{sourmash_hip.METHOD} comparison", err)
     mark("pairs_and_tile_files")
-    conn.execute("PRAGMA synchronous=OFF")
+    return _ingest_direct(conn, run, hashes, cols, ident, cov, null, mark)
+
+
+def _ingest_direct(conn, run: Run, hashes: list[str], cols: list[str], ident, cov, null, mark):
+    """Matrices in host memory (rows = ``hashes``, columns = ``cols``, both sorted) -> comparison rows in index order,
+    the five cached matrices formatted on a second thread meanwhile (when the block is the whole square)."""
+    # synchronous=NORMAL for the bulk insert: a handful of fsyncs per transaction instead of one per page group, and
+    # -- unlike OFF -- no way for a crash of the machine to corrupt the user's multi-run database
+    conn.execute("PRAGMA synchronous=NORMAL")
     conn.execute("PRAGMA cache_size=-1048576")
-    # the cached matrices are formatted on a second thread while the rows go in (the native insert releases the GIL)
     from concurrent.futures import ThreadPoolExecutor
 
+    square = cols == hashes
     with ThreadPoolExecutor(max_workers=1) as side:
-        formatting = side.submit(format_matrix_cache, hashes, ident, cov, null)
-        rows = ingest_matrices(conn, run, hashes, hashes, ident, cov, null)
-        formatted = formatting.result()
+        formatting = side.submit(format_matrix_cache, hashes, ident, cov, null) if square else None
+        ingest_matrices(conn, run, hashes, cols, ident, cov, null)
+        formatted = formatting.result() if formatting is not None else None
     conn.execute("PRAGMA synchronous=FULL")
     mark("insert_rows")
-    return rows, hashes, ident, cov, null, formatted
+    # what is in the database now, not what was handed to the insert (INSERT OR IGNORE reports nothing per row)
+    rows = count_run_comparisons(conn, run)
+    return rows, hashes, ident, cov, null, formatted if square else False
 
 
 def import_tile(logger: logging.Logger, conn, run: Run, tile_file: Path) -> int:
@@ -491,6 +503,61 @@ def import_tile(logger: logging.Logger, conn, run: Run, tile_file: Path) -> int:
 
 
 # ------------------------------------------------------------------ the run itself
+def _phase_clock(timings: dict | None):
+    import time
+
+    marks = {"start": time.perf_counter()}
+
+    def mark(name: str) -> None:
+        marks[name] = time.perf_counter()
+        if timings is not None:
+            prev = list(marks)[-2]
+            timings[name] = marks[name] - marks[prev]
+
+    return mark
+
+
+def _duplicate_md5_exit(logger, md5: str, filenames) -> None:
+    """Two input files with the same content (pyani_plus/public_cli.py:165-171)."""
+    dups = "\n" + "\n".join(sorted({str(f) for f in filenames}))
+    sourmash_hip.log_sys_exit(logger, f"Multiple genomes with same MD5 checksum {md5}:{dups}")
+
+
+def _file_cost(path: Path) -> int:
+    """Bases a FASTA file is expected to hold, from its size (gzip: about a quarter of the text)."""
+    try:
+        size = path.stat().st_size
+    except OSError:
+        return 0
+    return 4 * size if path.name.endswith(".gz") else size
+
+
+def _sharded_sourmash_tiles(logger, fasta: Path, fasta_names: list[Path], config: Configuration, cache_dir: Path, tmp_dir: Path,
+                            gpus: int, engine_factory: str | None):
+    """The multi-GPU form of "sketch everything, compare everything" (DESIGN.md section 6): ``gpus`` fresh worker
+    processes (``launch.launch_workers`` -- started before this process has touched a GPU), each sketching a
+    length-balanced share of the files, ONE all-gather of the sketches, each rank evaluating all queries against its
+    own genomes as subject columns.  Returns (metadata per file in file order, the ranks' tile files)."""
+    from . import launch
+    from .distributed import shard_bounds_by_cost
+
+    shards = shard_bounds_by_cost([max(1, _file_cost(p)) for p in fasta_names], gpus)
+    work_dir = tmp_dir / f"{sourmash_hip.METHOD}.workers"
+    spec = {
+        "task": "sourmash", "fasta_dir": str(fasta), "fasta_files": [str(p) for p in fasta_names], "shards": shards,
+        "configuration": {k: getattr(config, k) for k in wire.CONFIG_FIELDS}, "cache": str(cache_dir), "work_dir": str(work_dir),
+    }  # fmt: skip
+    if engine_factory:
+        spec["engine_factory"] = engine_factory
+    try:
+        results = launch.launch_workers(gpus, spec, work_dir)
+    except launch.WorkerFailure as err:
+        sourmash_hip.log_sys_exit(logger, str(err))
+    meta = [m for r in results for m in r["meta"]]
+    assert [m["path"] for m in meta] == [str(p) for p in fasta_names]
+    return meta, [Path(r["tile"]) for r in results if r.get("tile")], results
+
+
 def run_sourmash_hip(  # noqa: PLR0913
     fasta: Path,
     database: Path | str,
@@ -504,6 +571,8 @@ def run_sourmash_hip(  # noqa: PLR0913
     engine=None,
     ingest: str = "json",
     timings: dict | None = None,
+    gpus: int = 1,
+    engine_factory: str | None = None,
 ) -> Run:
     """FASTA directory -> database with all N^2 comparisons and cached matrices.
 
@@ -514,18 +583,10 @@ def run_sourmash_hip(  # noqa: PLR0913
     processes of the reference would do.  ``ingest="direct"`` keeps the subject tiles as binary column
     files (``wire.save_tile``) plus in-memory matrices, inserts the rows in index order straight from them and
     writes the matrix cache from memory: the form that stays feasible at N = 10^4 (10^8 rows).
-    ``timings`` (a dict) receives the wall seconds of the phases."""
-    import time
-
-    clock = time.perf_counter
-    marks = {"start": clock()}
-
-    def mark(name: str) -> None:
-        marks[name] = clock()
-        if timings is not None:
-            prev = list(marks)[-2]
-            timings[name] = marks[name] - marks[prev]
-
+    ``gpus`` > 1: the sketching and the comparisons are spread over that many worker processes, one per GPU
+    (``_sharded_sourmash_tiles``; the caller must not have initialised the GPU in this process); results always take
+    the direct route.  ``timings`` (a dict) receives the wall seconds of the phases."""
+    mark = _phase_clock(timings)
     logger = logger or logging.getLogger("pyani_plus_amd")
     fasta = Path(fasta)
     if not 1 <= int(kmersize) <= 64:  # before any file is read
@@ -534,6 +595,8 @@ def run_sourmash_hip(  # noqa: PLR0913
         sourmash_hip.log_sys_exit(logger, f"scaled must be a positive integer, not {scaled}")
     if ingest not in {"json", "direct"}:
         sourmash_hip.log_sys_exit(logger, f"ingest must be 'json' or 'direct', not {ingest!r}")
+    if int(gpus) < 1:
+        sourmash_hip.log_sys_exit(logger, f"gpus must be a positive integer, not {gpus}")
     fasta_names = check_fasta(logger, fasta)
     tool = sourmash_hip.get_sourmash_hip()
     conn = connect_to_db(database)
@@ -541,14 +604,54 @@ def run_sourmash_hip(  # noqa: PLR0913
         conn, sourmash_hip.METHOD, tool.exe_path.stem, tool.version, kmersize=kmersize, extra=f"scaled={scaled}"
     )
     filename_to_md5: dict[Path, str] = {}
-    seen: set[str] = set()
-    # One pass over the files: md5 of the decompressed bytes, length, first title AND the sketches -- the host
-    # front-end of the next batch of files runs while the device hashes the current one (sketch_fasta_batches).
-    presketched: dict[str, np.ndarray] = {}
+    seen: dict[str, Path] = {}
     own_cache = cache is None
     cache_dir = Path(tempfile.mkdtemp(prefix="pyani_hip_cache_")) if own_cache else Path(cache)
     cache_dir.mkdir(parents=True, exist_ok=True)
+    tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
+    tmp_dir.mkdir(parents=True, exist_ok=True)
     sig_dir = sourmash_hip.sig_cache_dir(cache_dir, kmersize, f"scaled={scaled}")
+    gpus = min(int(gpus), len(fasta_names))
+    if gpus > 1:
+        meta, tile_files, _results = _sharded_sourmash_tiles(logger, fasta, fasta_names, config, cache_dir, tmp_dir, gpus, engine_factory)
+        for filename, m in zip(fasta_names, meta):
+            if m["md5"] in seen:
+                _duplicate_md5_exit(logger, m["md5"], [seen[m["md5"]], filename])
+            seen[m["md5"]] = filename
+            filename_to_md5[filename] = m["md5"]
+            db_genome(conn, filename, m["md5"], m["length"], m["description"])
+        mark("workers_front_end_sketch_and_pairs")
+        run = add_run(
+            conn, config, " ".join(sys.argv), fasta, "Running",
+            f"{len(filename_to_md5)} genomes using {sourmash_hip.METHOD}" if name is None else name, filename_to_md5,
+        )  # fmt: skip
+        session = Session(conn, run)
+        n = len(filename_to_md5)
+        hashes = sorted(filename_to_md5.values())
+        pos = {h: i for i, h in enumerate(hashes)}
+        ident = np.empty((n, n), dtype=np.float64)
+        cov = np.empty((n, n), dtype=np.float64)
+        null = np.empty((n, n), dtype=bool)
+        filled = 0
+        for tile_file in tile_files:  # rows and columns arrive in the ranks' file order: place them by checksum
+            t_config, queries, subjects, t_ident, t_cov, t_null = wire.load_tile(tile_file)
+            for key in wire.CONFIG_FIELDS:
+                if t_config[key] != getattr(config, key):
+                    sourmash_hip.log_sys_exit(logger, f"Tile file {tile_file} configuration does not match the run ({key})")
+            rows = np.array([pos[q] for q in queries])
+            cols = np.array([pos[x] for x in subjects])
+            ident[np.ix_(rows, cols)] = t_ident
+            cov[np.ix_(rows, cols)] = t_cov
+            null[np.ix_(rows, cols)] = t_null
+            filled += len(cols)
+        if filled != n:
+            sourmash_hip.log_sys_exit(logger, f"The workers returned {filled} of {n} subject columns")
+        mark("assemble_tiles")
+        direct = _ingest_direct(conn, run, hashes, hashes, ident, cov, null, mark)
+        return _finish_run(logger, conn, session, run, direct, mark)
+    # One pass over the files: md5 of the decompressed bytes, length, first title AND the sketches -- the host
+    # front-end of the next batch of files runs while the device hashes the current one (sketch_fasta_batches).
+    presketched: dict[str, np.ndarray] = {}
     try:
         for batch_paths, infos, sketches in sourmash_hip.sketch_fasta_batches(
             logger, fasta_names, kmersize=kmersize, scaled=scaled, engine=engine, needed=lambda info: not (sig_dir / f"{info.md5}.sig").is_file()
@@ -556,9 +659,8 @@ def run_sourmash_hip(  # noqa: PLR0913
             for filename, info, mins in zip(batch_paths, infos, sketches):
                 md5 = info.md5
                 if md5 in seen:
-                    dups = "\n" + "\n".join(sorted({str(k) for k, v in filename_to_md5.items() if v == md5} | {str(filename)}))
-                    sourmash_hip.log_sys_exit(logger, f"Multiple genomes with same MD5 checksum {md5}:{dups}")
-                seen.add(md5)
+                    _duplicate_md5_exit(logger, md5, [k for k, v in filename_to_md5.items() if v == md5] + [filename])
+                seen[md5] = filename
                 filename_to_md5[filename] = md5
                 if mins is not None:
                     presketched[md5] = mins
@@ -571,46 +673,361 @@ def run_sourmash_hip(  # noqa: PLR0913
         f"{len(filename_to_md5)} genomes using {sourmash_hip.METHOD}" if name is None else name, filename_to_md5,
     )  # fmt: skip
     session = Session(conn, run)
-    n = len(filename_to_md5)
-    direct = None
-    if count_run_comparisons(conn, run) == n * n:
-        logger.info("Database already has all %d=%d^2 comparisons", n * n, n)
-    else:
-        run.status = "Running"
-        session.commit()
-        # the genomes were sketched while their checksums were taken: only the signature files remain to be written
-        for _ in sourmash_hip.prepare_genomes(logger, run, cache_dir, engine=engine, presketched=presketched):
-            pass
-        mark("signature_files")
-        tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
-        hash_to_filename = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}
-        if ingest == "direct":
-            direct = _compute_direct(logger, conn, run, cache_dir, tmp_dir, engine, mark)
-        else:
-            json_file = tmp_dir / f"{sourmash_hip.METHOD}.run_{run.run_id}.column_0.json"
-            lengths = dict(conn.execute("SELECT genome_hash, length FROM genomes"))
-            status = sourmash_hip.compute_sourmash_hip(
-                logger, tmp_dir, session, run, json_file, fasta, hash_to_filename,
-                {v: k for k, v in hash_to_filename.items()}, {h: lengths[h] for h in hash_to_filename}, "",
-                cache=cache_dir, engine=engine,
-            )  # fmt: skip
-            if status:
-                sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
-            mark("pairs_and_column_file")
-            import_json_comparisons(logger, conn, json_file)
-            mark("import_column_file")
+    direct = _compute_missing(logger, conn, session, run, cache_dir, tmp_dir, engine, ingest, mark, presketched=presketched)
+    return _finish_run(logger, conn, session, run, direct, mark)
+
+
+def _incomplete_columns(conn, run: Run) -> list[str]:
+    """Subject genomes of the run with fewer than N comparisons recorded (the columns the reference's ``resume``
+    recomputes, pyani_plus/public_cli.py:243-261)."""
+    n = len(run.fasta_hashes)
+    have = dict(
+        conn.execute(
+            "SELECT c.subject_hash, COUNT(*) FROM comparisons c "
+            "JOIN runs_genomes q ON c.query_hash = q.genome_hash AND q.run_id = ? "
+            "JOIN runs_genomes s ON c.subject_hash = s.genome_hash AND s.run_id = ? "
+            "WHERE c.configuration_id = ? GROUP BY c.subject_hash",
+            (run.run_id, run.run_id, run.configuration_id),
+        )
+    )
+    return sorted(a.genome_hash for a in run.fasta_hashes if have.get(a.genome_hash, 0) < n)
+
+
+def _compute_missing(logger, conn, session, run: Run, cache_dir: Path, tmp_dir: Path, engine, ingest: str, mark, *, presketched=None):
+    """The comparisons the database does not hold yet, for a new run (all of them) or a resumed one (the incomplete
+    subject columns only: rows that are there are never recomputed, nor -- INSERT OR IGNORE -- written twice)."""
+    n = len(run.fasta_hashes)
+    done = count_run_comparisons(conn, run)
+    if done == n * n:
+        logger.info("Database already has all %d=%d^2 %s comparisons", n * n, n, sourmash_hip.METHOD)
+        return None
+    logger.info("Database already has %d of %d^2=%d %s comparisons, %d needed", done, n, n * n, sourmash_hip.METHOD, n * n - done)
+    columns = None if done == 0 else _incomplete_columns(conn, run)
+    run.status = "Running"
+    session.commit()
+    # the genomes were sketched while their checksums were taken: only the signature files remain to be written
+    for _ in sourmash_hip.prepare_genomes(logger, run, cache_dir, engine=engine, presketched=presketched):
+        pass
+    mark("signature_files")
+    hash_to_filename = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}
+    if ingest == "direct":
+        return _compute_direct(logger, conn, run, cache_dir, tmp_dir, engine, mark, subjects=columns)
+    lengths = dict(conn.execute("SELECT genome_hash, length FROM genomes"))
+    for c, subject in enumerate([""] if columns is None else columns):
+        json_file = tmp_dir / f"{sourmash_hip.METHOD}.run_{run.run_id}.column_{c if subject else 0}.json"
+        status = sourmash_hip.compute_sourmash_hip(
+            logger, tmp_dir, session, run, json_file, Path(run.fasta_directory), hash_to_filename,
+            {v: k for k, v in hash_to_filename.items()}, {h: lengths[h] for h in hash_to_filename}, subject,
+            cache=cache_dir, engine=engine,
+        )  # fmt: skip
+        if status:
+            sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
+        mark("pairs_and_column_file")
+        import_json_comparisons(logger, conn, json_file)
+        mark("import_column_file")
+    return None
+
+
+def _finish_run(logger, conn, session, run: Run, direct, mark) -> Run:
+    """Completion test, matrix cache, status "Done" (pyani_plus/public_cli.py:302-324)."""
+    n = len(run.fasta_hashes)
     done = count_run_comparisons(conn, run) if direct is None else direct[0]
     if done != n * n:
-        sourmash_hip.log_sys_exit(logger, f"Only have {done} of {n}^2={n * n} {sourmash_hip.METHOD} comparisons needed")
-    if direct is None:
+        sourmash_hip.log_sys_exit(logger, f"Only have {done} of {n}^2={n * n} {run.configuration.method} comparisons needed")
+    if direct is None or direct[5] is False:  # JSON route, or a resumed run that only holds some columns in memory
         cache_comparisons(conn, run)
+    elif direct[5] is None:
+        _store_matrix_cache(conn, run, None)
     else:
-        if direct[5] is None:
-            _store_matrix_cache(conn, run, None)
-        else:
-            cache_matrices(conn, run, *direct[1:5], formatted=direct[5])
+        cache_matrices(conn, run, *direct[1:5], formatted=direct[5])
     mark("matrix_cache")
     run.status = "Done"
     session.commit()
     conn.close()
     return run
+
+
+# ------------------------------------------------------------------ resume (pyani_plus/public_cli.py:702-828)
+def resume(database: Path | str, *, run_id: int | None = None, cache: Path | None = None, temp: Path | None = None,
+           logger: logging.Logger | None = None, engine=None, ingest: str = "json", gpus: int = 1,
+           engine_factory: str | None = None) -> Run:
+    """Complete a partial run of this backend: the missing subject columns are computed, the run is marked done.
+
+    Same checks and messages as the reference's ``resume``: the database and the run must exist, the tool recorded
+    with the run must be the one at hand (``We have ... but run-id N used ... instead``), the FASTA directory and
+    every file of the run must still be there.  A complete run is left as it is."""
+    logger = logger or logging.getLogger("pyani_plus_amd")
+    if str(database) == ":memory:" or not Path(database).is_file():
+        sourmash_hip.log_sys_exit(logger, f"Database {database} does not exist")
+    conn = connect_to_db(database)
+    if run_id is None:
+        row = conn.execute("SELECT MAX(run_id) FROM runs").fetchone()
+        if row is None or row[0] is None:
+            sourmash_hip.log_sys_exit(logger, f"Database {database} contains no runs.")
+        run_id = row[0]
+        logger.info("Resuming run-id %d", run_id)
+    try:
+        run = load_run(conn, run_id)
+    except ValueError:
+        sourmash_hip.log_sys_exit(logger, f"Database {database} has no run-id {run_id}.")
+    config = run.configuration
+    n = len(run.fasta_hashes)
+    logger.info("This is a %s run on %d genomes, using %s version %s", config.method, n, config.program, config.version)
+    if not n:
+        sourmash_hip.log_sys_exit(logger, f"No genomes recorded for run-id {run_id}, cannot resume.")
+    from .methods import fastani_hip
+
+    if config.method not in {sourmash_hip.METHOD, fastani_hip.METHOD}:
+        sourmash_hip.log_sys_exit(logger, f"Unknown method {config.method} for run-id {run_id} in {database}")
+    tool = sourmash_hip.get_sourmash_hip()
+    if tool.exe_path.stem != config.program or tool.version != config.version:
+        sourmash_hip.log_sys_exit(
+            logger,
+            f"We have {tool.exe_path.stem} version {tool.version}, but run-id {run_id} used {config.program} version {config.version} instead.",
+        )
+    fasta = Path(run.fasta_directory)
+    if not fasta.is_dir():
+        sourmash_hip.log_sys_exit(logger, f"run-id {run_id} used input folder {fasta}, but that is not a directory (now).")
+    for link in run.fasta_hashes:
+        if not (fasta / link.fasta_filename).is_file():
+            sourmash_hip.log_sys_exit(
+                logger, f"run-id {run_id} used {fasta / link.fasta_filename} with MD5 {link.genome_hash} but this FASTA file no longer exists"
+            )
+    session = Session(conn, run)
+    run.status = "Resuming"
+    session.commit()
+    mark = _phase_clock(None)
+    tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
+    tmp_dir.mkdir(parents=True, exist_ok=True)
+    if config.method == fastani_hip.METHOD:
+        _compute_missing_fastani(logger, conn, session, run, tmp_dir, engine, gpus, engine_factory)
+        return _finish_run(logger, conn, session, run, None, mark)
+    cache_dir = Path(tempfile.mkdtemp(prefix="pyani_hip_cache_")) if cache is None else Path(cache)
+    cache_dir.mkdir(parents=True, exist_ok=True)
+    direct = _compute_missing(logger, conn, session, run, cache_dir, tmp_dir, engine, ingest, mark)
+    return _finish_run(logger, conn, session, run, direct, mark)
+
+
+# ------------------------------------------------------------------ export-run (pyani_plus/public_cli.py:974-1091)
+def filename_stem(filename: str) -> str:
+    """The file name without directory, ``.gz`` and extension (pyani_plus/utils.py:93-105)."""
+    if "/" in filename:
+        filename = filename.rsplit("/", 1)[1]
+    return Path(filename[:-3]).stem if filename.endswith(".gz") else Path(filename).stem
+
+
+def export_run(database: Path | str, outdir: Path, *, run_id: int | None = None, label: str = "stem",
+               logger: logging.Logger | None = None) -> list[Path]:
+    """Write ``<method>_run_<id>.tsv`` (long form) and the six matrices ``<method>_{identity,aln_lengths,sim_errors,
+    query_cov,hadamard,tANI}.tsv`` of a run, byte for byte what the reference's ``export-run`` writes from the same
+    database: long form in ``Run.comparisons()`` order with ``NA`` for NULL and Python ``str(float)``; matrices from
+    the cached ``df_*`` strings through pandas ``to_csv(sep="\t")``, labelled by ``md5``, ``filename`` or ``stem`` and
+    sorted by label (db_orm.py:590-624).  A partial run gets the long form only and then the reference's error."""
+    import math
+    from io import StringIO
+
+    import pandas as pd
+
+    logger = logger or logging.getLogger("pyani_plus_amd")
+    if str(database) == ":memory:" or not Path(database).is_file():
+        sourmash_hip.log_sys_exit(logger, f"Database {database} does not exist")
+    outdir = Path(outdir)
+    if not outdir.is_dir():
+        logger.warning("Output directory %s does not exist, making it.", outdir)
+        outdir.mkdir()
+    conn = connect_to_db(database)
+    if run_id is None:
+        row = conn.execute("SELECT MAX(run_id) FROM runs").fetchone()
+        if row is None or row[0] is None:
+            sourmash_hip.log_sys_exit(logger, f"Database {database} contains no runs.")
+        run_id = row[0]
+        logger.info("Exporting run-id %d", run_id)
+    try:
+        run = load_run(conn, run_id)
+    except ValueError:
+        sourmash_hip.log_sys_exit(logger, f"Database {database} has no run-id {run_id}.")
+    if not run.fasta_hashes:
+        sourmash_hip.log_sys_exit(logger, f"Run-id {run_id} has no genomes")
+    method = run.configuration.method
+    if label == "md5":
+        mapping = {a.genome_hash: a.genome_hash for a in run.fasta_hashes}
+    elif label == "filename":
+        mapping = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}
+    elif label == "stem":
+        mapping = {a.genome_hash: filename_stem(a.fasta_filename) for a in run.fasta_hashes}
+    else:
+        sourmash_hip.log_sys_exit(logger, f"Unexpected label scheme {label!r}")
+
+    def float_or_na(value) -> str:
+        return "NA" if value is None else str(value)
+
+    written = [outdir / f"{method}_run_{run_id}.tsv"]
+    rows = conn.execute(
+        "SELECT c.query_hash, c.subject_hash, c.identity, c.cov_query, c.cov_subject, c.aln_length, c.sim_errors FROM comparisons c "
+        "JOIN runs_genomes rq ON c.query_hash = rq.genome_hash AND rq.run_id = ? "
+        "JOIN runs_genomes rs ON c.subject_hash = rs.genome_hash AND rs.run_id = ? WHERE c.configuration_id = ? "
+        "ORDER BY c.comparison_id",
+        (run.run_id, run.run_id, run.configuration_id),
+    ).fetchall()
+    with written[0].open("w") as handle:
+        handle.write("#Query\tSubject\tIdentity\tQuery-Cov\tSubject-Cov\tHadamard\ttANI\tAlign-Len\tSim-Errors\n")
+        for q, s_hash, identity, cov_query, cov_subject, aln_length, sim_errors in rows:
+            hadamard = None if identity is None or cov_query is None else identity * cov_query
+            tani = None if hadamard is None else -math.log(hadamard)
+            handle.write(
+                f"{mapping[q]}\t{mapping[s_hash]}\t{float_or_na(identity)}\t{float_or_na(cov_query)}\t{float_or_na(cov_subject)}"
+                f"\t{float_or_na(hadamard)}\t{float_or_na(tani)}\t{float_or_na(aln_length)}\t{float_or_na(sim_errors)}\n"
+            )
+    logger.info("Wrote long-form to %s", written[0])
+    n = len(run.fasta_hashes)
+    if len(rows) != n * n:  # db_orm.load_run(check_complete=True)
+        sourmash_hip.log_sys_exit(logger, f"run-id {run_id} has {len(rows)} of {n}^2={n * n} comparisons, {n * n - len(rows)} needed")
+    cached = conn.execute(
+        "SELECT df_identity, df_aln_length, df_sim_errors, df_cov_query, df_hadamard FROM runs WHERE run_id=?", (run_id,)
+    ).fetchone()
+    if any(c is None for c in cached):
+        out = cache_comparisons(conn, run)
+        cached = tuple(out.get(k) for k in ("df_identity", "df_aln_length", "df_sim_errors", "df_cov_query", "df_hadamard"))
+        if any(c is None for c in cached):
+            sourmash_hip.log_sys_exit(logger, f"Could not load run {method} matrix")
+    frames = [pd.read_json(StringIO(c), orient="split", dtype=float) for c in cached]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        frames.append(-np.log(frames[4]))  # tANI = -ln(hadamard), not cached (db_orm.py:566-588)
+    if label == "stem" and len(set(mapping.values())) < len(mapping):
+        sourmash_hip.log_sys_exit(logger, "Duplicate filename stems, consider using MD5 labelling.")
+    for frame, kind in zip(frames, ("identity", "aln_lengths", "sim_errors", "query_cov", "hadamard", "tANI")):
+        if label != "md5":
+            frame = frame.rename(index=mapping, columns=mapping).sort_index(axis=0).sort_index(axis=1)  # noqa: PLW2901
+        written.append(outdir / f"{method}_{kind}.tsv")
+        frame.to_csv(written[-1], sep="\t")
+    logger.info("Wrote matrices to %s/%s_*.tsv", outdir, method)
+    conn.close()
+    return written
+
+
+# ------------------------------------------------------------------ the fragment-ANI run (pyani_plus/public_cli.py:502-554)
+def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, engine, gpus: int, engine_factory: str | None) -> None:
+    """The incomplete subject columns of a ``fastANI-hip`` run: in this process (one call per column, or one for all
+    of them on a new run), or as reference ranges of ``pa_fragani`` spread over ``gpus`` worker processes -- the
+    reference's own one-process-per-column layout (pyani_plus/public_cli.py:236-261) with a GPU per process and no
+    exchange between them.  Each worker writes the reference's JSON column file; this process imports them."""
+    from .methods import fastani_hip
+
+    n = len(run.fasta_hashes)
+    done = count_run_comparisons(conn, run)
+    if done == n * n:
+        logger.info("Database already has all %d=%d^2 %s comparisons", n * n, n, fastani_hip.METHOD)
+        return
+    logger.info("Database already has %d of %d^2=%d %s comparisons, %d needed", done, n, n * n, fastani_hip.METHOD, n * n - done)
+    hashes = sorted(a.genome_hash for a in run.fasta_hashes)
+    columns = hashes if done == 0 else _incomplete_columns(conn, run)
+    run.status = "Running"
+    session.commit()
+    hash_to_filename = {a.genome_hash: a.fasta_filename for a in run.fasta_hashes}
+    lengths = dict(conn.execute("SELECT genome_hash, length FROM genomes"))
+    query_hashes = {h: lengths[h] for h in hash_to_filename}
+    fasta_dir = Path(run.fasta_directory)
+    col_idx = [hashes.index(c) for c in columns]
+    # contiguous runs of missing columns; a new run is one run of all columns
+    runs_of_columns: list[tuple[int, int]] = []
+    for i in col_idx:
+        if runs_of_columns and runs_of_columns[-1][1] == i:
+            runs_of_columns[-1] = (runs_of_columns[-1][0], i + 1)
+        else:
+            runs_of_columns.append((i, i + 1))
+    gpus = max(1, min(int(gpus), len(columns)))
+    if gpus > 1:
+        from . import launch
+        from .distributed import shard_bounds_by_cost
+
+        # every rank maps all queries; what differs is the reference range, whose cost follows the subjects' lengths
+        pieces = [(a + i, a + i + 1) for a, b in runs_of_columns for i in range(b - a)]
+        bounds = shard_bounds_by_cost([max(1, lengths[hashes[a]]) for a, _ in pieces], gpus)
+        column_ranges = []
+        for a, b in bounds:
+            if a == b:
+                column_ranges.append((0, 0))
+                continue
+            lo, hi = pieces[a][0], pieces[b - 1][1]
+            if hi - lo != b - a:  # the rank's share is not one range (scattered missing columns): widen it, rows are idempotent
+                logger.debug("rank share %s widened to columns %d..%d", (a, b), lo, hi)
+            column_ranges.append((lo, hi))
+        work_dir = tmp_dir / f"{fastani_hip.METHOD}.run_{run.run_id}.workers"
+        spec = {
+            "task": "fastani", "run_id": run.run_id, "fasta_dir": str(fasta_dir), "hash_to_filename": hash_to_filename,
+            "query_hashes": query_hashes, "column_ranges": column_ranges, "work_dir": str(work_dir),
+            "configuration": {**{k: getattr(run.configuration, k) for k in wire.CONFIG_FIELDS}, "configuration_id": run.configuration_id},
+        }  # fmt: skip
+        if engine_factory:
+            spec["engine_factory"] = engine_factory
+        try:
+            results = launch.launch_workers(gpus, spec, work_dir)
+        except launch.WorkerFailure as err:
+            sourmash_hip.log_sys_exit(logger, str(err))
+        for r in results:
+            if r.get("json"):
+                import_json_comparisons(logger, conn, Path(r["json"]))
+            if r.get("interrupted"):
+                run.status = "Worker interrupted"
+        return
+    for a, b in runs_of_columns:
+        json_file = tmp_dir / f"{fastani_hip.METHOD}.run_{run.run_id}.columns_{a + 1}_{b}.json"
+        status = fastani_hip.compute_fastani_hip(
+            logger, tmp_dir, session, run, json_file, fasta_dir, hash_to_filename, {v: k for k, v in hash_to_filename.items()},
+            query_hashes, "", engine=engine, subject_range=(a, b),
+        )  # fmt: skip
+        if status:
+            sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
+        import_json_comparisons(logger, conn, json_file)
+
+
+def run_fastani_hip(  # noqa: PLR0913
+    fasta: Path,
+    database: Path | str,
+    *,
+    name: str | None = None,
+    kmersize: int | None = None,
+    fragsize: int | None = None,
+    minmatch: float | None = None,
+    temp: Path | None = None,
+    logger: logging.Logger | None = None,
+    engine=None,
+    gpus: int = 1,
+    engine_factory: str | None = None,
+) -> Run:
+    """FASTA directory -> database with all N^2 fragment-ANI comparisons and cached matrices: counterpart of
+    ``pyani-plus fastani <fasta> -d <db> --create-db`` (pyani_plus/public_cli.py:502-554) with one in-process call --
+    or ``gpus`` worker processes, each mapping all queries against its own range of subject columns -- in place of the
+    snakemake jobs.  Defaults as pyani_plus/methods/fastani.py:27-30.  The registration pass (checksum, length and
+    title of every file) runs on host threads only, so this process never touches a GPU when ``gpus`` > 1."""
+    from .engine import load_fasta_files
+    from .methods import fastani_hip
+
+    logger = logger or logging.getLogger("pyani_plus_amd")
+    kmersize = fastani_hip.KMER_SIZE if kmersize is None else int(kmersize)
+    fragsize = fastani_hip.FRAG_LEN if fragsize is None else int(fragsize)
+    minmatch = fastani_hip.MIN_FRACTION if minmatch is None else float(minmatch)
+    fasta = Path(fasta)
+    fasta_names = check_fasta(logger, fasta)
+    tool = fastani_hip.get_fastani_hip()
+    conn = connect_to_db(database)
+    config = db_configuration(conn, fastani_hip.METHOD, tool.exe_path.stem, tool.version, fragsize=fragsize, kmersize=kmersize, minmatch=minmatch)
+    infos, _arena = load_fasta_files(fasta_names)
+    filename_to_md5: dict[Path, str] = {}
+    for filename, info in zip(fasta_names, infos):
+        if info.status != 0:
+            sourmash_hip.log_sys_exit(logger, info.message)
+        if info.md5 in filename_to_md5.values():
+            _duplicate_md5_exit(logger, info.md5, [k for k, v in filename_to_md5.items() if v == info.md5] + [filename])
+        filename_to_md5[filename] = info.md5
+        db_genome(conn, filename, info.md5, info.length, info.description)
+    del _arena
+    run = add_run(
+        conn, config, " ".join(sys.argv), fasta, "Initialising",
+        f"{len(filename_to_md5)} genomes using {fastani_hip.METHOD}" if name is None else name, filename_to_md5,
+    )  # fmt: skip
+    session = Session(conn, run)
+    tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
+    tmp_dir.mkdir(parents=True, exist_ok=True)
+    _compute_missing_fastani(logger, conn, session, run, tmp_dir, engine, gpus, engine_factory)
+    return _finish_run(logger, conn, session, run, None, _phase_clock(None))

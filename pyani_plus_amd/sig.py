@@ -129,11 +129,66 @@ def _read_single_sketch_fast(text: str, ksize: int | None, max_hash: int | None)
     return mins, sketch
 
 
+def _check_sketch_md5(path, sketch: dict, mins: np.ndarray) -> None:
+    """A sketch's ``md5sum`` is md5(str(ksize) + its decimal hashes); a file whose list does not give its own
+    checksum has been damaged (the native reader applies the same test)."""
+    want = sketch.get("md5sum")
+    if isinstance(want, str) and len(want) == 32 and "ksize" in sketch and signature_md5(sketch["ksize"], mins) != want:
+        msg = f"{path}: md5sum {want} does not match the hashes listed"
+        raise ValueError(msg)
+
+
+def read_sigs(paths, *, ksize: int, max_hash: int, threads: int = 0) -> list[np.ndarray]:
+    """The sketches of many one-sketch signature files through the native threaded reader (``pa_read_sigs``): what
+    ``sourmash sig collect`` + ``manysearch`` do with a column worker's N cached files in the reference
+    (pyani_plus/methods/sourmash.py:160-200).  Files in another layout go through ``read_sig``; an unreadable or
+    damaged file raises ``ValueError`` / ``OSError`` naming it."""
+    import ctypes as C
+
+    from . import _capi
+
+    paths = [Path(p) for p in paths]
+    n = len(paths)
+    if n == 0:
+        return []
+    lib = _capi.load_library()
+    arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+    batch = C.c_void_p()
+    _capi.check(lib.pa_read_sigs(arr, n, int(ksize), int(max_hash), int(threads), C.byref(batch)), "pa_read_sigs")
+    try:
+        sizes = np.zeros(n, dtype=np.uint64)
+        status = []
+        for i in range(n):
+            n_mins, msg = C.c_uint64(0), C.c_char_p()
+            st = lib.pa_sig_batch_info(batch, i, C.byref(n_mins), C.byref(msg))
+            if st < 0:
+                text = (msg.value or b"").decode(errors="replace")
+                if st == _capi.PA_E_IO:
+                    raise OSError(text)
+                msg_text = f"{paths[i]}: {text}"
+                raise ValueError(msg_text)
+            status.append(st)
+            sizes[i] = n_mins.value
+        off = np.zeros(n + 1, dtype=np.uint64)
+        flat = np.empty(max(int(sizes.sum()), 1), dtype=np.uint64)
+        _capi.check(lib.pa_sig_batch_copy(batch, flat.ctypes.data, off.ctypes.data), "pa_sig_batch_copy")
+    finally:
+        lib.pa_sig_batch_free(batch)
+    out = []
+    for i, path in enumerate(paths):
+        if status[i] == _capi.PA_OK:
+            out.append(flat[int(off[i]) : int(off[i + 1])])
+        else:  # PA_SIG_UNHANDLED: several sketches in one file, other parameters beside the wanted ones, ...
+            out.append(read_sig(path, ksize=ksize, max_hash=max_hash)[0])
+    return out
+
+
 def read_sig(path: Path, *, ksize: int | None = None, max_hash: int | None = None) -> tuple[np.ndarray, dict]:
     """Return (ascending uint64 hashes, sketch dict) of the DNA sketch with the wanted k."""
     text = Path(path).read_text(encoding="utf-8")
     fast = _read_single_sketch_fast(text, ksize, max_hash)
     if fast is not None:
+        _check_sketch_md5(path, fast[1], fast[0])
         return fast
     data = json.loads(text)
     if not isinstance(data, list) or not data:
@@ -151,6 +206,7 @@ def read_sig(path: Path, *, ksize: int | None = None, max_hash: int | None = Non
                 msg = f"{path}: only scaled (num=0) sketches are supported, found num={sketch['num']}"
                 raise ValueError(msg)
             mins = np.array(sketch["mins"], dtype=np.uint64)
+            _check_sketch_md5(path, sketch, mins)
             if mins.size > 1 and not bool(np.all(mins[1:] > mins[:-1])):
                 mins = np.unique(mins)
             return mins, sketch

@@ -27,6 +27,8 @@ class _HostTensor:
 
 
 class _Sketches:
+    """Host stand-in for ``DeviceSketches``: same attributes (``hashes``/``off`` are CPU tensors built on demand)."""
+
     def __init__(self, sketches: list[np.ndarray]):
         self.sketches = [np.asarray(s, dtype=np.uint64) for s in sketches]
         self.n = len(sketches)
@@ -38,10 +40,32 @@ class _Sketches:
     def sizes(self):
         return np.array([len(s) for s in self.sketches], dtype=np.uint64)
 
+    @property
+    def hashes(self):
+        import torch
+
+        flat = np.concatenate(self.sketches) if self.total else np.zeros(1, dtype=np.uint64)
+        return torch.from_numpy(flat.view(np.int64).copy())
+
+    @property
+    def off(self):
+        import torch
+
+        off = np.zeros(self.n + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in self.sketches], out=off[1:])
+        return torch.from_numpy(off)
+
 
 class OracleEngine:
+    device = "cpu"  # where ``distributed.sharded_pair_step`` moves the gathered tensors
+
     def upload(self, arena: HostArena):
         return arena
+
+    def sketches_from_gathered(self, hashes, off, off_host):
+        flat = hashes.cpu().numpy().view(np.uint64)
+        off_host = np.asarray(off_host, dtype=np.int64)
+        return _Sketches([flat[off_host[g] : off_host[g + 1]] for g in range(len(off_host) - 1)])
 
     def sketch(self, arena: HostArena, k: int, scaled: int, *, max_hash=None):
         out = []
@@ -58,8 +82,11 @@ class OracleEngine:
         return _HostTensor(oracle.pair_counts(sk.sketches, q_range, s_range))
 
 
-    def fragani(self, arena: HostArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000, ref_range=None):
+    def fragani(self, arena: HostArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000, ref_range=None,
+                query_range=None, reuse_index: bool = False, out=None):
         """Fragment ANI of every ordered pair through the oracle: (total[n], matched[n, n], ident_sum[n, n])."""
+        self.fragani_calls = getattr(self, "fragani_calls", [])
+        self.fragani_calls.append({"ref_range": ref_range, "query_range": query_range, "reuse_index": reuse_index})
         n = arena.n_genomes
         contigs = [[] for _ in range(n)]
         for start, length, g in zip(contig_start, contig_len, contig_genome):
@@ -67,14 +94,19 @@ class OracleEngine:
             text = arena_to_ascii(HostArena(arena.packed, arena.mask, arena.genome_start), int(g))
             contigs[int(g)].append(text[int(start) - g0 : int(start) - g0 + int(length)])
         r0, r1 = (0, n) if ref_range is None else ref_range
-        total = np.zeros(n, dtype=np.uint32)
-        matched = np.zeros((n, n), dtype=np.uint32)
-        ident_sum = np.zeros((n, n), dtype=np.float64)
+        q0, q1 = (0, n) if query_range is None else query_range
+        if out is None:
+            out = (np.zeros(n, dtype=np.uint32), np.zeros((n, n), dtype=np.uint32), np.zeros((n, n), dtype=np.float64))
+        total, matched, ident_sum = out
         for q in range(n):
-            for r in range(n):
+            total[q] = sum(len(c) // frag_len for c in contigs[q])
+        matched[q0:q1] = 0
+        ident_sum[q0:q1] = 0.0
+        for q in range(q0, q1):
+            for r in range(r0, r1):
                 ani, m, t = oracle.fragani_pair(contigs[q], contigs[r], k, frag_len, 0.0)
-                total[q] = t
-                if r0 <= r < r1 and m:
+                assert t == total[q]
+                if m:
                     matched[q, r] = m
                     ident_sum[q, r] = ani * m
         return total, matched, ident_sum

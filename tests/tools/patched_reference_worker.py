@@ -82,7 +82,7 @@ from tests.fake_engine import OracleEngine  # noqa: E402
 
 from pyani_plus_amd.methods import fastani_hip  # noqa: E402
 
-sourmash_hip.get_engine = lambda: OracleEngine()  # no GPU here: the boundary is under test, not the arithmetic
+sourmash_hip.get_engine = lambda *_a, **_k: OracleEngine()  # no GPU here: the boundary is under test, not the arithmetic
 fastani_hip.get_engine = sourmash_hip.get_engine
 
 database, cache, json_file = scratch / "run.sqlite", scratch / "cache", scratch / "column_0.json"
