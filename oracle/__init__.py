@@ -13,6 +13,7 @@ from .pyoracle import (  # noqa: F401
     fragani_kmer_hash,
     fragani_map,
     fragani_minimizers,
+    fragani_many,
     fragani_pair,
     fragani_get_option,
     fragani_set_option,

@@ -27,6 +27,9 @@
  * |dANI| <= 0.3 percentage points, kept fragments within 5 %, total fragments exact.
  */
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -281,16 +284,29 @@ static int shared_in_bottom_s(const uint32_t *q, int s, const uint32_t *win, int
  * reference window id of the mapping, shared minimizers and sketch size. */
 typedef struct { int32_t frag, ref_seq, ref_pos, shared, s; } FragMap;
 
-static int map_fragments(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q_contigs, const uint8_t *r_seq,
-                         const uint64_t *r_off, uint32_t r_contigs, int k, int frag_len, int w, FragMap **maps_out,
-                         int *n_maps_out, int *total_out) {
+/* The reference genome's index: its minimizers in position order and in hash order.  fastANI builds it once per
+ * process and maps every query of its --ql list against it (the reference's worker: one process per subject column
+ * and batch of 500 queries, pyani_plus/private_cli.py:1029-1063). */
+typedef struct { MiniVec rpos; Mini *rhash; } RefIndex;
+
+static void ref_index_free(RefIndex *ix) { free(ix->rpos.v); free(ix->rhash); ix->rpos.v = NULL; ix->rhash = NULL; }
+
+static int ref_index_build(RefIndex *ix, const uint8_t *r_seq, const uint64_t *r_off, uint32_t r_contigs, int k, int w) {
   MiniVec rpos = {0, 0, 0};
+  ix->rpos = rpos; ix->rhash = NULL;
   for (uint32_t c = 0; c < r_contigs; ++c)
-    if (add_minimizers(&rpos, r_seq + r_off[c], (int64_t)(r_off[c + 1] - r_off[c]), k, w, (int32_t)c)) return -1;
-  Mini *rhash = (Mini *)malloc(sizeof(Mini) * (rpos.n ? rpos.n : 1));
-  if (!rhash) return -1;
-  memcpy(rhash, rpos.v, sizeof(Mini) * rpos.n);
-  qsort(rhash, rpos.n, sizeof(Mini), cmp_hash);
+    if (add_minimizers(&ix->rpos, r_seq + r_off[c], (int64_t)(r_off[c + 1] - r_off[c]), k, w, (int32_t)c)) { ref_index_free(ix); return -1; }
+  ix->rhash = (Mini *)malloc(sizeof(Mini) * (ix->rpos.n ? ix->rpos.n : 1));
+  if (!ix->rhash) { ref_index_free(ix); return -1; }
+  memcpy(ix->rhash, ix->rpos.v, sizeof(Mini) * ix->rpos.n);
+  qsort(ix->rhash, ix->rpos.n, sizeof(Mini), cmp_hash);
+  return 0;
+}
+
+static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q_contigs, const RefIndex *ix, int k,
+                            int frag_len, int w, FragMap **maps_out, int *n_maps_out, int *total_out) {
+  const MiniVec rpos = ix->rpos;
+  const Mini *rhash = ix->rhash;
 
   int total = 0;
   for (uint32_t c = 0; c < q_contigs; ++c) total += (int)((q_off[c + 1] - q_off[c]) / (uint64_t)frag_len);
@@ -421,9 +437,19 @@ static int map_fragments(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q
       }
     }
   }
-  free(qm.v); free(qall.v); free(hits); free(winh); free(rpos.v); free(rhash);
+  free(qm.v); free(qall.v); free(hits); free(winh);
   *maps_out = maps; *n_maps_out = n_maps; *total_out = total;
   return 0;
+}
+
+static int map_fragments(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q_contigs, const uint8_t *r_seq,
+                         const uint64_t *r_off, uint32_t r_contigs, int k, int frag_len, int w, FragMap **maps_out,
+                         int *n_maps_out, int *total_out) {
+  RefIndex ix;
+  if (ref_index_build(&ix, r_seq, r_off, r_contigs, k, w)) return -1;
+  const int st = map_fragments_ix(q_seq, q_off, q_contigs, &ix, k, frag_len, w, maps_out, n_maps_out, total_out);
+  ref_index_free(&ix);
+  return st;
 }
 
 /* per-fragment mappings of one (query genome, reference genome) pair; each out array has room for
@@ -444,6 +470,10 @@ ORC_API int orc_fragani_map(const uint8_t *q_seq, const uint64_t *q_off, uint32_
   return n;
 }
 
+static void reduce_pair(FragMap *maps, int n, int total, const uint64_t *q_off, uint32_t q_contigs, const uint64_t *r_off,
+                        uint32_t r_contigs, int k, int frag_len, double min_fraction, double *ani_out, int *matched_out,
+                        int *total_out);
+
 static int cmp_bin(const void *a, const void *b) {
   const FragMap *x = (const FragMap *)a, *y = (const FragMap *)b;
   if (x->ref_seq != y->ref_seq) return x->ref_seq < y->ref_seq ? -1 : 1;
@@ -461,6 +491,44 @@ ORC_API int orc_fragani_pair(const uint8_t *q_seq, const uint64_t *q_off, uint32
   const int w = window > 0 ? window : orc_fragani_window_size(k, frag_len);
   FragMap *maps; int n, total;
   if (map_fragments(q_seq, q_off, q_contigs, r_seq, r_off, r_contigs, k, frag_len, w, &maps, &n, &total)) return -1;
+  reduce_pair(maps, n, total, q_off, q_contigs, r_off, r_contigs, k, frag_len, min_fraction, ani_out, matched_out, total_out);
+  return 0;
+}
+
+/* One reference, many queries: the reference is indexed ONCE and the queries are mapped on `threads` OpenMP threads
+ * (0 = all) -- the shape of the reference's fastANI call (`--ql queries -r subject`), used as the CPU baseline of the
+ * fragment-ANI benchmark.  q_seqs[i] / q_offs[i] / q_contigs[i] describe query i as orc_fragani_pair's arguments do. */
+ORC_API int orc_fragani_many(const uint8_t *r_seq, const uint64_t *r_off, uint32_t r_contigs, uint32_t n_queries,
+                             const uint8_t *const *q_seqs, const uint64_t *const *q_offs, const uint32_t *q_contigs,
+                             int k, int frag_len, double min_fraction, int window, int threads, double *ani_out,
+                             int *matched_out, int *total_out) {
+  const int w = window > 0 ? window : orc_fragani_window_size(k, frag_len);
+  RefIndex ix;
+  if (ref_index_build(&ix, r_seq, r_off, r_contigs, k, w)) return -1;
+  int failed = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t i = 0; i < (int64_t)n_queries; ++i) {
+    FragMap *maps; int n, total;
+    if (map_fragments_ix(q_seqs[i], q_offs[i], q_contigs[i], &ix, k, frag_len, w, &maps, &n, &total)) {
+#pragma omp atomic write
+      failed = 1;
+      continue;
+    }
+    reduce_pair(maps, n, total, q_offs[i], q_contigs[i], r_off, r_contigs, k, frag_len, min_fraction, &ani_out[i], &matched_out[i], &total_out[i]);
+  }
+  ref_index_free(&ix);
+  return failed ? -1 : 0;
+}
+
+/* kept fragments -> (ANI, matched, total) of one ordered pair; frees `maps` */
+static void reduce_pair(FragMap *maps, int n, int total, const uint64_t *q_off, uint32_t q_contigs, const uint64_t *r_off,
+                        uint32_t r_contigs, int k, int frag_len, double min_fraction, double *ani_out, int *matched_out,
+                        int *total_out) {
   for (int i = 0; i < n; ++i)
     maps[i].ref_pos = g_opt[OPT_BIN_RULE] == 0.0 ? (maps[i].ref_pos + frag_len / 2) / frag_len : maps[i].ref_pos / (frag_len - 20);
   qsort(maps, (size_t)n, sizeof(FragMap), cmp_bin);
@@ -480,5 +548,4 @@ ORC_API int orc_fragani_pair(const uint8_t *q_seq, const uint64_t *q_off, uint32
   for (uint32_t c = 0; c < r_contigs; ++c) if (r_off[c + 1] - r_off[c] >= (uint64_t)frag_len) len_r += r_off[c + 1] - r_off[c];
   const double shorter = (double)(len_q < len_r ? len_q : len_r);
   *ani_out = (matched > 0 && total > 0 && (double)matched * frag_len >= min_fraction * shorter) ? sum / matched : NAN;
-  return 0;
 }

@@ -266,6 +266,32 @@ def fragani_pair(query: list[bytes], ref: list[bytes], k: int = 16, frag_len: in
     return float(ani_v.value), int(m.value), int(t.value)
 
 
+def fragani_many(queries: list[list[bytes]], ref: list[bytes], k: int = 16, frag_len: int = 3000, min_fraction: float = 0.2,
+                 window: int = 0, threads: int = 0):
+    """``fragani_pair`` of every query against ONE reference whose index is built once, queries on ``threads`` OpenMP
+    threads (0 = all): the shape of the reference's ``fastANI --ql queries -r subject`` call.  Returns three arrays
+    (ANI percent or NaN, kept fragments, total fragments)."""
+    lib = _load_frag()
+    lib.orc_fragani_many.restype = C.c_int
+    lib.orc_fragani_many.argtypes = [C.c_char_p, _u64p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(_u64p), _u32p, C.c_int,
+                                     C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rs, ro = _contig_blob(ref)
+    n = len(queries)
+    blobs = [_contig_blob(q) for q in queries]
+    q_seqs = (C.c_char_p * max(n, 1))(*[b[0] for b in blobs])
+    q_offs = (_u64p * max(n, 1))(*[_p(b[1], _u64p) for b in blobs])
+    q_contigs = np.array([len(q) for q in queries], dtype=np.uint32)
+    ani = np.zeros(max(n, 1), dtype=np.float64)
+    matched = np.zeros(max(n, 1), dtype=np.int32)
+    total = np.zeros(max(n, 1), dtype=np.int32)
+    rc = lib.orc_fragani_many(rs, _p(ro, _u64p), len(ref), n, q_seqs, q_offs, _p(q_contigs, _u32p), k, frag_len, min_fraction, window, threads,
+                              ani.ctypes.data_as(C.POINTER(C.c_double)), matched.ctypes.data_as(C.POINTER(C.c_int)),
+                              total.ctypes.data_as(C.POINTER(C.c_int)))
+    if rc:
+        raise MemoryError("oracle allocation failed")
+    return ani[:n], matched[:n], total[:n]
+
+
 # ---------------------------------------------------------------- bottom-m MinHash (parity unpinned)
 def sketch_bottom_seq(seq: bytes, k: int, m: int) -> np.ndarray:
     lib = _load()

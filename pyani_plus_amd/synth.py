@@ -76,10 +76,12 @@ def mixed_lengths(n_genomes: int, lo: int = 100_000, hi: int = 10_000_000, seed:
     return [int(x) for x in np.exp(rng.uniform(np.log(lo), np.log(hi), size=n_genomes))]
 
 
-def synth_arena_torch(engine, n_genomes: int, length, n_species: int = 40, seed: int = SEED, *, genome_offset: int = 0) -> DeviceArena:
+def synth_arena_torch(engine, n_genomes: int, length, n_species: int = 40, seed: int = SEED, *, genome_offset: int = 0,
+                      genome_ids=None) -> DeviceArena:
     """Generate the arena on the GPU (torch RNG).  ``length`` is one length or a list with one
     entry per genome of THIS shard; ``genome_offset`` numbers the shard's genomes globally so
-    that every rank of a multi-GPU run draws its own slice of one set."""
+    that every rank of a multi-GPU run draws its own slice of one set; ``genome_ids`` (optional) names the global
+    number of every genome of the arena instead (the same set in another order)."""
     t = engine.torch
     dev = engine.device
     lengths = [int(length)] * n_genomes if np.isscalar(length) else [int(x) for x in length]
@@ -98,7 +100,7 @@ def synth_arena_torch(engine, n_genomes: int, length, n_species: int = 40, seed:
     mask = t.empty(max(total // 32, 1), dtype=t.int32, device=dev)
     position = t.arange(max_pad, device=dev)
     for i in range(n_genomes):
-        g = genome_offset + i
+        g = genome_offset + i if genome_ids is None else int(genome_ids[i])
         sp, rate = species_and_rate(g, n_species)
         if sp not in roots:
             gen.manual_seed(seed * 1000003 + sp)

@@ -56,6 +56,9 @@ def test_bench_launches_its_own_ranks_two_ranks_on_one_gpu():
     assert res["config"]["genomes"] == 64 and res["config"]["genomes_per_gpu"] == 32
     assert res["value"] > 0 and res["scaling"] == "weak"
     assert len(res["shard_balance"]["busy_ms_per_step_by_rank"]) == 2
+    # the same 64 genomes on one GPU, measured in the same run: what a speed-up has to be taken against
+    assert res["strong_basis"]["genomes"] == 64 and res["strong_basis"]["one_gpu_pairs_per_s"] > 0
+    assert res["speedup_vs_one_gpu_same_workload"] == pytest.approx(res["value"] / res["strong_basis"]["one_gpu_pairs_per_s"])
 
 
 def test_bench_rccl_path_on_one_rank():
@@ -63,6 +66,72 @@ def test_bench_rccl_path_on_one_rank():
                      "--steps", "2", "--warmup", "1", "--no-also")
     assert res["rccl_ranks"] == 1 and res["collective_backend"] == "nccl"
     assert "overlapped" in res["config"]["parallelism"]
+
+
+def _dump(db):
+    import sqlite3
+
+    conn = sqlite3.connect(db)
+    out = (
+        conn.execute("SELECT genome_hash, length, description FROM genomes ORDER BY 1").fetchall(),
+        conn.execute("SELECT query_hash, subject_hash, identity, aln_length, sim_errors, cov_query FROM comparisons ORDER BY 1, 2").fetchall(),
+        conn.execute("SELECT status, df_identity, df_cov_query, df_aln_length, df_sim_errors, df_hadamard FROM runs").fetchall(),
+    )
+    conn.close()
+    return out
+
+
+def test_product_drivers_with_two_ranks_sharing_the_gpu(tmp_path, monkeypatch):
+    """The multi-GPU PRODUCT path on the device: ``rundb.run_sourmash_hip(gpus=2)`` and ``rundb.run_fastani_hip(gpus=2)``
+    start two worker processes (before this process has initialised HIP), which share the box's one GPU -- collectives
+    on host copies (gloo), kernels on the device -- and must give the databases the single-process drivers give."""
+    import gzip
+    import json
+
+    from pyani_plus_amd import rundb
+
+    monkeypatch.setenv("PYANI_HIP_DIST_BACKEND", "gloo")
+    monkeypatch.delenv("PYANI_HIP_DEVICE", raising=False)
+    lengths = [150_000, 40_000, 210_000, 64, 90_000, 120_000, 33_000, 175_000, 60_000]
+    arena = synth_arena_numpy(len(lengths), lengths, n_species=2)
+    indir = tmp_path / "in"
+    indir.mkdir()
+    for g in range(len(lengths)):
+        seq = arena_to_ascii(arena, g)
+        text = b">g%d a\n" % g + seq[: len(seq) // 3] + b"\n>g%d b\n" % g + seq[len(seq) // 3 :] + b"\n"
+        if g % 2:
+            (indir / f"g{g}.fna.gz").write_bytes(gzip.compress(text))
+        else:
+            (indir / f"g{g}.fasta").write_bytes(text)
+    many = rundb.run_sourmash_hip(indir, tmp_path / "s2.sqlite", cache=tmp_path / "c2", scaled=100, temp=tmp_path / "t2", gpus=2)
+    fmany = rundb.run_fastani_hip(indir, tmp_path / "f2.sqlite", temp=tmp_path / "tf2", gpus=2)
+    results = [json.loads(q.read_text()) for q in sorted((tmp_path / "t2" / "sourmash-hip.workers").glob("result_rank*.json"))]
+    assert len(results) == 2 and all(r["ok"] and r["device"].startswith("cuda") for r in results)
+    fresults = [json.loads(q.read_text()) for q in sorted((tmp_path / "tf2").glob("*.workers/result_rank*.json"))]
+    assert len(fresults) == 2 and all(r["ok"] and r["device"].startswith("cuda") for r in fresults)
+    # the single-process drivers, in this process (which initialises HIP only now)
+    one = rundb.run_sourmash_hip(indir, tmp_path / "s1.sqlite", cache=tmp_path / "c1", scaled=100, temp=tmp_path / "t1", ingest="direct")
+    fone = rundb.run_fastani_hip(indir, tmp_path / "f1.sqlite", temp=tmp_path / "tf1")
+    assert many.status == one.status == fmany.status == fone.status == "Done"
+    assert _dump(tmp_path / "s1.sqlite") == _dump(tmp_path / "s2.sqlite")
+    assert _dump(tmp_path / "f1.sqlite") == _dump(tmp_path / "f2.sqlite")
+    rows = _dump(tmp_path / "f2.sqlite")[1]
+    assert len(rows) == len(lengths) ** 2 and sum(r[2] is not None for r in rows) > len(lengths)  # related genomes do map
+    # against the oracle: every sourmash pair
+    sk = [oracle.sketch_fasta_text((gzip.decompress(q.read_bytes()) if q.suffix == ".gz" else q.read_bytes()), 31, 100)[0] for q in sorted(indir.iterdir())]
+    counts = oracle.pair_counts(sk)
+    sizes = [len(x) for x in sk]
+    o_ident, o_cov, o_null = oracle.ani(counts, sizes, sizes, 31)
+    import hashlib
+
+    md5s = [hashlib.md5(gzip.decompress(q.read_bytes()) if q.suffix == ".gz" else q.read_bytes()).hexdigest() for q in sorted(indir.iterdir())]  # noqa: S324
+    got = {(q, s): (i, c) for q, s, i, _a, _e, c in _dump(tmp_path / "s2.sqlite")[1]}
+    for qi, q in enumerate(md5s):
+        for si, s_ in enumerate(md5s):
+            if o_null[qi, si]:
+                assert got[(q, s_)] == (None, None)
+            else:
+                assert got[(q, s_)] == (o_ident[qi, si], o_cov[qi, si])
 
 
 @pytest.fixture(scope="module")
@@ -122,6 +191,17 @@ def test_prepared_dictionary_must_match_the_tile(engine):
     with pytest.raises(HipBackendError, match="prepared dictionary"):
         engine.pair_counts(sk)
     assert np.array_equal(ok, engine.pair_counts(sk).cpu().numpy())  # and dropped after the failure
+    # the same NUMBER of postings but other hashes (another sketch set of the same total): refused by content
+    other = sk.hashes.clone()
+    other[: sk.total] = other[: sk.total] + 1
+    engine.pair_dict_prepare(other, sk.total)
+    with pytest.raises(HipBackendError, match="other postings"):
+        engine.pair_counts(sk)
+    assert np.array_equal(ok, engine.pair_counts(sk).cpu().numpy())
+    # ... and a call of another phase in between (sketching uses the context's scalars) does not disturb a valid one
+    engine.pair_dict_prepare(sk.hashes, sk.total)
+    engine.sketch(engine.upload(arena), 21, 50)
+    assert np.array_equal(ok, engine.pair_counts(sk).cpu().numpy())
 
 
 def test_ten_thousand_genomes_on_one_gpu(engine):

@@ -16,9 +16,13 @@ from pyani_plus_amd.engine import HipEngine  # noqa: E402
 from pyani_plus_amd.synth import synth_arena_torch  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+order = sys.argv[3] if len(sys.argv) > 3 else "interleaved"  # "grouped": the genomes of one species next to each other
 length, k, frag = 5_000_000, 16, 3000
 eng = HipEngine(0)
-arena = synth_arena_torch(eng, n, length)
+ids = None
+if order == "grouped":
+    ids = sorted(range(n), key=lambda g: (g % 40, g))
+arena = synth_arena_torch(eng, n, length, genome_ids=ids)
 starts = arena.genome_start[:-1].copy()
 lens = np.full(n, length, dtype=np.uint32)
 genome = np.arange(n, dtype=np.uint32)
