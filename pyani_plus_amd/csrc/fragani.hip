@@ -21,6 +21,7 @@
 //      fragments and the sum of their identities.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "murmur_dev.h"
@@ -412,14 +413,17 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
                                                             int32_t *__restrict__ prev_same,
                                                             const uint32_t *__restrict__ mini_wpos,
                                                             const uint32_t *__restrict__ contig_genome,
-                                                            uint64_t *__restrict__ post_cw) {
+                                                            uint64_t *__restrict__ post_cw,
+                                                            uint16_t *__restrict__ post_genome) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= m) return;
   const uint32_t id = pos[i] + flags[i] - 1u, me = sorted_idx[i];
   mini_id[me] = id;
   // the posting as the low 44 bits of a hit key, its genome on top so that bucketing needs no second lookup
   const uint32_t mc = mini_contig[me];
-  post_cw[i] = ((uint64_t)contig_genome[mc] << 44) | ((uint64_t)mc << 24) | mini_wpos[me];
+  const uint32_t pg = contig_genome[mc];
+  post_cw[i] = ((uint64_t)pg << 44) | ((uint64_t)mc << 24) | mini_wpos[me];
+  post_genome[i] = (uint16_t)pg;  // used by the bucketed seeding only, which needs n_genomes <= 8192
   if (flags[i]) post_start[id] = i;
   if (i == m - 1) post_start[n_ids] = m;
   int32_t ps = -1;
@@ -437,7 +441,8 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     uint32_t count_windows, const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const uint32_t *__restrict__ mini_id, const uint32_t *__restrict__ post_start,
-    uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos, uint32_t *__restrict__ q_id, uint32_t *__restrict__ q_s,
+    uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos /* posting list length */,
+    uint32_t *__restrict__ q_id /* first posting */, uint32_t *__restrict__ q_s,
     uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow, uint32_t *__restrict__ max_hits) {
   __shared__ uint64_t s_key[kThreads / 64][kQMax];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -488,11 +493,13 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     if (keep) {
       const uint32_t o = s + __popcll(bal & ((1ULL << lane) - 1ULL));
       const uint32_t g = b0 + idx, id = mini_id[g];
-      const uint32_t wp = mini_wpos[g];
+      // the minimizer's posting list as (first posting, length): the seeding kernels then go straight to the postings
+      // instead of through two more dependent, uncoalesced reads of post_start per list
+      const uint32_t lo = post_start[id], cnt = post_start[id + 1] - lo;
       q_hash[(uint64_t)f * kQMax + o] = h;
-      q_pos[(uint64_t)f * kQMax + o] = wp > p ? wp - p : 0u;
-      q_id[(uint64_t)f * kQMax + o] = id;
-      hits += post_start[id + 1] - post_start[id];
+      q_pos[(uint64_t)f * kQMax + o] = cnt;
+      q_id[(uint64_t)f * kQMax + o] = lo;
+      hits += cnt;
     }
     s += __popcll(bal);
   }
@@ -521,10 +528,8 @@ __global__ __launch_bounds__(kThreads) void fill_hits_kernel(
     const uint32_t i = i0 + lane;
     uint32_t lo = 0, n = 0, qp = 0;
     if (i < s) {
-      const uint32_t id = q_id[(uint64_t)f * kQMax + i];
-      lo = post_start[id];
-      n = post_start[id + 1] - lo;
-      qp = q_pos[(uint64_t)f * kQMax + i];
+      lo = q_id[(uint64_t)f * kQMax + i];  // (first posting, length) as query_sketch_kernel left them
+      n = q_pos[(uint64_t)f * kQMax + i];
     }
     const uint32_t ex = wave_excl_scan(n, lane);
     for (uint32_t t = 0; t < n; ++t) {
@@ -559,7 +564,9 @@ __global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t
 
 // ---- hits of one fragment, bucketed by reference genome --------------------------------------------
 // One wave per fragment and an LDS counter per reference genome: count the postings of the fragment's
-// minimizers per genome, scan, then write every hit into its genome's slice of the fragment's hit range.
+// minimizers per genome (from the 2-byte genome of every posting: a list of ~15 is one 64-byte sector; the list
+// bounds come coalesced from query_sketch_kernel), scan, then write every hit into its genome's slice of the
+// fragment's hit range.
 // The (fragment, genome) segments fall out of the scan, so the ones that can hold an L1 run (>= min_hits
 // seed hits) are listed right here; nothing is sorted -- the mapping kernel orders the <= kHitCap hits of a
 // segment in LDS, longer segments (repeats) are listed for segment_sort.  Eight lanes walk one posting
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t
 constexpr int kBucketWaves = 4;
 __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     uint32_t n_frags, const uint32_t *__restrict__ q_pos, const uint32_t *__restrict__ q_id,
-    const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ hit_off, const uint32_t *__restrict__ post_start,
+    const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ hit_off, const uint16_t *__restrict__ post_genome,
     const uint64_t *__restrict__ post_cw, uint32_t n_genomes, const uint32_t *__restrict__ tab_min_hits,
     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
     uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t seg_cap, uint32_t *__restrict__ counters,
@@ -588,18 +595,17 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
 #pragma unroll
   for (int j = 0; j < kListRegs; ++j) {
     const uint32_t i = (uint32_t)j * 64u + lane;
-    uint32_t id = 0;
     const bool in = i < s;
-    if (in) id = q_id[(uint64_t)f * kQMax + i];
-    lo_r[j] = in ? post_start[id] : 0u;
-    n_r[j] = in ? post_start[id + 1] - lo_r[j] : 0u;
+    lo_r[j] = in ? q_id[(uint64_t)f * kQMax + i] : 0u;  // coalesced: (first posting, length) from query_sketch_kernel
+    n_r[j] = in ? q_pos[(uint64_t)f * kQMax + i] : 0u;
   }
   __builtin_amdgcn_wave_barrier();
   // Sixteen lists per step, 32 lanes' worth of slots each: a lane has eight independent posting loads in flight (the
   // kernel waits on memory 93 % of the time; what counts is how many loads are outstanding).  Lists longer than 32
   // (repeat families) take further rounds of the same step.
   constexpr int kLoads = 8;
-  auto for_each_posting = [&](auto &&visit) {
+  auto for_each_posting = [&](const auto *__restrict__ postings, auto &&visit) {
+    using Elem = std::remove_cv_t<std::remove_reference_t<decltype(postings[0])>>;
     for (uint32_t i0 = 0; i0 < s; i0 += 2u * kLoads) {
       uint32_t lo_blk = 0, n_blk = 0;  // this lane's pair of the 64 lists i0 belongs to
 #pragma unroll
@@ -618,53 +624,75 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
       for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o, 64));
       for (uint32_t r = 0; r < longest; r += 32) {
         const uint32_t slot = r + (lane & 31u);
-        uint64_t cw[kLoads];
+        Elem cw[kLoads];
 #pragma unroll
-        for (int u = 0; u < kLoads; ++u) cw[u] = slot < n_u[u] ? post_cw[lo_u[u] + slot] : 0ull;
+        for (int u = 0; u < kLoads; ++u) cw[u] = slot < n_u[u] ? postings[lo_u[u] + slot] : Elem(0);
 #pragma unroll
         for (int u = 0; u < kLoads; ++u)
           if (slot < n_u[u]) visit(i0 + 2u * (uint32_t)u + (lane >> 5), cw[u]);
       }
     }
   };
-  for_each_posting([&](uint32_t, uint64_t cw) { atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u); });
+  // counting pass over the genome of every posting only (2 bytes each: a list of ~15 fits one 64-byte sector)
+  for_each_posting(post_genome, [&](uint32_t, uint16_t g) { atomicAdd(&hist[g], 1u); });
   __builtin_amdgcn_wave_barrier();
-  // exclusive scan over the genomes; list the segments worth mapping
+  // exclusive scan over the genomes; then list the segments worth mapping.  The list cursors are global counters that
+  // every wave of the launch draws from: ONE fetch-and-add per wave and list (atomics on one address are served one
+  // after the other by the L2 -- with a draw per group of 64 genomes, as this kernel had it, 22 of its 23.7 ms per
+  // batch were spent queueing for that one address; profiles/r03_bucket_hits_ablation.txt).
   const uint32_t mh = s ? tab_min_hits[s] : 0xffffffffu;
-  uint32_t carry = 0;
+  uint32_t carry = 0, n_small = 0, n_large = 0, n_big = 0, max_big = 0;
   for (uint32_t g0 = 0; g0 < n_genomes; g0 += 64) {
     const uint32_t g = g0 + lane;
     const uint32_t cnt = g < n_genomes ? hist[g] : 0u;
     const uint32_t off = carry + wave_excl_scan(cnt, lane);
     if (g < n_genomes) hist[g] = off;
     const bool keep = cnt >= mh && g >= ref0 && g < ref1;  // only the reference genomes asked for are mapped
-    const uint64_t km = __ballot(keep);
-    if (km) {
-      // short segments fill the list from the front, the ones over kHitCapSmall hits from the back: the two
-      // classes are mapped by launches with different LDS footprints
+    const bool small = keep && cnt <= (uint32_t)kHitCapSmall;
+    n_small += (uint32_t)__popcll(__ballot(small));
+    n_large += (uint32_t)__popcll(__ballot(keep && !small));
+    n_big += (uint32_t)__popcll(__ballot(keep && cnt > (uint32_t)kHitCap));
+    if (keep && cnt > (uint32_t)kHitCap) max_big = max(max_big, cnt);
+    carry += wave_sum(cnt);
+  }
+  const uint32_t total_hits = carry;
+  uint32_t s0 = 0, l0 = 0;
+  if (n_big) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) max_big = max(max_big, (uint32_t)__shfl_xor((int)max_big, o, 64));
+  }
+  if (lane == 0) {
+    if (n_small) s0 = atomicAdd(&counters[0], n_small);
+    if (n_large) l0 = atomicAdd(&counters[3], n_large);
+    if (n_big) { atomicAdd(&counters[1], n_big); atomicMax(&counters[2], max_big); }
+  }
+  s0 = __shfl(s0, 0, 64);
+  l0 = __shfl(l0, 0, 64);
+  if (n_small | n_large) {
+    // short segments fill the list from the front, the ones over kHitCapSmall hits from the back: the two
+    // classes are mapped by launches with different LDS footprints
+    for (uint32_t g0 = 0; g0 < n_genomes; g0 += 64) {
+      const uint32_t g = g0 + lane;
+      uint32_t off = 0, cnt = 0;
+      if (g < n_genomes) {
+        off = hist[g];
+        cnt = (g + 1 < n_genomes ? hist[g + 1] : total_hits) - off;
+      }
+      const bool keep = cnt >= mh && g >= ref0 && g < ref1;
       const bool small = keep && cnt <= (uint32_t)kHitCapSmall, large = keep && !small;
       const uint64_t sm = __ballot(small), lm = __ballot(large);
-      uint32_t s0 = 0, l0 = 0;
-      if (lane == 0) {
-        if (sm) s0 = atomicAdd(&counters[0], (uint32_t)__popcll(sm));
-        if (lm) l0 = atomicAdd(&counters[3], (uint32_t)__popcll(lm));
-      }
-      s0 = __shfl(s0, 0, 64);
-      l0 = __shfl(l0, 0, 64);
       if (keep) {
         const uint64_t below = (1ULL << lane) - 1ULL;
         const uint32_t slot = small ? s0 + (uint32_t)__popcll(sm & below) : seg_cap - 1u - (l0 + (uint32_t)__popcll(lm & below));
         if (slot < seg_cap) { seg_a0[slot] = base + off; seg_nh[slot] = cnt; }
       }
-      const uint64_t bm = __ballot(keep && cnt > (uint32_t)kHitCap);
-      if (bm && lane == 0) atomicAdd(&counters[1], (uint32_t)__popcll(bm));
-      if (keep && cnt > (uint32_t)kHitCap) atomicMax(&counters[2], cnt);
+      s0 += (uint32_t)__popcll(sm);
+      l0 += (uint32_t)__popcll(lm);
     }
-    carry += wave_sum(cnt);
   }
   __builtin_amdgcn_wave_barrier();
   // (the query window id of a hit is no longer carried along: the mapping kernel slides over reference positions)
-  for_each_posting([&](uint32_t, uint64_t cw) {
+  for_each_posting(post_cw, [&](uint32_t, uint64_t cw) {
     const uint32_t slot = base + atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
     keys[slot] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
   });
@@ -1366,7 +1394,7 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first;
+      contig_bucket_off, bucket_first, post_g;
   // the reference index (stages 1 and 2) of the last pa_fragani(_ex) call, for PA_FRAGANI_REUSE_INDEX
   bool index_valid = false;
   const void *index_packed = nullptr;
@@ -1379,7 +1407,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -1610,6 +1638,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   PA_TRY(W.mini_id.reserve((uint64_t)m * 4));
   PA_TRY(W.prev_same.reserve((uint64_t)m * 4));
   PA_TRY(W.post_cw.reserve((uint64_t)m * 8));
+  PA_TRY(W.post_g.reserve((uint64_t)m * 2 + 16));
   uint64_t *keys[2] = {W.keys[0].as<uint64_t>(), W.keys[1].as<uint64_t>()};
   uint32_t *vals[2] = {W.vals[0].as<uint32_t>(), W.vals[1].as<uint32_t>()};
   int which = reuse ? W.index_which : 0;
@@ -1627,7 +1656,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
                        n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
                        W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
-                       W.post_cw.as<uint64_t>());
+                       W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>());
     W.index_ids = n_ids;
   }
   const uint32_t *d_sorted_idx = vals[which];
@@ -1764,7 +1793,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         hipLaunchKernelGGL(bucket_hits_kernel, dim3(ceil_div_u64(nf, kBucketWaves)), dim3(kBucketWaves * 64), lds_bytes,
                            c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
-                           W.hit_off.as<uint32_t>(), W.post_start.as<uint32_t>(), W.post_cw.as<uint64_t>(), n_genomes,
+                           W.hit_off.as<uint32_t>(), W.post_g.as<uint16_t>(), W.post_cw.as<uint64_t>(), n_genomes,
                            W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
                            W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters, ref0, ref1);
         PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters, 16, hipMemcpyDeviceToHost, c->stream));
