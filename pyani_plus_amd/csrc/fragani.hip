@@ -155,13 +155,17 @@ constexpr int kOwn = kTile - kHalo;
 // 2 running total) in the top two bits, the count below; `scalars`: [0] ticket, [1] total, [2] a wait ran out.
 constexpr uint64_t kLookTile = 1ULL << 62, kLookTotal = 2ULL << 62;
 constexpr uint32_t kLookSpinLimit = 1u << 24;
+// (A ticket per RUN of consecutive tiles was tried to take load off the ticket counter -- one address, ~11 ns per
+// returning atomic, 2.6 million tiles in the 1 000 x 5 Mb run: a floor of 29 ms under this 58 ms kernel -- and is wrong
+// for a chained scan: the first tile of a run waits for the last tile of the run before it, which its workgroup
+// reaches last, so the workgroups execute one after the other: 34 s.)
 
 template <int K>
 __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
     const uint64_t *__restrict__ contig_start, const uint32_t *__restrict__ contig_len, uint32_t n_contigs, int w,
     unsigned long long *__restrict__ look, uint32_t *__restrict__ scalars, uint32_t cap, uint32_t *__restrict__ out_hash,
-    uint32_t *__restrict__ out_wpos, uint32_t *__restrict__ out_contig) {
+    uint32_t *__restrict__ out_wpos, uint32_t *__restrict__ out_contig, uint32_t n_tiles) {
   static_assert(K >= 8 && K <= 16, "both k-mer registers are 32-bit");
   constexpr int kWords = (K + 7) / 8;
   __shared__ uint64_t s_lo[kWords][256];
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     }
     if (lane == 0) {
       s_before = before;
-      if (tile == gridDim.x - 1) scalars[1] = before + total;
+      if (tile == n_tiles - 1) scalars[1] = before + total;
     }
   }
   __syncthreads();
@@ -578,14 +582,15 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     const uint64_t *__restrict__ post_cw, uint32_t n_genomes, const uint32_t *__restrict__ tab_min_hits,
     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
     uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t seg_cap, uint32_t *__restrict__ counters,
-    uint32_t ref0, uint32_t ref1) {
+    unsigned long long *__restrict__ cursor64, uint32_t ref0, uint32_t ref1) {
   extern __shared__ uint32_t bk_lds[];
+  __shared__ uint32_t s_part[kBucketWaves][2], s_draw[2];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * kBucketWaves + wave;
-  if (f >= n_frags) return;  // no workgroup barriers below
+  const bool active = f < n_frags;  // a wave past the last fragment has an empty sketch and still takes part in the barriers
   uint32_t *hist = bk_lds + (uint64_t)wave * n_genomes;
-  const uint32_t s = q_s[f];
-  const uint32_t base = hit_off[f];
+  const uint32_t s = active ? q_s[f] : 0u;
+  const uint32_t base = active ? hit_off[f] : 0u;
   for (uint32_t g = lane; g < n_genomes; g += 64) hist[g] = 0;
   // The posting list of every minimizer of the fragment, (first posting, length), into registers: lane l holds the
   // lists of minimizers l, l + 64, ...  Two rounds of independent loads instead of a chain of three dependent ones
@@ -637,9 +642,9 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
   for_each_posting(post_genome, [&](uint32_t, uint16_t g) { atomicAdd(&hist[g], 1u); });
   __builtin_amdgcn_wave_barrier();
   // exclusive scan over the genomes; then list the segments worth mapping.  The list cursors are global counters that
-  // every wave of the launch draws from: ONE fetch-and-add per wave and list (atomics on one address are served one
-  // after the other by the L2 -- with a draw per group of 64 genomes, as this kernel had it, 22 of its 23.7 ms per
-  // batch were spent queueing for that one address; profiles/r03_bucket_hits_ablation.txt).
+  // every workgroup of the launch draws from: ONE fetch-and-add per workgroup for both lists (atomics on one address
+  // are served one after the other by the L2 -- with a draw per group of 64 genomes and wave, as this kernel had it,
+  // 22 of its 23.7 ms per batch were spent queueing for that one address; profiles/r03_bucket_hits_ablation.txt).
   const uint32_t mh = s ? tab_min_hits[s] : 0xffffffffu;
   uint32_t carry = 0, n_small = 0, n_large = 0, n_big = 0, max_big = 0;
   for (uint32_t g0 = 0; g0 < n_genomes; g0 += 64) {
@@ -656,18 +661,30 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     carry += wave_sum(cnt);
   }
   const uint32_t total_hits = carry;
-  uint32_t s0 = 0, l0 = 0;
   if (n_big) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) max_big = max(max_big, (uint32_t)__shfl_xor((int)max_big, o, 64));
   }
   if (lane == 0) {
-    if (n_small) s0 = atomicAdd(&counters[0], n_small);
-    if (n_large) l0 = atomicAdd(&counters[3], n_large);
+    s_part[wave][0] = n_small;
+    s_part[wave][1] = n_large;
     if (n_big) { atomicAdd(&counters[1], n_big); atomicMax(&counters[2], max_big); }
   }
-  s0 = __shfl(s0, 0, 64);
-  l0 = __shfl(l0, 0, 64);
+  __syncthreads();
+  if (threadIdx.x == 0) {  // both cursors in one 64-bit word: one draw per workgroup
+    uint32_t ws = 0, wl = 0;
+#pragma unroll
+    for (int q = 0; q < kBucketWaves; ++q) { ws += s_part[q][0]; wl += s_part[q][1]; }
+    unsigned long long got = 0;
+    if (ws | wl) got = atomicAdd(cursor64, ((unsigned long long)wl << 32) | ws);
+    s_draw[0] = (uint32_t)got;
+    s_draw[1] = (uint32_t)(got >> 32);
+  }
+  __syncthreads();
+  uint32_t s0 = s_draw[0], l0 = s_draw[1];
+#pragma unroll
+  for (int q = 0; q < kBucketWaves; ++q)
+    if ((uint32_t)q < wave) { s0 += s_part[q][0]; l0 += s_part[q][1]; }
   if (n_small | n_large) {
     // short segments fill the list from the front, the ones over kHitCapSmall hits from the back: the two
     // classes are mapped by launches with different LDS footprints
@@ -741,13 +758,24 @@ __global__ __launch_bounds__(kThreads) void prefilter_segments_kernel(
       }
     }
   }
+  // one draw from the list cursor per workgroup (same-address atomics queue up in the L2, ~11 ns each)
+  __shared__ uint32_t s_kept[kThreads / 64], s_base;
   const uint64_t km = __ballot(keep);
-  if (km == 0) return;
-  uint32_t slot0 = 0;
-  if (lane == (uint32_t)__builtin_ctzll(km)) slot0 = atomicAdd(counter, (uint32_t)__popcll(km));
-  slot0 = __shfl(slot0, __builtin_ctzll(km), 64);
+  const uint32_t wave = threadIdx.x >> 6;
+  if (lane == 0) s_kept[wave] = (uint32_t)__popcll(km);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < kThreads / 64; ++q) sum += s_kept[q];
+    s_base = sum ? atomicAdd(counter, sum) : 0u;
+  }
+  __syncthreads();
   if (keep) {
-    const uint32_t slot = slot0 + (uint32_t)__popcll(km & ((1ULL << lane) - 1ULL));
+    uint32_t slot = s_base + (uint32_t)__popcll(km & ((1ULL << lane) - 1ULL));
+#pragma unroll
+    for (int q = 0; q < kThreads / 64; ++q)
+      if ((uint32_t)q < wave) slot += s_kept[q];
     out_a0[slot] = a0;
     out_nh[slot] = nh;
   }
@@ -870,9 +898,11 @@ struct EvalShared {
                        //   bits 0-6 first lane (window start) that keeps the entry, 7-13 how many more lanes do,
                        //   14-23 rank among the query hashes, 24 the hash is one of them
   uint16_t *xe16;      // [64] per lane: where its window ends inside the stretch
+  uint16_t *qt;        // [kQtBuckets] the fragment's sketch bucketed by the top bits of the hash: first rank (10 bits) | hashes in the bucket (6 bits)
 };
+constexpr uint32_t kQtBits = 9, kQtBuckets = 1u << kQtBits, kQtShift = 32u - kQtBits;
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
-  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + ref_cap * 2u + (ref_cap + 4u) * 4u + 128u;
+  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + ref_cap * 2u + (ref_cap + 4u) * 4u + 128u + 2u * 512u;
 }
 __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap, uint32_t kRefCap) {
   EvalShared sh;
@@ -884,6 +914,7 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are even: the 32-bit array below stays aligned (to 16 bytes)
   sh.ent = reinterpret_cast<uint32_t *>(sh.ref_w + kRefCap);
   sh.xe16 = reinterpret_cast<uint16_t *>(sh.ent + kRefCap + 4u);
+  sh.qt = sh.xe16 + 64;
   return sh;
 }
 
@@ -896,8 +927,11 @@ __device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t i
 }
 
 // one wave per (fragment, reference genome) segment
+#ifndef PA_MAP_WAVES
+#define PA_MAP_WAVES 6  // waves per SIMD the register allocation aims at (80 VGPRs); 5 allows 96
+#endif
 template <uint32_t kRefCap>
-__global__ __launch_bounds__(64, 6) void map_segments_kernel(
+__global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_a0,
     const uint32_t *__restrict__ seg_nh, uint32_t n_segs, bool presorted, const uint32_t *__restrict__ contig_genome,
     const uint32_t *__restrict__ genome_first_contig, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
@@ -963,6 +997,29 @@ __global__ __launch_bounds__(64, 6) void map_segments_kernel(
   }
   for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
   if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
+  // The fragment's hashes bucketed by their top kQtBits bits: a reference minimizer's rank among them is then the
+  // bucket's first rank plus a search among the bucket's few hashes (a fraction of a hash per bucket on average)
+  // instead of log2(s) dependent LDS reads.  Buckets with more than 63 hashes (degenerate sketches) switch it off.
+  {
+    uint32_t *qt32 = reinterpret_cast<uint32_t *>(sh.qt);
+    for (uint32_t i = lane; i < kQtBuckets / 2u; i += 64) qt32[i] = 0;
+  }
+  __syncthreads();
+  for (uint32_t i = lane; i < s; i += 64) atomicAdd_u16(sh.qt, sh.qh[i] >> kQtShift);
+  __syncthreads();
+  uint32_t qsteps = 0;  // halving steps of the in-bucket search; 0xffffffff: table not usable
+  {
+    constexpr uint32_t kOwnB = kQtBuckets / 64u;  // consecutive buckets per lane
+    uint32_t cntb[kOwnB], local = 0, most = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < kOwnB; ++q) { cntb[q] = sh.qt[lane * kOwnB + q]; local += cntb[q]; most = max(most, cntb[q]); }
+    uint32_t run = wave_excl_scan(local, lane);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o, 64));
+#pragma unroll
+    for (uint32_t q = 0; q < kOwnB; ++q) { sh.qt[lane * kOwnB + q] = (uint16_t)(run | (cntb[q] << 10)); run += cntb[q]; }
+    qsteps = most > 63u ? 0xffffffffu : (most ? 32u - (uint32_t)__builtin_clz(most) : 0u);
+  }
   __syncthreads();
 
   // first hit index in [lo, hi) whose (contig, window id) is >= (c, w): the hits are in (contig, window) order
@@ -1152,7 +1209,6 @@ __global__ __launch_bounds__(64, 6) void map_segments_kernel(
           n_use = v;
         }
         xe = min(xe, n_use);
-        sh.xe16[lane] = (uint16_t)xe;
         // ranks among the fragment's hashes and the lanes that keep each minimizer; buckets of the counting sort
         const uint32_t n_keys = 2u * (s + 1u);
         uint16_t *bucket = reinterpret_cast<uint16_t *>(sh.cnt);  // 2 (s + 1) 16-bit counters in the 4 (s_cap + 64) bytes
@@ -1165,6 +1221,22 @@ __global__ __launch_bounds__(64, 6) void map_segments_kernel(
         uint32_t rank[kPer], l0[kPer];
 #pragma unroll
         for (int q = 0; q < kPer; ++q) { rank[q] = 0; l0[q] = 0; }
+        if (qsteps != 0xffffffffu) {
+          uint32_t hi_r[kPer];
+#pragma unroll
+          for (int q = 0; q < kPer; ++q) {
+            const uint32_t e = sh.qt[hh[q] >> kQtShift];
+            rank[q] = e & 0x3ffu;          // hashes in the buckets below: all smaller
+            hi_r[q] = rank[q] + (e >> 10);  // the hashes from here on are in higher buckets: all larger
+          }
+          for (uint32_t half = qsteps ? 1u << (qsteps - 1u) : 0u; half > 0; half >>= 1) {
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+              const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
+              if (idx <= hi_r[q] && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
+            }
+          }
+        } else {
         for (uint32_t half = half0; half > 0; half >>= 1) {  // half0 = largest power of two <= s: positions 0 .. 2*half0 - 1 >= s
 #pragma unroll
           for (int q = 0; q < kPer; ++q) {
@@ -1172,17 +1244,27 @@ __global__ __launch_bounds__(64, 6) void map_segments_kernel(
             if ((uint32_t)q * 64u + lane < n_use && idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
           }
         }
-        for (uint32_t half = 32; half > 0; half >>= 1) {  // l0 = number of lanes whose window ends at or before x (0 .. 63 here)
+        }
+        // l0[x] = number of lanes whose window ends at or before stretch position x: a histogram of the window ends
+        // (one LDS atomic per lane; it lives where the sorted entries go later) and a running sum over x, instead of a
+        // six-step search per minimizer
+        {
+          uint16_t *ends = reinterpret_cast<uint16_t *>(sh.ent);
+          uint32_t *ends32 = sh.ent;
+          for (uint32_t i = lane; i < n_use / 2u + 1u; i += 64) ends32[i] = 0;
+          __syncthreads();
+          if (xe < n_use) atomicAdd_u16(ends, xe);  // an end at n_use is at or before no position
+          __syncthreads();
+          uint32_t carry_l = 0;
 #pragma unroll
           for (int q = 0; q < kPer; ++q) {
-            const uint32_t x = (uint32_t)q * 64u + lane, idx = l0[q] + half;
-            if (x < n_use && (uint32_t)sh.xe16[idx - 1] <= x) l0[q] = idx;
+            const uint32_t x = (uint32_t)q * 64u + lane;
+            const uint32_t v = x < n_use ? (uint32_t)ends[x] : 0u;
+            const uint32_t incl = pa_dev::wave_incl_scan_dpp(v);
+            l0[q] = carry_l + incl;
+            carry_l += (uint32_t)__shfl((int)incl, 63, 64);
           }
-        }
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-          const uint32_t x = (uint32_t)q * 64u + lane;
-          if ((uint32_t)sh.xe16[l0[q]] <= x) l0[q] += 1u;  // the step to 64: no window holds the entry
+          __syncthreads();
         }
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
@@ -1436,10 +1518,10 @@ int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint3
     PA_TRY(W.mini_contig.reserve(cap * 4 + 16));
     PA_HIP(hipMemsetAsync(W.block_counts.p, 0, (uint64_t)blocks * 8, c->stream));
     PA_HIP(hipMemsetAsync(W.scalars.p, 0, 16, c->stream));
-    hipLaunchKernelGGL((minimizer_kernel<K>), dim3(blocks), dim3(kThreads), 0, c->stream, d_packed, d_mask, arena_bases,
-                       W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
+    hipLaunchKernelGGL((minimizer_kernel<K>), dim3(blocks), dim3(kThreads), 0, c->stream,
+                       d_packed, d_mask, arena_bases, W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
                        W.block_counts.as<unsigned long long>(), W.scalars.as<uint32_t>(), (uint32_t)cap,
-                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>());
+                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>(), blocks);
     PA_HIP(hipGetLastError());
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 16, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipStreamSynchronize(c->stream));
@@ -1788,6 +1870,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         PA_TRY(W.seg_a0.reserve((uint64_t)seg_cap * 4 + 16));
         PA_TRY(W.seg_nh.reserve((uint64_t)seg_cap * 4 + 16));
         PA_HIP(hipMemsetAsync(d_seg_counters, 0, 16, c->stream));
+        unsigned long long *d_cursor64 = reinterpret_cast<unsigned long long *>(W.scalars.as<uint32_t>() + 14);  // [lo] short, [hi] long segments
+        PA_HIP(hipMemsetAsync(d_cursor64, 0, 8, c->stream));
         const uint32_t lds_bytes = (uint32_t)kBucketWaves * n_genomes * 4u;
         PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_hits_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1795,12 +1879,13 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                            c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
                            W.hit_off.as<uint32_t>(), W.post_g.as<uint16_t>(), W.post_cw.as<uint64_t>(), n_genomes,
                            W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
-                           W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters, ref0, ref1);
+                           W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters, d_cursor64, ref0, ref1);
         PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters, 16, hipMemcpyDeviceToHost, c->stream));
+        PA_HIP(hipMemcpyAsync(c->h_pinned + 2, d_cursor64, 8, hipMemcpyDeviceToHost, c->stream));
         PA_HIP(hipStreamSynchronize(c->stream));
         const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(c->h_pinned);
-        n_keep = hc32[0];
-        n_large = hc32[3];
+        n_keep = (uint32_t)c->h_pinned[2];
+        n_large = (uint32_t)(c->h_pinned[2] >> 32);
         large_at = seg_cap - n_large;
         const uint32_t n_big = hc32[1], max_big = hc32[2];
         PA_REQUIRE((uint64_t)n_keep + n_large <= seg_cap, "pa_fragani: %u + %u segments exceed the list capacity %u",
