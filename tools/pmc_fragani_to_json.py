@@ -38,25 +38,31 @@ def main() -> None:
             "salu_busy": m["SQ_INSTS_SALU"] / CUS / cycles,
             "valu_instructions": m["SQ_INSTS_VALU"], "salu_instructions": m["SQ_INSTS_SALU"],
             "wait_share": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
-            "waves_per_simd": m["SQ_WAVE_CYCLES"] / SIMDS / cycles,
+            "waves_per_simd": m["SQ_WAVE_CYCLES"] * 4 / SIMDS / cycles,  # SQ_* cycle counters are in quad-cycles
             "avg_ms_per_dispatch": m["duration_ms"],
         },
     }
     cyc_b = b["GRBM_GUI_ACTIVE"] / XCDS
-    fetch = b["FETCH_SIZE"] * 1024 * 2  # KiB per dispatch; x2 per the gfx950 correction (MI355X_MICROARCH.md)
+    # FETCH_SIZE / WRITE_SIZE are KiB per dispatch.  The guide's gfx950 rule (FETCH_SIZE reports half the bytes) is
+    # calibrated for wide coalesced streaming reads; this kernel reads 2- and 8-byte items scattered over short lists,
+    # "other access widths are uncalibrated": both readings are given, the counted one first.
+    fetch = b["FETCH_SIZE"] * 1024 * 2
     write = b["WRITE_SIZE"] * 1024
     entry = {
-        "source": f"rocprofv3 --pmc passes of tools/bench_fragani.py 300 ({bucket_file.name}), FETCH_SIZE x2 per the gfx950 correction; not measured inside this run",
-        "fetch_bytes_per_dispatch": fetch, "write_bytes_per_dispatch": write, "avg_ms_per_dispatch": b["duration_ms"],
-        "counter_gbs": (fetch + write) / (b["duration_ms"] * 1e-3) / 1e9,
+        "source": f"rocprofv3 --pmc passes of tools/bench_fragani.py 300 ({bucket_file.name}); FETCH_SIZE as counted and doubled (the gfx950 rule is "
+        "calibrated for wide streaming reads only); not measured inside this run",
+        "fetch_bytes_per_dispatch_as_counted": fetch / 2, "write_bytes_per_dispatch": write, "avg_ms_per_dispatch": b["duration_ms"],
+        "counter_gbs": (fetch / 2 + write) / (b["duration_ms"] * 1e-3) / 1e9,
+        "counter_gbs_fetch_doubled": (fetch + write) / (b["duration_ms"] * 1e-3) / 1e9,
         "valu_busy": b["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / cyc_b,
         "wait_share": b["SQ_WAIT_ANY"] / b["SQ_WAVE_CYCLES"],
     }
     if hits_per_dispatch:
         entry["seed_hits_per_dispatch"] = hits_per_dispatch
-        entry["algorithmic_bytes_per_hit"] = 24.0  # two reads of the 8-byte posting (count pass, scatter pass) + one 8-byte hit written
-        entry["counter_bytes_per_hit"] = (fetch + write) / hits_per_dispatch
-        entry["algorithmic_gbs"] = 24.0 * hits_per_dispatch / (b["duration_ms"] * 1e-3) / 1e9
+        entry["algorithmic_bytes_per_hit"] = 18.0  # the posting's 2-byte genome (counting pass) + the 8-byte posting (scatter pass) + one 8-byte hit written
+        entry["counter_bytes_per_hit"] = (fetch / 2 + write) / hits_per_dispatch  # FETCH_SIZE as counted (the x2 rule is calibrated for wide streaming reads only)
+        entry["counter_bytes_per_hit_fetch_doubled"] = (fetch + write) / hits_per_dispatch
+        entry["algorithmic_gbs"] = 18.0 * hits_per_dispatch / (b["duration_ms"] * 1e-3) / 1e9
     out["bucket_hits_kernel"] = entry
     json.dump(out, sys.stdout, indent=1)
     print()

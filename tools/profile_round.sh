@@ -14,6 +14,9 @@ echo "fragani stats rc=$?"
 cd "$ROOT"
 bash tools/pmc_passes.sh ${TAG}_hash kmer_hash tools/pmc_hash.py 1000
 bash tools/pmc_passes.sh ${TAG}_fragmap map_segments tools/bench_fragani.py 300 0
+bash tools/pmc_passes.sh ${TAG}_bucket bucket_hits tools/bench_fragani.py 300 0
+# seed hits per bucket_hits dispatch of that run (the denominator of its bytes per hit)
+PA_FRAGANI_TRACE=1 python3 tools/bench_fragani.py 300 0 2>&1 | grep "seed hits" > gpurun_out/${TAG}_fragani300_trace.txt
 for d in gpurun_out/${TAG}_stats_bench gpurun_out/${TAG}_stats_fragani; do
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then
