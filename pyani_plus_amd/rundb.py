@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import datetime
 import logging
+import os
 import sqlite3
 import sys
 import tempfile
@@ -612,7 +613,9 @@ def run_sourmash_hip(  # noqa: PLR0913
     tmp_dir.mkdir(parents=True, exist_ok=True)
     sig_dir = sourmash_hip.sig_cache_dir(cache_dir, kmersize, f"scaled={scaled}")
     gpus = min(int(gpus), len(fasta_names))
-    if gpus > 1:
+    # PYANI_HIP_FORCE_WORKERS=1 sends even one GPU's worth of work through a worker process (RCCL with world size 1):
+    # the multi-GPU code path on a single-GPU box
+    if gpus > 1 or os.environ.get("PYANI_HIP_FORCE_WORKERS") == "1":
         meta, tile_files, _results = _sharded_sourmash_tiles(logger, fasta, fasta_names, config, cache_dir, tmp_dir, gpus, engine_factory)
         for filename, m in zip(fasta_names, meta):
             if m["md5"] in seen:

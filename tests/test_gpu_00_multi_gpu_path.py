@@ -105,6 +105,14 @@ def test_product_drivers_with_two_ranks_sharing_the_gpu(tmp_path, monkeypatch):
             (indir / f"g{g}.fasta").write_bytes(text)
     many = rundb.run_sourmash_hip(indir, tmp_path / "s2.sqlite", cache=tmp_path / "c2", scaled=100, temp=tmp_path / "t2", gpus=2)
     fmany = rundb.run_fastani_hip(indir, tmp_path / "f2.sqlite", temp=tmp_path / "tf2", gpus=2)
+    # the same worker code over RCCL (backend nccl, collectives on device tensors) with the one rank this box has a GPU for
+    monkeypatch.delenv("PYANI_HIP_DIST_BACKEND")
+    monkeypatch.setenv("PYANI_HIP_FORCE_WORKERS", "1")
+    rccl = rundb.run_sourmash_hip(indir, tmp_path / "s_rccl.sqlite", cache=tmp_path / "c_rccl", scaled=100, temp=tmp_path / "t_rccl", gpus=1)
+    monkeypatch.delenv("PYANI_HIP_FORCE_WORKERS")
+    monkeypatch.setenv("PYANI_HIP_DIST_BACKEND", "gloo")
+    r1 = [json.loads(q.read_text()) for q in sorted((tmp_path / "t_rccl" / "sourmash-hip.workers").glob("result_rank*.json"))]
+    assert len(r1) == 1 and r1[0]["ok"] and r1[0]["backend"] == "nccl" and rccl.status == "Done"
     results = [json.loads(q.read_text()) for q in sorted((tmp_path / "t2" / "sourmash-hip.workers").glob("result_rank*.json"))]
     assert len(results) == 2 and all(r["ok"] and r["device"].startswith("cuda") for r in results)
     fresults = [json.loads(q.read_text()) for q in sorted((tmp_path / "tf2").glob("*.workers/result_rank*.json"))]
@@ -113,7 +121,7 @@ def test_product_drivers_with_two_ranks_sharing_the_gpu(tmp_path, monkeypatch):
     one = rundb.run_sourmash_hip(indir, tmp_path / "s1.sqlite", cache=tmp_path / "c1", scaled=100, temp=tmp_path / "t1", ingest="direct")
     fone = rundb.run_fastani_hip(indir, tmp_path / "f1.sqlite", temp=tmp_path / "tf1")
     assert many.status == one.status == fmany.status == fone.status == "Done"
-    assert _dump(tmp_path / "s1.sqlite") == _dump(tmp_path / "s2.sqlite")
+    assert _dump(tmp_path / "s1.sqlite") == _dump(tmp_path / "s2.sqlite") == _dump(tmp_path / "s_rccl.sqlite")
     assert _dump(tmp_path / "f1.sqlite") == _dump(tmp_path / "f2.sqlite")
     rows = _dump(tmp_path / "f2.sqlite")[1]
     assert len(rows) == len(lengths) ** 2 and sum(r[2] is not None for r in rows) > len(lengths)  # related genomes do map
