@@ -299,7 +299,7 @@ PA_API int64_t pa_fasta_records(const uint8_t *h_text, uint64_t n_text, uint64_t
  * File i = heads[i] + "h0,h1,..." + mids[i] + md5sum + tails[i], where the hashes are
  * h_mins[h_off[i] .. h_off[i+1]) in decimal and md5sum = md5(str(ksize) + concatenated decimals), sourmash's
  * checksum of a sketch.  The three text parts come from the caller (json.dumps of everything around the
- * `mins` list and the `md5sum` value).  Files are written to <path>.tmp and renamed; n_threads 0 = pa_host_cpu_budget(). */
+ * `mins` list and the `md5sum` value).  Files are written to <path>.<pid>.tmp and renamed; n_threads 0 = pa_host_cpu_budget(). */
 PA_API int pa_write_sigs(uint32_t n_files, const char *const *paths, const char *const *heads, const char *const *mids,
                          const char *const *tails, uint32_t ksize, const uint64_t *h_mins, const uint64_t *h_off,
                          uint32_t n_threads);
@@ -342,6 +342,18 @@ PA_API int pa_append_comparisons_json(const char *path, const char *suffix, int 
                                const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
                                const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null);
 
+/* The same with the two proxy columns of the fastANI worker (pyani_plus/private_cli.py:1066-1080): rows become
+ * {"query_hash", "subject_hash", "identity", "aln_length", "sim_errors", "cov_query"}, integers in decimal, all four
+ * `null` where is_null.  aln_length == sim_errors == NULL: the four-key rows of pa_append_comparisons_json. */
+PA_API int pa_append_comparisons_json_ex(const char *path, const char *suffix, int file_has_rows,
+                                  const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
+                                  const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null,
+                                  const int64_t *h_aln_length, const int64_t *h_sim_errors);
+
+/* fastANI writes its identity with six significant digits and the reference parses that text
+ * (pyani_plus/methods/fastani.py:98-120): every value -> printf("%.6g") -> value, in place; NaN stays NaN. */
+PA_API int pa_round_sig6(double *h_values, uint64_t n);
+
 /* Host threads worth starting: the CPUs the process may run on, capped by the cgroup CPU quota when there is one
  * (the reference sizes its worker pools with len(os.sched_getaffinity(0)), pyani_plus/utils.py:199-214, which
  * counts 256 on a box whose container is allowed 16 CPUs' worth of time).  The default of every n_threads = 0
@@ -364,6 +376,15 @@ PA_API int pa_sqlite_insert_comparisons(const char *database, int64_t configurat
                                         const char *const *subject_hashes, uint32_t n_subjects,
                                         const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null,
                                         uint64_t *rows_inserted);
+
+/* The same with aln_length / sim_errors per comparison (both or neither; NULL where is_null): the fastANI worker's rows. */
+PA_API int pa_sqlite_insert_comparisons_ex(const char *database, int64_t configuration_id, const char *uname_system,
+                                           const char *uname_release, const char *uname_machine,
+                                           const char *const *query_hashes, uint32_t n_queries,
+                                           const char *const *subject_hashes, uint32_t n_subjects,
+                                           const double *h_identity, const double *h_cov_query, const uint8_t *h_is_null,
+                                           const int64_t *h_aln_length, const int64_t *h_sim_errors,
+                                           uint64_t *rows_inserted);
 
 /* ---- in-library HIP-event timing of the kernels (bench.py roofline) ----
  * Phases are timed with hipEvents on the context's stream when enabled. */

@@ -115,11 +115,21 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp],
     ),
+    "pa_append_comparisons_json_ex": (
+        C.c_int,
+        [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp, _vp, _vp],
+    ),
+    "pa_round_sig6": (C.c_int, [_vp, C.c_uint64]),
     "pa_host_cpu_budget": (C.c_uint32, []),
     "pa_gunzip": (C.c_int, [_vp, C.c_uint64, _vp, C.c_uint64, _u64p, C.c_int]),
     "pa_sqlite_insert_comparisons": (
         C.c_int,
         [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp, _u64p],
+    ),
+    "pa_sqlite_insert_comparisons_ex": (
+        C.c_int,
+        [C.c_char_p, C.c_int64, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_uint32, C.POINTER(C.c_char_p), C.c_uint32, _vp, _vp, _vp,
+         _vp, _vp, _u64p],
     ),
     "pa_prof_enable": (C.c_int, [_vp, C.c_int]),
     "pa_prof_reset": (C.c_int, [_vp]),

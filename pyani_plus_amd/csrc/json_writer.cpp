@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -74,7 +75,7 @@ inline char *put_double(char *p, char *end, double v) {
 // rows [q0, q1) x all subjects of one block, formatted into `out`; `first` = no ", " before the first row
 void format_rows(std::vector<char> &out, bool first, const char *const *q_hashes, const size_t *qlen, uint32_t q0,
                  uint32_t q1, const char *const *s_hashes, const size_t *slen, uint32_t ns, const double *identity,
-                 const double *cov_query, const uint8_t *is_null) {
+                 const double *cov_query, const uint8_t *is_null, const int64_t *aln_length, const int64_t *sim_errors) {
   size_t fill = 0;
   for (uint32_t q = q0; q < q1; ++q) {
     for (uint32_t s = 0; s < ns; ++s) {
@@ -90,6 +91,12 @@ void format_rows(std::vector<char> &out, bool first, const char *const *q_hashes
       memcpy(p, "\", \"identity\": ", 15); p += 15;
       const uint64_t idx = (uint64_t)q * ns + s;
       if (is_null[idx]) { memcpy(p, "null", 4); p += 4; } else p = put_double(p, end, identity[idx]);
+      if (aln_length) {  // the fastANI worker's proxy columns, in the key order of pyani_plus/private_cli.py:1066-1080
+        memcpy(p, ", \"aln_length\": ", 16); p += 16;
+        if (is_null[idx]) { memcpy(p, "null", 4); p += 4; } else p = std::to_chars(p, end, aln_length[idx]).ptr;
+        memcpy(p, ", \"sim_errors\": ", 16); p += 16;
+        if (is_null[idx]) { memcpy(p, "null", 4); p += 4; } else p = std::to_chars(p, end, sim_errors[idx]).ptr;
+      }
       memcpy(p, ", \"cov_query\": ", 15); p += 15;
       if (is_null[idx]) { memcpy(p, "null", 4); p += 4; } else p = put_double(p, end, cov_query[idx]);
       *p++ = '}';
@@ -101,7 +108,8 @@ void format_rows(std::vector<char> &out, bool first, const char *const *q_hashes
 
 // all rows of a block through `f`: host threads format runs of query rows, the caller writes them in order
 bool write_block(FILE *f, bool first, const char *const *q_hashes, uint32_t nq, const char *const *s_hashes, uint32_t ns,
-                 const double *identity, const double *cov_query, const uint8_t *is_null) {
+                 const double *identity, const double *cov_query, const uint8_t *is_null, const int64_t *aln_length = nullptr,
+                 const int64_t *sim_errors = nullptr) {
   if (nq == 0 || ns == 0) return true;
   std::vector<size_t> qlen(nq), slen(ns);
   for (uint32_t q = 0; q < nq; ++q) qlen[q] = strlen(q_hashes[q]);
@@ -117,7 +125,7 @@ bool write_block(FILE *f, bool first, const char *const *q_hashes, uint32_t nq, 
       const uint32_t c = c0 + w, q0 = c * rows_per_chunk, q1 = std::min(nq, q0 + rows_per_chunk);
       bufs[w].resize(std::max<size_t>(bufs[w].capacity(), 1 << 20));
       format_rows(bufs[w], first && c == 0, q_hashes, qlen.data(), q0, q1, s_hashes, slen.data(), ns, identity, cov_query,
-                  is_null);
+                  is_null, aln_length, sim_errors);
     });
     for (uint32_t w = 0; w < in_round && ok; ++w) ok = fwrite(bufs[w].data(), 1, bufs[w].size(), f) == bufs[w].size();
   }
@@ -153,7 +161,8 @@ static int write_comparisons_json(const char *path, const char *prefix, const ch
 static int append_comparisons_json(const char *path, const char *suffix, int file_has_rows,
                                    const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
                                    uint32_t ns, const double *identity, const double *cov_query,
-                                   const uint8_t *is_null) {
+                                   const uint8_t *is_null, const int64_t *aln_length = nullptr,
+                                   const int64_t *sim_errors = nullptr) {
   if (!path || !suffix || (nq && !q_hashes) || (ns && !s_hashes) || ((uint64_t)nq * ns && (!identity || !cov_query || !is_null))) {
     pa_set_error("pa_append_comparisons_json: null argument");
     return PA_E_INVALID;
@@ -166,7 +175,7 @@ static int append_comparisons_json(const char *path, const char *suffix, int fil
   if (!ok) { fclose(f); pa_set_error("%s does not end with the expected JSON suffix", path); return PA_E_INVALID; }
   ok = fseeko(f, -(off_t)ls, SEEK_END) == 0;
   try {
-    ok = ok && write_block(f, !file_has_rows, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
+    ok = ok && write_block(f, !file_has_rows, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null, aln_length, sim_errors);
   } catch (...) { fclose(f); throw; }
   ok = ok && fwrite(suffix, 1, ls, f) == ls;
   ok = (fclose(f) == 0) && ok;
@@ -191,4 +200,31 @@ extern "C" int pa_append_comparisons_json(const char *path, const char *suffix, 
   return pa_host_guard("pa_append_comparisons_json", pa_set_error, [&] {
     return append_comparisons_json(path, suffix, file_has_rows, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null);
   });
+}
+
+extern "C" int pa_append_comparisons_json_ex(const char *path, const char *suffix, int file_has_rows,
+                                             const char *const *q_hashes, uint32_t nq, const char *const *s_hashes,
+                                             uint32_t ns, const double *identity, const double *cov_query,
+                                             const uint8_t *is_null, const int64_t *aln_length, const int64_t *sim_errors) {
+  if ((aln_length == nullptr) != (sim_errors == nullptr)) {
+    pa_set_error("pa_append_comparisons_json_ex: aln_length and sim_errors go together");
+    return PA_E_INVALID;
+  }
+  return pa_host_guard("pa_append_comparisons_json_ex", pa_set_error, [&] {
+    return append_comparisons_json(path, suffix, file_has_rows, q_hashes, nq, s_hashes, ns, identity, cov_query, is_null, aln_length,
+                                   sim_errors);
+  });
+}
+
+// fastANI prints its identity through a C++ stream with the default precision (six significant digits) and the
+// reference parses that text (pyani_plus/methods/fastani.py:98-120): value -> "%.6g" -> value, in place; NaN stays.
+extern "C" int pa_round_sig6(double *h_values, uint64_t n) {
+  if (!h_values && n) { pa_set_error("pa_round_sig6: null argument"); return PA_E_INVALID; }
+  char buf[40];
+  for (uint64_t i = 0; i < n; ++i) {
+    if (std::isnan(h_values[i])) continue;
+    snprintf(buf, sizeof buf, "%.6g", h_values[i]);
+    h_values[i] = strtod(buf, nullptr);
+  }
+  return PA_OK;
 }

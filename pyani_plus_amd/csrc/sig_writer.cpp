@@ -5,6 +5,8 @@
 // (tests/snakemake/test_sourmash_workflow.py:43-67).  The host side formats everything around the hash
 // list with json.dumps (so string escaping is Python's); what is done here, on a pool of threads, is the
 // part that costs time at N = 1000: ~5 000 decimal numbers per file and the md5 over them.
+#include <unistd.h>
+
 #include <charconv>
 #include <cstdio>
 #include <string>
@@ -37,7 +39,9 @@ int write_one(const char *path, const char *head, const char *mid, const char *t
   }
   char hex[33];
   md5.hex(hex);
-  const std::string tmp = std::string(path) + ".tmp";
+  // the temporary name carries the process id: two workers of a multi-GPU run that hold the same genome (a duplicated
+  // input file, reported by the parent afterwards) must not write through one temporary file
+  const std::string tmp = std::string(path) + "." + std::to_string((long long)getpid()) + ".tmp";
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f) return PA_E_INVALID;
   bool ok = fputs(head, f) >= 0 && fwrite(body.data(), 1, body.size(), f) == body.size() && fputs(mid, f) >= 0 &&

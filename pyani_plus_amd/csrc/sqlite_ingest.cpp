@@ -92,7 +92,23 @@ extern "C" int pa_sqlite_insert_comparisons(const char *database, int64_t config
                                             const char *const *subject_hashes, uint32_t n_subjects,
                                             const double *identity, const double *cov_query, const uint8_t *is_null,
                                             uint64_t *rows_inserted) {
+  return pa_sqlite_insert_comparisons_ex(database, configuration_id, uname_system, uname_release, uname_machine, query_hashes,
+                                         n_queries, subject_hashes, n_subjects, identity, cov_query, is_null, nullptr, nullptr,
+                                         rows_inserted);
+}
+
+extern "C" int pa_sqlite_insert_comparisons_ex(const char *database, int64_t configuration_id, const char *uname_system,
+                                               const char *uname_release, const char *uname_machine,
+                                               const char *const *query_hashes, uint32_t n_queries,
+                                               const char *const *subject_hashes, uint32_t n_subjects,
+                                               const double *identity, const double *cov_query, const uint8_t *is_null,
+                                               const int64_t *aln_length, const int64_t *sim_errors,
+                                               uint64_t *rows_inserted) {
   if (rows_inserted) *rows_inserted = 0;
+  if ((aln_length == nullptr) != (sim_errors == nullptr)) {
+    pa_set_error("pa_sqlite_insert_comparisons_ex: aln_length and sim_errors go together");
+    return PA_E_INVALID;
+  }
   if (!database || !uname_system || !uname_release || !uname_machine || (n_queries && !query_hashes) ||
       (n_subjects && !subject_hashes) || ((uint64_t)n_queries * n_subjects && (!identity || !cov_query || !is_null))) {
     pa_set_error("pa_sqlite_insert_comparisons: null argument");
@@ -143,8 +159,8 @@ extern "C" int pa_sqlite_insert_comparisons(const char *database, int64_t config
     for (uint32_t r = 0; r < tuples; ++r) {
       const int o = (int)(r * kCols);
       bad |= a.bind_int64(s, o + 3, configuration_id) != kSqliteOk;
-      bad |= a.bind_null(s, o + 5) != kSqliteOk;  // aln_length and sim_errors are never set by this method
-      bad |= a.bind_null(s, o + 6) != kSqliteOk;  // (pyani_plus/private_cli.py:1866-1880)
+      bad |= a.bind_null(s, o + 5) != kSqliteOk;  // aln_length and sim_errors: never set by the sourmash method
+      bad |= a.bind_null(s, o + 6) != kSqliteOk;  // (pyani_plus/private_cli.py:1866-1880); bound per row for fastANI's
       bad |= a.bind_text(s, o + 8, uname_system, -1, kStatic) != kSqliteOk;
       bad |= a.bind_text(s, o + 9, uname_release, -1, kStatic) != kSqliteOk;
       bad |= a.bind_text(s, o + 10, uname_machine, -1, kStatic) != kSqliteOk;
@@ -157,9 +173,17 @@ extern "C" int pa_sqlite_insert_comparisons(const char *database, int64_t config
     if (is_null[cell]) {
       bad |= a.bind_null(s, o + 4) != kSqliteOk;
       bad |= a.bind_null(s, o + 7) != kSqliteOk;
+      if (aln_length) {
+        bad |= a.bind_null(s, o + 5) != kSqliteOk;
+        bad |= a.bind_null(s, o + 6) != kSqliteOk;
+      }
     } else {
       bad |= a.bind_double(s, o + 4, identity[cell]) != kSqliteOk;
       bad |= a.bind_double(s, o + 7, cov_query[cell]) != kSqliteOk;
+      if (aln_length) {  // fastANI's proxy columns (pyani_plus/private_cli.py:1072-1080)
+        bad |= a.bind_int64(s, o + 5, aln_length[cell]) != kSqliteOk;
+        bad |= a.bind_int64(s, o + 6, sim_errors[cell]) != kSqliteOk;
+      }
     }
   };
   uint64_t stepped = 0;

@@ -107,6 +107,33 @@ def comparison_entry(q: str, s: str, frags: int, matches: int, ani_percent: floa
     }
 
 
+def round_sig6(values: np.ndarray) -> np.ndarray:
+    """``fastani_print_round`` of every element (native ``pa_round_sig6``: printf("%.6g") and back; NaN stays)."""
+    from .. import _capi
+
+    out = np.ascontiguousarray(values, dtype=np.float64).copy()
+    _capi.check(_capi.load_library().pa_round_sig6(out.ctypes.data, out.size), "pa_round_sig6")
+    return out
+
+
+def comparison_block(total, matched, ident_sum, lengths, rows, cols, fragsize: int, minmatch: float):
+    """The five fields of the fastANI worker (private_cli.py:1066-1098) for a block of query rows x subject columns
+    as arrays: (identity f64, aln_length i64, sim_errors i64, cov_query f64, is_null bool); the array form of
+    ``comparison_entry``.  A pair fastANI would print no line for is NULL in all four."""
+    rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+    m = matched[np.ix_(rows, cols)].astype(np.int64)
+    frags = total[rows].astype(np.int64)[:, None]
+    shorter = np.minimum(lengths[rows].astype(np.int64)[:, None], lengths[cols].astype(np.int64)[None, :])
+    reported = (frags > 0) & (m > 0) & (m * int(fragsize) >= float(minmatch) * shorter)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ani = np.where(m > 0, ident_sum[np.ix_(rows, cols)] / np.maximum(m, 1), np.nan)
+        cov = np.where(reported, m / np.maximum(frags, 1), np.nan)
+    identity = np.where(reported, round_sig6(np.where(reported, ani, np.nan)) / 100.0, np.nan)
+    aln = np.where(reported, int(fragsize) * m, 0)
+    err = np.where(reported, frags - m, 0)
+    return identity, aln.astype(np.int64), err.astype(np.int64), cov, ~reported
+
+
 def compute_fastani_hip(  # noqa: PLR0913
     logger: logging.Logger,
     tmp_dir: Path,  # noqa: ARG001
@@ -123,6 +150,7 @@ def compute_fastani_hip(  # noqa: PLR0913
     engine=None,
     subject_range: tuple[int, int] | None = None,
     query_batch: int = QUERY_BATCH,
+    on_block=None,
 ) -> int:
     """Run many-vs-subject (all-vs-all when ``subject_hash == ""``) and log the column(s) to JSON.
 
@@ -130,18 +158,18 @@ def compute_fastani_hip(  # noqa: PLR0913
     ``fastANI -r subject`` process does; ``subject_range`` = (c0, c1) with ``subject_hash == ""`` takes the columns
     c0 .. c1-1 of the sorted genomes (one rank's share of a multi-GPU run, ``rundb.run_fastani_hip``).
     The queries go through in batches of ``query_batch`` genomes -- the reference's 500 (private_cli.py:1029-1033) --
-    and the column file is rewritten after each, so an interrupt keeps the finished batches
-    (private_cli.py:1101-1110); the reference index is built once and taken over by the later batches.
+    and the column file grows by one batch after each (natively formatted rows, a complete JSON document every time),
+    so an interrupt keeps the finished batches (private_cli.py:1101-1110); the reference index is built once and taken
+    over by the later batches.  ``on_block(queries, subjects, identity, aln_length, sim_errors, cov_query, is_null)``
+    (optional) receives every batch as arrays as well -- the run driver's direct ingest.
     Library failures end the worker through ``log_sys_exit`` like a failing tool (pyani_plus/utils.py:262-283); a
     failing save returns 2."""
     from .._capi import HipBackendError
     from .sourmash_hip import backend_failure
 
-    uname = platform.uname()
     configuration = run.configuration
     tool = get_fastani_hip()
     _check_tool_version(logger, tool, configuration)
-    config_id = getattr(configuration, "configuration_id", None)
     fragsize = configuration.fragsize
     if not fragsize:
         log_sys_exit(logger, f"{METHOD} run-id {run.run_id} is missing fragsize parameter")
@@ -164,8 +192,12 @@ def compute_fastani_hip(  # noqa: PLR0913
     sub_idx = [index[s] for s in subjects]
     contiguous = bool(sub_idx) and sub_idx == list(range(sub_idx[0], sub_idx[0] + len(sub_idx)))
     ref_range = (sub_idx[0], sub_idx[0] + len(sub_idx)) if contiguous else None
-    constants = {"configuration_id": config_id, "uname_system": uname.system, "uname_release": uname.release, "uname_machine": uname.machine}
-    db_entries: list[dict] = []
+    rows_done = 0
+    try:
+        writer = wire.ColumnFileWriter(logger, json_filename, configuration)
+    except Exception:
+        logger.exception("Unexpected exception saving JSON:")
+        return RECORDING_FAILED
     try:
         if engine is None:
             # one process per subject column in the reference's flow: PYANI_HIP_DEVICE=spread deals the columns over the GPUs
@@ -183,26 +215,21 @@ def compute_fastani_hip(  # noqa: PLR0913
                 dev, arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize, ref_range=ref_range,
                 query_range=(batch[0], batch[-1] + 1), reuse_index=b > 0, out=out,
             )  # fmt: skip
-            for qi in batch:
-                q = genomes[qi]
-                frags = int(total[qi])
-                for s, si in zip(subjects, sub_idx):
-                    matches = int(matched[qi, si])
-                    ani = ident_sum[qi, si] / matches if matches else float("nan")
-                    db_entries.append(comparison_entry(q, s, frags, matches, ani, fragsize, minmatch, int(lengths[qi]), int(lengths[si]), constants))
-            if b + 1 < len(batches):
-                wire.export_json_db_entries(logger, json_filename, configuration, db_entries)
+            ident, aln, sim, cov, null = comparison_block(total, matched, ident_sum, lengths, batch, sub_idx, fragsize, minmatch)
+            if on_block is not None:
+                on_block([genomes[i] for i in batch], subjects, ident, aln, sim, cov, null)
+            try:  # the column file grows by one batch of queries (a complete JSON document after each)
+                writer.append([genomes[i] for i in batch], subjects, ident, cov, null, aln_length=aln, sim_errors=sim)
+            except Exception:
+                logger.exception("Unexpected exception saving JSON:")
+                return RECORDING_FAILED
+            rows_done = writer.rows
     except KeyboardInterrupt:
-        logger.error("Interrupted with %d completed %s comparisons", len(db_entries), METHOD)  # noqa: TRY400
+        logger.error("Interrupted with %d completed %s comparisons", rows_done, METHOD)  # noqa: TRY400
         run.status = "Worker interrupted"
         session.commit()
     except HipBackendError as err:
         backend_failure(logger, f"{METHOD} comparison", err)
     except ValueError as err:  # an input file that does not load: what a failing fastANI process is to the reference
         log_sys_exit(logger, f"{METHOD} comparison failed: {err}")
-    try:
-        wire.export_json_db_entries(logger, json_filename, configuration, db_entries)
-    except Exception:  # pragma: no cover
-        logger.exception("Unexpected exception saving JSON:")
-        return RECORDING_FAILED
     return 0

@@ -281,7 +281,8 @@ def _database_file(conn) -> str | None:
     return None
 
 
-def ingest_matrices_native(conn, run: Run, queries: list[str], subjects: list[str], identity, cov_query, is_null) -> int | None:
+def ingest_matrices_native(conn, run: Run, queries: list[str], subjects: list[str], identity, cov_query, is_null, *,
+                           aln_length=None, sim_errors=None) -> int | None:
     """``ingest_matrices`` through ``pa_sqlite_insert_comparisons`` (one prepared statement stepped from C on a
     connection of its own).  Returns the number of comparisons handled, or None when the native route does not
     apply (in-memory database, libsqlite3.so.0 not loadable) -- the caller then uses Python's sqlite3 module."""
@@ -305,9 +306,15 @@ def ingest_matrices_native(conn, run: Run, queries: list[str], subjects: list[st
     s_arr = (C.c_char_p * ns)(*[s.encode() for s in subjects])
     conn.commit()  # the call opens its own connection: nothing of ours may hold the write lock
     inserted = C.c_uint64()
-    status = _capi.load_library().pa_sqlite_insert_comparisons(
+    aln = err = None
+    if aln_length is not None:
+        aln = np.ascontiguousarray(aln_length, dtype=np.int64)
+        err = np.ascontiguousarray(sim_errors, dtype=np.int64)
+        assert aln.shape == (nq, ns) == err.shape
+    status = _capi.load_library().pa_sqlite_insert_comparisons_ex(
         path.encode(), run.configuration_id, uname.system.encode(), uname.release.encode(), uname.machine.encode(),
-        q_arr, nq, s_arr, ns, identity.ctypes.data, cov_query.ctypes.data, null.ctypes.data, C.byref(inserted),
+        q_arr, nq, s_arr, ns, identity.ctypes.data, cov_query.ctypes.data, null.ctypes.data,
+        None if aln is None else aln.ctypes.data, None if err is None else err.ctypes.data, C.byref(inserted),
     )  # fmt: skip
     if status == _capi.PA_E_IO and "libsqlite3" in _capi.last_error():
         return None
@@ -316,7 +323,7 @@ def ingest_matrices_native(conn, run: Run, queries: list[str], subjects: list[st
 
 
 def ingest_matrices(conn, run: Run, queries: list[str], subjects: list[str], identity, cov_query, is_null, *,
-                    chunk_rows: int = 1_000_000, native: bool = True) -> int:
+                    chunk_rows: int = 1_000_000, native: bool = True, aln_length=None, sim_errors=None) -> int:
     """Comparison rows straight from the result matrices (the reference goes through one
     Python dict per row, a JSON file and its re-parse: pyani_plus/private_cli.py:1863-1888, 507-614).
 
@@ -327,7 +334,7 @@ def ingest_matrices(conn, run: Run, queries: list[str], subjects: list[str], ide
     import platform
 
     if native:
-        done = ingest_matrices_native(conn, run, queries, subjects, identity, cov_query, is_null)
+        done = ingest_matrices_native(conn, run, queries, subjects, identity, cov_query, is_null, aln_length=aln_length, sim_errors=sim_errors)
         if done is not None:
             return done
     uname = platform.uname()
@@ -344,17 +351,24 @@ def ingest_matrices(conn, run: Run, queries: list[str], subjects: list[str], ide
         cov = cov_query[q0:q1].astype(object)
         ident[null[q0:q1]] = None
         cov[null[q0:q1]] = None
+        if aln_length is None:
+            aln = err = np.full(ident.shape, None, dtype=object)
+        else:
+            aln = np.asarray(aln_length)[q0:q1].astype(np.int64).astype(object)  # Python ints: sqlite3 stores numpy scalars as blobs
+            err = np.asarray(sim_errors)[q0:q1].astype(np.int64).astype(object)
+            aln[null[q0:q1]] = None
+            err[null[q0:q1]] = None
         rows = (
-            (q, s, cid, i, None, None, c, *constants)
-            for q, irow, crow in zip(queries[q0:q1], ident, cov)
-            for s, i, c in zip(subjects, irow, crow)
+            (q, s, cid, i, a, e, c, *constants)
+            for q, irow, crow, arow, erow in zip(queries[q0:q1], ident, cov, aln, err)
+            for s, i, c, a, e in zip(subjects, irow, crow, arow, erow)
         )
         conn.executemany(INSERT_COMPARISON, rows)
     conn.commit()
     return nq * ns
 
 
-def format_matrix_cache(hashes: list[str], identity, cov_query, is_null) -> dict[str, str] | None:
+def format_matrix_cache(hashes: list[str], identity, cov_query, is_null, *, aln_length=None, sim_errors=None) -> dict[str, str] | None:
     """The five ``runs.df_*`` strings from matrices in memory (rows = query, columns = subject, both in ``hashes``
     order = sorted md5); None when they would not fit a SQLite value."""
     import pandas as pd
@@ -366,7 +380,9 @@ def format_matrix_cache(hashes: list[str], identity, cov_query, is_null) -> dict
     ident = np.where(is_null, np.nan, identity)
     cov = np.where(is_null, np.nan, cov_query)
     nan = np.full((n, n), np.nan)
-    mats = {"identity": ident, "cov_query": cov, "aln_length": nan, "sim_errors": nan, "hadamard": ident * cov}
+    aln = nan if aln_length is None else np.where(is_null, np.nan, np.asarray(aln_length, dtype=np.float64))
+    err = nan if sim_errors is None else np.where(is_null, np.nan, np.asarray(sim_errors, dtype=np.float64))
+    mats = {"identity": ident, "cov_query": cov, "aln_length": aln, "sim_errors": err, "hadamard": ident * cov}
     return {
         f"df_{key}": pd.DataFrame(data=mat, index=hashes, columns=hashes, dtype=float).to_json(orient="split")
         for key, mat in mats.items()
@@ -473,7 +489,7 @@ def _compute_direct(logger, conn, run: Run, cache_dir: Path, tmp_dir: Path, engi
     return _ingest_direct(conn, run, hashes, cols, ident, cov, null, mark)
 
 
-def _ingest_direct(conn, run: Run, hashes: list[str], cols: list[str], ident, cov, null, mark):
+def _ingest_direct(conn, run: Run, hashes: list[str], cols: list[str], ident, cov, null, mark, *, aln_length=None, sim_errors=None):
     """Matrices in host memory (rows = ``hashes``, columns = ``cols``, both sorted) -> comparison rows in index order,
     the five cached matrices formatted on a second thread meanwhile (when the block is the whole square)."""
     # synchronous=NORMAL for the bulk insert: a handful of fsyncs per transaction instead of one per page group, and
@@ -484,8 +500,8 @@ def _ingest_direct(conn, run: Run, hashes: list[str], cols: list[str], ident, co
 
     square = cols == hashes
     with ThreadPoolExecutor(max_workers=1) as side:
-        formatting = side.submit(format_matrix_cache, hashes, ident, cov, null) if square else None
-        ingest_matrices(conn, run, hashes, cols, ident, cov, null)
+        formatting = side.submit(format_matrix_cache, hashes, ident, cov, null, aln_length=aln_length, sim_errors=sim_errors) if square else None
+        ingest_matrices(conn, run, hashes, cols, ident, cov, null, aln_length=aln_length, sim_errors=sim_errors)
         formatted = formatting.result() if formatting is not None else None
     conn.execute("PRAGMA synchronous=FULL")
     mark("insert_rows")
@@ -803,8 +819,8 @@ def resume(database: Path | str, *, run_id: int | None = None, cache: Path | Non
     tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
     tmp_dir.mkdir(parents=True, exist_ok=True)
     if config.method == fastani_hip.METHOD:
-        _compute_missing_fastani(logger, conn, session, run, tmp_dir, engine, gpus, engine_factory)
-        return _finish_run(logger, conn, session, run, None, mark)
+        direct = _compute_missing_fastani(logger, conn, session, run, tmp_dir, engine, gpus, engine_factory, ingest, mark)
+        return _finish_run(logger, conn, session, run, direct, mark)
     cache_dir = Path(tempfile.mkdtemp(prefix="pyani_hip_cache_")) if cache is None else Path(cache)
     cache_dir.mkdir(parents=True, exist_ok=True)
     direct = _compute_missing(logger, conn, session, run, cache_dir, tmp_dir, engine, ingest, mark)
@@ -909,18 +925,23 @@ def export_run(database: Path | str, outdir: Path, *, run_id: int | None = None,
 
 
 # ------------------------------------------------------------------ the fragment-ANI run (pyani_plus/public_cli.py:502-554)
-def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, engine, gpus: int, engine_factory: str | None) -> None:
-    """The incomplete subject columns of a ``fastANI-hip`` run: in this process (one call per column, or one for all
-    of them on a new run), or as reference ranges of ``pa_fragani`` spread over ``gpus`` worker processes -- the
-    reference's own one-process-per-column layout (pyani_plus/public_cli.py:236-261) with a GPU per process and no
-    exchange between them.  Each worker writes the reference's JSON column file; this process imports them."""
+def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, engine, gpus: int, engine_factory: str | None,
+                             ingest: str = "json", mark=None):
+    """The incomplete subject columns of a ``fastANI-hip`` run: in this process (one call per run of missing columns; a
+    new run is one call for all of them), or as reference ranges of ``pa_fragani`` spread over ``gpus`` worker
+    processes -- the reference's own one-process-per-column layout (pyani_plus/public_cli.py:236-261) with a GPU per
+    process and no exchange between them.  Every worker writes the reference's JSON column file.  ``ingest="json"``:
+    this process imports those files, what the reference's parent does (pyani_plus/workflows/__init__.py:75-87);
+    ``"direct"``: the rows go from the result arrays (binary tile files between processes) straight into the table.
+    Returns the ``_ingest_direct`` tuple when a new run went in directly (matrix cache from memory), else None."""
     from .methods import fastani_hip
 
+    mark = mark or (lambda _name: None)
     n = len(run.fasta_hashes)
     done = count_run_comparisons(conn, run)
     if done == n * n:
         logger.info("Database already has all %d=%d^2 %s comparisons", n * n, n, fastani_hip.METHOD)
-        return
+        return None
     logger.info("Database already has %d of %d^2=%d %s comparisons, %d needed", done, n, n * n, fastani_hip.METHOD, n * n - done)
     hashes = sorted(a.genome_hash for a in run.fasta_hashes)
     columns = hashes if done == 0 else _incomplete_columns(conn, run)
@@ -938,6 +959,8 @@ def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, eng
             runs_of_columns[-1] = (runs_of_columns[-1][0], i + 1)
         else:
             runs_of_columns.append((i, i + 1))
+    direct = ingest == "direct"
+    blocks: list[tuple] = []  # (queries, subjects, identity, aln_length, sim_errors, cov_query, is_null) per block, direct route
     gpus = max(1, min(int(gpus), len(columns)))
     if gpus > 1:
         from . import launch
@@ -958,7 +981,7 @@ def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, eng
         work_dir = tmp_dir / f"{fastani_hip.METHOD}.run_{run.run_id}.workers"
         spec = {
             "task": "fastani", "run_id": run.run_id, "fasta_dir": str(fasta_dir), "hash_to_filename": hash_to_filename,
-            "query_hashes": query_hashes, "column_ranges": column_ranges, "work_dir": str(work_dir),
+            "query_hashes": query_hashes, "column_ranges": column_ranges, "work_dir": str(work_dir), "tiles": direct,
             "configuration": {**{k: getattr(run.configuration, k) for k in wire.CONFIG_FIELDS}, "configuration_id": run.configuration_id},
         }  # fmt: skip
         if engine_factory:
@@ -967,21 +990,52 @@ def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, eng
             results = launch.launch_workers(gpus, spec, work_dir)
         except launch.WorkerFailure as err:
             sourmash_hip.log_sys_exit(logger, str(err))
+        mark("workers")
         for r in results:
-            if r.get("json"):
-                import_json_comparisons(logger, conn, Path(r["json"]))
             if r.get("interrupted"):
                 run.status = "Worker interrupted"
-        return
-    for a, b in runs_of_columns:
-        json_file = tmp_dir / f"{fastani_hip.METHOD}.run_{run.run_id}.columns_{a + 1}_{b}.json"
-        status = fastani_hip.compute_fastani_hip(
-            logger, tmp_dir, session, run, json_file, fasta_dir, hash_to_filename, {v: k for k, v in hash_to_filename.items()},
-            query_hashes, "", engine=engine, subject_range=(a, b),
-        )  # fmt: skip
-        if status:
-            sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
-        import_json_comparisons(logger, conn, json_file)
+            if direct:
+                for tile in r.get("tiles") or []:
+                    _cfg, queries, subjects, ident, cov, null, aln, sim = wire.load_tile(Path(tile), with_proxies=True)
+                    blocks.append((queries, subjects, ident, aln, sim, cov, null))
+            elif r.get("json"):
+                import_json_comparisons(logger, conn, Path(r["json"]))
+    else:
+        if engine is None and engine_factory:  # the workers' engine, when their work has shrunk to one process's worth
+            import importlib
+
+            module, _, attr = engine_factory.partition(":")
+            engine = getattr(importlib.import_module(module), attr)()
+        for a, b in runs_of_columns:
+            json_file = tmp_dir / f"{fastani_hip.METHOD}.run_{run.run_id}.columns_{a + 1}_{b}.json"
+            status = fastani_hip.compute_fastani_hip(
+                logger, tmp_dir, session, run, json_file, fasta_dir, hash_to_filename, {v: k for k, v in hash_to_filename.items()},
+                query_hashes, "", engine=engine, subject_range=(a, b), on_block=(lambda *blk: blocks.append(blk)) if direct else None,
+            )  # fmt: skip
+            if status:
+                sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
+            if not direct:
+                import_json_comparisons(logger, conn, json_file)
+        mark("worker")
+    if not direct:
+        mark("import_column_files")
+        return None
+    whole = done == 0 and sum(len(b[0]) * len(b[1]) for b in blocks) == n * n
+    if whole:  # a new run: one square, rows in index order, matrix cache from memory
+        pos = {h: i for i, h in enumerate(hashes)}
+        ident = np.full((n, n), np.nan)
+        cov = np.full((n, n), np.nan)
+        null = np.ones((n, n), dtype=bool)
+        aln = np.zeros((n, n), dtype=np.int64)
+        sim = np.zeros((n, n), dtype=np.int64)
+        for queries, subjects, b_ident, b_aln, b_sim, b_cov, b_null in blocks:
+            at = np.ix_([pos[q] for q in queries], [pos[x] for x in subjects])
+            ident[at], cov[at], null[at], aln[at], sim[at] = b_ident, b_cov, b_null, b_aln, b_sim
+        return _ingest_direct(conn, run, hashes, hashes, ident, cov, null, mark, aln_length=aln, sim_errors=sim)
+    for queries, subjects, b_ident, b_aln, b_sim, b_cov, b_null in blocks:
+        ingest_matrices(conn, run, queries, subjects, b_ident, b_cov, b_null, aln_length=b_aln, sim_errors=b_sim)
+    mark("insert_rows")
+    return None
 
 
 def run_fastani_hip(  # noqa: PLR0913
@@ -997,6 +1051,8 @@ def run_fastani_hip(  # noqa: PLR0913
     engine=None,
     gpus: int = 1,
     engine_factory: str | None = None,
+    timings: dict | None = None,
+    ingest: str = "json",
 ) -> Run:
     """FASTA directory -> database with all N^2 fragment-ANI comparisons and cached matrices: counterpart of
     ``pyani-plus fastani <fasta> -d <db> --create-db`` (pyani_plus/public_cli.py:502-554) with one in-process call --
@@ -1006,6 +1062,7 @@ def run_fastani_hip(  # noqa: PLR0913
     from .engine import load_fasta_files
     from .methods import fastani_hip
 
+    mark = _phase_clock(timings)
     logger = logger or logging.getLogger("pyani_plus_amd")
     kmersize = fastani_hip.KMER_SIZE if kmersize is None else int(kmersize)
     fragsize = fastani_hip.FRAG_LEN if fragsize is None else int(fragsize)
@@ -1025,6 +1082,7 @@ def run_fastani_hip(  # noqa: PLR0913
         filename_to_md5[filename] = info.md5
         db_genome(conn, filename, info.md5, info.length, info.description)
     del _arena
+    mark("register_genomes")
     run = add_run(
         conn, config, " ".join(sys.argv), fasta, "Initialising",
         f"{len(filename_to_md5)} genomes using {fastani_hip.METHOD}" if name is None else name, filename_to_md5,
@@ -1032,5 +1090,7 @@ def run_fastani_hip(  # noqa: PLR0913
     session = Session(conn, run)
     tmp_dir = Path(temp) if temp else Path(tempfile.mkdtemp(prefix="pyani_hip_"))
     tmp_dir.mkdir(parents=True, exist_ok=True)
-    _compute_missing_fastani(logger, conn, session, run, tmp_dir, engine, gpus, engine_factory)
-    return _finish_run(logger, conn, session, run, None, _phase_clock(None))
+    if ingest not in {"json", "direct"}:
+        sourmash_hip.log_sys_exit(logger, f"ingest must be 'json' or 'direct', not {ingest!r}")
+    direct = _compute_missing_fastani(logger, conn, session, run, tmp_dir, engine, gpus, engine_factory, ingest, mark)
+    return _finish_run(logger, conn, session, run, direct, mark)

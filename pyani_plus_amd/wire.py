@@ -74,11 +74,16 @@ def export_json_matrices(
     logger.debug("Saved %d comparisons to %s", nq * ns, json_filename)
 
 
-def save_tile(path: Path, configuration, queries: list[str], subjects: list[str], identity, cov_query, is_null) -> None:
+def save_tile(path: Path, configuration, queries: list[str], subjects: list[str], identity, cov_query, is_null, *,
+              aln_length=None, sim_errors=None) -> None:
     """One subject tile as a binary column file: the JSON form costs ~170 bytes and two
-    float-to-text conversions per comparison, 17 GB at N = 10^4; this is 17 bytes per comparison and no text."""
+    float-to-text conversions per comparison, 17 GB at N = 10^4; this is 17 bytes per comparison and no text.
+    ``aln_length`` / ``sim_errors`` (int64, both or neither): the fastANI worker's proxy columns."""
     import numpy as np
 
+    extra = {}
+    if aln_length is not None:
+        extra = {"aln_length": np.asarray(aln_length, dtype=np.int64), "sim_errors": np.asarray(sim_errors, dtype=np.int64)}
     np.savez(
         path,
         configuration=np.array(json.dumps(configuration_dict(configuration))),
@@ -87,15 +92,21 @@ def save_tile(path: Path, configuration, queries: list[str], subjects: list[str]
         identity=np.asarray(identity, dtype=np.float64),
         cov_query=np.asarray(cov_query, dtype=np.float64),
         is_null=np.asarray(is_null, dtype=bool),
+        **extra,
     )
 
 
-def load_tile(path: Path):
+def load_tile(path: Path, *, with_proxies: bool = False):
+    """(configuration, queries, subjects, identity, cov_query, is_null) of a tile file; with ``with_proxies`` also
+    (aln_length, sim_errors), None for a tile that has none."""
     import numpy as np
 
     with np.load(path) as data:
-        return (json.loads(str(data["configuration"])), [str(x) for x in data["queries"]], [str(x) for x in data["subjects"]],
-                data["identity"], data["cov_query"], data["is_null"])  # fmt: skip
+        out = (json.loads(str(data["configuration"])), [str(x) for x in data["queries"]], [str(x) for x in data["subjects"]],
+               data["identity"], data["cov_query"], data["is_null"])  # fmt: skip
+        if with_proxies:
+            out += ((data["aln_length"], data["sim_errors"]) if "aln_length" in data else (None, None))
+        return out
 
 
 class ColumnFileWriter:
@@ -115,7 +126,9 @@ class ColumnFileWriter:
         self.rows = 0
         export_json_matrices(logger, self.path, configuration, [], [], _empty(), _empty(), _empty(bool))
 
-    def append(self, queries: list[str], subjects: list[str], identity, cov_query, is_null) -> None:
+    def append(self, queries: list[str], subjects: list[str], identity, cov_query, is_null, *, aln_length=None, sim_errors=None) -> None:
+        """One more block of comparisons (query-major).  ``aln_length`` / ``sim_errors`` (int64 matrices, both or neither):
+        the rows then carry the fastANI worker's six keys (pyani_plus/private_cli.py:1066-1080)."""
         import ctypes as C
 
         import numpy as np
@@ -132,13 +145,25 @@ class ColumnFileWriter:
         assert identity.shape == (nq, ns) == cov_query.shape == null.shape
         q_arr = (C.c_char_p * nq)(*[q.encode() for q in queries])
         s_arr = (C.c_char_p * ns)(*[s.encode() for s in subjects])
-        _capi.check(
-            lib.pa_append_comparisons_json(
-                str(self.path).encode(), self.SUFFIX.encode(), int(self.rows > 0), q_arr, nq, s_arr, ns,
-                identity.ctypes.data, cov_query.ctypes.data, null.ctypes.data,
-            ),  # fmt: skip
-            "pa_append_comparisons_json",
-        )
+        if aln_length is not None:
+            aln = np.ascontiguousarray(aln_length, dtype=np.int64)
+            err = np.ascontiguousarray(sim_errors, dtype=np.int64)
+            assert aln.shape == (nq, ns) == err.shape
+            _capi.check(
+                lib.pa_append_comparisons_json_ex(
+                    str(self.path).encode(), self.SUFFIX.encode(), int(self.rows > 0), q_arr, nq, s_arr, ns,
+                    identity.ctypes.data, cov_query.ctypes.data, null.ctypes.data, aln.ctypes.data, err.ctypes.data,
+                ),  # fmt: skip
+                "pa_append_comparisons_json_ex",
+            )
+        else:
+            _capi.check(
+                lib.pa_append_comparisons_json(
+                    str(self.path).encode(), self.SUFFIX.encode(), int(self.rows > 0), q_arr, nq, s_arr, ns,
+                    identity.ctypes.data, cov_query.ctypes.data, null.ctypes.data,
+                ),  # fmt: skip
+                "pa_append_comparisons_json",
+            )
         self.rows += nq * ns
         self.logger.debug("Saved %d comparisons to %s", self.rows, self.path)
 

@@ -124,13 +124,24 @@ def fastani_rank(spec: dict, rank: int, world: int, dist, torch, logger: logging
         return {"ok": True, "json": None}
     json_file = Path(spec["work_dir"]) / f"{fastani_hip.METHOD}.run_{spec['run_id']}.columns_{c0 + 1}_{c1}.json"
     engine = _make_engine(spec)
+    tiles: list[str] = []
+
+    def keep_tile(queries, subjects, ident, aln, sim, cov, null) -> None:
+        """The batch as a binary tile file next to the JSON column file (the parent's direct ingest)."""
+        from . import wire
+
+        path = Path(spec["work_dir"]) / f"{fastani_hip.METHOD}.rank_{rank}.tile_{len(tiles)}.npz"
+        wire.save_tile(path, config, queries, subjects, ident, cov, null, aln_length=aln, sim_errors=sim)
+        tiles.append(str(path))
+
     status = fastani_hip.compute_fastani_hip(
         logger, Path(spec["work_dir"]), session, run, json_file, Path(spec["fasta_dir"]), hash_to_filename,
         {v: k for k, v in hash_to_filename.items()}, query_hashes, "", engine=engine, subject_range=(c0, c1),
+        on_block=keep_tile if spec.get("tiles") else None,
     )  # fmt: skip
     if status:
         return {"ok": False, "error": f"Column worker failed with return code {status}"}
-    return {"ok": True, "json": str(json_file), "interrupted": run.status == "Worker interrupted",
+    return {"ok": True, "json": str(json_file), "tiles": tiles, "interrupted": run.status == "Worker interrupted",
             "device": str(getattr(engine, "device", "test engine"))}  # fmt: skip
 
 

@@ -280,3 +280,66 @@ def test_fastani_worker_flushes_every_query_batch_and_keeps_them_on_interrupt(tm
         assert fastani_hip.compute_fastani_hip(LOGGER, tmp_path, _Session(), run, path, GOLDEN / name, hash_to_filename, {}, queries, "",
                                                engine=OracleEngine(), query_batch=qb) == 0
     assert json.loads(whole.read_text()) == json.loads(batched.read_text())
+
+
+def test_fastani_rows_as_arrays_equal_the_row_by_row_form_and_json_dumps(tmp_path):
+    """The worker's vectorised rows (``comparison_block``) against the per-row statement of the reference's mapping
+    (``comparison_entry``, pyani_plus/private_cli.py:1066-1098), and the natively written six-key rows against
+    ``json.dumps`` of those dicts, byte for byte."""
+    import json
+
+    from pyani_plus_amd import wire
+
+    rng = np.random.default_rng(5)
+    n = 7
+    total = rng.integers(0, 40, size=n).astype(np.uint32)
+    total[2] = 0
+    matched = np.minimum(rng.integers(0, 45, size=(n, n)), total[:, None]).astype(np.uint32)
+    matched[rng.random((n, n)) < 0.3] = 0
+    ani = rng.uniform(74.0, 100.0, size=(n, n))
+    ani[0, 1], ani[1, 0], ani[3, 3] = 100.0, 99.99995, 82.91245
+    ident_sum = ani * matched
+    lengths = rng.integers(30_000, 200_000, size=n)
+    rows, cols = [0, 1, 3, 4, 6], [1, 2, 3, 5]
+    ident, aln, sim, cov, null = fastani_hip.comparison_block(total, matched, ident_sum, lengths, rows, cols, 3000, 0.2)
+    hashes = [f"{i:032x}" for i in range(n)]
+    entries = []
+    for a, qi in enumerate(rows):
+        for b, si in enumerate(cols):
+            m = int(matched[qi, si])
+            want = fastani_hip.comparison_entry(hashes[qi], hashes[si], int(total[qi]), m, ident_sum[qi, si] / m if m else float("nan"), 3000, 0.2,
+                                                int(lengths[qi]), int(lengths[si]), {})
+            entries.append(want)
+            if want["identity"] is None:
+                assert null[a, b]
+            else:
+                assert not null[a, b] and ident[a, b] == want["identity"] and cov[a, b] == want["cov_query"]
+                assert aln[a, b] == want["aln_length"] and sim[a, b] == want["sim_errors"]
+    assert null.any() and not null.all()
+    cfg = rundb.Configuration(1, fastani_hip.METHOD, "libpyani_hip", "0", fragsize=3000, kmersize=16, minmatch=0.2)
+    writer = wire.ColumnFileWriter(LOGGER, tmp_path / "native.json", cfg)
+    writer.append([hashes[i] for i in rows[:2]], [hashes[i] for i in cols], ident[:2], cov[:2], null[:2], aln_length=aln[:2], sim_errors=sim[:2])
+    writer.append([hashes[i] for i in rows[2:]], [hashes[i] for i in cols], ident[2:], cov[2:], null[2:], aln_length=aln[2:], sim_errors=sim[2:])
+    wire.export_json_db_entries(LOGGER, tmp_path / "python.json", cfg, entries)
+    assert (tmp_path / "native.json").read_bytes() == (tmp_path / "python.json").read_bytes()
+    assert json.loads((tmp_path / "native.json").read_text())["comparisons"] == entries
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_fastani_direct_ingest_equals_the_json_route(tmp_path, gpus, monkeypatch):
+    monkeypatch.setenv("PYANI_HIP_DIST_BACKEND", "gloo")
+    name = "viral_example"
+    rundb.run_fastani_hip(GOLDEN / name, tmp_path / "json.sqlite", engine=OracleEngine(), temp=tmp_path / "t1")
+    kwargs = {"engine": OracleEngine()} if gpus == 1 else {"gpus": gpus, "engine_factory": FACTORY}
+    run = rundb.run_fastani_hip(GOLDEN / name, tmp_path / "direct.sqlite", temp=tmp_path / "t2", ingest="direct", **kwargs)
+    assert run.status == "Done"
+    assert _dump(tmp_path / "json.sqlite") == _dump(tmp_path / "direct.sqlite")
+    # a resumed run takes the direct route block by block
+    conn = sqlite3.connect(tmp_path / "direct.sqlite")
+    victim = sorted({r[1] for r in conn.execute("SELECT query_hash, subject_hash FROM comparisons")})[1]
+    conn.execute("DELETE FROM comparisons WHERE subject_hash = ?", (victim,))
+    conn.execute("UPDATE runs SET status='Running', df_identity=NULL, df_aln_length=NULL")
+    conn.commit()
+    conn.close()
+    assert rundb.resume(tmp_path / "direct.sqlite", temp=tmp_path / "t3", ingest="direct", **kwargs).status == "Done"
+    assert _dump(tmp_path / "json.sqlite") == _dump(tmp_path / "direct.sqlite")

@@ -1,7 +1,8 @@
 """Whole path on files at a size between BASELINE configs[0] and configs[1]: N synthetic 5 Mb genomes written
 as FASTA files, then FASTA directory -> database with N^2 comparisons through rundb.run_sourmash_hip.
 
-    python tools/config2_file.py [n_genomes=200] [length=5000000] [ingest=json|direct] [reps=2] [gz]
+    python tools/config2_file.py [n_genomes=200] [length=5000000] [ingest=json|direct|fastani|fastani-direct] [reps=2] [gz]
+(`fastani`: the same files through rundb.run_fastani_hip -- BASELINE configs[3] on files.)
 Prints the wall time of the run and of its parts (threaded FASTA front-end, device work, column files, SQLite, matrix cache).
 """
 import logging
@@ -48,7 +49,10 @@ with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         db = Path(tmp) / f"run{rep}.sqlite"
         t0 = time.perf_counter()
         timings = {}
-        run = rundb.run_sourmash_hip(fasta, db, ingest=ingest, timings=timings)
+        if ingest.startswith("fastani"):  # "fastani" (JSON column files imported) or "fastani-direct"
+            run = rundb.run_fastani_hip(fasta, db, timings=timings, ingest="direct" if ingest.endswith("direct") else "json")
+        else:
+            run = rundb.run_sourmash_hip(fasta, db, ingest=ingest, timings=timings)
         dt = time.perf_counter() - t0
         print(f"rep {rep} ({ingest}): files -> database in {dt:.2f} s for {n} genomes = {n * n / dt:.3e} pairs/s end to end; "
               + ", ".join(f"{k} {v:.2f}" for k, v in timings.items()) + f"; database {db.stat().st_size / 1e6:.0f} MB", flush=True)
