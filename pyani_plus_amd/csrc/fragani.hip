@@ -889,32 +889,37 @@ constexpr uint32_t kRefCapMax = 512;
 // sets how many of these latency-bound waves a CU keeps in flight.
 struct EvalShared {
   uint32_t *qh;        // [s_cap] the fragment's sketch, ascending
-  uint32_t *cnt;       // [s_cap + 64] counting-sort buckets over (query rank, is-match) / reference-only hashes per rank gap
+  uint32_t *cnt;       // [s_cap + 64] reference-only hashes per rank gap (cooperative evaluation of one over-long window);
+  uint32_t *tab;       //   the same memory: the bit tables of the windowed evaluation (eval_tab_words)
   uint32_t *matched;   // [kQMax / 32] bitset over query ranks (cooperative evaluation of one over-long window)
   uint32_t *hw;        // [kHitCap] window id of each staged hit
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
   uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
-  uint32_t *ent;       // [kRefCap + 4] the stretch in (rank, reference-only before match) order, one packed word each:
-                       //   bits 0-6 first lane (window start) that keeps the entry, 7-13 how many more lanes do,
-                       //   14-23 rank among the query hashes, 24 the hash is one of them
-  uint16_t *xe16;      // [64] per lane: where its window ends inside the stretch
   uint16_t *qt;        // [kQtBuckets] the fragment's sketch bucketed by the top bits of the hash: first rank (10 bits) | hashes in the bucket (6 bits)
 };
 constexpr uint32_t kQtBits = 9, kQtBuckets = 1u << kQtBits, kQtShift = 32u - kQtBits;
+// Bit tables of the windowed evaluation: one row per query rank r = the stretch positions (one bit each, kRefCap / 32
+// words) whose minimizer has rank <= r among the fragment's hashes.  Coarse rows stand at every kCoarse-th rank; the
+// fine rows cover kFineGroups coarse groups at a time, every rank of them.
+constexpr uint32_t kCoarseShift = 4, kCoarse = 1u << kCoarseShift;
+constexpr uint32_t kFineGroups = 2, kFineRows = kFineGroups * kCoarse + 1u;
+__host__ __device__ inline uint32_t eval_tab_words(uint32_t s_cap, uint32_t ref_cap) {
+  const uint32_t t = (s_cap / kCoarse + 1u + kFineRows) * (ref_cap / 16u), c = s_cap + 64u;  // coarse and fine rows of two halves
+  return ((t > c ? t : c) + 3u) & ~3u;
+}
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
-  return 4u * s_cap + 4u * (s_cap + 64u) + 4u * (kQMax / 32) + hit_cap * 6u + ref_cap * 2u + (ref_cap + 4u) * 4u + 128u + 2u * 512u;
+  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + hit_cap * 6u + ref_cap * 2u + 2u * kQtBuckets;
 }
 __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap, uint32_t kRefCap) {
   EvalShared sh;
   sh.qh = base;
-  sh.cnt = sh.qh + s_cap;
-  sh.matched = sh.cnt + s_cap + 64u;
+  sh.cnt = sh.qh + s_cap;  // s_cap is a multiple of 64: the tables start on a 16-byte boundary
+  sh.tab = sh.cnt;
+  sh.matched = sh.tab + eval_tab_words(s_cap, kRefCap);
   sh.hw = sh.matched + kQMax / 32;
   sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
-  sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are even: the 32-bit array below stays aligned (to 16 bytes)
-  sh.ent = reinterpret_cast<uint32_t *>(sh.ref_w + kRefCap);
-  sh.xe16 = reinterpret_cast<uint16_t *>(sh.ent + kRefCap + 4u);
-  sh.qt = sh.xe16 + 64;
+  sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are even: the 32-bit view of qt stays aligned
+  sh.qt = sh.ref_w + kRefCap;
   return sh;
 }
 
@@ -941,13 +946,19 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const int32_t *__restrict__ prev_same,
     const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride, unsigned long long *__restrict__ table,
-    uint32_t *__restrict__ run_g, uint32_t s_cap, uint32_t hit_cap) {
+    uint32_t *__restrict__ run_g, uint32_t s_cap, uint32_t hit_cap, uint32_t cut) {
   extern __shared__ uint32_t eval_lds[];
   const EvalShared sh = eval_carve(eval_lds, s_cap, hit_cap, kRefCap);
   const uint32_t lane = threadIdx.x;
-  (void)run_g;
   (void)vals;
   if (blockIdx.x >= n_segs) return;
+#define PA_CUT(k) do { if (cut == (k)) return; } while (0)
+#ifdef PA_MAP_STATS  // event counts of the mapping kernel in run_g[0 .. 15] (tools: -DPA_MAP_STATS, PA_FRAGANI_TRACE=1)
+#define PA_STAT(slot, v) do { if (lane == 0) atomicAdd(&run_g[slot], (uint32_t)(v)); } while (0)
+#else
+#define PA_STAT(slot, v) do { } while (0)
+  (void)run_g;
+#endif
   const uint32_t a0 = seg_a0[blockIdx.x];
   uint32_t nh = seg_nh[blockIdx.x];
   const uint32_t f = (uint32_t)(keys[a0] >> 44);
@@ -955,6 +966,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   if (s == 0) return;
   const uint32_t mh = tab_min_hits[s];
   if (nh < mh) return;  // chance matches with unrelated genomes: fewer seed hits than any L1 run needs
+  PA_STAT(0, 1);   // segments that reach L1
+  PA_STAT(1, nh);  // their seed hits
   // segments of up to kHitCap hits are staged in LDS; larger ones (repeats: rRNA operons, IS elements)
   // are read in place from the sorted hit arrays
   // contigs are kept relative to the reference genome's first one, window ids of the query as 16 bits: the
@@ -1088,6 +1101,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     return shared;
   };
 
+  PA_CUT(1);  // staging, sort, bucket table
   int32_t best_shared = -1;
   uint32_t best_c = 0xffffffffu, best_p = 0;
   uint32_t half0 = 1;
@@ -1101,6 +1115,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // what lies in its own window -- a union walk that stops at the s-th element.  Starts whose seed-hit count
   // cannot reach the best so far are never evaluated, which leaves one or two groups per candidate.
   auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) {
+    PA_CUT(2);  // L1 only
     const uint32_t m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
     // first start: through the bucket index, the bucket itself searched by the whole wave (two memory round trips
@@ -1139,6 +1154,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     if (b_hi == 0xffffffffu) b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + 1u);  // a range of more than 512 starts
     if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
     if (b_lo >= b_hi) return;
+    PA_STAT(2, 1);  // candidates with starts
     int32_t c_best = -1;
     uint32_t c_first = 0, c_last = 0;
     const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
@@ -1149,6 +1165,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
     // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, ce + count_windows)
     const uint32_t h_lo = hit_lower_bound(0, nh, c, cs), h_hi = hit_lower_bound(h_lo, nh, c, ce + count_windows);
+    PA_CUT(3);  // candidate set-up
     const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
       const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
@@ -1165,7 +1182,11 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         ub = (int32_t)(hit_lower_bound_w(i0, h_hi, wp + count_windows) - i0);
       }
       bool pending = ub >= bar;
+      if (cut == 4) pending = false;  // seed-hit bounds of every group
+      PA_STAT(3, 1);                              // groups of 64 starts
+      PA_STAT(4, __popcll(__ballot(pending)));    // starts that pass the seed-hit bound
       while (__any(pending)) {
+        PA_STAT(5, 1);  // rounds
         const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
         const uint32_t base = sb + first_lane;  // stretch = minimizers [base, base + n)
         const uint32_t n = min(m1 - base, kRefCap);
@@ -1179,12 +1200,12 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
           const bool in = x < n;
-          hh[q] = in ? mini_hash[base + x] : 0u;
-          pp[q] = in ? prev_same[base + x] : -1;
-          if (in) {
-            const uint32_t dw = mini_wpos[base + x] - wbase;
-            sh.ref_w[x] = (uint16_t)(dw > 0xfffeu ? 0xffffu : dw);  // far beyond any window of this stretch
-          }
+          const uint32_t t = base + min(x, n - 1u);  // loads without a branch: beyond the stretch its last entry, discarded
+          const uint32_t h = mini_hash[t], dw = mini_wpos[t] - wbase;
+          const int32_t pv = prev_same[t];
+          hh[q] = in ? h : 0u;
+          pp[q] = in ? pv : -1;
+          sh.ref_w[x] = (uint16_t)((dw > 0xfffeu || !in) ? 0xffffu : dw);  // 0xffff: far beyond any window of this stretch
         }
         __syncthreads();
         // per lane: where its window ends inside the stretch and whether the stretch holds all of it.  Lanes in front
@@ -1203,24 +1224,17 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         // only the part of the stretch that some window of this round reaches is ranked, sorted and walked
         uint32_t n_use = 0;
         {
-          uint32_t v = (pending && covered) ? xe : 0u;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-          n_use = v;
+          n_use = pa_dev::wave_max_dpp((pending && covered) ? xe : 0u);
         }
         xe = min(xe, n_use);
-        // ranks among the fragment's hashes and the lanes that keep each minimizer; buckets of the counting sort
-        const uint32_t n_keys = 2u * (s + 1u);
-        uint16_t *bucket = reinterpret_cast<uint16_t *>(sh.cnt);  // 2 (s + 1) 16-bit counters in the 4 (s_cap + 64) bytes
-        for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;
-        __syncthreads();
-        uint32_t key[kPer], packed_ent[kPer];
-        // ranks of the lane's kPer minimizers among the fragment's hashes, and the first lane whose window still holds
-        // each of them: the binary searches advance together, one halving step for all of them at a time, so the LDS
-        // reads of a step are in flight at once
-        uint32_t rank[kPer], l0[kPer];
+        PA_CUT(5);  // stretch loads and window ends
+        PA_STAT(6, n_use);                                      // stretch entries ranked
+        PA_STAT(7, __popcll(__ballot(pending && covered)));    // windows evaluated in the round
+        // ranks of the lane's kPer minimizers among the fragment's hashes: the binary searches advance together, one
+        // halving step for all of them at a time, so the LDS reads of a step are in flight at once
+        uint32_t rank[kPer];
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) { rank[q] = 0; l0[q] = 0; }
+        for (int q = 0; q < kPer; ++q) rank[q] = 0;
         if (qsteps != 0xffffffffu) {
           uint32_t hi_r[kPer];
 #pragma unroll
@@ -1237,124 +1251,179 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             }
           }
         } else {
-        for (uint32_t half = half0; half > 0; half >>= 1) {  // half0 = largest power of two <= s: positions 0 .. 2*half0 - 1 >= s
+          for (uint32_t half = half0; half > 0; half >>= 1) {  // half0 = largest power of two <= s: positions 0 .. 2*half0 - 1 >= s
 #pragma unroll
-          for (int q = 0; q < kPer; ++q) {
-            const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
-            if ((uint32_t)q * 64u + lane < n_use && idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
+            for (int q = 0; q < kPer; ++q) {
+              const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
+              if ((uint32_t)q * 64u + lane < n_use && idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
+            }
           }
         }
-        }
-        // l0[x] = number of lanes whose window ends at or before stretch position x: a histogram of the window ends
-        // (one LDS atomic per lane; it lives where the sorted entries go later) and a running sum over x, instead of a
-        // six-step search per minimizer
-        {
-          uint16_t *ends = reinterpret_cast<uint16_t *>(sh.ent);
-          uint32_t *ends32 = sh.ent;
-          for (uint32_t i = lane; i < n_use / 2u + 1u; i += 64) ends32[i] = 0;
-          __syncthreads();
-          if (xe < n_use) atomicAdd_u16(ends, xe);  // an end at n_use is at or before no position
-          __syncthreads();
-          uint32_t carry_l = 0;
-#pragma unroll
-          for (int q = 0; q < kPer; ++q) {
-            const uint32_t x = (uint32_t)q * 64u + lane;
-            const uint32_t v = x < n_use ? (uint32_t)ends[x] : 0u;
-            const uint32_t incl = pa_dev::wave_incl_scan_dpp(v);
-            l0[q] = carry_l + incl;
-            carry_l += (uint32_t)__shfl((int)incl, 63, 64);
-          }
-          __syncthreads();
-        }
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-          const uint32_t x = (uint32_t)q * 64u + lane;
-          key[q] = 0;
-          packed_ent[q] = 0;
-          if (x < n_use) {
-            const uint32_t r = rank[q];
-            const bool is_match = r < s && sh.qh[r] == hh[q];
-            // kept by lane l iff its window holds the entry (l >= l0, start at or before x) as the first occurrence of
-            // its hash (the previous one lies before the start)
-            const uint32_t prev1 = pp[q] >= (int32_t)base ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
-            uint32_t lane_lo = max(l0[q], prev1 + first_lane), lane_hi = min(63u, x + first_lane);
-            uint32_t span = 0;
-            if (lane_lo > lane_hi) lane_lo = 64u; else span = lane_hi - lane_lo;
-            key[q] = 2u * r + (is_match ? 1u : 0u);
-            packed_ent[q] = lane_lo | (span << 7) | (r << 14) | (is_match ? 1u << 24 : 0u);
-          }
-        }
-        // stable order is not needed: entries of one key are interchangeable in the union walk
-        uint32_t slot[kPer];
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-          const uint32_t x = (uint32_t)q * 64u + lane;
-          slot[q] = 0;
-          if (x < n_use) slot[q] = atomicAdd_u16(bucket, key[q]);
-        }
-        __syncthreads();
-        {  // exclusive scan of the buckets (n_keys <= 1026): each lane owns a run of them
-          const uint32_t per = (n_keys + 63u) / 64u;
-          uint32_t local = 0;
-          for (uint32_t q = 0; q < per; ++q) { const uint32_t i = lane * per + q; if (i < n_keys) local += bucket[i]; }
-          uint32_t run = wave_excl_scan(local, lane);
-          for (uint32_t q = 0; q < per; ++q) {
-            const uint32_t i = lane * per + q;
-            if (i < n_keys) { const uint32_t v = bucket[i]; bucket[i] = (uint16_t)run; run += v; }
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-          const uint32_t x = (uint32_t)q * 64u + lane;
-          if (x < n_use) sh.ent[bucket[key[q]] + slot[q]] = packed_ent[q];
-        }
-        if (lane < 4) sh.ent[n_use + lane] = 64u;  // padding of the last 16-byte read: an entry no lane keeps
-        __syncthreads();
+        PA_CUT(6);  // ranks
         const bool first_uncovered = __shfl((int)covered, (int)first_lane, 64) == 0;
         uint32_t f_shared = 0;
         bool done_now = pending && covered;
         if (first_uncovered) {
+          PA_STAT(9, 1);  // cooperative evaluations
           // the first pending window alone is longer than the stretch: the whole wave takes it from HBM
           const uint32_t wp0 = __shfl(wp, (int)first_lane, 64);
           const uint32_t e0 = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, wp0 + count_windows);
           __syncthreads();
-          for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;  // sh.cnt back to zero for the cooperative form
+          for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
           __syncthreads();
           const uint32_t v = eval_window_coop(base, e0);
           if (lane == first_lane) { f_shared = v; done_now = true; }
         } else {
-          // union walk: the stretch in (rank, reference-only first) order; a lane keeps what lies in its window and is
-          // the first occurrence of its hash there.  k = reference-only hashes taken so far; an entry of rank r sits at
-          // position r + k of the union and counts while that is < s.
-          uint32_t k = 0;
-          bool walking = done_now;
-          const uint4 *ent4 = reinterpret_cast<const uint4 *>(sh.ent);
-          for (uint32_t j = 0; j < n_use && __any(walking); j += 4) {
-            const uint4 e4 = ent4[j >> 2];  // the same four entries for every lane: one broadcast read
-            const uint32_t es[4] = {e4.x, e4.y, e4.z, e4.w};
+          // Every window of the round at once, one lane each, without ordering the stretch.  A window holds the stretch
+          // positions [xs, xe) minus later occurrences of a hash it already holds: a bit mask W over the positions.  With
+          // R_r / M_r = the positions of reference-only / matching minimizers of rank <= r among the fragment's hashes, the
+          // reference-only minimizers below the fragment's hash of rank r number c(r) = |R_r & W|; that hash lies in the
+          // bottom-s of the union iff r + c(r) < s, which holds for r < T and no other (r + c(r) grows strictly), and the
+          // window shares |M_(T-1) & W| minimizers.  T comes from two searches per lane: over the rows at every kCoarse-th
+          // rank, then over all ranks of the coarse group that holds it.  A row is R_r followed by M_r.
+          constexpr uint32_t kW = kRefCap / 32u;  // words per half row; stretch position q * 64 + lane is bit (lane & 31) of word 2 q + (lane >> 5)
+          constexpr uint32_t kRow = 2u * kW;
+          const uint32_t n_coarse = s / kCoarse + 1u;  // the last row stands at a rank >= s: r + c(r) >= s holds there
+          uint32_t *bc = sh.tab, *bf = sh.tab + n_coarse * kRow;
+          {
+            uint4 *t4 = reinterpret_cast<uint4 *>(sh.tab);
+            for (uint32_t i = lane; i < n_coarse * kRow / 4u; i += 64) t4[i] = make_uint4(0u, 0u, 0u, 0u);  // kRow is a multiple of 4
+          }
+          uint16_t *prev16 = sh.ref_w;  // [kRefCap] the window ends are known: the array now takes the duplicate links
+          uint32_t dup_q = 0, col[kPer];  // col: word of the entry's bit inside a row (the matching half comes second)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const uint32_t e = es[q], r = (e >> 14) & 0x3ffu;
-              const bool mine = walking && lane - (e & 0x7fu) <= ((e >> 7) & 0x7fu);  // one of the lanes that keep the entry
-              const bool fits = r + k < s;
-              f_shared += (mine && fits && (e & (1u << 24))) ? 1u : 0u;
-              k += (mine && fits && !(e & (1u << 24))) ? 1u : 0u;
-              walking = walking && !(mine && !fits);
-            }
+          for (int q = 0; q < kPer; ++q) {
+            const uint32_t x = (uint32_t)q * 64u + lane;
+            const uint32_t r = rank[q];
+            const bool valid = (x < n_use) & (r < s);  // inside the used part and below some hash of the fragment: in the rows from r on
+            const bool is_match = valid & (sh.qh[min(r, s - 1u)] == hh[q]);
+            col[q] = 2u * (uint32_t)q + (lane >> 5) + (is_match ? kW : 0u);
+            // the same hash earlier in the stretch (position + 1): a window keeps this occurrence only if it starts after that one
+            const uint32_t p1 = (x < n_use && pp[q] >= (int32_t)base) ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
+            prev16[x] = (uint16_t)p1;
+            dup_q |= (p1 ? 1u : 0u) << q;
+            rank[q] = valid ? r : 0xffffffffu;
+          }
+          const bool any_dup = __any(dup_q != 0u);
+          __syncthreads();
+#pragma unroll
+          for (int q = 0; q < kPer; ++q) {  // no branch: entries that are in no row add nothing to a word of the (not yet filled) fine rows
+            const bool valid = rank[q] != 0xffffffffu;
+            atomicOr(valid ? &bc[(rank[q] >> kCoarseShift) * kRow + col[q]] : &bf[lane], valid ? 1u << (lane & 31u) : 0u);
           }
           __syncthreads();
-          for (uint32_t i = lane; i < n_keys; i += 64) bucket[i] = 0;  // leave sh.cnt clean
+          // rows become prefixes: row g |= rows below it.  Lane = (pair of columns, run of rows); the runs of one column
+          // pair are chained through the totals of the runs before
+          auto prefix_or_rows = [&](uint32_t *rows, uint32_t n_rows) {
+            constexpr uint32_t kRuns = 64u / kW;
+            uint2 *rows2 = reinterpret_cast<uint2 *>(rows);  // kW column pairs per row
+            const uint32_t cp = lane % kW, run = lane / kW;
+            const uint32_t per = (n_rows + kRuns - 1u) / kRuns;
+            const uint32_t r0 = min(n_rows, run * per), r1 = run < kRuns ? min(n_rows, r0 + per) : r0;
+            uint2 acc = make_uint2(0u, 0u);
+            for (uint32_t r = r0; r < r1; ++r) { const uint2 v = rows2[r * kW + cp]; acc.x |= v.x; acc.y |= v.y; }
+            uint2 before = make_uint2(0u, 0u);
+#pragma unroll
+            for (uint32_t j = 1; j < kRuns; ++j) {
+              const int from = (int)(lane >= kW * j ? lane - kW * j : lane);
+              const uint32_t vx = (uint32_t)__shfl((int)acc.x, from, 64), vy = (uint32_t)__shfl((int)acc.y, from, 64);
+              if (run >= j) { before.x |= vx; before.y |= vy; }
+            }
+            for (uint32_t r = r0; r < r1; ++r) {
+              const uint2 v = rows2[r * kW + cp];
+              before.x |= v.x; before.y |= v.y;
+              rows2[r * kW + cp] = before;
+            }
+          };
+          prefix_or_rows(bc, n_coarse);
+          PA_CUT(7);  // coarse table
+          // the lane's window as a mask over the stretch positions
+          const bool walking = done_now;
+          const uint32_t xs = walking ? xb : 0u, xw = walking ? xe : 0u;
+          uint32_t wm[kW];
+#pragma unroll
+          for (uint32_t w = 0; w < kW; ++w) {
+            // bits [lo, hi) of the word, lo and hi clamped to 0 .. 32
+            const int32_t lo = min(max((int32_t)xs - (int32_t)(32u * w), 0), 32), hi = min(max((int32_t)xw - (int32_t)(32u * w), 0), 32);
+            const uint32_t below_hi = hi >= 32 ? 0xffffffffu : (1u << hi) - 1u, below_lo = lo >= 32 ? 0xffffffffu : (1u << lo) - 1u;
+            wm[w] = below_hi & ~below_lo;
+          }
+          if (any_dup) {
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+              for (uint64_t dmask = __ballot((dup_q >> q) & 1u); dmask; dmask &= dmask - 1) {
+                const uint32_t bit = (uint32_t)__builtin_ctzll(dmask);
+                if ((uint32_t)prev16[(uint32_t)q * 64u + bit] > xs) {  // the earlier occurrence lies inside this lane's window
+                  if (bit < 32u) wm[2 * q] &= ~(1u << bit); else wm[2 * q + 1] &= ~(1u << (bit - 32u));
+                }
+              }
+            }
+          }
+          auto count_in = [&](const uint32_t *half_row) -> uint32_t {
+            const uint2 *row2 = reinterpret_cast<const uint2 *>(half_row);  // half rows start on 8-byte boundaries (kW is even)
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < kW / 2u; ++w) {
+              const uint2 v = row2[w];
+              c += __popc(v.x & wm[2 * w]) + __popc(v.y & wm[2 * w + 1]);
+            }
+            return c;
+          };
+          __syncthreads();
+          // coarse: the first group g whose last rank r = kCoarse g + kCoarse - 1 has r + c(r) >= s (the last row always has)
+          uint32_t g_lo = 0, g_hi = n_coarse - 1u;
+          for (uint32_t span = n_coarse - 1u; span > 0u; span >>= 1) {  // as many halvings as the widest range needs
+            const uint32_t mid = (g_lo + g_hi) >> 1;
+            const bool ge = mid * kCoarse + (kCoarse - 1u) + count_in(bc + mid * kRow) >= s;
+            const bool open = g_lo < g_hi;
+            g_hi = (open & ge) ? mid : g_hi;
+            g_lo = (open & !ge) ? mid + 1u : g_lo;
+          }
+          PA_CUT(8);  // window masks, coarse search
+          // fine: the groups of the lanes lie next to each other as a rule; kFineGroups of them per pass
+          bool unresolved = walking;
+          while (__any(unresolved)) {
+            PA_STAT(8, 1);  // fine passes
+            const uint32_t g_cur = pa_dev::wave_min_dpp(unresolved ? g_lo : 0xffffffffu);
+            const uint32_t band0 = g_cur * kCoarse;  // row t of the band: ranks <= band0 + t - 1; row 0 is the coarse row below
+            __syncthreads();
+            {
+              uint4 *f4 = reinterpret_cast<uint4 *>(bf);  // bf starts on a 16-byte boundary: kRow is a multiple of 4 words
+              const uint4 *below = reinterpret_cast<const uint4 *>(bc + (g_cur ? g_cur - 1u : 0u) * kRow);
+              for (uint32_t i = lane; i < kFineRows * kRow / 4u; i += 64)
+                f4[i] = (i < kRow / 4u && g_cur > 0u) ? below[i] : make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+              const uint32_t t = rank[q] - band0;  // wraps to something huge below the band
+              const bool valid = (rank[q] != 0xffffffffu) & (t < kFineRows - 1u);
+              atomicOr(valid ? &bf[(t + 1u) * kRow + col[q]] : &bc[lane], valid ? 1u << (lane & 31u) : 0u);
+            }
+            __syncthreads();
+            prefix_or_rows(bf, kFineRows);
+            __syncthreads();
+            const bool now = unresolved && g_lo - g_cur < kFineGroups;
+            // first rank r of the lane's group with r + c(r) >= s: the group's last rank has it
+            uint32_t r_lo = g_lo * kCoarse, r_hi = r_lo + kCoarse - 1u;
+            if (!now) r_lo = r_hi = band0;
+            for (uint32_t step = 0; step < kCoarseShift; ++step) {
+              const uint32_t mid = (r_lo + r_hi) >> 1;
+              const bool ge = mid + count_in(bf + (mid - band0 + 1u) * kRow) >= s;
+              const bool open = r_lo < r_hi;
+              r_hi = (open & ge) ? mid : r_hi;
+              r_lo = (open & !ge) ? mid + 1u : r_lo;
+            }
+            const uint32_t c = count_in(bf + (r_lo - band0) * kRow + kW);  // matches of rank < T = r_lo
+            if (now) { f_shared = c; unresolved = false; }
+          }
           __syncthreads();
         }
         // fold the evaluated starts into the candidate's optimum: most shared; first and last position of it
         const uint64_t dm = __ballot(done_now);
         int32_t group_best = -1;
         {
-          uint32_t v = done_now ? f_shared + 1u : 0u;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-          group_best = (int32_t)v - 1;
+          group_best = (int32_t)pa_dev::wave_max_dpp(done_now ? f_shared + 1u : 0u) - 1;
         }
         if (dm && group_best >= c_best) {
           const uint64_t top = __ballot(done_now && (int32_t)f_shared == group_best);
@@ -1967,6 +2036,11 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
       // stretch capacity: the expected minimizers of one window (density 2 / (w + 1)) plus a third, in steps of 64
       const uint32_t per_window = (uint32_t)(2.0 * count_windows / (w + 1.0));
       const uint32_t ref_cap = std::min<uint32_t>(kRefCapMax, std::max<uint32_t>(256u, (per_window * 4u / 3u + 63u) / 64u * 64u));
+#ifdef PA_MAP_STATS
+      PA_HIP(hipMemsetAsync(W.run_g.p, 0, 64, c->stream));
+#endif
+      const char *cut_env = getenv("PA_MAP_CUT");  // tools: the mapping kernel cut short after a phase (timing by difference)
+      const uint32_t map_cut = cut_env ? (uint32_t)atoi(cut_env) : 0xffffffffu;
       auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap) {
         if (count == 0) return;
 #define PA_MAP_CASE(CAP)                                                                                                  \
@@ -1978,7 +2052,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),                                  \
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),      \
                        W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), total_bins, \
-                       W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap);                          \
+                       W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap, map_cut);                 \
     break;
         switch (ref_cap) {
           PA_MAP_CASE(256) PA_MAP_CASE(320) PA_MAP_CASE(384) PA_MAP_CASE(448)
@@ -2007,6 +2081,15 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
       } else {
         launch_map(W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, (uint32_t)kHitCap);
       }
+#ifdef PA_MAP_STATS
+      if (trace) {
+        uint32_t st[16];
+        PA_HIP(hipMemcpy(st, W.run_g.p, 64, hipMemcpyDeviceToHost));
+        fprintf(stderr, "pa_fragani: map stats: %u segments at L1 with %u hits, %u candidates, %u groups, %u starts past the bound, "
+                        "%u rounds, %u stretch entries, %u windows evaluated, %u fine passes, %u cooperative\n",
+                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9]);
+      }
+#endif
     }
     PA_TRY(W.matched.reserve((uint64_t)nq * n_genomes * 4));
     PA_TRY(W.ident_sum.reserve((uint64_t)nq * n_genomes * 8));

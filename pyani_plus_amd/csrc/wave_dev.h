@@ -34,6 +34,17 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
          (uint32_t)__builtin_amdgcn_readlane((int)v, 32) + (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
+// maximum over the 64 lanes, uniform result (unsigned)
+__device__ __forceinline__ uint32_t wave_max_dpp(uint32_t v) {
+  v = max(v, dpp_or_zero<kDppQuadSwap1>(v));
+  v = max(v, dpp_or_zero<kDppQuadSwap2>(v));
+  v = max(v, dpp_or_zero<kDppRowHalfMirror>(v));
+  v = max(v, dpp_or_zero<kDppRowMirror>(v));  // every lane: the maximum of its row of 16
+  return max(max((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+             max((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+}
+__device__ __forceinline__ uint32_t wave_min_dpp(uint32_t v) { return ~wave_max_dpp(~v); }
+
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
   uint32_t x = v;

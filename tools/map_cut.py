@@ -1,0 +1,37 @@
+"""Where the time of map_segments_kernel goes: the kernel cut short after each phase (PA_MAP_CUT), timed by difference.
+
+    python tools/map_cut.py [n_genomes=1000]
+"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from pyani_plus_amd.engine import HipEngine  # noqa: E402
+from pyani_plus_amd.synth import synth_arena_torch  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+length, k, frag = 5_000_000, 16, 3000
+eng = HipEngine(0)
+arena = synth_arena_torch(eng, n, length)
+starts = arena.genome_start[:-1].copy()
+lens = np.full(n, length, dtype=np.uint32)
+genome = np.arange(n, dtype=np.uint32)
+eng.prof_enable(True)
+names = {1: "staging + sort + bucket table", 2: "L1", 3: "candidate set-up", 4: "seed-hit bounds per group", 5: "stretch loads + window ends",
+         6: "ranks", 7: "coarse table", 8: "window masks + coarse search", 9: "fine passes (whole kernel)"}
+prev = 0.0
+for cut in [9, 9, 1, 2, 3, 4, 5, 6, 7, 8, 9]:
+    os.environ["PA_MAP_CUT"] = str(cut)
+    eng.prof_reset()
+    t0 = time.perf_counter()
+    eng.fragani(arena, starts, lens, genome, k, frag)
+    dt = time.perf_counter() - t0
+    ms = eng.prof_get()["frag_map"][0]
+    print(f"cut {cut}: frag_map {ms:8.1f} ms  (+{ms - prev:7.1f})  {names[cut]}   [run {dt:.3f} s]", flush=True)
+    prev = ms if cut != 9 or prev else prev
+    if cut == 9:
+        prev = 0.0
