@@ -935,7 +935,9 @@ __device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t i
 #ifndef PA_MAP_WAVES
 #define PA_MAP_WAVES 6  // waves per SIMD the register allocation aims at (80 VGPRs); 5 allows 96
 #endif
-template <uint32_t kRefCap>
+// kAllStaged: the launch holds only segments of at most hit_cap hits (the bucketed path's list of short segments), so
+// every access to a hit is an LDS read and the choice is not made per access.
+template <uint32_t kRefCap, bool kAllStaged>
 __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_a0,
     const uint32_t *__restrict__ seg_nh, uint32_t n_segs, bool presorted, const uint32_t *__restrict__ contig_genome,
@@ -973,7 +975,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // contigs are kept relative to the reference genome's first one, window ids of the query as 16 bits: the
   // host takes this kernel only when both fit
   const uint32_t hc_base = genome_first_contig[contig_genome[(uint32_t)(keys[a0] >> 24) & 0xfffffu]];
-  const bool staged = nh <= hit_cap;  // hit_cap is kHitCapSmall or kHitCap, a power of two
+  const bool staged = kAllStaged || nh <= hit_cap;  // hit_cap is kHitCapSmall or kHitCap, a power of two
   auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] : (uint32_t)(keys[a0 + i] & 0xffffffu); };
   auto HC = [&](uint32_t i) -> uint32_t {
     return staged ? hc_base + sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu;
@@ -1035,22 +1037,32 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   }
   __syncthreads();
 
-  // first hit index in [lo, hi) whose (contig, window id) is >= (c, w): the hits are in (contig, window) order
-  auto hit_lower_bound = [&](uint32_t lo, uint32_t hi, uint32_t c, uint32_t w) -> uint32_t {
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      const uint32_t mc = HC(mid);
-      if (mc < c || (mc == c && HW(mid) < w)) lo = mid + 1; else hi = mid;
+  // number of hits whose (contig, window id) is below (c, w0) and below (c, w1) -- the hits are in that order, so these
+  // are the bounds of the hits on contig c with window id in [w0, w1).  Uniform arguments: the wave counts side by
+  // side, every lane its own hits, instead of searching (no chain of dependent reads).
+  auto hit_range = [&](uint32_t c, uint32_t w0, uint32_t w1, uint32_t &below0, uint32_t &below1) {
+    const uint64_t k0 = ((uint64_t)c << 32) | w0, k1 = ((uint64_t)c << 32) | w1;
+    uint32_t n0 = 0, n1 = 0;
+    for (uint32_t chunk = 0; chunk < nh; chunk += 64) {
+      const uint32_t i = min(chunk + lane, nh - 1u);
+      const uint64_t k = ((uint64_t)HC(i) << 32) | HW(i);
+      const bool in = chunk + lane < nh;
+      n0 += (uint32_t)__popcll(__ballot(in & (k < k0)));
+      n1 += (uint32_t)__popcll(__ballot(in & (k < k1)));
     }
-    return lo;
+    below0 = n0;
+    below1 = n1;
   };
-  // the same inside an index range that lies on one contig: window ids only
-  auto hit_lower_bound_w = [&](uint32_t lo, uint32_t hi, uint32_t w) -> uint32_t {
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (HW(mid) < w) lo = mid + 1; else hi = mid;
+  // first hit index in [lo, lo + 2^steps) and below hi whose window id is >= w, inside an index range that lies on one
+  // contig; `steps` is uniform (the longest range any lane has), every lane takes that many halvings without a branch
+  auto hit_lower_bound_w = [&](uint32_t lo, uint32_t hi, uint32_t w, uint32_t steps) -> uint32_t {
+    uint32_t pos = lo;  // hits [lo, pos) are below w
+    for (uint32_t step = steps ? 1u << (steps - 1u) : 0u; step > 0u; step >>= 1) {
+      const uint32_t idx = pos + step;
+      const bool ok = (idx <= hi) & (HW(min(idx, nh) - 1u) < w);
+      pos = ok ? idx : pos;
     }
-    return lo;
+    return pos;
   };
 
   // One over-long window (more than kRefCap minimizers: low-complexity or N-riddled sequence) straight from HBM,
@@ -1164,7 +1176,9 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     // first per group (seed hits between its first start and the end of its last window), then per start.
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
     // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, ce + count_windows)
-    const uint32_t h_lo = hit_lower_bound(0, nh, c, cs), h_hi = hit_lower_bound(h_lo, nh, c, ce + count_windows);
+    uint32_t h_lo, h_hi;
+    hit_range(c, cs, ce + count_windows, h_lo, h_hi);
+    const uint32_t h_steps = 32u - (uint32_t)__builtin_clz(h_hi - h_lo + 1u);  // 2^steps > the number of hits: enough halvings
     PA_CUT(3);  // candidate set-up
     const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
@@ -1175,12 +1189,16 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       const uint32_t wp = has ? mini_wpos[b] : 0u;
       int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a start must reach to matter (ties matter)
       if (bar < floor_bar) bar = floor_bar;
-      // seed hits inside the start's window: every occurrence of every query hash is a hit, so no window shares more
-      int32_t ub = -1;
-      if (has) {
-        const uint32_t i0 = hit_lower_bound_w(h_lo, h_hi, wp);
-        ub = (int32_t)(hit_lower_bound_w(i0, h_hi, wp + count_windows) - i0);
+      // A window with `bar` of the candidate's hits starts after (the bar-th hit - count_windows) and not after the
+      // bar-th hit from the end: groups without such a start are passed over before any counting
+      if (bar > 0) {
+        if ((uint32_t)bar > h_hi - h_lo) break;  // no window of this candidate holds that many (the bar only rises)
+        const uint32_t w_after = HW(h_lo + (uint32_t)bar - 1u), w_upto = HW(h_hi - (uint32_t)bar);
+        if (!__any(has && wp + count_windows > w_after && wp <= w_upto)) continue;
       }
+      // seed hits inside the start's window: every occurrence of every query hash is a hit, so no window shares more
+      const uint32_t i0 = hit_lower_bound_w(h_lo, h_hi, wp, h_steps);
+      const int32_t ub = has ? (int32_t)(hit_lower_bound_w(i0, h_hi, wp + count_windows, h_steps) - i0) : -1;
       bool pending = ub >= bar;
       if (cut == 4) pending = false;  // seed-hit bounds of every group
       PA_STAT(3, 1);                              // groups of 64 starts
@@ -2041,11 +2059,12 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
 #endif
       const char *cut_env = getenv("PA_MAP_CUT");  // tools: the mapping kernel cut short after a phase (timing by difference)
       const uint32_t map_cut = cut_env ? (uint32_t)atoi(cut_env) : 0xffffffffu;
-      auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap) {
+      auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap, auto all_staged) {
         if (count == 0) return;
+        constexpr bool kAll = decltype(all_staged)::value;
 #define PA_MAP_CASE(CAP)                                                                                                  \
   case CAP:                                                                                                               \
-    hipLaunchKernelGGL((map_segments_kernel<CAP>), dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap, CAP), c->stream,  \
+    hipLaunchKernelGGL((map_segments_kernel<CAP, kAll>), dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap, CAP), c->stream,  \
                        hk[hw], hv[hw], list_a0, list_nh, count, presorted, W.contig_genome.as<uint32_t>(),                 \
                        W.genome_first_contig.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_s.as<uint32_t>(),                \
                        W.frag_genome_local.as<uint32_t>(), frag_len, count_windows, W.tab_min_hits.as<uint32_t>(),         \
@@ -2075,11 +2094,11 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
           if (trace)
             fprintf(stderr, "pa_fragani: genomes %u..%u: %u fragments, %llu seed hits, %u + %u listed segments, %u left "
                             "after the tiny-segment filter\n", g0, g1, nf, (unsigned long long)n_hits, n_keep, n_large, n_small);
-          launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall);
+          launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall, std::true_type{});
         }
-        launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, n_large, (uint32_t)kHitCap);
+        launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, n_large, (uint32_t)kHitCap, std::false_type{});
       } else {
-        launch_map(W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, (uint32_t)kHitCap);
+        launch_map(W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, (uint32_t)kHitCap, std::false_type{});
       }
 #ifdef PA_MAP_STATS
       if (trace) {
