@@ -892,6 +892,7 @@ struct EvalShared {
   uint32_t *cnt;       // [s_cap + 64] reference-only hashes per rank gap (cooperative evaluation of one over-long window);
   uint32_t *tab;       //   the same memory: the bit tables of the windowed evaluation (eval_tab_words)
   uint32_t *matched;   // [kQMax / 32] bitset over query ranks (cooperative evaluation of one over-long window)
+  uint32_t *cand;      // [4 * 8] candidates of the L1 scan waiting for their evaluation: contig, first and last start, first hit
   uint32_t *hw;        // [kHitCap] window id of each staged hit
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
   uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
@@ -908,7 +909,7 @@ __host__ __device__ inline uint32_t eval_tab_words(uint32_t s_cap, uint32_t ref_
   return ((t > c ? t : c) + 3u) & ~3u;
 }
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
-  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + hit_cap * 6u + ref_cap * 2u + 2u * kQtBuckets;
+  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + hit_cap * 6u + ref_cap * 2u + 2u * kQtBuckets;
 }
 __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap, uint32_t kRefCap) {
   EvalShared sh;
@@ -916,7 +917,8 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   sh.cnt = sh.qh + s_cap;  // s_cap is a multiple of 64: the tables start on a 16-byte boundary
   sh.tab = sh.cnt;
   sh.matched = sh.tab + eval_tab_words(s_cap, kRefCap);
-  sh.hw = sh.matched + kQMax / 32;
+  sh.cand = sh.matched + kQMax / 32;  // 16 words after the tables: a 16-byte boundary
+  sh.hw = sh.cand + 32;
   sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
   sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are even: the 32-bit view of qt stays aligned
   sh.qt = sh.ref_w + kRefCap;
@@ -931,9 +933,72 @@ __device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t i
   return (idx & 1u) ? (old >> 16) : (old & 0xffffu);
 }
 
+// A segment's hits ordered by (contig, window id) in registers: E keys per lane, element e = lane * E + q, bitonic
+// network over 64 E elements.  Strides of E and more exchange between lanes (two ds_bpermute per key, no LDS memory,
+// no barrier), the strides below E between the registers of a lane.  Missing elements are keys above any real one.
+template <int E, int J>
+__device__ __forceinline__ void bitonic_inside_lane(uint64_t (&k)[E], uint32_t e0, uint32_t span) {
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    if ((q & J) == 0) {
+      const bool asc = ((e0 + (uint32_t)q) & span) == 0u;
+      const uint64_t a = k[q], b = k[q | J];
+      const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+      k[q] = asc ? lo : hi;
+      k[q | J] = asc ? hi : lo;
+    }
+  }
+}
+template <int E>
+__device__ __forceinline__ void bitonic_sort_lanes(uint64_t (&k)[E], uint32_t lane) {
+  const uint32_t e0 = lane * (uint32_t)E;
+  for (uint32_t span = 2; span <= 64u * (uint32_t)E; span <<= 1) {
+    for (uint32_t j = span >> 1; j > 0; j >>= 1) {
+      if (j >= (uint32_t)E) {
+        const uint32_t lj = j / (uint32_t)E;
+        const int partner = (int)(lane ^ lj);
+        const bool lower = (lane & lj) == 0u;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const uint64_t other = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(k[q] >> 32), partner, 64) << 32) |
+                                 (uint32_t)__shfl((int)(uint32_t)k[q], partner, 64);
+          const bool take_min = lower == (((e0 + (uint32_t)q) & span) == 0u);
+          k[q] = ((other < k[q]) == take_min) ? other : k[q];
+        }
+      } else if (E > 4 && j == 4u) {
+        bitonic_inside_lane<E, (E > 4 ? 4 : 1)>(k, e0, span);
+      } else if (E > 2 && j == 2u) {
+        bitonic_inside_lane<E, (E > 2 ? 2 : 1)>(k, e0, span);
+      } else if (E > 1) {
+        bitonic_inside_lane<E, 1>(k, e0, span);
+      }
+    }
+  }
+}
+// the segment's hits from the hit array into LDS, in order: window id and contig (relative to the genome's first)
+template <int E>
+__device__ __forceinline__ void stage_hits_sorted(const uint64_t *__restrict__ seg_keys, uint32_t nh, uint32_t hc_base,
+                                                  uint32_t lane, uint32_t *hw, uint16_t *hc) {
+  uint64_t k[E];
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
+    k[q] = e < nh ? (seg_keys[e] & 0xfffffffffffULL) : ~0ULL;  // (contig, window id): the low 44 bits of a hit
+  }
+  bitonic_sort_lanes<E>(k, lane);
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
+    if (e < nh) {
+      hw[e] = (uint32_t)k[q] & 0xffffffu;
+      hc[e] = (uint16_t)(((uint32_t)(k[q] >> 24) & 0xfffffu) - hc_base);
+    }
+  }
+}
+
 // one wave per (fragment, reference genome) segment
 #ifndef PA_MAP_WAVES
-#define PA_MAP_WAVES 6  // waves per SIMD the register allocation aims at (80 VGPRs); 5 allows 96
+#define PA_MAP_WAVES 4  // waves per SIMD the register allocation aims at: 128 VGPRs, the kernel needs 117 without spilling (80 registers / 6 waves: 0.64 s instead of 0.48 s for the 1 000-genome run)
 #endif
 // kAllStaged: the launch holds only segments of at most hit_cap hits (the bucketed path's list of short segments), so
 // every access to a hit is an LDS read and the choice is not made per access.
@@ -982,32 +1047,18 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   };
   for (uint32_t i = lane; i < s; i += 64) sh.qh[i] = q_hash[(uint64_t)f * kQMax + i];
   if (staged) {
-    for (uint32_t i = lane; i < nh; i += 64) {
-      const uint64_t key = keys[a0 + i];
-      sh.hw[i] = (uint32_t)(key & 0xffffffu);
-      sh.hc[i] = (uint16_t)(((uint32_t)(key >> 24) & 0xfffffu) - hc_base);
-    }
-    if (!presorted) {
-      // the bucketing pass leaves a segment's hits in no particular order: bitonic sort by (contig, window)
-      // in LDS, padded to a power of two with keys above any real one
-      uint32_t np2 = 2;
-      while (np2 < nh) np2 <<= 1;
-      for (uint32_t i = nh + lane; i < np2; i += 64) { sh.hw[i] = 0xffffffffu; sh.hc[i] = 0xffffu; }
-      __syncthreads();
-      for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-          for (uint32_t t = lane; t < (np2 >> 1); t += 64) {
-            const uint32_t i = 2u * t - (t & (j - 1u)), l = i + j;
-            const uint64_t ka = ((uint64_t)sh.hc[i] << 32) | sh.hw[i], kb = ((uint64_t)sh.hc[l] << 32) | sh.hw[l];
-            const bool up = (i & k) == 0u;
-            if ((ka > kb) == up && ka != kb) {
-              sh.hw[i] = (uint32_t)kb; sh.hc[i] = (uint16_t)(kb >> 32);
-              sh.hw[l] = (uint32_t)ka; sh.hc[l] = (uint16_t)(ka >> 32);
-            }
-          }
-          __syncthreads();
-        }
+    if (presorted) {
+      for (uint32_t i = lane; i < nh; i += 64) {
+        const uint64_t key = keys[a0 + i];
+        sh.hw[i] = (uint32_t)(key & 0xffffffu);
+        sh.hc[i] = (uint16_t)(((uint32_t)(key >> 24) & 0xfffffu) - hc_base);
       }
+    } else {
+      // the bucketing pass leaves a segment's hits in no particular order: ordered in registers on their way to LDS
+      if (nh <= 64u) stage_hits_sorted<1>(keys + a0, nh, hc_base, lane, sh.hw, sh.hc);
+      else if (nh <= 128u) stage_hits_sorted<2>(keys + a0, nh, hc_base, lane, sh.hw, sh.hc);
+      else if (kAllStaged || nh <= 256u) stage_hits_sorted<4>(keys + a0, nh, hc_base, lane, sh.hw, sh.hc);
+      else if constexpr (!kAllStaged) stage_hits_sorted<8>(keys + a0, nh, hc_base, lane, sh.hw, sh.hc);
     }
   }
   for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
@@ -1468,50 +1519,83 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // ---- L1: run a is valid when hits a .. a+mh-1 share a contig and span < frag_len window ids; its candidate range
   // of window starts is [y.w - fragLen + 1, x.w]; ranges that touch on one contig merge (hits are in (contig, window)
   // order, so both ends only grow and "touches the merged range" is "touches the previous run's")
+  // The candidates a chunk of 64 runs closes are first listed (LDS, kListCap at a time), then evaluated: the evaluation
+  // is in the code once and none of the scan's per-lane state is alive across it.  A chunk that closes more than
+  // kListCap candidates is scanned again for the rest (`handled` = its breaks already listed).
+  constexpr uint32_t kListCap = 8;
   bool have_cur = false, have_prev = false;
   uint32_t cur_c = 0, cur_cs = 0, cur_ce = 0, cur_fw = 0, prev_c = 0, prev_ce = 0;
-  for (uint32_t chunk = 0; chunk < nh; chunk += 64) {
-    const uint32_t i = chunk + lane;
-    bool v = false;
-    uint32_t c_i = 0, cs_i = 0, ce_i = 0;
-    if (i + mh <= nh) {
-      c_i = HC(i);
-      ce_i = HW(i);
-      const uint32_t yw = HW(i + mh - 1);
-      v = HC(i + mh - 1) == c_i && yw - ce_i < frag_len;
-      cs_i = yw + 1u > frag_len ? yw + 1u - frag_len : 0u;
+  uint64_t handled = 0;
+  for (uint32_t chunk = 0;;) {
+    const bool tail = chunk >= nh;  // one more turn after the last chunk lists the candidate still open
+    uint32_t n_list = 0;
+    auto list_current = [&]() {
+      if (lane == 0) {
+        uint4 *slot = reinterpret_cast<uint4 *>(sh.cand) + n_list;
+        *slot = make_uint4(cur_c, cur_cs, cur_ce, cur_fw);
+      }
+      ++n_list;
+    };
+    if (tail) {
+      if (have_cur) list_current();
+    } else {
+      const uint32_t i = chunk + lane;
+      bool v = false;
+      uint32_t c_i = 0, cs_i = 0, ce_i = 0;
+      if (i + mh <= nh) {
+        c_i = HC(i);
+        ce_i = HW(i);
+        const uint32_t yw = HW(i + mh - 1);
+        v = HC(i + mh - 1) == c_i && yw - ce_i < frag_len;
+        cs_i = yw + 1u > frag_len ? yw + 1u - frag_len : 0u;
+      }
+      const uint64_t vm = __ballot(v);
+      if (!vm) { chunk += 64; continue; }
+      // the valid run before this lane's: in this chunk, or carried over from the chunks before
+      const uint64_t below = vm & ((1ULL << lane) - 1ULL);
+      const int pl = below ? 63 - __builtin_clzll(below) : 0;
+      const uint32_t sc = __shfl(c_i, pl, 64), se = __shfl(ce_i, pl, 64);
+      const bool hp = below ? true : have_prev;
+      const uint32_t pc = below ? sc : prev_c, pe = below ? se : prev_ce;
+      const bool brk = v && (!hp || pc != c_i || cs_i > pe);
+      const uint64_t bm_all = __ballot(brk);
+      uint64_t bm = bm_all & ~handled;
+      if (!handled) {
+        // valid runs before the first break of the chunk extend the carried candidate
+        const uint64_t head = bm_all ? vm & ((1ULL << __builtin_ctzll(bm_all)) - 1ULL) : vm;
+        if (head && have_cur) cur_ce = max(cur_ce, (uint32_t)__shfl(ce_i, 63 - __builtin_clzll(head), 64));
+      }
+      while (bm && n_list < kListCap) {
+        const int bit = __builtin_ctzll(bm);
+        bm &= bm - 1;
+        handled |= 1ULL << bit;
+        if (have_cur) list_current();
+        const uint64_t upto = bm ? ((1ULL << __builtin_ctzll(bm)) - 1ULL) : ~0ULL;
+        const uint64_t mine = vm & upto & ~((1ULL << bit) - 1ULL);  // the valid runs of this group inside the chunk
+        cur_c = __shfl(c_i, bit, 64);
+        cur_cs = __shfl(cs_i, bit, 64);
+        cur_fw = __shfl(ce_i, bit, 64);  // window id of the first hit of the candidate's first run
+        cur_ce = __shfl(ce_i, 63 - __builtin_clzll(mine), 64);
+        have_cur = true;
+      }
+      if (!bm) {  // the chunk is done
+        const int last = 63 - __builtin_clzll(vm);
+        prev_c = __shfl(c_i, last, 64);
+        prev_ce = __shfl(ce_i, last, 64);
+        have_prev = true;
+        handled = 0;
+        chunk += 64;
+      }
     }
-    const uint64_t vm = __ballot(v);
-    if (!vm) continue;
-    // the valid run before this lane's: in this chunk, or carried over from the chunks before
-    const uint64_t below = vm & ((1ULL << lane) - 1ULL);
-    const int pl = below ? 63 - __builtin_clzll(below) : 0;
-    const uint32_t sc = __shfl(c_i, pl, 64), se = __shfl(ce_i, pl, 64);
-    const bool hp = below ? true : have_prev;
-    const uint32_t pc = below ? sc : prev_c, pe = below ? se : prev_ce;
-    const bool brk = v && (!hp || pc != c_i || cs_i > pe);
-    uint64_t bm = __ballot(brk);
-    // valid runs before the first break of the chunk extend the carried candidate
-    const uint64_t head = bm ? vm & ((1ULL << __builtin_ctzll(bm)) - 1ULL) : vm;
-    if (head && have_cur) cur_ce = max(cur_ce, (uint32_t)__shfl(ce_i, 63 - __builtin_clzll(head), 64));
-    while (bm) {
-      const int bit = __builtin_ctzll(bm);
-      bm &= bm - 1;
-      if (have_cur) process_candidate(cur_c, cur_cs, cur_ce, cur_fw);
-      const uint64_t upto = bm ? ((1ULL << __builtin_ctzll(bm)) - 1ULL) : ~0ULL;
-      const uint64_t mine = vm & upto & ~((1ULL << bit) - 1ULL);  // the valid runs of this group inside the chunk
-      cur_c = __shfl(c_i, bit, 64);
-      cur_cs = __shfl(cs_i, bit, 64);
-      cur_fw = __shfl(ce_i, bit, 64);  // window id of the first hit of the candidate's first run
-      cur_ce = __shfl(ce_i, 63 - __builtin_clzll(mine), 64);
-      have_cur = true;
+    __syncthreads();
+    for (uint32_t t = 0; t < n_list; ++t) {
+      const uint4 cand = reinterpret_cast<const uint4 *>(sh.cand)[t];
+      process_candidate((uint32_t)__builtin_amdgcn_readfirstlane((int)cand.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cand.y),
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)cand.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)cand.w));
     }
-    const int last = 63 - __builtin_clzll(vm);
-    prev_c = __shfl(c_i, last, 64);
-    prev_ce = __shfl(ce_i, last, 64);
-    have_prev = true;
+    if (tail) break;
+    __syncthreads();
   }
-  if (have_cur) process_candidate(cur_c, cur_cs, cur_ce, cur_fw);
 
   if (best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s] && lane == 0) {
     const uint64_t jq = ((uint64_t)best_shared << 30) / s;

@@ -1,6 +1,6 @@
 """Where the time of map_segments_kernel goes: the kernel cut short after each phase (PA_MAP_CUT), timed by difference.
 
-    python tools/map_cut.py [n_genomes=1000]
+    python tools/map_cut.py [n_genomes=1000] [cuts, e.g. 9,9,4,9]
 """
 import os
 import sys
@@ -24,7 +24,8 @@ eng.prof_enable(True)
 names = {1: "staging + sort + bucket table", 2: "L1", 3: "candidate set-up", 4: "seed-hit bounds per group", 5: "stretch loads + window ends",
          6: "ranks", 7: "coarse table", 8: "window masks + coarse search", 9: "fine passes (whole kernel)"}
 prev = 0.0
-for cut in [9, 9, 1, 2, 3, 4, 5, 6, 7, 8, 9]:
+cuts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9, 9, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+for cut in cuts:
     os.environ["PA_MAP_CUT"] = str(cut)
     eng.prof_reset()
     t0 = time.perf_counter()
