@@ -137,22 +137,45 @@ __global__ __launch_bounds__(kThreads) void row_sum_kernel(const uint32_t *__res
     pending = 0;
   };
 
-  // TPR need not divide the workgroup: the threads past the last whole row sit the loop out
-  for (uint64_t j = slot < (uint32_t)kRowsPerIter ? slot : len; j < len; j += kRowsPerIter) {
-    const uint32_t id = ids[j];
-    if (id == kNone) continue;  // hash absent from every subject of the tile (hash-dictionary variant)
-    const uint4 r = *reinterpret_cast<const uint4 *>(rows + (uint64_t)id * kW32 + quad * 4);
-    uint32_t carry[4] = {r.x, r.y, r.z, r.w};
+  // TPR need not divide the workgroup: the threads past the last whole row sit the loop out.  Eight rows per turn:
+  // their loads are in flight together, and they enter the vertical counters through a tree of carry-save adders
+  // (sum = a ^ b ^ c, carry = majority(a, b, c): two three-input bit operations on gfx950) -- ones, twos and fours
+  // are kept across turns, the eights ripple into the five upper planes -- about 3 operations per row and word
+  // instead of the 24 of adding every row to all eight planes.
+  constexpr int kBatch = 8;
+  auto csa = [](uint32_t &carry, uint32_t &sum, uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t u = a ^ b;
+    carry = (a & b) | (u & c);
+    sum = u ^ c;
+  };
+  for (uint64_t j0 = slot < (uint32_t)kRowsPerIter ? slot : len; j0 < len; j0 += (uint64_t)kRowsPerIter * kBatch) {
+    uint4 r[kBatch];
 #pragma unroll
-    for (int p = 0; p < kPlanes; ++p) {
+    for (int u = 0; u < kBatch; ++u) {
+      const uint64_t j = j0 + (uint64_t)u * kRowsPerIter;
+      const uint32_t id = j < len ? ids[j] : kNone;  // kNone: hash absent from every subject of the tile
+      r[u] = id != kNone ? *reinterpret_cast<const uint4 *>(rows + (uint64_t)id * kW32 + quad * 4) : make_uint4(0u, 0u, 0u, 0u);
+    }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint32_t t = plane[p][c] & carry[c];
-        plane[p][c] ^= carry[c];
-        carry[c] = t;
+    for (int c = 0; c < 4; ++c) {
+      auto word = [&](int u) -> uint32_t { return c == 0 ? r[u].x : c == 1 ? r[u].y : c == 2 ? r[u].z : r[u].w; };
+      uint32_t twos_a, twos_b, fours_a, fours_b, eights;
+      csa(twos_a, plane[0][c], plane[0][c], word(0), word(1));
+      csa(twos_b, plane[0][c], plane[0][c], word(2), word(3));
+      csa(fours_a, plane[1][c], plane[1][c], twos_a, twos_b);
+      csa(twos_a, plane[0][c], plane[0][c], word(4), word(5));
+      csa(twos_b, plane[0][c], plane[0][c], word(6), word(7));
+      csa(fours_b, plane[1][c], plane[1][c], twos_a, twos_b);
+      csa(eights, plane[2][c], plane[2][c], fours_a, fours_b);
+#pragma unroll
+      for (int p = 3; p < kPlanes; ++p) {
+        const uint32_t t = plane[p][c] & eights;
+        plane[p][c] ^= eights;
+        eights = t;
       }
     }
-    if (++pending == (1u << kPlanes) - 1u) flush();
+    pending += kBatch;
+    if (pending + kBatch > (1u << kPlanes) - 1u) flush();
   }
   if (pending) flush();
   __syncthreads();
