@@ -911,17 +911,19 @@ __host__ __device__ inline uint32_t eval_tab_words(uint32_t s_cap, uint32_t ref_
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
   return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + hit_cap * 6u + ref_cap * 2u + 2u * kQtBuckets;
 }
+// The arrays whose length is known at compile time come first, so that their addresses are constants of the kernel
+// (immediate offsets of the LDS instructions, no registers); the fragment's sketch and the tables follow.
 __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap, uint32_t hit_cap, uint32_t kRefCap) {
   EvalShared sh;
-  sh.qh = base;
+  sh.matched = base;
+  sh.cand = sh.matched + kQMax / 32;
+  sh.qt = reinterpret_cast<uint16_t *>(sh.cand + 32);
+  sh.hw = reinterpret_cast<uint32_t *>(sh.qt + kQtBuckets);
+  sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
+  sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are multiples of 64: everything stays on 16-byte boundaries
+  sh.qh = reinterpret_cast<uint32_t *>(sh.ref_w + kRefCap);
   sh.cnt = sh.qh + s_cap;  // s_cap is a multiple of 64: the tables start on a 16-byte boundary
   sh.tab = sh.cnt;
-  sh.matched = sh.tab + eval_tab_words(s_cap, kRefCap);
-  sh.cand = sh.matched + kQMax / 32;  // 16 words after the tables: a 16-byte boundary
-  sh.hw = sh.cand + 32;
-  sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
-  sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are even: the 32-bit view of qt stays aligned
-  sh.qt = sh.ref_w + kRefCap;
   return sh;
 }
 
@@ -1015,7 +1017,9 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride, unsigned long long *__restrict__ table,
     uint32_t *__restrict__ run_g, uint32_t s_cap, uint32_t hit_cap, uint32_t cut) {
   extern __shared__ uint32_t eval_lds[];
-  const EvalShared sh = eval_carve(eval_lds, s_cap, hit_cap, kRefCap);
+  // the short-segment launch stages up to kHitCapSmall hits, the other one up to kHitCap (what the host passes as hit_cap)
+  constexpr uint32_t kStageCap = kAllStaged ? (uint32_t)kHitCapSmall : (uint32_t)kHitCap;
+  const EvalShared sh = eval_carve(eval_lds, s_cap, kStageCap, kRefCap);
   const uint32_t lane = threadIdx.x;
   (void)vals;
   if (blockIdx.x >= n_segs) return;
@@ -1040,7 +1044,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // contigs are kept relative to the reference genome's first one, window ids of the query as 16 bits: the
   // host takes this kernel only when both fit
   const uint32_t hc_base = genome_first_contig[contig_genome[(uint32_t)(keys[a0] >> 24) & 0xfffffu]];
-  const bool staged = kAllStaged || nh <= hit_cap;  // hit_cap is kHitCapSmall or kHitCap, a power of two
+  const bool staged = kAllStaged || nh <= kStageCap;
+  (void)hit_cap;
   auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] : (uint32_t)(keys[a0 + i] & 0xffffffu); };
   auto HC = [&](uint32_t i) -> uint32_t {
     return staged ? hc_base + sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu;
@@ -1522,7 +1527,10 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // The candidates a chunk of 64 runs closes are first listed (LDS, kListCap at a time), then evaluated: the evaluation
   // is in the code once and none of the scan's per-lane state is alive across it.  A chunk that closes more than
   // kListCap candidates is scanned again for the rest (`handled` = its breaks already listed).
-  constexpr uint32_t kListCap = 8;
+#ifndef PA_MAP_LIST_CAP
+#define PA_MAP_LIST_CAP 8  // 1 in a test build: every chunk with two closed candidates is then scanned twice
+#endif
+  constexpr uint32_t kListCap = PA_MAP_LIST_CAP;
   bool have_cur = false, have_prev = false;
   uint32_t cur_c = 0, cur_cs = 0, cur_ce = 0, cur_fw = 0, prev_c = 0, prev_ce = 0;
   uint64_t handled = 0;
