@@ -958,13 +958,15 @@ __device__ __forceinline__ void bitonic_sort_lanes(uint64_t (&k)[E], uint32_t la
     for (uint32_t j = span >> 1; j > 0; j >>= 1) {
       if (j >= (uint32_t)E) {
         const uint32_t lj = j / (uint32_t)E;
-        const int partner = (int)(lane ^ lj);
-        const bool lower = (lane & lj) == 0u;
+        const int partner = (int)((lane ^ lj) << 2);  // byte address of the partner lane for ds_bpermute
+        // the lower lane of a pair keeps the smaller key in an ascending run: span > j >= E, so the run's direction is a
+        // bit of the lane number, the same for all E keys of the lane
+        const bool take_min = ((lane & lj) == 0u) == ((lane & (span / (uint32_t)E)) == 0u);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-          const uint64_t other = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(k[q] >> 32), partner, 64) << 32) |
-                                 (uint32_t)__shfl((int)(uint32_t)k[q], partner, 64);
-          const bool take_min = lower == (((e0 + (uint32_t)q) & span) == 0u);
+          const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)(uint32_t)k[q]);
+          const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)(uint32_t)(k[q] >> 32));
+          const uint64_t other = ((uint64_t)ohi << 32) | olo;
           k[q] = ((other < k[q]) == take_min) ? other : k[q];
         }
       } else if (E > 4 && j == 4u) {
@@ -1050,7 +1052,11 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   auto HC = [&](uint32_t i) -> uint32_t {
     return staged ? hc_base + sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu;
   };
-  for (uint32_t i = lane; i < s; i += 64) sh.qh[i] = q_hash[(uint64_t)f * kQMax + i];
+  {  // the fragment's sketch, 16 bytes per lane and turn (s_cap is a multiple of 64; a row of q_hash holds kQMax hashes)
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(q_hash + (uint64_t)f * kQMax);
+    uint4 *dst4 = reinterpret_cast<uint4 *>(sh.qh);
+    for (uint32_t i = lane; i < s_cap / 4u; i += 64) dst4[i] = src4[i];
+  }
   if (staged) {
     if (presorted) {
       for (uint32_t i = lane; i < nh; i += 64) {
@@ -1085,8 +1091,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
 #pragma unroll
     for (uint32_t q = 0; q < kOwnB; ++q) { cntb[q] = sh.qt[lane * kOwnB + q]; local += cntb[q]; most = max(most, cntb[q]); }
     uint32_t run = wave_excl_scan(local, lane);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o, 64));
+    most = pa_dev::wave_max_dpp(most);
 #pragma unroll
     for (uint32_t q = 0; q < kOwnB; ++q) { sh.qt[lane * kOwnB + q] = (uint16_t)(run | (cntb[q] << 10)); run += cntb[q]; }
     qsteps = most > 63u ? 0xffffffffu : (most ? 32u - (uint32_t)__builtin_clz(most) : 0u);
@@ -1212,12 +1217,17 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         const uint32_t t = b_lo + (uint32_t)q * 64u + lane;
         wpv[q] = t < m1 ? mini_wpos[t] : 0xffffffffu;
       }
+      // the first start past the range and the first one at the first seed hit: every lane the first of its own eight,
+      // then the minimum over the wave (the window ids ascend with the start index)
+      uint32_t my_over = 0xffffffffu, my_reach = 0xffffffffu;
 #pragma unroll
-      for (int q = 0; q < kStartBatch; ++q) {
-        const uint64_t over = __ballot(wpv[q] > ce), reach = __ballot(wpv[q] >= first_hit_w);
-        if (over && b_hi == 0xffffffffu) b_hi = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(over);
-        if (reach && at == 0xffffffffu) at = b_lo + (uint32_t)q * 64u + (uint32_t)__builtin_ctzll(reach);
+      for (int q = kStartBatch - 1; q >= 0; --q) {
+        my_over = wpv[q] > ce ? (uint32_t)q * 64u + lane : my_over;
+        my_reach = wpv[q] >= first_hit_w ? (uint32_t)q * 64u + lane : my_reach;
       }
+      const uint32_t w_over = pa_dev::wave_min_dpp(my_over), w_reach = pa_dev::wave_min_dpp(my_reach);
+      if (w_over != 0xffffffffu) b_hi = b_lo + w_over;
+      if (w_reach != 0xffffffffu) at = b_lo + w_reach;
     }
     if (b_hi == 0xffffffffu) b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + 1u);  // a range of more than 512 starts
     if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
@@ -1415,12 +1425,19 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           const bool walking = done_now;
           const uint32_t xs = walking ? xb : 0u, xw = walking ? xe : 0u;
           uint32_t wm[kW];
+          {
+            // bits [xs, xw) of the row, two words at a time: xs is below 64, so only the first pair has a lower end
+            auto below = [](int32_t b) -> uint64_t {  // the b lowest bits of a pair of words, b clamped to 0 .. 64
+              const uint64_t m = b >= 64 ? ~0ULL : (1ULL << (b & 63)) - 1ULL;
+              return b <= 0 ? 0ULL : m;
+            };
 #pragma unroll
-          for (uint32_t w = 0; w < kW; ++w) {
-            // bits [lo, hi) of the word, lo and hi clamped to 0 .. 32
-            const int32_t lo = min(max((int32_t)xs - (int32_t)(32u * w), 0), 32), hi = min(max((int32_t)xw - (int32_t)(32u * w), 0), 32);
-            const uint32_t below_hi = hi >= 32 ? 0xffffffffu : (1u << hi) - 1u, below_lo = lo >= 32 ? 0xffffffffu : (1u << lo) - 1u;
-            wm[w] = below_hi & ~below_lo;
+            for (uint32_t w2 = 0; w2 < kW / 2u; ++w2) {
+              uint64_t m = below((int32_t)xw - (int32_t)(64u * w2));
+              if (w2 == 0) m &= ~below((int32_t)xs);
+              wm[2 * w2] = (uint32_t)m;
+              wm[2 * w2 + 1] = (uint32_t)(m >> 32);
+            }
           }
           if (any_dup) {
 #pragma unroll
