@@ -935,6 +935,27 @@ __device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t i
   return (idx & 1u) ? (old >> 16) : (old & 0xffffu);
 }
 
+// One record per listed segment: what a mapping wave needs before it can load anything else -- where the hits are, the
+// fragment, its sketch size, the seed hits a run needs, the first contig of the reference genome -- gathered by one
+// thread per segment, so that the wave starts with one scalar load instead of a chain of five dependent ones.
+// Two uint4: {first hit, hits, fragment, sketch size} {hits a run needs, first contig, 0, 0}; sketch size 0 = nothing to do.
+__global__ __launch_bounds__(kThreads) void segment_records_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh, uint32_t n_segs,
+    const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ contig_genome,
+    const uint32_t *__restrict__ genome_first_contig, uint4 *__restrict__ rec) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n_segs) return;
+  const uint32_t a0 = seg_a0[i], nh = seg_nh[i];
+  const uint64_t key = keys[a0];
+  const uint32_t f = (uint32_t)(key >> 44);
+  uint32_t s = q_s[f];
+  const uint32_t mh = s ? tab_min_hits[s] : 0u;
+  if (nh < mh) s = 0;  // chance matches with unrelated genomes: fewer seed hits than any L1 run needs
+  const uint32_t hc_base = genome_first_contig[contig_genome[(uint32_t)(key >> 24) & 0xfffffu]];
+  rec[2 * (uint64_t)i] = make_uint4(a0, nh, f, s);
+  rec[2 * (uint64_t)i + 1] = make_uint4(mh, hc_base, 0u, 0u);
+}
+
 // A segment's hits ordered by (contig, window id) in registers: E keys per lane, element e = lane * E + q, bitonic
 // network over 64 E elements.  Strides of E and more exchange between lanes (two ds_bpermute per key, no LDS memory,
 // no barrier), the strides below E between the registers of a lane.  Missing elements are keys above any real one.
@@ -1008,11 +1029,9 @@ __device__ __forceinline__ void stage_hits_sorted(const uint64_t *__restrict__ s
 // every access to a hit is an LDS read and the choice is not made per access.
 template <uint32_t kRefCap, bool kAllStaged>
 __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
-    uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ seg_a0,
-    const uint32_t *__restrict__ seg_nh, uint32_t n_segs, bool presorted, const uint32_t *__restrict__ contig_genome,
-    const uint32_t *__restrict__ genome_first_contig, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ q_s,
-    const uint32_t *__restrict__ frag_genome_local, uint32_t frag_len, uint32_t count_windows,
-    const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ tab_min_shared,
+    uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals, const uint4 *__restrict__ seg_rec, uint32_t n_segs,
+    bool presorted, const uint32_t *__restrict__ q_hash, const uint32_t *__restrict__ frag_genome_local, uint32_t frag_len,
+    uint32_t count_windows, const uint32_t *__restrict__ tab_min_shared,
     const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const int32_t *__restrict__ prev_same,
@@ -1032,20 +1051,16 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
 #define PA_STAT(slot, v) do { } while (0)
   (void)run_g;
 #endif
-  const uint32_t a0 = seg_a0[blockIdx.x];
-  uint32_t nh = seg_nh[blockIdx.x];
-  const uint32_t f = (uint32_t)(keys[a0] >> 44);
-  const uint32_t s = q_s[f];
-  if (s == 0) return;
-  const uint32_t mh = tab_min_hits[s];
-  if (nh < mh) return;  // chance matches with unrelated genomes: fewer seed hits than any L1 run needs
+  const uint4 rec0 = seg_rec[2 * (uint64_t)blockIdx.x], rec1 = seg_rec[2 * (uint64_t)blockIdx.x + 1];  // segment_records_kernel
+  const uint32_t a0 = rec0.x, nh = rec0.y, f = rec0.z, s = rec0.w, mh = rec1.x;
+  if (s == 0) return;  // no sketch, or fewer seed hits than any L1 run needs
   PA_STAT(0, 1);   // segments that reach L1
   PA_STAT(1, nh);  // their seed hits
   // segments of up to kHitCap hits are staged in LDS; larger ones (repeats: rRNA operons, IS elements)
   // are read in place from the sorted hit arrays
   // contigs are kept relative to the reference genome's first one, window ids of the query as 16 bits: the
   // host takes this kernel only when both fit
-  const uint32_t hc_base = genome_first_contig[contig_genome[(uint32_t)(keys[a0] >> 24) & 0xfffffu]];
+  const uint32_t hc_base = rec1.y;
   const bool staged = kAllStaged || nh <= kStageCap;
   (void)hit_cap;
   auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] : (uint32_t)(keys[a0 + i] & 0xffffffu); };
@@ -1057,6 +1072,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     uint4 *dst4 = reinterpret_cast<uint4 *>(sh.qh);
     for (uint32_t i = lane; i < s_cap / 4u; i += 64) dst4[i] = src4[i];
   }
+  PA_CUT(10);  // segment header and sketch
   if (staged) {
     if (presorted) {
       for (uint32_t i = lane; i < nh; i += 64) {
@@ -1072,6 +1088,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       else if constexpr (!kAllStaged) stage_hits_sorted<8>(keys + a0, nh, hc_base, lane, sh.hw, sh.hc);
     }
   }
+  PA_CUT(11);  // hits staged in order
   for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
   if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
   // The fragment's hashes bucketed by their top kQtBits bits: a reference minimizer's rank among them is then the
@@ -1672,7 +1689,7 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first, post_g;
+      contig_bucket_off, bucket_first, post_g, seg_rec;
   // the reference index (stages 1 and 2) of the last pa_fragani(_ex) call, for PA_FRAGANI_REUSE_INDEX
   bool index_valid = false;
   const void *index_packed = nullptr;
@@ -1685,7 +1702,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -2168,15 +2185,18 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
 #endif
       const char *cut_env = getenv("PA_MAP_CUT");  // tools: the mapping kernel cut short after a phase (timing by difference)
       const uint32_t map_cut = cut_env ? (uint32_t)atoi(cut_env) : 0xffffffffu;
-      auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap, auto all_staged) {
-        if (count == 0) return;
+      auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap, auto all_staged) -> int {
+        if (count == 0) return PA_OK;
         constexpr bool kAll = decltype(all_staged)::value;
+        PA_TRY(W.seg_rec.reserve((uint64_t)count * 32));
+        hipLaunchKernelGGL(segment_records_kernel, dim3(ceil_div_u64(count, kThreads)), dim3(kThreads), 0, c->stream, hk[hw],
+                           list_a0, list_nh, count, W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(),
+                           W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(), W.seg_rec.as<uint4>());
 #define PA_MAP_CASE(CAP)                                                                                                  \
   case CAP:                                                                                                               \
     hipLaunchKernelGGL((map_segments_kernel<CAP, kAll>), dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap, CAP), c->stream,  \
-                       hk[hw], hv[hw], list_a0, list_nh, count, presorted, W.contig_genome.as<uint32_t>(),                 \
-                       W.genome_first_contig.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_s.as<uint32_t>(),                \
-                       W.frag_genome_local.as<uint32_t>(), frag_len, count_windows, W.tab_min_hits.as<uint32_t>(),         \
+                       hk[hw], hv[hw], W.seg_rec.as<uint4>(), count, presorted, W.q_hash.as<uint32_t>(),                   \
+                       W.frag_genome_local.as<uint32_t>(), frag_len, count_windows,                                        \
                        W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),                                  \
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),      \
                        W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), total_bins, \
@@ -2187,6 +2207,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
           default: PA_MAP_CASE(512)
         }
 #undef PA_MAP_CASE
+        return PA_OK;
       };
       if (use_buckets) {
         if (n_keep) {
@@ -2203,11 +2224,11 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
           if (trace)
             fprintf(stderr, "pa_fragani: genomes %u..%u: %u fragments, %llu seed hits, %u + %u listed segments, %u left "
                             "after the tiny-segment filter\n", g0, g1, nf, (unsigned long long)n_hits, n_keep, n_large, n_small);
-          launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall, std::true_type{});
+          PA_TRY(launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall, std::true_type{}));
         }
-        launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, n_large, (uint32_t)kHitCap, std::false_type{});
+        PA_TRY(launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, n_large, (uint32_t)kHitCap, std::false_type{}));
       } else {
-        launch_map(W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, (uint32_t)kHitCap, std::false_type{});
+        PA_TRY(launch_map(W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, (uint32_t)kHitCap, std::false_type{}));
       }
 #ifdef PA_MAP_STATS
       if (trace) {

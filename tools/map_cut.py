@@ -21,10 +21,10 @@ starts = arena.genome_start[:-1].copy()
 lens = np.full(n, length, dtype=np.uint32)
 genome = np.arange(n, dtype=np.uint32)
 eng.prof_enable(True)
-names = {1: "staging + sort + bucket table", 2: "L1", 3: "candidate set-up", 4: "seed-hit bounds per group", 5: "stretch loads + window ends",
+names = {10: "segment header + sketch load", 11: "hits loaded, ordered, staged", 1: "staging + sort + bucket table", 2: "L1", 3: "candidate set-up", 4: "seed-hit bounds per group", 5: "stretch loads + window ends",
          6: "ranks", 7: "coarse table", 8: "window masks + coarse search", 9: "fine passes (whole kernel)"}
 prev = 0.0
-cuts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9, 9, 1, 2, 3, 4, 5, 6, 7, 8, 9]
+cuts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7, 8, 9]
 for cut in cuts:
     os.environ["PA_MAP_CUT"] = str(cut)
     eng.prof_reset()
