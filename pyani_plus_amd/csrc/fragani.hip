@@ -2068,7 +2068,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         hv[1] = W.hvals[1].as<uint32_t>();
         return PA_OK;
       };
-      PA_TRY(W.run_g.reserve(n_hits * 4 + 16));
+      PA_TRY(W.run_g.reserve(64));  // the mapping kernel's event counters (-DPA_MAP_STATS)
       int bits = 44;
       for (uint32_t x = nf; x > 1; x >>= 1) ++bits;
       bits = (bits + 1 + 7) & ~7;

@@ -170,6 +170,31 @@ def test_repeat_families_take_the_long_segment_paths(engine):
     _check_against_oracle(engine, texts[:2], [[g] for g in genomes[:2]])
 
 
+def test_two_copy_repeats_take_the_wide_register_sort(engine):
+    """Two tandem copies give segments of 257 .. 512 seed hits: staged in LDS by the launch for long segments, ordered
+    eight keys per lane in registers on the way (the widest form of the bitonic network); duplicates of every hash inside
+    the windows.  Same integers as the oracle."""
+    rng = np.random.default_rng(33)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = rng.choice(acgt, size=3_000)
+    flank = rng.choice(acgt, size=6_000)
+
+    def with_copies(copies: int, rate: float) -> bytes:
+        parts = [flank[:3_000]]
+        for _ in range(copies):
+            u = unit.copy()
+            hit = rng.random(u.size) < rate
+            u[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+            parts.append(u)
+        parts.append(flank[3_000:])
+        return np.concatenate(parts).tobytes()
+
+    genomes = [with_copies(2, 0.0), with_copies(2, 0.01), with_copies(3, 0.005), with_copies(1, 0.0)]
+    texts = [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)]
+    total, matched, _ = _check_against_oracle(engine, texts, [[g] for g in genomes])
+    assert matched[0, 1] > 0 and matched[3, 2] > 0
+
+
 def test_viral_fixture_rows(engine):
     files = sorted((GOLDEN / "viral_example").glob("*.f*"))
     texts = [read_fasta_bytes(p) for p in files]
