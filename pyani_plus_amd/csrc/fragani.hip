@@ -419,12 +419,21 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
                                                             const uint32_t *__restrict__ contig_genome,
                                                             uint64_t *__restrict__ post_cw,
                                                             uint16_t *__restrict__ post_genome) {
+  // the contig of the posting before this one comes from the thread before it (LDS) instead of a second random read
+  __shared__ uint32_t s_contig[kThreads];
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-  if (i >= m) return;
-  const uint32_t id = pos[i] + flags[i] - 1u, me = sorted_idx[i];
+  const bool in = i < m;
+  uint32_t id = 0, me = 0, mc = 0;
+  if (in) {
+    id = pos[i] + flags[i] - 1u;
+    me = sorted_idx[i];
+    mc = mini_contig[me];
+  }
+  s_contig[threadIdx.x] = mc;
+  __syncthreads();
+  if (!in) return;
   mini_id[me] = id;
   // the posting as the low 44 bits of a hit key, its genome on top so that bucketing needs no second lookup
-  const uint32_t mc = mini_contig[me];
   const uint32_t pg = contig_genome[mc];
   post_cw[i] = ((uint64_t)pg << 44) | ((uint64_t)mc << 24) | mini_wpos[me];
   post_genome[i] = (uint16_t)pg;  // used by the bucketed seeding only, which needs n_genomes <= 8192
@@ -433,7 +442,8 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
   int32_t ps = -1;
   if (i > 0 && keys[i] == keys[i - 1]) {
     const uint32_t other = sorted_idx[i - 1];  // stable sort: other < me
-    if (mini_contig[other] == mini_contig[me]) ps = (int32_t)other;
+    const uint32_t oc = threadIdx.x > 0 ? s_contig[threadIdx.x - 1] : mini_contig[other];
+    if (oc == mc) ps = (int32_t)other;
   }
   prev_same[me] = ps;
 }
