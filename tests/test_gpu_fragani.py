@@ -128,6 +128,8 @@ def test_pairs_equal_oracle_on_random_genomes(engine):
     total, matched, _ = _check_against_oracle(engine, texts, contig_lists)
     assert matched[0, 0] == total[0] and matched[0, 4] == 0 and matched[4, 0] == 0
     _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
+    # fragments of 5 000: window 40, stretches of up to 384 minimizers -- twelve words per row of the mapping kernel's bit tables
+    _check_against_oracle(engine, texts, contig_lists, frag=5000, k=16)
 
 
 def test_batches_are_halved_when_the_seed_hits_outgrow_their_indices(engine, monkeypatch):
