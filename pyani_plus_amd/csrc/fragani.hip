@@ -14,9 +14,10 @@
 //                         inside the fragment + the one still active at its first window): sort,
 //                         de-duplicate in LDS, no re-hashing
 //   4. seed hits           every posting of every sketch hash -> (fragment, ref contig, window id),
-//                         radix sorted; one wave per (fragment, reference genome) segment then
-//                         applies the L1 run test and evaluates the winnowed-MinHash Jaccard at the
-//                         window starts the hits imply (rank histogram in LDS, no per-window sort)
+//                         bucketed by reference genome; one wave per (fragment, reference genome)
+//                         segment then orders its hits in registers, applies the L1 run test and
+//                         evaluates the winnowed-MinHash Jaccard at the window starts the hits imply
+//                         (bit tables over query rank x reference position in LDS, no per-window sort)
 //   5. one best fragment per reference bin by atomicMax on (J, shared, s); per pair the kept
 //      fragments and the sum of their identities.
 #include <cmath>
@@ -1210,10 +1211,11 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // ---- L2 as Mashmap slides it: a window starts at every reference minimizer position of the candidate range
   // and holds the minimizers recorded in [start, start + count_windows); per candidate the position is the mean
   // of the first and the last start with the most shared minimizers.  One LANE per start: the stretch of
-  // minimizers the up to 64 windows of a group cover (~300) is ranked against the fragment's hashes once, put in
-  // (rank, reference-only before match) order by a counting sort, and every lane walks that one list keeping
-  // what lies in its own window -- a union walk that stops at the s-th element.  Starts whose seed-hit count
-  // cannot reach the best so far are never evaluated, which leaves one or two groups per candidate.
+  // minimizers the up to 64 windows of a group cover (~300) is ranked against the fragment's hashes once and
+  // entered into bit tables over (query rank x stretch position); every lane finds, by two short searches over
+  // rows of those tables, how many of the fragment's smallest hashes lie in the bottom-s of the union with its
+  // own window and how many of them the window holds (see the round below).  Starts whose seed-hit count cannot
+  // reach the best so far are never evaluated, which leaves two or three rounds per candidate.
   auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) {
     PA_CUT(2);  // L1 only
     const uint32_t m1 = contig_mini_off[c + 1];
