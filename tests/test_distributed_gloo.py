@@ -50,7 +50,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8: the node size of BASELINE configs[2]; ranks with one genome each
 def test_allgather_and_column_tiles(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     arena = synth_arena_numpy(len(LENGTHS), LENGTHS, n_species=2)

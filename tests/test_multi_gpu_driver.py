@@ -49,7 +49,7 @@ def _dump(db: Path):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8: the node size of BASELINE configs[2]; ranks with one genome each
 def test_sharded_sourmash_driver_equals_the_single_process_one(tmp_path, world, monkeypatch):
     monkeypatch.setenv("PYANI_HIP_DIST_BACKEND", "gloo")
     lengths = [30_000, 4_000, 52_000, 64, 21_000, 33_000, 9_000]
@@ -71,7 +71,8 @@ def test_sharded_sourmash_driver_equals_the_single_process_one(tmp_path, world, 
     import json
 
     results = [json.loads(p.read_text()) for p in sorted((tmp_path / "tN" / "sourmash-hip.workers").glob("result_rank*.json"))]
-    assert len(results) == world and all(r["ok"] and r["backend"] == "gloo" for r in results)
+    ranks = min(world, len(lengths))  # never more workers than genomes
+    assert len(results) == ranks and all(r["ok"] and r["backend"] == "gloo" for r in results)
 
 
 def test_sharded_sourmash_driver_reports_duplicates_and_bad_files(tmp_path, monkeypatch):
