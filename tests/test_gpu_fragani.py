@@ -132,6 +132,26 @@ def test_pairs_equal_oracle_on_random_genomes(engine):
     _check_against_oracle(engine, texts, contig_lists, frag=5000, k=16)
 
 
+def test_fragments_that_are_mostly_n(engine):
+    """Fragments with a handful of usable k-mers: sketches of a few minimizers (fewer than one coarse step of the mapping
+    kernel's rank tables), windows with hardly anything in them.  Same integers as the oracle."""
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    root = rng.choice(acgt, size=30_000)
+    genomes = []
+    for rate, gaps in [(0.0, [(3_050, 5_950), (9_100, 11_990)]), (0.02, [(3_200, 5_800)]), (0.0, []), (0.05, [(15_010, 17_995), (18_020, 20_900)])]:
+        seq = root.copy()
+        hit = rng.random(seq.size) < rate
+        seq[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+        for a, b in gaps:
+            seq[a:b] = ord("N")
+        genomes.append(seq.tobytes())
+    texts = [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)]
+    total, matched, _ = _check_against_oracle(engine, texts, [[g] for g in genomes])
+    assert total[0] == 10 and matched[2, 0] > 0
+    _check_against_oracle(engine, texts, [[g] for g in genomes], frag=1000, k=15)
+
+
 def test_batches_are_halved_when_the_seed_hits_outgrow_their_indices(engine, monkeypatch):
     """A batch of query genomes whose seed hits pass 2^31 is halved and started again; forced here with a limit of a few
     thousand hits, down to one query genome per batch.  Same integers as the one-batch run and as the oracle."""
