@@ -26,7 +26,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kPlanes = 8;                       // vertical counter planes -> flush every 255 rows
+constexpr int kPlanes = 10;                      // vertical counter planes -> flush every 1023 rows (a thread of a 16-thread row sees 312 of a 5 000-hash sketch: one flush)
 constexpr uint32_t kMaxTileSubjects = 2048;      // widest bit row: 64 words = 256 bytes
 constexpr uint32_t kNone = 0xffffffffu;          // "no id": the hash occurs in no subject of the tile
 constexpr uint64_t kEmptyKey = ~0ULL;            // empty slot of the hash dictionary
@@ -119,15 +119,21 @@ __global__ __launch_bounds__(kThreads) void row_sum_kernel(const uint32_t *__res
     for (int c = 0; c < 4; ++c) plane[p][c] = 0;
   uint32_t pending = 0;
 
+  // The vertical counters into the LDS counts: only the columns whose counter is not zero are visited (a hash of one
+  // species sets ~50 of a tile's 2 048 columns; walking all 128 columns of a thread was more work than the row sums)
   auto flush = [&]() {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-#pragma unroll 4
-      for (int b = 0; b < 32; ++b) {
+      uint32_t any = 0;
+#pragma unroll
+      for (int p = 0; p < kPlanes; ++p) any |= plane[p][c];
+      while (any) {
+        const uint32_t b = (uint32_t)__builtin_ctz(any);
+        any &= any - 1u;
         uint32_t v = 0;
 #pragma unroll
         for (int p = 0; p < kPlanes; ++p) v |= ((plane[p][c] >> b) & 1u) << p;
-        if (v) atomicAdd(&s_cnt[(quad * 4 + c) * 32 + b], v);
+        atomicAdd(&s_cnt[(quad * 4 + c) * 32 + b], v);
       }
     }
 #pragma unroll
@@ -140,21 +146,34 @@ __global__ __launch_bounds__(kThreads) void row_sum_kernel(const uint32_t *__res
   // TPR need not divide the workgroup: the threads past the last whole row sit the loop out.  Eight rows per turn:
   // their loads are in flight together, and they enter the vertical counters through a tree of carry-save adders
   // (sum = a ^ b ^ c, carry = majority(a, b, c): two three-input bit operations on gfx950) -- ones, twos and fours
-  // are kept across turns, the eights ripple into the five upper planes -- about 3 operations per row and word
-  // instead of the 24 of adding every row to all eight planes.
+  // are kept across turns, the eights ripple into the seven upper planes -- about 3 operations per row and word
+  // instead of the 30 of adding every row to all ten planes.
   constexpr int kBatch = 8;
   auto csa = [](uint32_t &carry, uint32_t &sum, uint32_t a, uint32_t b, uint32_t c) {
     const uint32_t u = a ^ b;
     carry = (a & b) | (u & c);
     sum = u ^ c;
   };
-  for (uint64_t j0 = slot < (uint32_t)kRowsPerIter ? slot : len; j0 < len; j0 += (uint64_t)kRowsPerIter * kBatch) {
+  // the ids of a turn are loaded one turn ahead: a row's address depends on its id, and the two loads in a row were
+  // what a turn waited for
+  const uint64_t j_begin = slot < (uint32_t)kRowsPerIter ? slot : len;
+  uint32_t id_next[kBatch];
+#pragma unroll
+  for (int u = 0; u < kBatch; ++u) {
+    const uint64_t j = j_begin + (uint64_t)u * kRowsPerIter;
+    id_next[u] = j < len ? ids[j] : kNone;
+  }
+  for (uint64_t j0 = j_begin; j0 < len; j0 += (uint64_t)kRowsPerIter * kBatch) {
     uint4 r[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
-      const uint64_t j = j0 + (uint64_t)u * kRowsPerIter;
-      const uint32_t id = j < len ? ids[j] : kNone;  // kNone: hash absent from every subject of the tile
+      const uint32_t id = id_next[u];  // kNone: hash absent from every subject of the tile
       r[u] = id != kNone ? *reinterpret_cast<const uint4 *>(rows + (uint64_t)id * kW32 + quad * 4) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      const uint64_t j = j0 + (uint64_t)(kBatch + u) * kRowsPerIter;
+      id_next[u] = j < len ? ids[j] : kNone;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
