@@ -1376,6 +1376,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         const bool first_uncovered = __shfl((int)covered, (int)first_lane, 64) == 0;
         uint32_t f_shared = 0;
         bool done_now = pending && covered;
+        bool counted = done_now;  // evaluated exactly (a window found out of reach of the bar is done, but not counted)
         if (first_uncovered) {
           PA_STAT(9, 1);  // cooperative evaluations
           // the first pending window alone is longer than the stretch: the whole wave takes it from HBM
@@ -1385,7 +1386,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
           __syncthreads();
           const uint32_t v = eval_window_coop(base, e0);
-          if (lane == first_lane) { f_shared = v; done_now = true; }
+          if (lane == first_lane) { f_shared = v; done_now = true; counted = true; }
+          else counted = false;
         } else {
           // Every window of the round at once, one lane each, without ordering the stretch.  A window holds the stretch
           // positions [xs, xe) minus later occurrences of a hash it already holds: a bit mask W over the positions.  With
@@ -1501,7 +1503,15 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           }
           PA_CUT(8);  // window masks, coarse search
           // fine: the groups of the lanes lie next to each other as a rule; kFineGroups of them per pass
-          bool unresolved = walking;
+          // A window shares |M_(T-1) & W| minimizers and T - 1 lies in the coarse group just found, so the matches up to the
+          // group's last rank bound it from above (by the matches of at most 15 more ranks): windows that cannot reach
+          // the bar any more -- most of a candidate's windows away from its optimum -- are done here, without the fine
+          // tables, and are left out of the fold below (their exact value is below the bar, which is all that matters).
+          int32_t bar_now = c_best > best_shared ? c_best : best_shared;
+          if (bar_now < floor_bar) bar_now = floor_bar;
+          const bool in_reach = (int32_t)count_in(bc + g_lo * kRow + kW) >= bar_now;
+          counted = walking && in_reach;
+          bool unresolved = counted;
           while (__any(unresolved)) {
             PA_STAT(8, 1);  // fine passes
             const uint32_t g_cur = pa_dev::wave_min_dpp(unresolved ? g_lo : 0xffffffffu);
@@ -1540,13 +1550,13 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           __syncthreads();
         }
         // fold the evaluated starts into the candidate's optimum: most shared; first and last position of it
-        const uint64_t dm = __ballot(done_now);
+        const uint64_t dm = __ballot(counted);
         int32_t group_best = -1;
         {
-          group_best = (int32_t)pa_dev::wave_max_dpp(done_now ? f_shared + 1u : 0u) - 1;
+          group_best = (int32_t)pa_dev::wave_max_dpp(counted ? f_shared + 1u : 0u) - 1;
         }
         if (dm && group_best >= c_best) {
-          const uint64_t top = __ballot(done_now && (int32_t)f_shared == group_best);
+          const uint64_t top = __ballot(counted && (int32_t)f_shared == group_best);
           const uint32_t w_first = __shfl(wp, __builtin_ctzll(top), 64), w_last = __shfl(wp, 63 - __builtin_clzll(top), 64);
           if (group_best > c_best) { c_best = group_best; c_first = w_first; c_last = w_last; }
           else { c_first = min(c_first, w_first); c_last = max(c_last, w_last); }
