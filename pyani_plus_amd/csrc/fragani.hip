@@ -1291,10 +1291,15 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         const uint32_t w_after = HW(h_lo + (uint32_t)bar - 1u), w_upto = HW(h_hi - (uint32_t)bar);
         if (!__any(has && wp + count_windows > w_after && wp <= w_upto)) continue;
       }
-      // seed hits inside the start's window: every occurrence of every query hash is a hit, so no window shares more
+      // Seed hits inside the start's window: every occurrence of every query hash is a hit, so no window shares more.
+      // Only "at least b of them" is ever asked: with i0 = the first hit at or after the start, that is "hit i0 + b - 1
+      // exists and lies before the window's end" -- one search and one read instead of two searches.
       const uint32_t i0 = hit_lower_bound_w(h_lo, h_hi, wp, h_steps);
-      const int32_t ub = has ? (int32_t)(hit_lower_bound_w(i0, h_hi, wp + count_windows, h_steps) - i0) : -1;
-      bool pending = ub >= bar;
+      auto holds_hits = [&](int32_t b) -> bool {
+        const uint32_t idx = i0 + (uint32_t)max(b, 1) - 1u;
+        return has & (idx < h_hi) & (HW(min(idx, nh - 1u)) < wp + count_windows);
+      };
+      bool pending = bar > 0 ? holds_hits(bar) : has;
       if (cut == 4) pending = false;  // seed-hit bounds of every group
       PA_STAT(3, 1);                              // groups of 64 starts
       PA_STAT(4, __popcll(__ballot(pending)));    // starts that pass the seed-hit bound
@@ -1566,7 +1571,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         {
           int32_t bar2 = c_best > best_shared ? c_best : best_shared;
           if (bar2 < floor_bar) bar2 = floor_bar;
-          pending = pending && ub >= bar2;
+          pending = pending && (bar2 > 0 ? holds_hits(bar2) : true);
         }
       }
     }
