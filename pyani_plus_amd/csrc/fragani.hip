@@ -968,23 +968,35 @@ __global__ __launch_bounds__(kThreads) void segment_records_kernel(
 }
 
 // A segment's hits ordered by (contig, window id) in registers: E keys per lane, element e = lane * E + q, bitonic
-// network over 64 E elements.  Strides of E and more exchange between lanes (two ds_bpermute per key, no LDS memory,
-// no barrier), the strides below E between the registers of a lane.  Missing elements are keys above any real one.
-template <int E, int J>
-__device__ __forceinline__ void bitonic_inside_lane(uint64_t (&k)[E], uint32_t e0, uint32_t span) {
+// network over 64 E elements.  Strides of E and more exchange between lanes (ds_bpermute, no LDS memory, no barrier),
+// the strides below E between the registers of a lane.  Missing elements are keys above any real one.  Key = uint32_t
+// (contig relative to the genome's first in 8 bits | window id in 24) when the segment's contigs allow it -- one
+// shuffle, a minimum, a maximum and a select per key and stage --, else uint64_t (20 + 24 bits).
+template <typename Key>
+__device__ __forceinline__ Key lane_exchange(Key v, int partner_byte_address) {
+  if constexpr (sizeof(Key) == 4) {
+    return (Key)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)v);
+  } else {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)(uint32_t)(v >> 32));
+    return ((Key)hi << 32) | lo;
+  }
+}
+template <int E, int J, typename Key>
+__device__ __forceinline__ void bitonic_inside_lane(Key (&k)[E], uint32_t e0, uint32_t span) {
 #pragma unroll
   for (int q = 0; q < E; ++q) {
     if ((q & J) == 0) {
       const bool asc = ((e0 + (uint32_t)q) & span) == 0u;
-      const uint64_t a = k[q], b = k[q | J];
-      const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+      const Key a = k[q], b = k[q | J];
+      const Key lo = a < b ? a : b, hi = a < b ? b : a;
       k[q] = asc ? lo : hi;
       k[q | J] = asc ? hi : lo;
     }
   }
 }
-template <int E>
-__device__ __forceinline__ void bitonic_sort_lanes(uint64_t (&k)[E], uint32_t lane) {
+template <int E, typename Key>
+__device__ __forceinline__ void bitonic_sort_lanes(Key (&k)[E], uint32_t lane) {
   const uint32_t e0 = lane * (uint32_t)E;
   for (uint32_t span = 2; span <= 64u * (uint32_t)E; span <<= 1) {
     for (uint32_t j = span >> 1; j > 0; j >>= 1) {
@@ -996,17 +1008,20 @@ __device__ __forceinline__ void bitonic_sort_lanes(uint64_t (&k)[E], uint32_t la
         const bool take_min = ((lane & lj) == 0u) == ((lane & (span / (uint32_t)E)) == 0u);
 #pragma unroll
         for (int q = 0; q < E; ++q) {
-          const uint32_t olo = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)(uint32_t)k[q]);
-          const uint32_t ohi = (uint32_t)__builtin_amdgcn_ds_bpermute(partner, (int)(uint32_t)(k[q] >> 32));
-          const uint64_t other = ((uint64_t)ohi << 32) | olo;
-          k[q] = ((other < k[q]) == take_min) ? other : k[q];
+          const Key other = lane_exchange<Key>(k[q], partner);
+          if constexpr (sizeof(Key) == 4) {
+            const Key lo = min(k[q], other), hi = max(k[q], other);
+            k[q] = take_min ? lo : hi;
+          } else {
+            k[q] = ((other < k[q]) == take_min) ? other : k[q];
+          }
         }
       } else if (E > 4 && j == 4u) {
-        bitonic_inside_lane<E, (E > 4 ? 4 : 1)>(k, e0, span);
+        bitonic_inside_lane<E, (E > 4 ? 4 : 1), Key>(k, e0, span);
       } else if (E > 2 && j == 2u) {
-        bitonic_inside_lane<E, (E > 2 ? 2 : 1)>(k, e0, span);
+        bitonic_inside_lane<E, (E > 2 ? 2 : 1), Key>(k, e0, span);
       } else if (E > 1) {
-        bitonic_inside_lane<E, 1>(k, e0, span);
+        bitonic_inside_lane<E, 1, Key>(k, e0, span);
       }
     }
   }
@@ -1016,12 +1031,32 @@ template <int E>
 __device__ __forceinline__ void stage_hits_sorted(const uint64_t *__restrict__ seg_keys, uint32_t nh, uint32_t hc_base,
                                                   uint32_t lane, uint32_t *hw, uint16_t *hc) {
   uint64_t k[E];
+  uint32_t widest = 0;  // largest relative contig of the segment
 #pragma unroll
   for (int q = 0; q < E; ++q) {
     const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
     k[q] = e < nh ? (seg_keys[e] & 0xfffffffffffULL) : ~0ULL;  // (contig, window id): the low 44 bits of a hit
+    if (e < nh) widest = max(widest, ((uint32_t)(k[q] >> 24) & 0xfffffu) - hc_base);
   }
-  bitonic_sort_lanes<E>(k, lane);
+  if (pa_dev::wave_max_dpp(widest) < 255u) {  // uniform
+    uint32_t k32[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
+      k32[q] = e < nh ? ((((uint32_t)(k[q] >> 24) & 0xfffffu) - hc_base) << 24) | ((uint32_t)k[q] & 0xffffffu) : 0xffffffffu;
+    }
+    bitonic_sort_lanes<E, uint32_t>(k32, lane);
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
+      if (e < nh) {
+        hw[e] = k32[q] & 0xffffffu;
+        hc[e] = (uint16_t)(k32[q] >> 24);
+      }
+    }
+    return;
+  }
+  bitonic_sort_lanes<E, uint64_t>(k, lane);
 #pragma unroll
   for (int q = 0; q < E; ++q) {
     const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
