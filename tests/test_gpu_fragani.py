@@ -152,6 +152,24 @@ def test_fragments_that_are_mostly_n(engine):
     _check_against_oracle(engine, texts, [[g] for g in genomes], frag=1000, k=15)
 
 
+def test_reference_of_hundreds_of_contigs(engine):
+    """A draft assembly of 320 contigs: hits on contigs past the 255th of their genome do not fit the mapping kernel's
+    32-bit sort keys and take the 64-bit ones; candidates on many contigs per segment.  Same integers as the oracle."""
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    root = rng.choice(acgt, size=320 * 1_150)
+    whole = root.tobytes()
+    pieces = [root[i * 1_150 : (i + 1) * 1_150].tobytes() for i in range(320)]
+    mutated = root.copy()
+    hit = rng.random(mutated.size) < 0.02
+    mutated[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+    contig_lists = [[whole], pieces, [mutated.tobytes()]]
+    texts = [b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs)) for contigs in contig_lists]
+    total, matched, _ = _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
+    assert matched[0, 1] > 300 and matched[2, 1] > 200  # mappings onto contigs of every index
+    assert total[1] == 320  # one fragment per contig of the draft
+
+
 def test_batches_are_halved_when_the_seed_hits_outgrow_their_indices(engine, monkeypatch):
     """A batch of query genomes whose seed hits pass 2^31 is halved and started again; forced here with a limit of a few
     thousand hits, down to one query genome per batch.  Same integers as the one-batch run and as the oracle."""
