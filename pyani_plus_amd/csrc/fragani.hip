@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     }
   }
   PA_CUT(11);  // hits staged in order
-  for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;
+  // (sh.cnt is zeroed where the cooperative evaluation uses it: the bit tables of the rounds live in the same memory)
   if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
   // The fragment's hashes bucketed by their top kQtBits bits: a reference minimizer's rank among them is then the
   // bucket's first rank plus a search among the bucket's few hashes (a fraction of a hash per bucket on average)
