@@ -130,6 +130,8 @@ def test_pairs_equal_oracle_on_random_genomes(engine):
     _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
     # fragments of 5 000: window 40, stretches of up to 384 minimizers -- twelve words per row of the mapping kernel's bit tables
     _check_against_oracle(engine, texts, contig_lists, frag=5000, k=16)
+    # 9-mers: unrelated genomes share thousands of minimizers by chance, the same hash several times in a window
+    _check_against_oracle(engine, texts, contig_lists, frag=600, k=9)
 
 
 def test_fragments_that_are_mostly_n(engine):
