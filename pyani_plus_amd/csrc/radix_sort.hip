@@ -24,6 +24,14 @@ constexpr int kTile = kSortThreads * kItems;      // 2048 elements per workgroup
 constexpr int kRadix = 256;
 
 __device__ __forceinline__ uint32_t digit_of(uint64_t key, int shift) { return (uint32_t)(key >> shift) & 0xffu; }
+__device__ __forceinline__ uint32_t wave_incl_scan_rs(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(v, o, 64);
+    if (lane >= (uint32_t)o) v += t;
+  }
+  return v;
+}
 
 // BY_VAL: the digit comes from the 32-bit value instead of the 64-bit key
 template <bool BY_VAL>
@@ -86,15 +94,29 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter_kernel(
     rank[it] = pre + below;
   }
   __syncthreads();
-  // per digit: global start of this tile, then of each wave's slice within it
+  // The tile is put in order in LDS first and leaves from there: thread t writes the elements t, t + 256, ... of the
+  // ordered tile, so the elements of one digit go to consecutive addresses from consecutive lanes (runs of 8 on
+  // average: whole 64-byte sectors of keys) instead of one 8-byte store per element wherever its wave's rank put it.
+  __shared__ uint64_t s_key[kTile];
+  __shared__ uint32_t s_val[kTile];
+  __shared__ uint32_t s_delta[kRadix];  // per digit: global start of the tile's run minus its start inside the tile
+  __shared__ uint32_t s_w[kWaves];
   {
-    uint32_t run = offs[(uint64_t)tid * n_tiles + blockIdx.x];
+    // thread = digit: the digit's elements in the tile, the waves' slices inside them, the run's start inside the tile
+    uint32_t wave_cnt[kWaves], total = 0;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      const uint32_t c = s_cnt[w][tid];
-      s_cnt[w][tid] = run;
-      run += c;
-    }
+    for (int w = 0; w < kWaves; ++w) { wave_cnt[w] = s_cnt[w][tid]; total += wave_cnt[w]; }
+    const uint32_t inc = wave_incl_scan_rs(total, lane);
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint32_t local = inc - total;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+      if ((uint32_t)w < wave) local += s_w[w];
+    s_delta[tid] = offs[(uint64_t)tid * n_tiles + blockIdx.x] - local;
+    uint32_t run = local;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { s_cnt[w][tid] = run; run += wave_cnt[w]; }
   }
   __syncthreads();
 #pragma unroll
@@ -102,9 +124,24 @@ __global__ __launch_bounds__(kSortThreads) void rs_scatter_kernel(
     const uint64_t i = wbase + (uint64_t)it * 64 + lane;
     if (i < n) {
       const uint32_t d = BY_VAL ? ((val[it] >> shift) & 0xffu) : digit_of(key[it], shift);
-      const uint32_t dst = s_cnt[wave][d] + rank[it];
-      keys_out[dst] = key[it];
-      vals_out[dst] = val[it];
+      const uint32_t at = s_cnt[wave][d] + rank[it];  // position inside the ordered tile
+      s_key[at] = key[it];
+      s_val[at] = val[it];
+    }
+  }
+  __syncthreads();
+  const uint64_t tile_base = (uint64_t)blockIdx.x * kTile;
+  const uint32_t live = (uint32_t)(n - tile_base < (uint64_t)kTile ? n - tile_base : (uint64_t)kTile);
+#pragma unroll
+  for (int it = 0; it < kItems; ++it) {
+    const uint32_t at = (uint32_t)it * kSortThreads + tid;
+    if (at < live) {
+      const uint64_t k = s_key[at];
+      const uint32_t v = s_val[at];
+      const uint32_t d = BY_VAL ? ((v >> shift) & 0xffu) : digit_of(k, shift);
+      const uint32_t dst = s_delta[d] + at;
+      keys_out[dst] = k;
+      vals_out[dst] = v;
     }
   }
 }
