@@ -419,7 +419,8 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
                                                             const uint32_t *__restrict__ mini_wpos,
                                                             const uint32_t *__restrict__ contig_genome,
                                                             uint64_t *__restrict__ post_cw,
-                                                            uint16_t *__restrict__ post_genome) {
+                                                            uint16_t *__restrict__ post_genome,
+                                                            const uint32_t *__restrict__ contig_mini_off, uint32_t n_contigs) {
   // the contig of the posting before this one comes from the thread before it (LDS) instead of a second random read
   __shared__ uint32_t s_contig[kThreads];
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
@@ -428,7 +429,14 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
   if (in) {
     id = pos[i] + flags[i] - 1u;
     me = sorted_idx[i];
-    mc = mini_contig[me];
+    // the minimizers are stored contig by contig: the contig of minimizer `me` is a search in the contigs' first
+    // minimizers (a few KB, cached) instead of one more random 4-byte read from HBM
+    uint32_t lo = 0, hi = n_contigs;  // largest c with contig_mini_off[c] <= me
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (contig_mini_off[mid] <= me) lo = mid; else hi = mid;
+    }
+    mc = lo;
   }
   s_contig[threadIdx.x] = mc;
   __syncthreads();
@@ -2013,7 +2021,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
                        n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
                        W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
-                       W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>());
+                       W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>(), W.contig_mini_off.as<uint32_t>(), n_contigs);
     W.index_ids = n_ids;
   }
   const uint32_t *d_sorted_idx = vals[which];
