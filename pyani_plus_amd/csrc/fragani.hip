@@ -399,15 +399,17 @@ __global__ __launch_bounds__(kThreads) void bucket_index_kernel(const uint32_t *
 }
 
 // ============================================================== 2. dictionary of minimizer hashes
-__global__ __launch_bounds__(kThreads) void mini_keys_kernel(const uint32_t *__restrict__ hash, uint32_t m,
-                                                             uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+// Sort key of a minimizer: its hash in the low word -- the only bits the radix passes look at -- and its window id as a
+// passenger in the high word, so that the posting build reads it in posting order instead of gathering it.
+__global__ __launch_bounds__(kThreads) void mini_keys_kernel(const uint32_t *__restrict__ hash, const uint32_t *__restrict__ wpos,
+                                                             uint32_t m, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-  if (i < m) { keys[i] = hash[i]; vals[i] = i; }
+  if (i < m) { keys[i] = ((uint64_t)wpos[i] << 32) | hash[i]; vals[i] = i; }
 }
 __global__ __launch_bounds__(kThreads) void key_heads_kernel(const uint64_t *__restrict__ keys, uint32_t m,
                                                              uint32_t *__restrict__ flags) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-  if (i < m) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+  if (i < m) flags[i] = (i == 0 || (uint32_t)keys[i] != (uint32_t)keys[i - 1]) ? 1u : 0u;
 }
 __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__restrict__ keys,
                                                             const uint32_t *__restrict__ sorted_idx,
@@ -444,17 +446,17 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
   mini_id[me] = id;
   // the posting as the low 44 bits of a hit key, its genome on top so that bucketing needs no second lookup
   const uint32_t pg = contig_genome[mc];
-  post_cw[i] = ((uint64_t)pg << 44) | ((uint64_t)mc << 24) | mini_wpos[me];
+  const uint64_t key = keys[i];
+  post_cw[i] = ((uint64_t)pg << 44) | ((uint64_t)mc << 24) | (uint32_t)(key >> 32);  // the window id rode along in the sort key
   post_genome[i] = (uint16_t)pg;  // used by the bucketed seeding only, which needs n_genomes <= 8192
   if (flags[i]) post_start[id] = i;
   if (i == m - 1) post_start[n_ids] = m;
-  int32_t ps = -1;
-  if (i > 0 && keys[i] == keys[i - 1]) {
+  // "the same hash earlier in this contig": rare (repeats inside a contig), and the array has been filled with -1
+  if (i > 0 && (uint32_t)key == (uint32_t)keys[i - 1]) {
     const uint32_t other = sorted_idx[i - 1];  // stable sort: other < me
     const uint32_t oc = threadIdx.x > 0 ? s_contig[threadIdx.x - 1] : mini_contig[other];
-    if (oc == mc) ps = (int32_t)other;
+    if (oc == mc) prev_same[me] = (int32_t)other;
   }
-  prev_same[me] = ps;
 }
 
 // ============================================================== 3. fragment sketches
@@ -2009,7 +2011,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   int which = reuse ? W.index_which : 0;
   if (!reuse) {
     const uint32_t gm = ceil_div_u64(m, kThreads);
-    hipLaunchKernelGGL(mini_keys_kernel, dim3(gm), dim3(kThreads), 0, c->stream, W.mini_hash.as<uint32_t>(), m, keys[0], vals[0]);
+    hipLaunchKernelGGL(mini_keys_kernel, dim3(gm), dim3(kThreads), 0, c->stream, W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), m,
+                       keys[0], vals[0]);
     PA_TRY(pa_radix_sort_pairs(c, keys, vals, m, 0, 32, false, &which));
     uint32_t *d_flags = W.flags.as<uint32_t>(), *d_pos = d_flags + m;
     hipLaunchKernelGGL(key_heads_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], m, d_flags);
@@ -2018,6 +2021,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_HIP(hipStreamSynchronize(c->stream));
     const uint32_t n_ids = (uint32_t)c->h_pinned[0];
     PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
+    PA_HIP(hipMemsetAsync(W.prev_same.p, 0xff, (uint64_t)m * 4, c->stream));  // -1: no earlier occurrence
     hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
                        n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
                        W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
