@@ -258,7 +258,17 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
   __syncthreads();
   uint32_t c = 0;
   bool have_c = false;
-  if (p0 >= 0 && (uint64_t)p0 < arena_bases) { c = contig_of(contig_start, n_contigs, (uint64_t)p0); have_c = true; }
+  // the contig of the thread's first position, and its bounds in registers: they change at a contig boundary only
+  // (asking contig_start again for every position was a load, and a wait, per position)
+  uint64_t c_beg = 0, c_next = ~0ULL;
+  uint32_t c_len = 0;
+  if (p0 >= 0 && (uint64_t)p0 < arena_bases) {
+    c = contig_of(contig_start, n_contigs, (uint64_t)p0);
+    have_c = true;
+    c_beg = contig_start[c];
+    c_len = contig_len[c];
+    c_next = c + 1 < n_contigs ? contig_start[c + 1] : ~0ULL;
+  }
   uint32_t local[kPPT];
   uint32_t cidx[kPPT];
 #pragma unroll
@@ -268,9 +278,14 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     local[j] = 0; cidx[j] = 0;
     if (have_c && x >= kHalo / 2) {
       const uint64_t pos = (uint64_t)(p0 + j);
-      while (c + 1 < n_contigs && contig_start[c + 1] <= pos) ++c;
-      const uint64_t loc = pos - contig_start[c];
-      if (loc < contig_len[c] && loc + 1 >= (uint64_t)w && s_h[x] != kSkip) {
+      while (pos >= c_next) {  // into the next contig
+        ++c;
+        c_beg = c_next;
+        c_len = contig_len[c];
+        c_next = c + 1 < n_contigs ? contig_start[c + 1] : ~0ULL;
+      }
+      const uint64_t loc = pos - c_beg;
+      if (loc < c_len && loc + 1 >= (uint64_t)w && s_h[x] != kSkip) {
         uint32_t best = s_h[x];
         mp = x;
         if (w > kPPT) {
