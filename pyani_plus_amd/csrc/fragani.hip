@@ -474,6 +474,65 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
   }
 }
 
+// Keys ordered in registers (a segment's hits by (contig, window id) in the mapping kernel, a fragment's minimizers by
+// hash below): E keys per lane, element e = lane * E + q, bitonic network over 64 E elements.  Strides of E and more exchange between lanes (ds_bpermute, no LDS memory, no barrier),
+// the strides below E between the registers of a lane.  Missing elements are keys above any real one.  Key = uint32_t
+// (contig relative to the genome's first in 8 bits | window id in 24) when the segment's contigs allow it -- one
+// shuffle, a minimum, a maximum and a select per key and stage --, else uint64_t (20 + 24 bits).
+template <typename Key>
+__device__ __forceinline__ Key lane_exchange(Key v, int partner_byte_address) {
+  if constexpr (sizeof(Key) == 4) {
+    return (Key)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)v);
+  } else {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)(uint32_t)(v >> 32));
+    return ((Key)hi << 32) | lo;
+  }
+}
+template <int E, int J, typename Key>
+__device__ __forceinline__ void bitonic_inside_lane(Key (&k)[E], uint32_t e0, uint32_t span) {
+#pragma unroll
+  for (int q = 0; q < E; ++q) {
+    if ((q & J) == 0) {
+      const bool asc = ((e0 + (uint32_t)q) & span) == 0u;
+      const Key a = k[q], b = k[q | J];
+      const Key lo = a < b ? a : b, hi = a < b ? b : a;
+      k[q] = asc ? lo : hi;
+      k[q | J] = asc ? hi : lo;
+    }
+  }
+}
+template <int E, typename Key>
+__device__ __forceinline__ void bitonic_sort_lanes(Key (&k)[E], uint32_t lane) {
+  const uint32_t e0 = lane * (uint32_t)E;
+  for (uint32_t span = 2; span <= 64u * (uint32_t)E; span <<= 1) {
+    for (uint32_t j = span >> 1; j > 0; j >>= 1) {
+      if (j >= (uint32_t)E) {
+        const uint32_t lj = j / (uint32_t)E;
+        const int partner = (int)((lane ^ lj) << 2);  // byte address of the partner lane for ds_bpermute
+        // the lower lane of a pair keeps the smaller key in an ascending run: span > j >= E, so the run's direction is a
+        // bit of the lane number, the same for all E keys of the lane
+        const bool take_min = ((lane & lj) == 0u) == ((lane & (span / (uint32_t)E)) == 0u);
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const Key other = lane_exchange<Key>(k[q], partner);
+          if constexpr (sizeof(Key) == 4) {
+            const Key lo = min(k[q], other), hi = max(k[q], other);
+            k[q] = take_min ? lo : hi;
+          } else {
+            k[q] = ((other < k[q]) == take_min) ? other : k[q];
+          }
+        }
+      } else if (E > 4 && j == 4u) {
+        bitonic_inside_lane<E, (E > 4 ? 4 : 1), Key>(k, e0, span);
+      } else if (E > 2 && j == 2u) {
+        bitonic_inside_lane<E, (E > 2 ? 2 : 1), Key>(k, e0, span);
+      } else if (E > 1) {
+        bitonic_inside_lane<E, 1, Key>(k, e0, span);
+      }
+    }
+  }
+}
 // ============================================================== 3. fragment sketches
 // one wave per fragment: slice of the contig's minimizers, sorted by (hash, slice index), first of each hash kept
 __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
@@ -502,21 +561,25 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     n = e - b0;
     if (n > (uint32_t)kQMax) { if (lane == 0) atomicAdd(overflow, 1u); n = kQMax; }
   }
-  for (uint32_t i = lane; i < (uint32_t)kQMax; i += 64)
-    key[i] = i < n ? (((uint64_t)mini_hash[b0 + i] << 16) | i) : ~0ULL;
-  __syncthreads();
-  // bitonic sort of kQMax keys, one wave per fragment
-  for (uint32_t size = 2; size <= (uint32_t)kQMax; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t t = lane; t < (uint32_t)kQMax / 2; t += 64) {
-        const uint32_t i = 2 * t - (t & (stride - 1)), j = i + stride;
-        const bool up = (i & size) == 0;
-        const uint64_t a = key[i], bb = key[j];
-        if ((a > bb) == up) { key[i] = bb; key[j] = a; }
-      }
-      __syncthreads();
+  // the slice's (hash, slice index) keys ordered in registers, E = 1, 2, 4 or 8 per lane by the size of the slice, and
+  // left in LDS for the pass below (every wave has its own keys: no barrier between the waves of the workgroup)
+  auto sort_slice = [&](auto e_tag) {
+    constexpr int E = decltype(e_tag)::value;
+    uint64_t k[E];
+#pragma unroll
+    for (int q = 0; q < E; ++q) {
+      const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
+      k[q] = e < n ? (((uint64_t)mini_hash[b0 + e] << 16) | e) : ~0ULL;
     }
-  }
+    bitonic_sort_lanes<E, uint64_t>(k, lane);
+#pragma unroll
+    for (int q = 0; q < E; ++q) key[lane * (uint32_t)E + (uint32_t)q] = k[q];
+  };
+  if (n <= 64u) sort_slice(std::integral_constant<int, 1>{});
+  else if (n <= 128u) sort_slice(std::integral_constant<int, 2>{});
+  else if (n <= 256u) sort_slice(std::integral_constant<int, 4>{});
+  else sort_slice(std::integral_constant<int, 8>{});
+  __builtin_amdgcn_wave_barrier();
   if (!active) return;
   // keep the first entry of every hash run (smallest slice index = smallest window id)
   uint32_t s = 0, hits = 0;
@@ -992,65 +1055,6 @@ __global__ __launch_bounds__(kThreads) void segment_records_kernel(
   rec[2 * (uint64_t)i + 1] = make_uint4(mh, hc_base, 0u, 0u);
 }
 
-// A segment's hits ordered by (contig, window id) in registers: E keys per lane, element e = lane * E + q, bitonic
-// network over 64 E elements.  Strides of E and more exchange between lanes (ds_bpermute, no LDS memory, no barrier),
-// the strides below E between the registers of a lane.  Missing elements are keys above any real one.  Key = uint32_t
-// (contig relative to the genome's first in 8 bits | window id in 24) when the segment's contigs allow it -- one
-// shuffle, a minimum, a maximum and a select per key and stage --, else uint64_t (20 + 24 bits).
-template <typename Key>
-__device__ __forceinline__ Key lane_exchange(Key v, int partner_byte_address) {
-  if constexpr (sizeof(Key) == 4) {
-    return (Key)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)v);
-  } else {
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(partner_byte_address, (int)(uint32_t)(v >> 32));
-    return ((Key)hi << 32) | lo;
-  }
-}
-template <int E, int J, typename Key>
-__device__ __forceinline__ void bitonic_inside_lane(Key (&k)[E], uint32_t e0, uint32_t span) {
-#pragma unroll
-  for (int q = 0; q < E; ++q) {
-    if ((q & J) == 0) {
-      const bool asc = ((e0 + (uint32_t)q) & span) == 0u;
-      const Key a = k[q], b = k[q | J];
-      const Key lo = a < b ? a : b, hi = a < b ? b : a;
-      k[q] = asc ? lo : hi;
-      k[q | J] = asc ? hi : lo;
-    }
-  }
-}
-template <int E, typename Key>
-__device__ __forceinline__ void bitonic_sort_lanes(Key (&k)[E], uint32_t lane) {
-  const uint32_t e0 = lane * (uint32_t)E;
-  for (uint32_t span = 2; span <= 64u * (uint32_t)E; span <<= 1) {
-    for (uint32_t j = span >> 1; j > 0; j >>= 1) {
-      if (j >= (uint32_t)E) {
-        const uint32_t lj = j / (uint32_t)E;
-        const int partner = (int)((lane ^ lj) << 2);  // byte address of the partner lane for ds_bpermute
-        // the lower lane of a pair keeps the smaller key in an ascending run: span > j >= E, so the run's direction is a
-        // bit of the lane number, the same for all E keys of the lane
-        const bool take_min = ((lane & lj) == 0u) == ((lane & (span / (uint32_t)E)) == 0u);
-#pragma unroll
-        for (int q = 0; q < E; ++q) {
-          const Key other = lane_exchange<Key>(k[q], partner);
-          if constexpr (sizeof(Key) == 4) {
-            const Key lo = min(k[q], other), hi = max(k[q], other);
-            k[q] = take_min ? lo : hi;
-          } else {
-            k[q] = ((other < k[q]) == take_min) ? other : k[q];
-          }
-        }
-      } else if (E > 4 && j == 4u) {
-        bitonic_inside_lane<E, (E > 4 ? 4 : 1), Key>(k, e0, span);
-      } else if (E > 2 && j == 2u) {
-        bitonic_inside_lane<E, (E > 2 ? 2 : 1), Key>(k, e0, span);
-      } else if (E > 1) {
-        bitonic_inside_lane<E, 1, Key>(k, e0, span);
-      }
-    }
-  }
-}
 // the segment's hits from the hit array into LDS, in order: window id and contig (relative to the genome's first)
 template <int E>
 __device__ __forceinline__ void stage_hits_sorted(const uint64_t *__restrict__ seg_keys, uint32_t nh, uint32_t hc_base,
