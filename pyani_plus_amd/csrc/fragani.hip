@@ -724,8 +724,7 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
         n_u[u] = __shfl(n_blk, (int)(i & 63u), 64);  // 0 past the fragment's last minimizer; every lane takes part in the shuffle
         longest = max(longest, n_u[u]);
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, o, 64));
+      longest = pa_dev::wave_max_dpp(longest);
       for (uint32_t r = 0; r < longest; r += 32) {
         const uint32_t slot = r + (lane & 31u);
         Elem cw[kLoads];
