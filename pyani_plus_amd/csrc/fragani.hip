@@ -749,8 +749,10 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     const uint32_t g = g0 + lane;
     const uint32_t cnt = g < n_genomes ? hist[g] : 0u;
     const uint32_t off = carry + wave_excl_scan(cnt, lane);
-    if (g < n_genomes) hist[g] = off;
     const bool keep = cnt >= mh && g >= ref0 && g < ref1;  // only the reference genomes asked for are mapped
+    // the top bit marks a genome whose hits nobody will read (fewer than a run needs, or not asked for): the scatter
+    // pass then does not write them -- lone 8-byte stores, a 64-byte sector each (offsets stay below 2^31)
+    if (g < n_genomes) hist[g] = off | (keep ? 0u : 0x80000000u);
     const bool small = keep && cnt <= (uint32_t)kHitCapSmall;
     n_small += (uint32_t)__popcll(__ballot(small));
     n_large += (uint32_t)__popcll(__ballot(keep && !small));
@@ -790,8 +792,8 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
       const uint32_t g = g0 + lane;
       uint32_t off = 0, cnt = 0;
       if (g < n_genomes) {
-        off = hist[g];
-        cnt = (g + 1 < n_genomes ? hist[g + 1] : total_hits) - off;
+        off = hist[g] & 0x7fffffffu;
+        cnt = (g + 1 < n_genomes ? (hist[g + 1] & 0x7fffffffu) : total_hits) - off;
       }
       const bool keep = cnt >= mh && g >= ref0 && g < ref1;
       const bool small = keep && cnt <= (uint32_t)kHitCapSmall, large = keep && !small;
@@ -808,8 +810,8 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
   __builtin_amdgcn_wave_barrier();
   // (the query window id of a hit is no longer carried along: the mapping kernel slides over reference positions)
   for_each_posting(post_cw, [&](uint32_t, uint64_t cw) {
-    const uint32_t slot = base + atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
-    keys[slot] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
+    const uint32_t at = atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
+    if (!(at & 0x80000000u)) keys[base + at] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
   });
 }
 
