@@ -42,13 +42,18 @@ uint64_t orc_murmur3_h1(const uint8_t *data, uint32_t len, uint32_t seed);
  * The five RESTATEMENT choices can be switched at run time so that tools/fragani_bisect.py can measure, on
  * the reference's 25 fastANI rows, what each of them costs (table in profiles/ and DESIGN.md).  The defaults
  * are the variant the HIP path implements. */
-enum { OPT_WINDOW_RULE = 0, OPT_BIN_RULE = 1, OPT_L2_RULE = 2, OPT_CONF = 3, OPT_COUNT = 4 };
+enum { OPT_WINDOW_RULE = 0, OPT_BIN_RULE = 1, OPT_L2_RULE = 2, OPT_CONF = 3, OPT_L2_POS = 4, OPT_L2_STOP = 5, OPT_COUNT = 6 };
 static double g_opt[OPT_COUNT] = {
     1.0, /* OPT_WINDOW_RULE: 0 = sketch sizes 10, 60, 110, ... (round 1); 1 = 1, 2, 5, 10, 20, 30, ... (Mashmap's list) */
     1.0, /* OPT_BIN_RULE:    0 = (pos + fragLen/2) / fragLen (round 1); 1 = pos / (fragLen - 20) (fastANI's bucket) */
     1.0, /* OPT_L2_RULE:     0 = Jaccard at the window starts the seed hits imply (round 1); 1 = slide over reference minimizer positions,
-                                  position = mean of the first and last optimum (Mashmap's slide) */
+                                  position = mean of the first and last optimum (rounds 2 and 3); 2 = the exact slide: the window at
+                                  every position i holds the minimizers of the reference windows [i, i + count_windows) -- the one still
+                                  active at i included --, and the slide ends when the window's end reaches the candidate's last end */
     0.9, /* OPT_CONF:        confidence level of the identity bounds */
+    0.0, /* OPT_L2_POS:      (rule 2) position of a window: 0 = window id of its first minimizer, 1 = the position i itself */
+    0.0, /* OPT_L2_STOP:     (rule 2) 0 = the slide ends when the window's end reaches the first minimizer at or past rangeEnd + fragLen;
+                                  1 = it also ends past position rangeEnd; 2 = past rangeEnd only (no end rule) */
 };
 ORC_API void orc_fragani_set_option(int which, double value) { if (which >= 0 && which < OPT_COUNT) g_opt[which] = value; }
 ORC_API double orc_fragani_get_option(int which) { return (which >= 0 && which < OPT_COUNT) ? g_opt[which] : NAN; }
@@ -377,7 +382,54 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
        * fragment's own sketch holds for the fragment.  Best = most shared; ties: lowest contig,
        * then smallest start. */
       int best_shared = -1, best_seq = -1; int64_t best_pos = 0;
-      if (g_opt[OPT_L2_RULE] != 0.0) {
+      if (g_opt[OPT_L2_RULE] == 2.0) {
+        /* The exact slide.  State at position i of the candidate's contig: begin b = the last minimizer recorded at or
+         * before i (the one active in window i), end e = the first minimizer recorded at or after i + count_windows; the
+         * window holds minimizers [b, e) = those of the reference windows [i, i + count_windows), which is what the
+         * fragment's own sketch holds for the fragment.  The slide starts at the first minimizer recorded in the candidate
+         * range, moves from event to event (the next minimizer becoming active, or the next one entering at the end) and
+         * ends as soon as e reaches `last_end`, the first minimizer at or past rangeEnd + fragLen or the contig's end:
+         * the state that would take in the contig's last minimizer is never evaluated (this is what makes the last
+         * fragment of MIBY01000011 -- a contig one residue longer than six fragments -- lose two minimizers against
+         * itself: 99.9953 % in tests/test_self_vs_self.py:121-122 and 0.999959 / 0.99997 in tests/test_coverage.py:150). */
+        for (size_t ci = 0; ci < nc; ++ci) {
+          const int32_t cseq = cands[ci].seq;
+          const size_t c1 = lower_bound_pos(rpos.v, rpos.n, cseq + 1, -1);
+          size_t b = lower_bound_pos(rpos.v, rpos.n, cseq, cands[ci].start);
+          if (b >= c1) continue;
+          const int stop = (int)g_opt[OPT_L2_STOP];
+          const size_t last_end = stop == 2 ? c1 + 1 : lower_bound_pos(rpos.v, c1, cseq, cands[ci].end + frag_len);
+          int64_t i = rpos.v[b].wpos;
+          size_t e = lower_bound_pos(rpos.v, c1, cseq, i + count_windows);
+          int c_best = -1; int64_t c_first = 0, c_last = 0;
+          while (e != last_end && !(stop >= 1 && i > cands[ci].end)) {
+            const size_t nw = e - b;
+            if (nw > win_cap) { win_cap = nw * 2 + 64; winh = (uint32_t *)realloc(winh, win_cap * sizeof(uint32_t)); }
+            for (size_t t = 0; t < nw; ++t) winh[t] = rpos.v[b + t].hash;
+            qsort(winh, nw, sizeof(uint32_t), cmp_u32);
+            size_t u = 0;
+            for (size_t t = 0; t < nw; ++t) if (t == 0 || winh[t] != winh[t - 1]) winh[u++] = winh[t];
+            const int sh = shared_in_bottom_s(qh, s, winh, (int)u);
+            /* the next event: minimizer b + 1 becomes the active one, or minimizer e enters at the end */
+            const int64_t next_b = b + 1 < c1 ? (int64_t)rpos.v[b + 1].wpos : INT64_MAX;
+            const int64_t next_e = e < c1 ? (int64_t)rpos.v[e].wpos - count_windows + 1 : INT64_MAX;
+            const int64_t next_i = next_b < next_e ? next_b : next_e;
+            const int64_t p_first = g_opt[OPT_L2_POS] != 0.0 ? i : (int64_t)rpos.v[b].wpos;
+            const int64_t p_last = g_opt[OPT_L2_POS] != 0.0 ? (next_i == INT64_MAX ? i : next_i - 1) : p_first;
+            if (sh > c_best) { c_best = sh; c_first = p_first; c_last = p_last; }
+            else if (sh == c_best) c_last = p_last;
+            if (next_i == INT64_MAX) break;
+            i = next_i;
+            if (next_b == i) ++b;
+            while (e < c1 && (int64_t)rpos.v[e].wpos < i + count_windows) ++e;
+          }
+          if (c_best < 0) continue;
+          const int64_t pos = (c_first + c_last) / 2;
+          if (c_best > best_shared || (c_best == best_shared && (cseq < best_seq || (cseq == best_seq && pos < best_pos)))) {
+            best_shared = c_best; best_seq = cseq; best_pos = pos;
+          }
+        }
+      } else if (g_opt[OPT_L2_RULE] != 0.0) {
         /* Mashmap's slide: a window starts at every reference minimizer position of the candidate range and
          * holds the minimizers recorded in [start, start + count_windows); per candidate the position is the
          * mean of the first and the last start with the most shared minimizers */

@@ -681,7 +681,7 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     const uint64_t *__restrict__ post_cw, uint32_t n_genomes, const uint32_t *__restrict__ tab_min_hits,
     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
     uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t seg_cap, uint32_t *__restrict__ counters,
-    unsigned long long *__restrict__ cursor64, uint32_t ref0, uint32_t ref1) {
+    unsigned long long *__restrict__ cursor64, uint32_t ref0, uint32_t ref1, bool write_all) {
   extern __shared__ uint32_t bk_lds[];
   __shared__ uint32_t s_part[kBucketWaves][2], s_draw[2];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -811,7 +811,9 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
   // (the query window id of a hit is no longer carried along: the mapping kernel slides over reference positions)
   for_each_posting(post_cw, [&](uint32_t, uint64_t cw) {
     const uint32_t at = atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
-    if (!(at & 0x80000000u)) keys[base + at] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
+    // write_all: the batch is about to be ordered as a whole (a repeat family too long for an LDS sort), and that keeps
+    // the (fragment, genome) slices in place only when every slot holds its own key
+    if (!(at & 0x80000000u) || write_all) keys[base + (at & 0x7fffffffu)] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
   });
 }
 
@@ -1957,6 +1959,16 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   // ---- 1. minimizers of every contig
   std::optional<ProfScope> prof;  // phases timed for bench.py: index build, seeding, mapping
   const bool reuse = (flags & PA_FRAGANI_REUSE_INDEX) != 0;
+  {
+    // no contig holds a fragment: every pair is 0 of 0, whatever index an earlier call left (or did not leave) behind
+    uint64_t any_frags = 0;
+    for (uint32_t ci = 0; ci < n_contigs; ++ci) any_frags += h_contig_len[ci] / frag_len;
+    if (reuse && any_frags == 0) {
+      for (uint32_t g = 0; g < n_genomes; ++g) h_total_frags[g] = 0;
+      for (uint64_t i = (uint64_t)qry0 * n_genomes; i < (uint64_t)qry1 * n_genomes; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
+      return PA_OK;
+    }
+  }
   if (reuse) {
     PA_REQUIRE(W.index_valid && W.index_packed == (const void *)d_packed && W.index_arena_bases == arena_bases &&
                    W.index_contigs == n_contigs && W.index_genomes == n_genomes && W.index_k == k && W.index_frag_len == frag_len,
@@ -2176,31 +2188,43 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         const uint32_t seg_cap = (uint32_t)std::min<uint64_t>(seg_cap64, 0xfffffff0ull);
         PA_TRY(W.seg_a0.reserve((uint64_t)seg_cap * 4 + 16));
         PA_TRY(W.seg_nh.reserve((uint64_t)seg_cap * 4 + 16));
-        PA_HIP(hipMemsetAsync(d_seg_counters, 0, 16, c->stream));
         unsigned long long *d_cursor64 = reinterpret_cast<unsigned long long *>(W.scalars.as<uint32_t>() + 14);  // [lo] short, [hi] long segments
-        PA_HIP(hipMemsetAsync(d_cursor64, 0, 8, c->stream));
         const uint32_t lds_bytes = (uint32_t)kBucketWaves * n_genomes * 4u;
         PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_hits_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(bucket_hits_kernel, dim3(ceil_div_u64(nf, kBucketWaves)), dim3(kBucketWaves * 64), lds_bytes,
-                           c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
-                           W.hit_off.as<uint32_t>(), W.post_g.as<uint16_t>(), W.post_cw.as<uint64_t>(), n_genomes,
-                           W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
-                           W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters, d_cursor64, ref0, ref1);
-        PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters, 16, hipMemcpyDeviceToHost, c->stream));
-        PA_HIP(hipMemcpyAsync(c->h_pinned + 2, d_cursor64, 8, hipMemcpyDeviceToHost, c->stream));
-        PA_HIP(hipStreamSynchronize(c->stream));
-        const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(c->h_pinned);
-        n_keep = (uint32_t)c->h_pinned[2];
-        n_large = (uint32_t)(c->h_pinned[2] >> 32);
-        large_at = seg_cap - n_large;
-        const uint32_t n_big = hc32[1], max_big = hc32[2];
-        PA_REQUIRE((uint64_t)n_keep + n_large <= seg_cap, "pa_fragani: %u + %u segments exceed the list capacity %u",
-                   n_keep, n_large, seg_cap);
+        uint32_t n_big = 0, max_big = 0;
+        auto bucket_pass = [&](bool write_all) -> int {
+          PA_HIP(hipMemsetAsync(d_seg_counters, 0, 16, c->stream));
+          PA_HIP(hipMemsetAsync(d_cursor64, 0, 8, c->stream));
+          hipLaunchKernelGGL(bucket_hits_kernel, dim3(ceil_div_u64(nf, kBucketWaves)), dim3(kBucketWaves * 64), lds_bytes,
+                             c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
+                             W.hit_off.as<uint32_t>(), W.post_g.as<uint16_t>(), W.post_cw.as<uint64_t>(), n_genomes,
+                             W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
+                             W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters, d_cursor64, ref0, ref1,
+                             write_all);
+          PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters, 16, hipMemcpyDeviceToHost, c->stream));
+          PA_HIP(hipMemcpyAsync(c->h_pinned + 2, d_cursor64, 8, hipMemcpyDeviceToHost, c->stream));
+          PA_HIP(hipStreamSynchronize(c->stream));
+          const uint32_t *hc32 = reinterpret_cast<const uint32_t *>(c->h_pinned);
+          n_keep = (uint32_t)c->h_pinned[2];
+          n_large = (uint32_t)(c->h_pinned[2] >> 32);
+          large_at = seg_cap - n_large;
+          n_big = hc32[1];
+          max_big = hc32[2];
+          PA_REQUIRE((uint64_t)n_keep + n_large <= seg_cap, "pa_fragani: %u + %u segments exceed the list capacity %u",
+                     n_keep, n_large, seg_cap);
+          return PA_OK;
+        };
+        PA_TRY(bucket_pass(false));
         presorted = false;
-        if (n_big && max_big > kFragSortMax) {
+        uint32_t frag_sort_max = kFragSortMax;  // tests: PA_FRAGANI_SORT_MAX=600 sends a 60-copy repeat family down this path
+        if (const char *v = getenv("PA_FRAGANI_SORT_MAX")) frag_sort_max = (uint32_t)std::max(1, atoi(v));
+        if (n_big && max_big > frag_sort_max) {
           // a repeat family with more hits than one LDS sort takes: order the whole batch by key; the
-          // (fragment, genome) slices keep their places because contigs are numbered genome by genome
+          // (fragment, genome) slices keep their places because contigs are numbered genome by genome -- provided every
+          // slot holds its own key, so the bucketing runs again and this time also writes the hits of the pairs that are
+          // not listed (they are skipped otherwise: unwritten slots would be sorted into other fragments' ranges)
+          PA_TRY(bucket_pass(true));
           PA_TRY(second_buffers());
           PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
           presorted = true;

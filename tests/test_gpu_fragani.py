@@ -212,6 +212,58 @@ def test_repeat_families_take_the_long_segment_paths(engine):
     _check_against_oracle(engine, texts[:2], [[g] for g in genomes[:2]])
 
 
+def test_whole_batch_sort_with_unlisted_pairs(engine, monkeypatch):
+    """The whole-batch radix sort of a repeat family (more hits in one segment than an LDS sort takes) must leave every
+    (fragment, genome) slice in place although the bucketing does not write the hits of pairs nobody maps: chance hits of
+    an unrelated genome and everything outside the reference range.  A 60-copy repeat genome, a relative, an unrelated
+    genome sharing a short stretch (a few seed hits per fragment: below what an L1 run needs) and a reference range;
+    once with the real limit (8 192 hits) and once with the limit lowered so that the 8-copy segments take the path too."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(212)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = rng.choice(acgt, size=3_000)
+    flank = rng.choice(acgt, size=9_000)
+
+    def with_copies(copies: int, rate: float) -> bytes:
+        parts = [flank[:4_500]]
+        for _ in range(copies):
+            u = unit.copy()
+            hit = rng.random(u.size) < rate
+            u[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+            parts.append(u)
+        parts.append(flank[4_500:])
+        return np.concatenate(parts).tobytes()
+
+    other = rng.choice(acgt, size=30_000)
+    other[10_000:10_060] = unit[500:560]  # a few shared minimizers with every copy of the unit: seed hits, never a run
+    genomes = [other.tobytes(), with_copies(60, 0.001), with_copies(8, 0.01), rng.choice(acgt, size=12_000).tobytes()]
+    texts = [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)]
+    arena = pack_genomes(texts)
+    n = len(genomes)
+    want = {(q, r): oracle.fragani_pair([genomes[q]], [genomes[r]], K, FRAG, 0.0) for q in range(n) for r in range(n)}
+    for sort_max in (None, "600"):
+        if sort_max is None:
+            monkeypatch.delenv("PA_FRAGANI_SORT_MAX", raising=False)
+        else:
+            monkeypatch.setenv("PA_FRAGANI_SORT_MAX", sort_max)
+        for ref_range in (None, (1, 3), (1, 2), (2, 4)):
+            total, matched, ident_sum = engine.fragani(engine.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome,
+                                                       K, FRAG, ref_range=ref_range)
+            r0, r1 = ref_range or (0, n)
+            for q in range(n):
+                for r in range(n):
+                    ani, m, t = want[q, r]
+                    assert total[q] == t
+                    if not r0 <= r < r1:
+                        assert matched[q, r] == 0 and ident_sum[q, r] == 0.0
+                        continue
+                    assert matched[q, r] == m, (sort_max, ref_range, q, r, matched[q, r], m)
+                    if m:
+                        assert abs(ident_sum[q, r] / m - ani) <= 1e-9 * ani
+    assert want[1, 1][1] > 0 and want[2, 1][1] > 0 and want[0, 1][1] == 0
+
+
 def test_two_copy_repeats_take_the_wide_register_sort(engine):
     """Two tandem copies give segments of 257 .. 512 seed hits: staged in LDS by the launch for long segments, ordered
     eight keys per lane in registers on the way (the widest form of the bitonic network); duplicates of every hash inside
@@ -328,3 +380,19 @@ def test_plugin_column_matches_reference_matrices(engine, tmp_path):
     cfg.minmatch = 1.5
     assert fastani_hip.compute_fastani_hip(logging.getLogger("t"), tmp_path, _S(), run, out, GOLDEN / "viral_example", hash_to_filename, {}, lengths, subject, engine=engine) == 0
     assert all(e["identity"] is None and e["cov_query"] is None for e in json.loads(out.read_text())["comparisons"])
+
+
+def test_reuse_index_when_no_contig_holds_a_fragment(engine):
+    """Every contig shorter than a fragment: nothing to map, and a follow-up call that asks for the previous call's index
+    (what the column worker does for every query batch after the first) gets zeros as well instead of an error."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    texts = [b">g%d\n" % i + rng.choice(acgt, size=2_000 + 100 * i).tobytes() + b"\n" for i in range(3)]
+    arena = pack_genomes(texts)
+    dev = engine.upload(arena)
+    first = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG, query_range=(0, 2))
+    again = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG, query_range=(2, 3), reuse_index=True)
+    for total, matched, ident_sum in (first, again):
+        assert not total.any() and not matched.any() and not ident_sum.any()
