@@ -46,12 +46,13 @@ enum { OPT_WINDOW_RULE = 0, OPT_BIN_RULE = 1, OPT_L2_RULE = 2, OPT_CONF = 3, OPT
 static double g_opt[OPT_COUNT] = {
     1.0, /* OPT_WINDOW_RULE: 0 = sketch sizes 10, 60, 110, ... (round 1); 1 = 1, 2, 5, 10, 20, 30, ... (Mashmap's list) */
     1.0, /* OPT_BIN_RULE:    0 = (pos + fragLen/2) / fragLen (round 1); 1 = pos / (fragLen - 20) (fastANI's bucket) */
-    1.0, /* OPT_L2_RULE:     0 = Jaccard at the window starts the seed hits imply (round 1); 1 = slide over reference minimizer positions,
+    2.0, /* OPT_L2_RULE:     0 = Jaccard at the window starts the seed hits imply (round 1); 1 = slide over reference minimizer positions,
                                   position = mean of the first and last optimum (rounds 2 and 3); 2 = the exact slide: the window at
                                   every position i holds the minimizers of the reference windows [i, i + count_windows) -- the one still
                                   active at i included --, and the slide ends when the window's end reaches the candidate's last end */
     0.9, /* OPT_CONF:        confidence level of the identity bounds */
-    0.0, /* OPT_L2_POS:      (rule 2) position of a window: 0 = window id of its first minimizer, 1 = the position i itself */
+    1.0, /* OPT_L2_POS:      (rule 2) position of a window: 0 = window id of its first minimizer, 1 = the positions i it stands for (first to last),
+                                  2 = the first position i it stands for (where the slide arrives at it) */
     0.0, /* OPT_L2_STOP:     (rule 2) 0 = the slide ends when the window's end reaches the first minimizer at or past rangeEnd + fragLen;
                                   1 = it also ends past position rangeEnd; 2 = past rangeEnd only (no end rule) */
 };
@@ -415,7 +416,7 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
             const int64_t next_e = e < c1 ? (int64_t)rpos.v[e].wpos - count_windows + 1 : INT64_MAX;
             const int64_t next_i = next_b < next_e ? next_b : next_e;
             const int64_t p_first = g_opt[OPT_L2_POS] != 0.0 ? i : (int64_t)rpos.v[b].wpos;
-            const int64_t p_last = g_opt[OPT_L2_POS] != 0.0 ? (next_i == INT64_MAX ? i : next_i - 1) : p_first;
+            const int64_t p_last = g_opt[OPT_L2_POS] == 1.0 ? (next_i == INT64_MAX ? i : next_i - 1) : p_first;
             if (sh > c_best) { c_best = sh; c_first = p_first; c_last = p_last; }
             else if (sh == c_best) c_last = p_last;
             if (next_i == INT64_MAX) break;

@@ -1275,19 +1275,25 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   uint32_t half0 = 1;
   while (2u * half0 <= s) half0 *= 2u;
 
-  // ---- L2 as Mashmap slides it: a window starts at every reference minimizer position of the candidate range
-  // and holds the minimizers recorded in [start, start + count_windows); per candidate the position is the mean
-  // of the first and the last start with the most shared minimizers.  One LANE per start: the stretch of
-  // minimizers the up to 64 windows of a group cover (~300) is ranked against the fragment's hashes once and
-  // entered into bit tables over (query rank x stretch position); every lane finds, by two short searches over
-  // rows of those tables, how many of the fragment's smallest hashes lie in the bottom-s of the union with its
-  // own window and how many of them the window holds (see the round below).  Starts whose seed-hit count cannot
-  // reach the best so far are never evaluated, which leaves two or three rounds per candidate.
+  // ---- L2, the exact slide (oracle/fragani_oracle.c, L2 rule 2).  The window at position i of the candidate's contig
+  // holds the minimizers of the reference windows [i, i + count_windows): from b = the last minimizer recorded at or
+  // before i (still active in window i) to e = the first one recorded at or after i + count_windows.  The slide starts
+  // at the first minimizer of the candidate range and ends as soon as e reaches the first minimizer at or past
+  // rangeEnd + fragLen (or the contig's end): positions up to i_max = (window id of the minimizer before that) -
+  // count_windows.  A STATE is a maximal run of positions with the same (b, e); per candidate the mapping position is
+  // the mean of the first position of the first and the last position of the last state with the most shared minimizers.
+  // One lane per begin b, as a group of 64 begins is taken up: its states are the ends e from "first minimizer at or
+  // after P[b] + count_windows" to "first at or after min(P[b+1] - 1, i_max) + count_windows", usually one or two.  In a
+  // round the states of the group's pending begins are spread over the lanes in slide order (up to 64 of them: ITEMS),
+  // the stretch of minimizers they cover (~300) is ranked against the fragment's hashes once and entered into bit tables
+  // over (query rank x stretch position), and every lane finds, by two short searches over rows of those tables, how many
+  // of the fragment's smallest hashes lie in the bottom-s of the union with its own window and how many of them the window
+  // holds.  Begins none of whose windows can hold as many seed hits as the best so far shares are never evaluated.
   auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) {
     PA_CUT(2);  // L1 only
     const uint32_t m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
-    // first start: through the bucket index, the bucket itself searched by the whole wave (two memory round trips
+    // first begin: through the bucket index, the bucket itself searched by the whole wave (two memory round trips
     // instead of the six or so of a binary search)
     uint32_t b_lo;
     {
@@ -1302,10 +1308,15 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         if (ge) { b_lo = base + (uint32_t)__builtin_ctzll(ge); break; }
       }
     }
-    // window ids of the first 512 starts in one batch of loads: they say where the range ends and where the first seed
+    if (b_lo >= m1) return;
+    // where the slide ends: the window's end may not reach `last_end`
+    const uint32_t last_end = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + frag_len);
+    if (last_end <= b_lo) return;
+    const uint32_t z = mini_wpos[last_end - 1];
+    // window ids of the first 512 begins in one batch of loads: they say where the range ends and where the first seed
     // hit sits (the groups re-read their own 64 window ids later: they are in L2 by then, and eight registers are free)
     constexpr int kStartBatch = 8;
-    uint32_t b_hi = 0xffffffffu, at = 0xffffffffu;
+    uint32_t b_hi = 0xffffffffu, at = 0xffffffffu, i_max;
     {
       uint32_t wpv[kStartBatch];
 #pragma unroll
@@ -1313,33 +1324,36 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         const uint32_t t = b_lo + (uint32_t)q * 64u + lane;
         wpv[q] = t < m1 ? mini_wpos[t] : 0xffffffffu;
       }
-      // the first start past the range and the first one at the first seed hit: every lane the first of its own eight,
-      // then the minimum over the wave (the window ids ascend with the start index)
+      const uint32_t wp_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)wpv[0]);  // window id of the first begin
+      if (z < wp_lo + count_windows) return;  // the first window's end is already at `last_end`: nothing is evaluated
+      i_max = z - count_windows;
+      // the first begin past the slide's last position and the first one at the first seed hit: every lane the first of
+      // its own eight, then the minimum over the wave (the window ids ascend with the begin index)
       uint32_t my_over = 0xffffffffu, my_reach = 0xffffffffu;
 #pragma unroll
       for (int q = kStartBatch - 1; q >= 0; --q) {
-        my_over = wpv[q] > ce ? (uint32_t)q * 64u + lane : my_over;
+        my_over = wpv[q] > i_max ? (uint32_t)q * 64u + lane : my_over;
         my_reach = wpv[q] >= first_hit_w ? (uint32_t)q * 64u + lane : my_reach;
       }
       const uint32_t w_over = pa_dev::wave_min_dpp(my_over), w_reach = pa_dev::wave_min_dpp(my_reach);
       if (w_over != 0xffffffffu) b_hi = b_lo + w_over;
       if (w_reach != 0xffffffffu) at = b_lo + w_reach;
     }
-    if (b_hi == 0xffffffffu) b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + 1u);  // a range of more than 512 starts
+    if (b_hi == 0xffffffffu) b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, i_max + 1u);  // a range of more than 512 begins
     if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
     if (b_lo >= b_hi) return;
-    PA_STAT(2, 1);  // candidates with starts
+    PA_STAT(2, 1);  // candidates with begins
     int32_t c_best = -1;
     uint32_t c_first = 0, c_last = 0;
     const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
-    // A start matters only if its window can hold min_shared minimizers of the fragment (less is never reported) and
-    // reach the best so far.  The group holding the candidate's first seed hit goes first -- for a true mapping the
+    // A begin matters only if one of its windows can hold min_shared minimizers of the fragment (less is never reported)
+    // and reach the best so far.  The group holding the candidate's first seed hit goes first -- for a true mapping the
     // window that starts there is at or next to the optimum -- and sets the bar the other groups are pruned against:
-    // first per group (seed hits between its first start and the end of its last window), then per start.
+    // first per group (seed hits between its first begin and the end of its last window), then per begin.
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
-    // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, ce + count_windows)
+    // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, i_max + count_windows)
     uint32_t h_lo, h_hi;
-    hit_range(c, cs, ce + count_windows, h_lo, h_hi);
+    hit_range(c, cs, z, h_lo, h_hi);
     const uint32_t h_steps = 32u - (uint32_t)__builtin_clz(h_hi - h_lo + 1u);  // 2^steps > the number of hits: enough halvings
     PA_CUT(3);  // candidate set-up
     const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
@@ -1349,27 +1363,30 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       const uint32_t b = sb + lane;
       const bool has = b < b_hi;
       const uint32_t wp = has ? mini_wpos[b] : 0u;
-      int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a start must reach to matter (ties matter)
+      const uint32_t wp_next = (has && b + 1u < m1) ? mini_wpos[b + 1u] : 0xffffffffu;
+      const uint32_t w_end = min(wp_next - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
+      int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a window must reach to matter (ties matter)
       if (bar < floor_bar) bar = floor_bar;
-      // A window with `bar` of the candidate's hits starts after (the bar-th hit - count_windows) and not after the
-      // bar-th hit from the end: groups without such a start are passed over before any counting
+      // A window with `bar` of the candidate's hits ends after the bar-th hit and does not begin after the bar-th hit
+      // from the end: groups without such a begin are passed over before any counting
       if (bar > 0) {
         if ((uint32_t)bar > h_hi - h_lo) break;  // no window of this candidate holds that many (the bar only rises)
         const uint32_t w_after = HW(h_lo + (uint32_t)bar - 1u), w_upto = HW(h_hi - (uint32_t)bar);
-        if (!__any(has && wp + count_windows > w_after && wp <= w_upto)) continue;
+        if (!__any(has && w_end > w_after && wp <= w_upto)) continue;
       }
-      // Seed hits inside the start's window: every occurrence of every query hash is a hit, so no window shares more.
-      // Only "at least b of them" is ever asked: with i0 = the first hit at or after the start, that is "hit i0 + b - 1
-      // exists and lies before the window's end" -- one search and one read instead of two searches.
+      // Seed hits inside the begin's widest window: every occurrence of every query hash is a hit, so no window shares
+      // more.  Only "at least b of them" is ever asked: with i0 = the first hit at or after the begin, that is "hit
+      // i0 + b - 1 exists and lies before the window's end" -- one search and one read instead of two searches.
       const uint32_t i0 = hit_lower_bound_w(h_lo, h_hi, wp, h_steps);
       auto holds_hits = [&](int32_t b) -> bool {
         const uint32_t idx = i0 + (uint32_t)max(b, 1) - 1u;
-        return has & (idx < h_hi) & (HW(min(idx, nh - 1u)) < wp + count_windows);
+        return has & (idx < h_hi) & (HW(min(idx, nh - 1u)) < w_end);
       };
       bool pending = bar > 0 ? holds_hits(bar) : has;
       if (cut == 4) pending = false;  // seed-hit bounds of every group
-      PA_STAT(3, 1);                              // groups of 64 starts
-      PA_STAT(4, __popcll(__ballot(pending)));    // starts that pass the seed-hit bound
+      PA_STAT(3, 1);                              // groups of 64 begins
+      PA_STAT(4, __popcll(__ballot(pending)));    // begins that pass the seed-hit bound
+      uint32_t e_next = 0;  // end (minimizer index) of the begin's next state; 0: none of its states has been evaluated yet
       while (__any(pending)) {
         PA_STAT(5, 1);  // rounds
         const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
@@ -1393,76 +1410,120 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           sh.ref_w[x] = (uint16_t)((dw > 0xfffeu || !in) ? 0xffffu : dw);  // 0xffff: far beyond any window of this stretch
         }
         __syncthreads();
-        // per lane: where its window ends inside the stretch and whether the stretch holds all of it.  Lanes in front
-        // of the stretch end at 0, lanes without a start at n: the ends are non-decreasing over the lanes, which is what
-        // lets an entry name the lanes that keep it as one range.
-        const uint32_t xb = b - base;  // meaningful for lanes from first_lane on
-        uint32_t xe = lane < first_lane ? 0u : n;
-        bool covered = false;
-        if (has && lane >= first_lane) {
-          const uint32_t target = wp + count_windows - wbase;
-          uint32_t lo = min(xb, n), hi = n;
-          while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)sh.ref_w[mid] < target) lo = mid + 1; else hi = mid; }
-          xe = lo;
-          covered = xe < n || base + n == m1;
-        }
-        // only the part of the stretch that some window of this round reaches is ranked, sorted and walked
-        uint32_t n_use = 0;
+        // per begin: the ends of its first and last state inside the stretch, and how many of its remaining states the
+        // stretch holds (a state with end x is held when entry x is in the stretch, or the stretch runs to the contig's end)
+        const bool at_end = base + n == m1;
+        const uint32_t lim = at_end ? n : n - 1u;
+        const bool lane_on = pending && lane >= first_lane;  // (pending lanes are at or after first_lane by definition)
+        uint32_t cnt = 0, xs0 = 0, xe_hi = 0;
+        bool hi_known = false;
         {
-          n_use = pa_dev::wave_max_dpp((pending && covered) ? xe : 0u);
-        }
-        xe = min(xe, n_use);
-        PA_CUT(5);  // stretch loads and window ends
-        PA_STAT(6, n_use);                                      // stretch entries ranked
-        PA_STAT(7, __popcll(__ballot(pending && covered)));    // windows evaluated in the round
-        // ranks of the lane's kPer minimizers among the fragment's hashes: the binary searches advance together, one
-        // halving step for all of them at a time, so the LDS reads of a step are in flight at once
-        uint32_t rank[kPer];
-#pragma unroll
-        for (int q = 0; q < kPer; ++q) rank[q] = 0;
-        if (qsteps != 0xffffffffu) {
-          uint32_t hi_r[kPer];
-#pragma unroll
-          for (int q = 0; q < kPer; ++q) {
-            const uint32_t e = sh.qt[hh[q] >> kQtShift];
-            rank[q] = e & 0x3ffu;          // hashes in the buckets below: all smaller
-            hi_r[q] = rank[q] + (e >> 10);  // the hashes from here on are in higher buckets: all larger
-          }
-          for (uint32_t half = qsteps ? 1u << (qsteps - 1u) : 0u; half > 0; half >>= 1) {
-#pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-              const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
-              if (idx <= hi_r[q] && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
-            }
-          }
-        } else {
-          for (uint32_t half = half0; half > 0; half >>= 1) {  // half0 = largest power of two <= s: positions 0 .. 2*half0 - 1 >= s
-#pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-              const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
-              if ((uint32_t)q * 64u + lane < n_use && idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
-            }
+          auto first_at_or_after = [&](uint32_t lo, uint32_t target) -> uint32_t {
+            uint32_t hi = n;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)sh.ref_w[mid] < target) lo = mid + 1; else hi = mid; }
+            return lo;
+          };
+          if (lane_on) {
+            const uint32_t xe_lo = first_at_or_after(min(b - base, n), wp + count_windows - wbase);
+            xe_hi = first_at_or_after(xe_lo, w_end - wbase);
+            xs0 = e_next ? e_next - base : xe_lo;
+            const uint32_t top = min(xe_hi, lim);
+            cnt = xs0 <= top ? top - xs0 + 1u : 0u;
+            hi_known = xe_hi < n || at_end;
           }
         }
-        PA_CUT(6);  // ranks
-        const bool first_uncovered = __shfl((int)covered, (int)first_lane, 64) == 0;
-        uint32_t f_shared = 0;
-        bool done_now = pending && covered;
-        bool counted = done_now;  // evaluated exactly (a window found out of reach of the bar is done, but not counted)
-        if (first_uncovered) {
+        uint32_t f_shared = 0, p_first = 0, p_last = 0;
+        bool counted = false;  // the lane holds the exact value of a state (a window found out of reach of the bar is done, but not counted)
+        uint32_t taken = 0;
+        bool complete = false;  // the begin's last state is behind it
+        if (__builtin_amdgcn_readlane((int)cnt, (int)first_lane) == 0) {
           PA_STAT(9, 1);  // cooperative evaluations
-          // the first pending window alone is longer than the stretch: the whole wave takes it from HBM
-          const uint32_t wp0 = __shfl(wp, (int)first_lane, 64);
-          const uint32_t e0 = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, wp0 + count_windows);
-          __syncthreads();
-          for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
-          __syncthreads();
-          const uint32_t v = eval_window_coop(base, e0);
-          if (lane == first_lane) { f_shared = v; done_now = true; counted = true; }
-          else counted = false;
+          // the first pending begin's next window is longer than the stretch: the whole wave takes that one state from HBM
+          const uint32_t wp0 = __shfl(wp, (int)first_lane, 64), we0 = __shfl(w_end, (int)first_lane, 64);
+          const uint32_t en0 = __shfl(e_next, (int)first_lane, 64);
+          const uint32_t e_abs = en0 ? en0 : wpos_lower_bound(mini_wpos, bucket_first, bb, nb, wp0 + count_windows);
+          const uint32_t e_last = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, we0);
+          if (e_abs <= e_last) {
+            __syncthreads();
+            for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
+            __syncthreads();
+            const uint32_t v = eval_window_coop(base, e_abs);
+            const uint32_t w_in = mini_wpos[e_abs - 1u];                                  // the last minimizer the window holds
+            const uint32_t w_out = e_abs < m1 ? mini_wpos[e_abs] : 0xffffffffu;           // the first one past it
+            if (lane == first_lane) {
+              f_shared = v;
+              counted = true;
+              p_first = w_in + 1u > wp0 + count_windows ? w_in + 1u - count_windows : wp0;
+              p_last = min(we0, w_out) - count_windows;
+              e_next = e_abs + 1u;
+            }
+          }
+          complete = lane == first_lane && e_abs + 1u > e_last;
         } else {
+          // ---- the states of the pending begins, in slide order, spread over the lanes: item t is state t - off of the
+          // begin whose run of items starts at off (runs laid out by a prefix sum of the counts; the begin of an item is
+          // found by marking the run starts in LDS and taking a running maximum over the lanes)
+          const uint32_t incl = pa_dev::wave_incl_scan_dpp(cnt), off = incl - cnt;
+          const uint32_t n_items = min(64u, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
+          taken = off < 64u ? min(cnt, 64u - off) : 0u;
+          sh.tab[lane] = 0u;  // (the tables of the round are built later in this memory)
+          __builtin_amdgcn_wave_barrier();
+          if (taken) sh.tab[off] = lane + 1u;
+          __builtin_amdgcn_wave_barrier();
+          const uint32_t src = pa_dev::wave_incl_max_scan_dpp(sh.tab[lane]) - 1u;  // item 0 exists: src >= 0 on every lane
+          const bool it_on = lane < n_items;
+          const int src_addr = (int)(src << 2);
+          const uint32_t packed = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)((b - base) | (xs0 << 10) | (off << 20)));
+          const uint32_t wp_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)wp);
+          const uint32_t we_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)w_end);
+          const uint32_t xs = it_on ? (packed & 0x3ffu) : 0u;                                   // the window: stretch entries [xs, xw)
+          const uint32_t xw = it_on ? ((packed >> 10) & 0x3ffu) + (lane - (packed >> 20)) : 0u;
+          if (it_on) {
+            // the positions the state stands for: from where entry xw - 1 comes in (or the begin becomes active) to where
+            // entry xw would come in (or the next begin becomes active, or the slide ends)
+            uint32_t w_in = sh.ref_w[xw - 1u], w_out = xw < n ? (uint32_t)sh.ref_w[xw] : 0xffffu;
+            w_in = w_in == 0xffffu ? mini_wpos[base + xw - 1u] : wbase + w_in;  // (0xffff: more than 65 534 window ids past the stretch's first)
+            w_out = w_out == 0xffffu ? (base + xw < m1 ? mini_wpos[base + xw] : 0xffffffffu) : wbase + w_out;
+            p_first = w_in + 1u > wp_s + count_windows ? w_in + 1u - count_windows : wp_s;
+            p_last = min(we_s, w_out) - count_windows;
+          }
+          // only the part of the stretch that some window of this round reaches is ranked and entered into the tables
+          const uint32_t n_use = pa_dev::wave_max_dpp(xw);
+          PA_CUT(5);  // stretch loads and window ends
+          PA_STAT(6, n_use);                            // stretch entries ranked
+          PA_STAT(7, n_items);                          // windows evaluated in the round
+          // ranks of the lane's kPer minimizers among the fragment's hashes: the binary searches advance together, one
+          // halving step for all of them at a time, so the LDS reads of a step are in flight at once
+          uint32_t rank[kPer];
+#pragma unroll
+          for (int q = 0; q < kPer; ++q) rank[q] = 0;
+          if (qsteps != 0xffffffffu) {
+            uint32_t hi_r[kPer];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+              const uint32_t e = sh.qt[hh[q] >> kQtShift];
+              rank[q] = e & 0x3ffu;          // hashes in the buckets below: all smaller
+              hi_r[q] = rank[q] + (e >> 10);  // the hashes from here on are in higher buckets: all larger
+            }
+            for (uint32_t half = qsteps ? 1u << (qsteps - 1u) : 0u; half > 0; half >>= 1) {
+#pragma unroll
+              for (int q = 0; q < kPer; ++q) {
+                const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
+                if (idx <= hi_r[q] && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
+              }
+            }
+          } else {
+            for (uint32_t half = half0; half > 0; half >>= 1) {  // half0 = largest power of two <= s: positions 0 .. 2*half0 - 1 >= s
+#pragma unroll
+              for (int q = 0; q < kPer; ++q) {
+                const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
+                if ((uint32_t)q * 64u + lane < n_use && idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
+              }
+            }
+          }
+          PA_CUT(6);  // ranks
           // Every window of the round at once, one lane each, without ordering the stretch.  A window holds the stretch
-          // positions [xs, xe) minus later occurrences of a hash it already holds: a bit mask W over the positions.  With
+          // positions [xs, xw) minus later occurrences of a hash it already holds: a bit mask W over the positions.  With
           // R_r / M_r = the positions of reference-only / matching minimizers of rank <= r among the fragment's hashes, the
           // reference-only minimizers below the fragment's hash of rank r number c(r) = |R_r & W|; that hash lies in the
           // bottom-s of the union iff r + c(r) < s, which holds for r < T and no other (r + c(r) grows strictly), and the
@@ -1472,6 +1533,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           constexpr uint32_t kRow = 2u * kW;
           const uint32_t n_coarse = s / kCoarse + 1u;  // the last row stands at a rank >= s: r + c(r) >= s holds there
           uint32_t *bc = sh.tab, *bf = sh.tab + n_coarse * kRow;
+          __syncthreads();
           {
             uint4 *t4 = reinterpret_cast<uint4 *>(sh.tab);
             for (uint32_t i = lane; i < n_coarse * kRow / 4u; i += 64) t4[i] = make_uint4(0u, 0u, 0u, 0u);  // kRow is a multiple of 4
@@ -1525,8 +1587,6 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           prefix_or_rows(bc, n_coarse);
           PA_CUT(7);  // coarse table
           // the lane's window as a mask over the stretch positions
-          const bool walking = done_now;
-          const uint32_t xs = walking ? xb : 0u, xw = walking ? xe : 0u;
           uint32_t wm[kW];
           {
             // bits [xs, xw) of the row, two words at a time: xs is below 64, so only the first pair has a lower end
@@ -1582,7 +1642,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           int32_t bar_now = c_best > best_shared ? c_best : best_shared;
           if (bar_now < floor_bar) bar_now = floor_bar;
           const bool in_reach = (int32_t)count_in(bc + g_lo * kRow + kW) >= bar_now;
-          counted = walking && in_reach;
+          counted = it_on && in_reach;
           bool unresolved = counted;
           while (__any(unresolved)) {
             PA_STAT(8, 1);  // fine passes
@@ -1620,8 +1680,12 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             if (now) { f_shared = c; unresolved = false; }
           }
           __syncthreads();
+          // the begins: where their next state ends, and whether the last one is behind them
+          if (taken) e_next = base + xs0 + taken;
+          complete = lane_on && hi_known && xs0 + taken > xe_hi;
         }
-        // fold the evaluated starts into the candidate's optimum: most shared; first and last position of it
+        // fold the evaluated states into the candidate's optimum: most shared; first position of the first and last
+        // position of the last state that has it (the lanes hold the states in slide order)
         const uint64_t dm = __ballot(counted);
         int32_t group_best = -1;
         {
@@ -1629,11 +1693,11 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         }
         if (dm && group_best >= c_best) {
           const uint64_t top = __ballot(counted && (int32_t)f_shared == group_best);
-          const uint32_t w_first = __shfl(wp, __builtin_ctzll(top), 64), w_last = __shfl(wp, 63 - __builtin_clzll(top), 64);
+          const uint32_t w_first = __shfl(p_first, __builtin_ctzll(top), 64), w_last = __shfl(p_last, 63 - __builtin_clzll(top), 64);
           if (group_best > c_best) { c_best = group_best; c_first = w_first; c_last = w_last; }
           else { c_first = min(c_first, w_first); c_last = max(c_last, w_last); }
         }
-        pending = pending && !done_now;
+        pending = pending && !complete;
         // whoever can no longer reach the bar drops out
         {
           int32_t bar2 = c_best > best_shared ? c_best : best_shared;

@@ -58,4 +58,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
   return x;
 }
 
+// inclusive prefix maximum over the 64 lanes (unsigned; lanes a step does not reach take 0, the identity)
+__device__ __forceinline__ uint32_t wave_incl_max_scan_dpp(uint32_t v) {
+  uint32_t x = v;
+  x = max(x, dpp_or_zero<kDppRowShr + 1>(v));
+  x = max(x, dpp_or_zero<kDppRowShr + 2>(v));
+  x = max(x, dpp_or_zero<kDppRowShr + 3>(v));
+  x = max(x, dpp_or_zero<kDppRowShr + 4, 0xf, 0xe>(x));
+  x = max(x, dpp_or_zero<kDppRowShr + 8, 0xf, 0xc>(x));
+  x = max(x, dpp_or_zero<kDppRowBcast15, 0xa, 0xf>(x));
+  x = max(x, dpp_or_zero<kDppRowBcast31, 0xc, 0xf>(x));
+  return x;
+}
+
 }  // namespace pa_dev

@@ -27,12 +27,13 @@ VARIANTS = {
     "seed-implied starts, window 24, bins pos/(L-20)": {"l2_rule": 0},
     "rounds 2-3: slide over reference minimizer starts": {"l2_rule": 1},
     "exact slide, ends with the window's end; position = first minimizer": {"l2_rule": 2, "l2_pos": 0, "l2_stop": 0},
-    "exact slide, ends with the window's end; position = i": {"l2_rule": 2, "l2_pos": 1, "l2_stop": 0},
+    "ADOPTED: exact slide, ends with the window's end; position = the positions a state stands for": {"l2_rule": 2, "l2_pos": 1, "l2_stop": 0},
+    "exact slide, ends with the window's end; position = where the slide arrives at a state": {"l2_rule": 2, "l2_pos": 2, "l2_stop": 0},
     "exact slide, ends with the window's end or past rangeEnd; position = first minimizer": {"l2_rule": 2, "l2_pos": 0, "l2_stop": 1},
     "exact slide, ends past rangeEnd only; position = first minimizer": {"l2_rule": 2, "l2_pos": 0, "l2_stop": 2},
-    "exact slide, ends with the window's end; position = first minimizer; confidence 0.75": {"l2_rule": 2, "conf": 0.75},
+    "exact slide, ends with the window's end; position = first minimizer; confidence 0.75": {"l2_rule": 2, "l2_pos": 0, "conf": 0.75},
 }
-DEFAULTS = {"window_rule": 1, "bin_rule": 1, "l2_rule": 1, "conf": 0.9, "l2_pos": 0, "l2_stop": 0}
+DEFAULTS = {"window_rule": 1, "bin_rule": 1, "l2_rule": 2, "conf": 0.9, "l2_pos": 1, "l2_stop": 0}
 
 
 def contigs_of(path):
