@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   if (blockIdx.x >= n_segs) return;
 #define PA_CUT(k) do { if (cut == (k)) return; } while (0)
 #ifdef PA_MAP_STATS  // event counts of the mapping kernel in run_g[0 .. 15] (tools: -DPA_MAP_STATS, PA_FRAGANI_TRACE=1)
-#define PA_STAT(slot, v) do { if (lane == 0) atomicAdd(&run_g[slot], (uint32_t)(v)); } while (0)
+#define PA_STAT(slot, v) do { const uint32_t pa_stat_v = (uint32_t)(v); if (lane == 0) atomicAdd(&run_g[slot], pa_stat_v); } while (0)  // (v may hold a ballot: every lane evaluates it)
 #else
 #define PA_STAT(slot, v) do { } while (0)
   (void)run_g;
@@ -1387,6 +1387,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       PA_STAT(3, 1);                              // groups of 64 begins
       PA_STAT(4, __popcll(__ballot(pending)));    // begins that pass the seed-hit bound
       uint32_t e_next = 0;  // end (minimizer index) of the begin's next state; 0: none of its states has been evaluated yet
+      int32_t pv = -1;      // shared minimizers of the state before that one, -1 when known to be below the bar
       while (__any(pending)) {
         PA_STAT(5, 1);  // rounds
         const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
@@ -1415,7 +1416,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         const bool at_end = base + n == m1;
         const uint32_t lim = at_end ? n : n - 1u;
         const bool lane_on = pending && lane >= first_lane;  // (pending lanes are at or after first_lane by definition)
-        uint32_t cnt = 0, xs0 = 0, xe_hi = 0;
+        uint32_t cnt = 0, xs0 = 0, xe_lo = 0, xe_hi = 0, top = 0;
         bool hi_known = false;
         {
           auto first_at_or_after = [&](uint32_t lo, uint32_t target) -> uint32_t {
@@ -1423,12 +1424,22 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)sh.ref_w[mid] < target) lo = mid + 1; else hi = mid; }
             return lo;
           };
+          const bool lane_has = has && lane >= first_lane;
+          if (lane_has) xe_lo = first_at_or_after(min(b - base, n), wp + count_windows - wbase);
+          // the last state of a begin ends where the first state of the next begin does, or one entry before that when
+          // this very entry comes in at the next begin's position (the next lane has searched for it); the last begin of
+          // the slide and the last lane search themselves
+          const uint32_t xe_lo_next = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(lane + 1u, 63u) << 2), (int)xe_lo);
           if (lane_on) {
-            const uint32_t xe_lo = first_at_or_after(min(b - base, n), wp + count_windows - wbase);
-            xe_hi = first_at_or_after(xe_lo, w_end - wbase);
+            if (lane < 63u && b + 1u < b_hi) {
+              const bool comes_in_there = xe_lo_next > 0u && (uint32_t)sh.ref_w[xe_lo_next - 1u] == wp_next + count_windows - 1u - wbase;
+              xe_hi = xe_lo_next - (comes_in_there ? 1u : 0u);
+            } else {
+              xe_hi = first_at_or_after(xe_lo, w_end - wbase);
+            }
             xs0 = e_next ? e_next - base : xe_lo;
-            const uint32_t top = min(xe_hi, lim);
-            cnt = xs0 <= top ? top - xs0 + 1u : 0u;
+            top = min(xe_hi, lim);
+            cnt = xs0 <= top ? top - xs0 + 1u : 0u;  // states of the begin the stretch holds
             hi_known = xe_hi < n || at_end;
           }
         }
@@ -1436,6 +1447,18 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         bool counted = false;  // the lane holds the exact value of a state (a window found out of reach of the bar is done, but not counted)
         uint32_t taken = 0;
         bool complete = false;  // the begin's last state is behind it
+        // fold the evaluated states into the candidate's optimum: most shared; first position of the first and last
+        // position of the last state that has it (the lanes hold the states in slide order)
+        auto fold_items = [&]() {
+          const uint64_t dm = __ballot(counted);
+          const int32_t group_best = (int32_t)pa_dev::wave_max_dpp(counted ? f_shared + 1u : 0u) - 1;
+          if (dm && group_best >= c_best) {
+            const uint64_t top_items = __ballot(counted && (int32_t)f_shared == group_best);
+            const uint32_t w_first = __shfl(p_first, __builtin_ctzll(top_items), 64), w_last = __shfl(p_last, 63 - __builtin_clzll(top_items), 64);
+            if (group_best > c_best) { c_best = group_best; c_first = w_first; c_last = w_last; }
+            else { c_first = min(c_first, w_first); c_last = max(c_last, w_last); }
+          }
+        };
         if (__builtin_amdgcn_readlane((int)cnt, (int)first_lane) == 0) {
           PA_STAT(9, 1);  // cooperative evaluations
           // the first pending begin's next window is longer than the stretch: the whole wave takes that one state from HBM
@@ -1446,6 +1469,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           if (e_abs <= e_last) {
             __syncthreads();
             for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
+            if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;    // (the rounds keep their bitmap of matching entries there)
             __syncthreads();
             const uint32_t v = eval_window_coop(base, e_abs);
             const uint32_t w_in = mini_wpos[e_abs - 1u];                                  // the last minimizer the window holds
@@ -1456,44 +1480,16 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
               p_first = w_in + 1u > wp0 + count_windows ? w_in + 1u - count_windows : wp0;
               p_last = min(we0, w_out) - count_windows;
               e_next = e_abs + 1u;
+              pv = (int32_t)v;
             }
           }
           complete = lane == first_lane && e_abs + 1u > e_last;
+          fold_items();
         } else {
-          // ---- the states of the pending begins, in slide order, spread over the lanes: item t is state t - off of the
-          // begin whose run of items starts at off (runs laid out by a prefix sum of the counts; the begin of an item is
-          // found by marking the run starts in LDS and taking a running maximum over the lanes)
-          const uint32_t incl = pa_dev::wave_incl_scan_dpp(cnt), off = incl - cnt;
-          const uint32_t n_items = min(64u, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
-          taken = off < 64u ? min(cnt, 64u - off) : 0u;
-          sh.tab[lane] = 0u;  // (the tables of the round are built later in this memory)
-          __builtin_amdgcn_wave_barrier();
-          if (taken) sh.tab[off] = lane + 1u;
-          __builtin_amdgcn_wave_barrier();
-          const uint32_t src = pa_dev::wave_incl_max_scan_dpp(sh.tab[lane]) - 1u;  // item 0 exists: src >= 0 on every lane
-          const bool it_on = lane < n_items;
-          const int src_addr = (int)(src << 2);
-          const uint32_t packed = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)((b - base) | (xs0 << 10) | (off << 20)));
-          const uint32_t wp_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)wp);
-          const uint32_t we_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)w_end);
-          const uint32_t xs = it_on ? (packed & 0x3ffu) : 0u;                                   // the window: stretch entries [xs, xw)
-          const uint32_t xw = it_on ? ((packed >> 10) & 0x3ffu) + (lane - (packed >> 20)) : 0u;
-          if (it_on) {
-            // the positions the state stands for: from where entry xw - 1 comes in (or the begin becomes active) to where
-            // entry xw would come in (or the next begin becomes active, or the slide ends)
-            uint32_t w_in = sh.ref_w[xw - 1u], w_out = xw < n ? (uint32_t)sh.ref_w[xw] : 0xffffu;
-            w_in = w_in == 0xffffu ? mini_wpos[base + xw - 1u] : wbase + w_in;  // (0xffff: more than 65 534 window ids past the stretch's first)
-            w_out = w_out == 0xffffu ? (base + xw < m1 ? mini_wpos[base + xw] : 0xffffffffu) : wbase + w_out;
-            p_first = w_in + 1u > wp_s + count_windows ? w_in + 1u - count_windows : wp_s;
-            p_last = min(we_s, w_out) - count_windows;
-          }
-          // only the part of the stretch that some window of this round reaches is ranked and entered into the tables
-          const uint32_t n_use = pa_dev::wave_max_dpp(xw);
-          PA_CUT(5);  // stretch loads and window ends
-          PA_STAT(6, n_use);                            // stretch entries ranked
-          PA_STAT(7, n_items);                          // windows evaluated in the round
-          // ranks of the lane's kPer minimizers among the fragment's hashes: the binary searches advance together, one
-          // halving step for all of them at a time, so the LDS reads of a step are in flight at once
+          // ---- ranks of the lane's kPer minimizers among the fragment's hashes, for the part of the stretch that some
+          // window of the pending begins reaches: the binary searches advance together, one halving step for all of them at
+          // a time, so the LDS reads of a step are in flight at once
+          const uint32_t n_rank = pa_dev::wave_max_dpp(lane_on ? top : 0u);
           uint32_t rank[kPer];
 #pragma unroll
           for (int q = 0; q < kPer; ++q) rank[q] = 0;
@@ -1517,18 +1513,114 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
 #pragma unroll
               for (int q = 0; q < kPer; ++q) {
                 const uint32_t idx = rank[q] + half;  // number of hashes below h is >= idx iff qh[idx - 1] < h
-                if ((uint32_t)q * 64u + lane < n_use && idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
+                if ((uint32_t)q * 64u + lane < n_rank && idx <= s && sh.qh[idx - 1] < hh[q]) rank[q] = idx;
               }
             }
           }
-          PA_CUT(6);  // ranks
-          // Every window of the round at once, one lane each, without ordering the stretch.  A window holds the stretch
-          // positions [xs, xw) minus later occurrences of a hash it already holds: a bit mask W over the positions.  With
-          // R_r / M_r = the positions of reference-only / matching minimizers of rank <= r among the fragment's hashes, the
-          // reference-only minimizers below the fragment's hash of rank r number c(r) = |R_r & W|; that hash lies in the
-          // bottom-s of the union iff r + c(r) < s, which holds for r < T and no other (r + c(r) grows strictly), and the
-          // window shares |M_(T-1) & W| minimizers.  T comes from two searches per lane: over the rows at every kCoarse-th
-          // rank, then over all ranks of the coarse group that holds it.  A row is R_r followed by M_r.
+          // which entries match a hash of the fragment, as a bitmap over the stretch (scratch in the memory of the tables,
+          // which are built later in the round)
+          uint32_t match_q = 0;
+          uint32_t *bm = sh.matched;  // (the cooperative evaluation, the other user of these words, clears them before it counts)
+#pragma unroll
+          for (int q = 0; q < kPer; ++q) {
+            const uint32_t x = (uint32_t)q * 64u + lane;
+            const bool is_match = (x < n_rank) & (rank[q] < s) & (sh.qh[min(rank[q], s - 1u)] == hh[q]);
+            match_q |= (is_match ? 1u : 0u) << q;
+            const uint64_t mb = __ballot(is_match);
+            if (lane == 0) { bm[2 * q] = (uint32_t)mb; bm[2 * q + 1] = (uint32_t)(mb >> 32); }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // ---- which states are evaluated.  A state reached by taking in a minimizer that matches no hash of the fragment
+          // (or repeats a hash the window holds) shares no more than the state before it: it matters only when that one
+          // reaches the bar (it may tie with it, and ties move the mapping position).  So a begin's first state and every
+          // state reached by taking in a MATCHING minimizer are evaluated; the others only right after a state at or above
+          // the bar.  Per round a begin contributes one run of consecutive states [xa, xa + len): either the single state
+          // after one that reached the bar, or -- the states below the bar passed over -- a run of matching ones.
+          int32_t bar_cur = c_best > best_shared ? c_best : best_shared;
+          if (bar_cur < floor_bar) bar_cur = floor_bar;
+          // bit j: state xs0 + j is evaluated anyway (its last entry matches, or it is the begin's first state), for the up
+          // to 16 states of the begin that a round looks at
+          auto anyway_mask = [&]() -> uint32_t {
+            const uint32_t p0 = xs0 - 1u, w0 = p0 >> 5;  // (xs0 >= 1: a window holds its begin)
+            const uint64_t two = ((uint64_t)(w0 + 1u < (uint32_t)kQMax / 32u ? bm[w0 + 1u] : 0u) << 32) | bm[w0];
+            uint32_t m = (uint32_t)(two >> (p0 & 31u));
+            if (xs0 == xe_lo) m |= 1u;
+            return m & ((2u << min(top - xs0, 15u)) - 1u);
+          };
+          uint32_t xa = xs0, len = 0;
+          if (cnt) {
+            const uint32_t m = anyway_mask();
+            if (!(m & 1u) && pv >= bar_cur) {
+              len = 1;  // the state after one that reached the bar
+            } else if (m == 0u) {
+              xa = xs0 + min(top - xs0, 15u) + 1u;  // nothing here matters
+            } else {  // from the first to the last state that is evaluated anyway (the few between them ride along)
+              const uint32_t first = (uint32_t)__builtin_ctz(m), last = 31u - (uint32_t)__builtin_clz(m);
+              xa = xs0 + first;
+              len = last - first + 1u;
+            }
+          }
+          // ---- the chosen states of the pending begins, in slide order, spread over the lanes: item t is state t - off of
+          // the begin whose run of items [off, incl) holds t (runs laid out by a prefix sum of the counts).  A round takes up
+          // to 128 items: the tables are built once, the lanes go through them twice when there are more than 64.
+          const uint32_t incl = pa_dev::wave_incl_scan_dpp(len), off = incl - len;
+          const uint32_t n_items = min(128u, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
+          taken = off < 128u ? min(len, 128u - off) : 0u;
+          PA_CUT(5);  // stretch loads and window ends
+          PA_STAT(6, n_rank);                           // stretch entries ranked
+          PA_STAT(7, n_items);                          // windows evaluated in the round
+          PA_STAT(12, n_items == 0u ? 1u : 0u);
+          PA_STAT(13, n_items > 64u ? 1u : 0u);
+          int32_t last_val = -1, round_best = -1;
+          if (n_items) {
+            PA_CUT(6);  // ranks
+            // Every window of the round, one lane each, without ordering the stretch.  A window holds the stretch
+            // positions [xs, xw) minus later occurrences of a hash it already holds: a bit mask W over the positions.  With
+            // R_r / M_r = the positions of reference-only / matching minimizers of rank <= r among the fragment's hashes, the
+            // reference-only minimizers below the fragment's hash of rank r number c(r) = |R_r & W|; that hash lies in the
+            // bottom-s of the union iff r + c(r) < s, which holds for r < T and no other (r + c(r) grows strictly), and the
+            // window shares |M_(T-1) & W| minimizers.  T comes from two searches per lane: over the rows at every kCoarse-th
+            // rank, then over all ranks of the coarse group that holds it.  A row is R_r followed by M_r.
+            uint32_t xs = 0, xw = 0;
+            bool it_on = false;
+            // the begin of item t: the first lane whose run ends past t (the run ends do not decrease over the lanes)
+            auto item_setup = [&](uint32_t pass, bool window_ids_in_lds) {
+              const uint32_t t = pass * 64u + lane;
+              it_on = t < n_items;
+              uint32_t src = 0;
+              if (pass == 0u) {  // the run starts marked in LDS (scratch in the memory of the tables), then a running maximum over the lanes
+                sh.tab[lane] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (len && off < 64u) sh.tab[off] = lane + 1u;
+                __builtin_amdgcn_wave_barrier();
+                src = max(pa_dev::wave_incl_max_scan_dpp(sh.tab[lane]), 1u) - 1u;
+              } else {  // a search: the first lane whose run ends past t
+#pragma unroll
+                for (uint32_t step = 32; step > 0; step >>= 1) {
+                  const uint32_t probe = src + step - 1u;
+                  const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(min(probe, 63u) << 2), (int)incl);
+                  src += (probe < 64u && v <= t) ? step : 0u;
+                }
+              }
+              const int src_addr = (int)(min(src, 63u) << 2);
+              const uint32_t packed = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)(((b - base) & 0x3ffu) | (xa << 10)));
+              const uint32_t off_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)off);
+              const uint32_t wp_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)wp);
+              const uint32_t we_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)w_end);
+              xs = it_on ? (packed & 0x3ffu) : 0u;                  // the window: stretch entries [xs, xw)
+              xw = it_on ? (packed >> 10) + (t - off_s) : 0u;
+              if (it_on) {
+                // the positions the state stands for: from where entry xw - 1 comes in (or the begin becomes active) to where
+                // entry xw would come in (or the next begin becomes active, or the slide ends)
+                uint32_t w_in = 0xffffu, w_out = 0xffffu;
+                if (window_ids_in_lds) { w_in = sh.ref_w[xw - 1u]; w_out = xw < n ? (uint32_t)sh.ref_w[xw] : 0xffffu; }
+                w_in = w_in == 0xffffu ? mini_wpos[base + xw - 1u] : wbase + w_in;  // (0xffff: more than 65 534 window ids past the stretch's first)
+                w_out = w_out == 0xffffu ? (base + xw < m1 ? mini_wpos[base + xw] : 0xffffffffu) : wbase + w_out;
+                p_first = w_in + 1u > wp_s + count_windows ? w_in + 1u - count_windows : wp_s;
+                p_last = min(we_s, w_out) - count_windows;
+              }
+            };
+            item_setup(0u, true);  // (the window ids in LDS make way for the duplicate links below)
           constexpr uint32_t kW = kRefCap / 32u;  // words per half row; stretch position q * 64 + lane is bit (lane & 31) of word 2 q + (lane >> 5)
           constexpr uint32_t kRow = 2u * kW;
           const uint32_t n_coarse = s / kCoarse + 1u;  // the last row stands at a rank >= s: r + c(r) >= s holds there
@@ -1544,11 +1636,11 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           for (int q = 0; q < kPer; ++q) {
             const uint32_t x = (uint32_t)q * 64u + lane;
             const uint32_t r = rank[q];
-            const bool valid = (x < n_use) & (r < s);  // inside the used part and below some hash of the fragment: in the rows from r on
-            const bool is_match = valid & (sh.qh[min(r, s - 1u)] == hh[q]);
+            const bool valid = (x < n_rank) & (r < s);  // inside the used part and below some hash of the fragment: in the rows from r on
+            const bool is_match = (match_q >> q) & 1u;
             col[q] = 2u * (uint32_t)q + (lane >> 5) + (is_match ? kW : 0u);
             // the same hash earlier in the stretch (position + 1): a window keeps this occurrence only if it starts after that one
-            const uint32_t p1 = (x < n_use && pp[q] >= (int32_t)base) ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
+            const uint32_t p1 = (x < n_rank && pp[q] >= (int32_t)base) ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
             prev16[x] = (uint16_t)p1;
             dup_q |= (p1 ? 1u : 0u) << q;
             rank[q] = valid ? r : 0xffffffffu;
@@ -1586,117 +1678,135 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           };
           prefix_or_rows(bc, n_coarse);
           PA_CUT(7);  // coarse table
-          // the lane's window as a mask over the stretch positions
-          uint32_t wm[kW];
-          {
-            // bits [xs, xw) of the row, two words at a time: xs is below 64, so only the first pair has a lower end
-            auto below = [](int32_t b) -> uint64_t {  // the b lowest bits of a pair of words, b clamped to 0 .. 64
-              const uint64_t m = b >= 64 ? ~0ULL : (1ULL << (b & 63)) - 1ULL;
-              return b <= 0 ? 0ULL : m;
-            };
-#pragma unroll
-            for (uint32_t w2 = 0; w2 < kW / 2u; ++w2) {
-              uint64_t m = below((int32_t)xw - (int32_t)(64u * w2));
-              if (w2 == 0) m &= ~below((int32_t)xs);
-              wm[2 * w2] = (uint32_t)m;
-              wm[2 * w2 + 1] = (uint32_t)(m >> 32);
-            }
-          }
-          if (any_dup) {
-#pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-              for (uint64_t dmask = __ballot((dup_q >> q) & 1u); dmask; dmask &= dmask - 1) {
-                const uint32_t bit = (uint32_t)__builtin_ctzll(dmask);
-                if ((uint32_t)prev16[(uint32_t)q * 64u + bit] > xs) {  // the earlier occurrence lies inside this lane's window
-                  if (bit < 32u) wm[2 * q] &= ~(1u << bit); else wm[2 * q + 1] &= ~(1u << (bit - 32u));
+            for (uint32_t pass = 0; pass * 64u < n_items; ++pass) {
+              if (pass) item_setup(pass, false);
+              // the lane's window as a mask over the stretch positions
+              uint32_t wm[kW];
+              {
+                // bits [xs, xw) of the row, two words at a time: xs is below 64, so only the first pair has a lower end
+                auto below = [](int32_t b) -> uint64_t {  // the b lowest bits of a pair of words, b clamped to 0 .. 64
+                  const uint64_t m = b >= 64 ? ~0ULL : (1ULL << (b & 63)) - 1ULL;
+                  return b <= 0 ? 0ULL : m;
+                };
+    #pragma unroll
+                for (uint32_t w2 = 0; w2 < kW / 2u; ++w2) {
+                  uint64_t m = below((int32_t)xw - (int32_t)(64u * w2));
+                  if (w2 == 0) m &= ~below((int32_t)xs);
+                  wm[2 * w2] = (uint32_t)m;
+                  wm[2 * w2 + 1] = (uint32_t)(m >> 32);
                 }
               }
+              if (any_dup) {
+    #pragma unroll
+                for (int q = 0; q < kPer; ++q) {
+                  for (uint64_t dmask = __ballot((dup_q >> q) & 1u); dmask; dmask &= dmask - 1) {
+                    const uint32_t bit = (uint32_t)__builtin_ctzll(dmask);
+                    if ((uint32_t)prev16[(uint32_t)q * 64u + bit] > xs) {  // the earlier occurrence lies inside this lane's window
+                      if (bit < 32u) wm[2 * q] &= ~(1u << bit); else wm[2 * q + 1] &= ~(1u << (bit - 32u));
+                    }
+                  }
+                }
+              }
+              auto count_in = [&](const uint32_t *half_row) -> uint32_t {
+                const uint2 *row2 = reinterpret_cast<const uint2 *>(half_row);  // half rows start on 8-byte boundaries (kW is even)
+                uint32_t c = 0;
+    #pragma unroll
+                for (uint32_t w = 0; w < kW / 2u; ++w) {
+                  const uint2 v = row2[w];
+                  c += __popc(v.x & wm[2 * w]) + __popc(v.y & wm[2 * w + 1]);
+                }
+                return c;
+              };
+              __syncthreads();
+              // coarse: the first group g whose last rank r = kCoarse g + kCoarse - 1 has r + c(r) >= s (the last row always has)
+              uint32_t g_lo = 0, g_hi = n_coarse - 1u;
+              for (uint32_t span = n_coarse - 1u; span > 0u; span >>= 1) {  // as many halvings as the widest range needs
+                const uint32_t mid = (g_lo + g_hi) >> 1;
+                const bool ge = mid * kCoarse + (kCoarse - 1u) + count_in(bc + mid * kRow) >= s;
+                const bool open = g_lo < g_hi;
+                g_hi = (open & ge) ? mid : g_hi;
+                g_lo = (open & !ge) ? mid + 1u : g_lo;
+              }
+              PA_CUT(8);  // window masks, coarse search
+              // fine: the groups of the lanes lie next to each other as a rule; kFineGroups of them per pass
+              // A window shares |M_(T-1) & W| minimizers and T - 1 lies in the coarse group just found, so the matches up to the
+              // group's last rank bound it from above (by the matches of at most 15 more ranks): windows that cannot reach
+              // the bar any more -- most of a candidate's windows away from its optimum -- are done here, without the fine
+              // tables, and are left out of the fold below (their exact value is below the bar, which is all that matters).
+              int32_t bar_now = c_best > best_shared ? c_best : best_shared;
+              if (bar_now < floor_bar) bar_now = floor_bar;
+              const bool in_reach = (int32_t)count_in(bc + g_lo * kRow + kW) >= bar_now;
+              counted = it_on && in_reach;
+              bool unresolved = counted;
+              while (__any(unresolved)) {
+                PA_STAT(8, 1);  // fine passes
+                const uint32_t g_cur = pa_dev::wave_min_dpp(unresolved ? g_lo : 0xffffffffu);
+                const uint32_t band0 = g_cur * kCoarse;  // row t of the band: ranks <= band0 + t - 1; row 0 is the coarse row below
+                __syncthreads();
+                {
+                  uint4 *f4 = reinterpret_cast<uint4 *>(bf);  // bf starts on a 16-byte boundary: kRow is a multiple of 4 words
+                  const uint4 *below = reinterpret_cast<const uint4 *>(bc + (g_cur ? g_cur - 1u : 0u) * kRow);
+                  for (uint32_t i = lane; i < kFineRows * kRow / 4u; i += 64)
+                    f4[i] = (i < kRow / 4u && g_cur > 0u) ? below[i] : make_uint4(0u, 0u, 0u, 0u);
+                }
+                __syncthreads();
+    #pragma unroll
+                for (int q = 0; q < kPer; ++q) {
+                  const uint32_t t = rank[q] - band0;  // wraps to something huge below the band
+                  const bool valid = (rank[q] != 0xffffffffu) & (t < kFineRows - 1u);
+                  atomicOr(valid ? &bf[(t + 1u) * kRow + col[q]] : &bc[lane], valid ? 1u << (lane & 31u) : 0u);
+                }
+                __syncthreads();
+                prefix_or_rows(bf, kFineRows);
+                __syncthreads();
+                const bool now = unresolved && g_lo - g_cur < kFineGroups;
+                // first rank r of the lane's group with r + c(r) >= s: the group's last rank has it
+                uint32_t r_lo = g_lo * kCoarse, r_hi = r_lo + kCoarse - 1u;
+                if (!now) r_lo = r_hi = band0;
+                for (uint32_t step = 0; step < kCoarseShift; ++step) {
+                  const uint32_t mid = (r_lo + r_hi) >> 1;
+                  const bool ge = mid + count_in(bf + (mid - band0 + 1u) * kRow) >= s;
+                  const bool open = r_lo < r_hi;
+                  r_hi = (open & ge) ? mid : r_hi;
+                  r_lo = (open & !ge) ? mid + 1u : r_lo;
+                }
+                const uint32_t c = count_in(bf + (r_lo - band0) * kRow + kW);  // matches of rank < T = r_lo
+                if (now) { f_shared = c; unresolved = false; }
+              }
+              __syncthreads();
+              fold_items();
+              // what the begin's last item shares, for the begins whose run ends in this pass
+              const int32_t item_val = counted ? (int32_t)f_shared : -1;
+              const uint32_t last_item = off + taken - 1u;
+              const int32_t got = __shfl(item_val, (int)(last_item & 63u), 64);
+              if (taken && (last_item >> 6) == pass) last_val = got;
+              const int32_t pass_best = (int32_t)pa_dev::wave_max_dpp((uint32_t)(item_val + 1)) - 1;
+              round_best = max(round_best, pass_best);
             }
           }
-          auto count_in = [&](const uint32_t *half_row) -> uint32_t {
-            const uint2 *row2 = reinterpret_cast<const uint2 *>(half_row);  // half rows start on 8-byte boundaries (kW is even)
-            uint32_t c = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < kW / 2u; ++w) {
-              const uint2 v = row2[w];
-              c += __popc(v.x & wm[2 * w]) + __popc(v.y & wm[2 * w + 1]);
+          // the begins: where their next state ends, what the state before it shares (the value of the begin's last item,
+          // -1 when that one was out of reach of the bar or states were passed over), whether the last state is behind them
+          {
+            uint32_t x_next = xs0;
+            const int32_t bar_new = max(bar_cur, round_best);  // the best of this round's items, or the bar as it stood
+            if (cnt) {
+              x_next = xa + taken;
+              pv = taken ? last_val : (xa > xs0 ? -1 : pv);
+              // the states after a run that ended below the bar are passed over right away (up to the next one that is
+              // evaluated anyway): the begin is done in this round unless it holds a state that matters
+              if (taken == len && pv < bar_new) {
+                const uint32_t x_from = x_next, j0 = x_next - xs0;
+                const uint32_t rest = j0 < 32u ? anyway_mask() >> j0 : 0u;
+                x_next = rest ? x_next + (uint32_t)__builtin_ctz(rest) : max(x_next, xs0 + min(top - xs0, 15u) + 1u);
+                if (x_next > x_from) pv = -1;
+              }
+              e_next = base + x_next;
             }
-            return c;
-          };
-          __syncthreads();
-          // coarse: the first group g whose last rank r = kCoarse g + kCoarse - 1 has r + c(r) >= s (the last row always has)
-          uint32_t g_lo = 0, g_hi = n_coarse - 1u;
-          for (uint32_t span = n_coarse - 1u; span > 0u; span >>= 1) {  // as many halvings as the widest range needs
-            const uint32_t mid = (g_lo + g_hi) >> 1;
-            const bool ge = mid * kCoarse + (kCoarse - 1u) + count_in(bc + mid * kRow) >= s;
-            const bool open = g_lo < g_hi;
-            g_hi = (open & ge) ? mid : g_hi;
-            g_lo = (open & !ge) ? mid + 1u : g_lo;
+            complete = lane_on && hi_known && x_next > xe_hi;
           }
-          PA_CUT(8);  // window masks, coarse search
-          // fine: the groups of the lanes lie next to each other as a rule; kFineGroups of them per pass
-          // A window shares |M_(T-1) & W| minimizers and T - 1 lies in the coarse group just found, so the matches up to the
-          // group's last rank bound it from above (by the matches of at most 15 more ranks): windows that cannot reach
-          // the bar any more -- most of a candidate's windows away from its optimum -- are done here, without the fine
-          // tables, and are left out of the fold below (their exact value is below the bar, which is all that matters).
-          int32_t bar_now = c_best > best_shared ? c_best : best_shared;
-          if (bar_now < floor_bar) bar_now = floor_bar;
-          const bool in_reach = (int32_t)count_in(bc + g_lo * kRow + kW) >= bar_now;
-          counted = it_on && in_reach;
-          bool unresolved = counted;
-          while (__any(unresolved)) {
-            PA_STAT(8, 1);  // fine passes
-            const uint32_t g_cur = pa_dev::wave_min_dpp(unresolved ? g_lo : 0xffffffffu);
-            const uint32_t band0 = g_cur * kCoarse;  // row t of the band: ranks <= band0 + t - 1; row 0 is the coarse row below
-            __syncthreads();
-            {
-              uint4 *f4 = reinterpret_cast<uint4 *>(bf);  // bf starts on a 16-byte boundary: kRow is a multiple of 4 words
-              const uint4 *below = reinterpret_cast<const uint4 *>(bc + (g_cur ? g_cur - 1u : 0u) * kRow);
-              for (uint32_t i = lane; i < kFineRows * kRow / 4u; i += 64)
-                f4[i] = (i < kRow / 4u && g_cur > 0u) ? below[i] : make_uint4(0u, 0u, 0u, 0u);
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-              const uint32_t t = rank[q] - band0;  // wraps to something huge below the band
-              const bool valid = (rank[q] != 0xffffffffu) & (t < kFineRows - 1u);
-              atomicOr(valid ? &bf[(t + 1u) * kRow + col[q]] : &bc[lane], valid ? 1u << (lane & 31u) : 0u);
-            }
-            __syncthreads();
-            prefix_or_rows(bf, kFineRows);
-            __syncthreads();
-            const bool now = unresolved && g_lo - g_cur < kFineGroups;
-            // first rank r of the lane's group with r + c(r) >= s: the group's last rank has it
-            uint32_t r_lo = g_lo * kCoarse, r_hi = r_lo + kCoarse - 1u;
-            if (!now) r_lo = r_hi = band0;
-            for (uint32_t step = 0; step < kCoarseShift; ++step) {
-              const uint32_t mid = (r_lo + r_hi) >> 1;
-              const bool ge = mid + count_in(bf + (mid - band0 + 1u) * kRow) >= s;
-              const bool open = r_lo < r_hi;
-              r_hi = (open & ge) ? mid : r_hi;
-              r_lo = (open & !ge) ? mid + 1u : r_lo;
-            }
-            const uint32_t c = count_in(bf + (r_lo - band0) * kRow + kW);  // matches of rank < T = r_lo
-            if (now) { f_shared = c; unresolved = false; }
-          }
-          __syncthreads();
-          // the begins: where their next state ends, and whether the last one is behind them
-          if (taken) e_next = base + xs0 + taken;
-          complete = lane_on && hi_known && xs0 + taken > xe_hi;
         }
-        // fold the evaluated states into the candidate's optimum: most shared; first position of the first and last
-        // position of the last state that has it (the lanes hold the states in slide order)
-        const uint64_t dm = __ballot(counted);
-        int32_t group_best = -1;
-        {
-          group_best = (int32_t)pa_dev::wave_max_dpp(counted ? f_shared + 1u : 0u) - 1;
-        }
-        if (dm && group_best >= c_best) {
-          const uint64_t top = __ballot(counted && (int32_t)f_shared == group_best);
-          const uint32_t w_first = __shfl(p_first, __builtin_ctzll(top), 64), w_last = __shfl(p_last, 63 - __builtin_clzll(top), 64);
-          if (group_best > c_best) { c_best = group_best; c_first = w_first; c_last = w_last; }
-          else { c_first = min(c_first, w_first); c_last = max(c_last, w_last); }
-        }
+        PA_STAT(10, __popcll(__ballot(lane_on)));   // begins taking part in the rounds
+        PA_STAT(11, __popcll(__ballot(complete)));  // begins finished by the rounds
         pending = pending && !complete;
         // whoever can no longer reach the bar drops out
         {
@@ -2416,9 +2526,10 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
       if (trace) {
         uint32_t st[16];
         PA_HIP(hipMemcpy(st, W.run_g.p, 64, hipMemcpyDeviceToHost));
-        fprintf(stderr, "pa_fragani: map stats: %u segments at L1 with %u hits, %u candidates, %u groups, %u starts past the bound, "
-                        "%u rounds, %u stretch entries, %u windows evaluated, %u fine passes, %u cooperative\n",
-                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9]);
+        fprintf(stderr, "pa_fragani: map stats: %u segments at L1 with %u hits, %u candidates, %u groups, %u begins past the bound, "
+                        "%u rounds, %u stretch entries, %u windows evaluated, %u fine passes, %u cooperative, %u begins in rounds, "
+                        "%u begins finished, %u rounds without items, %u second passes\n",
+                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13]);
       }
 #endif
     }

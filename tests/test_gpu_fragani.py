@@ -10,7 +10,7 @@ import pytest
 
 import oracle
 from tests.helpers import GOLDEN, read_fasta_bytes
-from tests.test_fragani_oracle import ANI_TOL, MATCHED_TOL, contigs_of, fixture_rows
+from tests.test_fragani_oracle import bacterial_row_bounds, contigs_of, fixture_rows, printed
 
 pytestmark = pytest.mark.gpu
 K, FRAG = 16, 3000
@@ -297,8 +297,8 @@ def test_viral_fixture_rows(engine):
     names = [p.name for p in files]
     for q, r, ani, m, t in fixture_rows("viral_example"):
         qi, ri = names.index(q), names.index(r)
-        assert total[qi] == t and abs(int(matched[qi, ri]) - m) <= 1
-        assert abs(ident_sum[qi, ri] / matched[qi, ri] - ani) <= ANI_TOL
+        assert total[qi] == t and int(matched[qi, ri]) == m
+        assert printed(ident_sum[qi, ri] / matched[qi, ri]) == ani, (q, r)  # as fastANI prints it: six significant digits
 
 
 def test_bacterial_fixture_rows(engine):
@@ -311,9 +311,7 @@ def test_bacterial_fixture_rows(engine):
     names = [p.name for p in files]
     for q, r, ani, m, t in fixture_rows("bacterial_example"):
         qi, ri = names.index(q), names.index(r)
-        assert total[qi] == t
-        assert abs(int(matched[qi, ri]) - m) <= MATCHED_TOL * t
-        assert abs(ident_sum[qi, ri] / matched[qi, ri] - ani) <= ANI_TOL, (q, r)
+        bacterial_row_bounds(q, r, ani, m, t, ident_sum[qi, ri] / matched[qi, ri], int(matched[qi, ri]), int(total[qi]))
     for qi, ri in ((1, 0), (0, 2)):
         ani, m, t = oracle.fragani_pair(contigs_of(files[qi]), contigs_of(files[ri]), K, FRAG, 0.0)
         assert matched[qi, ri] == m and abs(ident_sum[qi, ri] / m - ani) <= 1e-9 * ani
@@ -347,7 +345,8 @@ def test_plugin_column_matches_reference_matrices(engine, tmp_path):
     rows = {(e["query_hash"], e["subject_hash"]): e for e in data["comparisons"]}
     assert len(rows) == 9
     stem_of = {h: name.split(".")[0] for h, name in hash_to_filename.items()}
-    for fname, key, tol in (("fastANI_identity.tsv", "identity", ANI_TOL / 100), ("fastANI_coverage.tsv", "cov_query", 1 / 13 + 1e-9)):
+    # the viral matrices are reproduced as fastANI printed them: identity to its six significant digits, coverage exactly
+    for fname, key, tol in (("fastANI_identity.tsv", "identity", 1e-12), ("fastANI_coverage.tsv", "cov_query", 1e-15)):
         labels, want = load_matrix_tsv(GOLDEN / "viral_example" / "matrices" / fname)
         for (q, s), e in rows.items():
             w = want[labels.index(stem_of[q]), labels.index(stem_of[s])]
