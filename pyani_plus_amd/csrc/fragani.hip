@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     if (b_lo >= b_hi) return;
     PA_STAT(2, 1);  // candidates with begins
     int32_t c_best = -1;
-    uint32_t c_first = 0, c_last = 0;
+    uint32_t c_first = 0, c_last = 0, c_last_b = 0, c_last_e = 0;  // c_last_b/e: begin and end of the state c_last comes from
     const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
     // A begin matters only if one of its windows can hold min_shared minimizers of the fragment (less is never reported)
     // and reach the best so far.  The group holding the candidate's first seed hit goes first -- for a true mapping the
@@ -1387,7 +1387,6 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       PA_STAT(3, 1);                              // groups of 64 begins
       PA_STAT(4, __popcll(__ballot(pending)));    // begins that pass the seed-hit bound
       uint32_t e_next = 0;  // end (minimizer index) of the begin's next state; 0: none of its states has been evaluated yet
-      int32_t pv = -1;      // shared minimizers of the state before that one, -1 when known to be below the bar
       while (__any(pending)) {
         PA_STAT(5, 1);  // rounds
         const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
@@ -1449,14 +1448,17 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         bool complete = false;  // the begin's last state is behind it
         // fold the evaluated states into the candidate's optimum: most shared; first position of the first and last
         // position of the last state that has it (the lanes hold the states in slide order)
-        auto fold_items = [&]() {
+        auto fold_items = [&](uint32_t item_b, uint32_t item_e) {  // the lane's state: minimizers [item_b, item_e)
           const uint64_t dm = __ballot(counted);
           const int32_t group_best = (int32_t)pa_dev::wave_max_dpp(counted ? f_shared + 1u : 0u) - 1;
           if (dm && group_best >= c_best) {
             const uint64_t top_items = __ballot(counted && (int32_t)f_shared == group_best);
-            const uint32_t w_first = __shfl(p_first, __builtin_ctzll(top_items), 64), w_last = __shfl(p_last, 63 - __builtin_clzll(top_items), 64);
-            if (group_best > c_best) { c_best = group_best; c_first = w_first; c_last = w_last; }
-            else { c_first = min(c_first, w_first); c_last = max(c_last, w_last); }
+            const int last_lane = 63 - __builtin_clzll(top_items);
+            const uint32_t w_first = __shfl(p_first, __builtin_ctzll(top_items), 64), w_last = __shfl(p_last, last_lane, 64);
+            const uint32_t l_b = __shfl(item_b, last_lane, 64), l_e = __shfl(item_e, last_lane, 64);
+            if (group_best > c_best || w_last > c_last) { c_last = w_last; c_last_b = l_b; c_last_e = l_e; }
+            c_first = group_best > c_best ? w_first : min(c_first, w_first);
+            c_best = group_best;
           }
         };
         if (__builtin_amdgcn_readlane((int)cnt, (int)first_lane) == 0) {
@@ -1480,11 +1482,10 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
               p_first = w_in + 1u > wp0 + count_windows ? w_in + 1u - count_windows : wp0;
               p_last = min(we0, w_out) - count_windows;
               e_next = e_abs + 1u;
-              pv = (int32_t)v;
             }
           }
           complete = lane == first_lane && e_abs + 1u > e_last;
-          fold_items();
+          fold_items(base, e_abs);
         } else {
           // ---- ranks of the lane's kPer minimizers among the fragment's hashes, for the part of the stretch that some
           // window of the pending begins reaches: the binary searches advance together, one halving step for all of them at
@@ -1531,30 +1532,23 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           }
           __builtin_amdgcn_wave_barrier();
           // ---- which states are evaluated.  A state reached by taking in a minimizer that matches no hash of the fragment
-          // (or repeats a hash the window holds) shares no more than the state before it: it matters only when that one
-          // reaches the bar (it may tie with it, and ties move the mapping position).  So a begin's first state and every
-          // state reached by taking in a MATCHING minimizer are evaluated; the others only right after a state at or above
-          // the bar.  Per round a begin contributes one run of consecutive states [xa, xa + len): either the single state
-          // after one that reached the bar, or -- the states below the bar passed over -- a run of matching ones.
-          int32_t bar_cur = c_best > best_shared ? c_best : best_shared;
-          if (bar_cur < floor_bar) bar_cur = floor_bar;
-          // bit j: state xs0 + j is evaluated anyway (its last entry matches, or it is the begin's first state), for the up
-          // to 16 states of the begin that a round looks at
-          auto anyway_mask = [&]() -> uint32_t {
+          // (or repeats a hash the window holds) shares no more than the state before it, so the first state with the most
+          // shared minimizers is never such a state, and the last one is the last evaluated state that has them or one of
+          // the states right after it -- those are looked at once, when the candidate's other states are through (below).
+          // Evaluated here: a begin's first state and every state reached by taking in a MATCHING minimizer.  Per round a
+          // begin contributes the run of states from its first to its last such state among the next 16 (the few between
+          // them ride along).
+          // bit j: state xs0 + j is such a state
+          uint32_t xa = xs0, len = 0;
+          if (cnt) {
             const uint32_t p0 = xs0 - 1u, w0 = p0 >> 5;  // (xs0 >= 1: a window holds its begin)
             const uint64_t two = ((uint64_t)(w0 + 1u < (uint32_t)kQMax / 32u ? bm[w0 + 1u] : 0u) << 32) | bm[w0];
             uint32_t m = (uint32_t)(two >> (p0 & 31u));
             if (xs0 == xe_lo) m |= 1u;
-            return m & ((2u << min(top - xs0, 15u)) - 1u);
-          };
-          uint32_t xa = xs0, len = 0;
-          if (cnt) {
-            const uint32_t m = anyway_mask();
-            if (!(m & 1u) && pv >= bar_cur) {
-              len = 1;  // the state after one that reached the bar
-            } else if (m == 0u) {
-              xa = xs0 + min(top - xs0, 15u) + 1u;  // nothing here matters
-            } else {  // from the first to the last state that is evaluated anyway (the few between them ride along)
+            m &= (2u << min(top - xs0, 15u)) - 1u;
+            if (m == 0u) {
+              xa = xs0 + min(top - xs0, 15u) + 1u;  // nothing to evaluate among them
+            } else {
               const uint32_t first = (uint32_t)__builtin_ctz(m), last = 31u - (uint32_t)__builtin_clz(m);
               xa = xs0 + first;
               len = last - first + 1u;
@@ -1571,7 +1565,6 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           PA_STAT(7, n_items);                          // windows evaluated in the round
           PA_STAT(12, n_items == 0u ? 1u : 0u);
           PA_STAT(13, n_items > 64u ? 1u : 0u);
-          int32_t last_val = -1, round_best = -1;
           if (n_items) {
             PA_CUT(6);  // ranks
             // Every window of the round, one lane each, without ordering the stretch.  A window holds the stretch
@@ -1774,32 +1767,15 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
                 if (now) { f_shared = c; unresolved = false; }
               }
               __syncthreads();
-              fold_items();
-              // what the begin's last item shares, for the begins whose run ends in this pass
-              const int32_t item_val = counted ? (int32_t)f_shared : -1;
-              const uint32_t last_item = off + taken - 1u;
-              const int32_t got = __shfl(item_val, (int)(last_item & 63u), 64);
-              if (taken && (last_item >> 6) == pass) last_val = got;
-              const int32_t pass_best = (int32_t)pa_dev::wave_max_dpp((uint32_t)(item_val + 1)) - 1;
-              round_best = max(round_best, pass_best);
+              fold_items(base + xs, base + xw);
             }
           }
-          // the begins: where their next state ends, what the state before it shares (the value of the begin's last item,
-          // -1 when that one was out of reach of the bar or states were passed over), whether the last state is behind them
+          // the begins: where their next state ends (past the states after the run that are not evaluated), and whether
+          // the last state is behind them
           {
             uint32_t x_next = xs0;
-            const int32_t bar_new = max(bar_cur, round_best);  // the best of this round's items, or the bar as it stood
             if (cnt) {
-              x_next = xa + taken;
-              pv = taken ? last_val : (xa > xs0 ? -1 : pv);
-              // the states after a run that ended below the bar are passed over right away (up to the next one that is
-              // evaluated anyway): the begin is done in this round unless it holds a state that matters
-              if (taken == len && pv < bar_new) {
-                const uint32_t x_from = x_next, j0 = x_next - xs0;
-                const uint32_t rest = j0 < 32u ? anyway_mask() >> j0 : 0u;
-                x_next = rest ? x_next + (uint32_t)__builtin_ctz(rest) : max(x_next, xs0 + min(top - xs0, 15u) + 1u);
-                if (x_next > x_from) pv = -1;
-              }
+              x_next = taken == len ? xs0 + min(top - xs0, 15u) + 1u : xa + taken;
               e_next = base + x_next;
             }
             complete = lane_on && hi_known && x_next > xe_hi;
@@ -1817,6 +1793,26 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       }
     }
     if (c_best < 0) return;
+    // The states right after the last evaluated state with the most shared minimizers (same begin, one more minimizer taken
+    // in each) share as many or fewer: while they share as many, the optimum extends over them.  Only where the position
+    // can matter: the candidate is reported, and wins or ties with the best so far.
+    if (c_best >= floor_bar && c_best >= best_shared) {
+      const uint32_t wp_after = c_last_b + 1u < m1 ? mini_wpos[c_last_b + 1u] : 0xffffffffu;
+      const uint32_t we = min(wp_after - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
+      if (c_last + count_windows < we) {  // the state is not the begin's last
+        const uint32_t e_last = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, we);
+        for (uint32_t e = c_last_e + 1u; e <= e_last; ++e) {
+          PA_STAT(14, 1);  // states evaluated after the optimum
+          __syncthreads();
+          for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
+          if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
+          __syncthreads();
+          if ((int32_t)eval_window_coop(c_last_b, e) != c_best) break;
+          const uint32_t w_out = e < m1 ? mini_wpos[e] : 0xffffffffu;  // the first minimizer past the window
+          c_last = min(we, w_out) - count_windows;
+        }
+      }
+    }
     const uint32_t pos = (c_first + c_last) / 2u;
     if (c_best > best_shared || (c_best == best_shared && (c < best_c || (c == best_c && pos < best_p)))) {
       best_shared = c_best; best_c = c; best_p = pos;
@@ -2528,8 +2524,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         PA_HIP(hipMemcpy(st, W.run_g.p, 64, hipMemcpyDeviceToHost));
         fprintf(stderr, "pa_fragani: map stats: %u segments at L1 with %u hits, %u candidates, %u groups, %u begins past the bound, "
                         "%u rounds, %u stretch entries, %u windows evaluated, %u fine passes, %u cooperative, %u begins in rounds, "
-                        "%u begins finished, %u rounds without items, %u second passes\n",
-                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13]);
+                        "%u begins finished, %u rounds without items, %u second passes, %u states evaluated after the optimum\n",
+                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14]);
       }
 #endif
     }
