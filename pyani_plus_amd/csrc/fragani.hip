@@ -1309,12 +1309,9 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       }
     }
     if (b_lo >= m1) return;
-    // where the slide ends: the window's end may not reach `last_end`
-    const uint32_t last_end = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, ce + frag_len);
-    if (last_end <= b_lo) return;
-    const uint32_t z = mini_wpos[last_end - 1];
-    // window ids of the first 512 begins in one batch of loads: they say where the range ends and where the first seed
-    // hit sits (the groups re-read their own 64 window ids later: they are in L2 by then, and eight registers are free)
+    // window ids of the first 512 begins in one batch of loads: they say where the slide ends, where the range of begins
+    // ends and where the first seed hit sits (the groups re-read their own 64 window ids later: they are in L2 by then,
+    // and eight registers are free)
     constexpr int kStartBatch = 8;
     uint32_t b_hi = 0xffffffffu, at = 0xffffffffu, i_max;
     {
@@ -1324,8 +1321,26 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         const uint32_t t = b_lo + (uint32_t)q * 64u + lane;
         wpv[q] = t < m1 ? mini_wpos[t] : 0xffffffffu;
       }
+      // where the slide ends: the window's end may not reach the first minimizer at or past rangeEnd + fragLen (or the
+      // contig's end); z = the window id of the minimizer before that one -- the largest of the batch below the limit when
+      // the batch reaches the limit (it nearly always does: a candidate range spans at most two fragment lengths)
+      const uint32_t limit = ce + frag_len;
+      uint32_t z = 0;
+      bool reached = false;
+#pragma unroll
+      for (int q = 0; q < kStartBatch; ++q) {
+        z = wpv[q] < limit ? max(z, wpv[q]) : z;
+        reached = reached || wpv[q] >= limit;
+      }
       const uint32_t wp_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)wpv[0]);  // window id of the first begin
-      if (z < wp_lo + count_windows) return;  // the first window's end is already at `last_end`: nothing is evaluated
+      if (wp_lo >= limit) return;  // no minimizer between the range's start and the limit
+      if (__any(reached)) {
+        z = pa_dev::wave_max_dpp(z);
+      } else {
+        const uint32_t last_end = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, limit);
+        z = mini_wpos[last_end - 1];
+      }
+      if (z < wp_lo + count_windows) return;  // the first window's end is already at the limit: nothing is evaluated
       i_max = z - count_windows;
       // the first begin past the slide's last position and the first one at the first seed hit: every lane the first of
       // its own eight, then the minimum over the wave (the window ids ascend with the begin index)
@@ -1353,7 +1368,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
     // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, i_max + count_windows)
     uint32_t h_lo, h_hi;
-    hit_range(c, cs, z, h_lo, h_hi);
+    hit_range(c, cs, i_max + count_windows, h_lo, h_hi);
     const uint32_t h_steps = 32u - (uint32_t)__builtin_clz(h_hi - h_lo + 1u);  // 2^steps > the number of hits: enough halvings
     PA_CUT(3);  // candidate set-up
     const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
@@ -1560,6 +1575,16 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           const uint32_t incl = pa_dev::wave_incl_scan_dpp(len), off = incl - len;
           const uint32_t n_items = min(128u, (uint32_t)__builtin_amdgcn_readlane((int)incl, 63));
           taken = off < 128u ? min(len, 128u - off) : 0u;
+          // the begins: where their next state ends (past the states after the run that are not evaluated), and whether
+          // the last state is behind them -- settled here, so that none of this is alive across the evaluation
+          {
+            uint32_t x_next = xs0;
+            if (cnt) {
+              x_next = taken == len ? xs0 + min(top - xs0, 15u) + 1u : xa + taken;
+              e_next = base + x_next;
+            }
+            complete = lane_on && hi_known && x_next > xe_hi;
+          }
           PA_CUT(5);  // stretch loads and window ends
           PA_STAT(6, n_rank);                           // stretch entries ranked
           PA_STAT(7, n_items);                          // windows evaluated in the round
@@ -1624,14 +1649,14 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             for (uint32_t i = lane; i < n_coarse * kRow / 4u; i += 64) t4[i] = make_uint4(0u, 0u, 0u, 0u);  // kRow is a multiple of 4
           }
           uint16_t *prev16 = sh.ref_w;  // [kRefCap] the window ends are known: the array now takes the duplicate links
-          uint32_t dup_q = 0, col[kPer];  // col: word of the entry's bit inside a row (the matching half comes second)
+          uint32_t dup_q = 0;
+          // word of an entry's bit inside a row (the matching half comes second)
+          auto col_of = [&](int q) -> uint32_t { return 2u * (uint32_t)q + (lane >> 5) + (((match_q >> q) & 1u) ? kW : 0u); };
 #pragma unroll
           for (int q = 0; q < kPer; ++q) {
             const uint32_t x = (uint32_t)q * 64u + lane;
             const uint32_t r = rank[q];
             const bool valid = (x < n_rank) & (r < s);  // inside the used part and below some hash of the fragment: in the rows from r on
-            const bool is_match = (match_q >> q) & 1u;
-            col[q] = 2u * (uint32_t)q + (lane >> 5) + (is_match ? kW : 0u);
             // the same hash earlier in the stretch (position + 1): a window keeps this occurrence only if it starts after that one
             const uint32_t p1 = (x < n_rank && pp[q] >= (int32_t)base) ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
             prev16[x] = (uint16_t)p1;
@@ -1643,7 +1668,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
 #pragma unroll
           for (int q = 0; q < kPer; ++q) {  // no branch: entries that are in no row add nothing to a word of the (not yet filled) fine rows
             const bool valid = rank[q] != 0xffffffffu;
-            atomicOr(valid ? &bc[(rank[q] >> kCoarseShift) * kRow + col[q]] : &bf[lane], valid ? 1u << (lane & 31u) : 0u);
+            atomicOr(valid ? &bc[(rank[q] >> kCoarseShift) * kRow + col_of(q)] : &bf[lane], valid ? 1u << (lane & 31u) : 0u);
           }
           __syncthreads();
           // rows become prefixes: row g |= rows below it.  Lane = (pair of columns, run of rows); the runs of one column
@@ -1671,7 +1696,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           };
           prefix_or_rows(bc, n_coarse);
           PA_CUT(7);  // coarse table
-            for (uint32_t pass = 0; pass * 64u < n_items; ++pass) {
+            for (uint32_t pass = 0; pass * 64u < n_items && !(pass && cut == 21); ++pass) {
               if (pass) item_setup(pass, false);
               // the lane's window as a mask over the stretch positions
               uint32_t wm[kW];
@@ -1730,7 +1755,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
               if (bar_now < floor_bar) bar_now = floor_bar;
               const bool in_reach = (int32_t)count_in(bc + g_lo * kRow + kW) >= bar_now;
               counted = it_on && in_reach;
-              bool unresolved = counted;
+              bool unresolved = counted && cut != 22;
               while (__any(unresolved)) {
                 PA_STAT(8, 1);  // fine passes
                 const uint32_t g_cur = pa_dev::wave_min_dpp(unresolved ? g_lo : 0xffffffffu);
@@ -1747,7 +1772,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
                 for (int q = 0; q < kPer; ++q) {
                   const uint32_t t = rank[q] - band0;  // wraps to something huge below the band
                   const bool valid = (rank[q] != 0xffffffffu) & (t < kFineRows - 1u);
-                  atomicOr(valid ? &bf[(t + 1u) * kRow + col[q]] : &bc[lane], valid ? 1u << (lane & 31u) : 0u);
+                  atomicOr(valid ? &bf[(t + 1u) * kRow + col_of(q)] : &bc[lane], valid ? 1u << (lane & 31u) : 0u);
                 }
                 __syncthreads();
                 prefix_or_rows(bf, kFineRows);
@@ -1770,16 +1795,6 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
               fold_items(base + xs, base + xw);
             }
           }
-          // the begins: where their next state ends (past the states after the run that are not evaluated), and whether
-          // the last state is behind them
-          {
-            uint32_t x_next = xs0;
-            if (cnt) {
-              x_next = taken == len ? xs0 + min(top - xs0, 15u) + 1u : xa + taken;
-              e_next = base + x_next;
-            }
-            complete = lane_on && hi_known && x_next > xe_hi;
-          }
         }
         PA_STAT(10, __popcll(__ballot(lane_on)));   // begins taking part in the rounds
         PA_STAT(11, __popcll(__ballot(complete)));  // begins finished by the rounds
@@ -1796,7 +1811,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     // The states right after the last evaluated state with the most shared minimizers (same begin, one more minimizer taken
     // in each) share as many or fewer: while they share as many, the optimum extends over them.  Only where the position
     // can matter: the candidate is reported, and wins or ties with the best so far.
-    if (c_best >= floor_bar && c_best >= best_shared) {
+    if (c_best >= floor_bar && c_best >= best_shared && cut != 20) {  // (cut 20..23: timing experiments, results wrong)
       const uint32_t wp_after = c_last_b + 1u < m1 ? mini_wpos[c_last_b + 1u] : 0xffffffffu;
       const uint32_t we = min(wp_after - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
       if (c_last + count_windows < we) {  // the state is not the begin's last
