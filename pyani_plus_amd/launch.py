@@ -12,11 +12,14 @@ on the MI355X pool a process that has touched the GPU must not fork or exec work
 
 from __future__ import annotations
 
+import contextlib
 import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -27,11 +30,49 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def visible_devices() -> int:
-    """HIP devices a child would see, counted without initialising the GPU in this process."""
-    import torch
+_DEVICE_COUNT: int | None = None
 
-    return int(torch.cuda.device_count())
+
+def visible_devices() -> int:
+    """HIP devices a worker would see.  Counted in a short-lived child process (once; the answer is kept): asking the
+    runtime here -- ``torch.cuda.device_count()`` falls back to ``hipGetDeviceCount`` -- would initialise the GPU in the
+    very process that goes on to start the workers, which this module promises not to do."""
+    global _DEVICE_COUNT
+    if _DEVICE_COUNT is None:
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                                 timeout=300, check=False)  # fmt: skip
+            _DEVICE_COUNT = int(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else 0
+        except (OSError, ValueError, subprocess.TimeoutExpired):
+            _DEVICE_COUNT = 0
+    return _DEVICE_COUNT
+
+
+@contextlib.contextmanager
+def signals_as_interrupt():
+    """SIGINT and SIGTERM (``scancel``, ``kill``) both raise ``KeyboardInterrupt`` while the block runs, as the reference's
+    worker arranges for itself (pyani_plus/private_cli.py:816-823): the code that flushes partial results on Ctrl-C then
+    also runs when a scheduler ends the job.  Main thread only (elsewhere the block just runs)."""
+    if threading.current_thread() is not threading.main_thread():
+        yield
+        return
+    previous = {sig: signal.signal(sig, signal.default_int_handler) for sig in (signal.SIGINT, signal.SIGTERM)}
+    try:
+        yield
+    finally:
+        for sig, handler in previous.items():
+            signal.signal(sig, handler)
+
+
+def _die_with_parent() -> None:  # runs in the child between fork and exec
+    """The worker gets SIGTERM when the process that started it goes away, however that happens (``kill -9`` included):
+    no rank is left computing on a GPU for a parent that no longer exists."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
+    except (OSError, AttributeError):
+        pass
 
 
 def choose_backend(world: int) -> str:
@@ -44,54 +85,104 @@ def choose_backend(world: int) -> str:
     return "nccl" if visible_devices() >= world else "gloo"
 
 
-def launch_workers(world: int, spec: dict, work_dir: Path, *, timeout: float | None = None, poll: float = 0.2) -> list[dict]:
+def launch_workers(world: int, spec: dict, work_dir: Path, *, timeout: float | None = None, poll: float = 0.2, grace: float = 60.0) -> list[dict]:
     """Run ``world`` workers on ``spec`` (written to ``work_dir/spec.json``); returns each rank's result dict.
 
-    A worker reports through ``work_dir/result_rank<r>.json`` (``{"ok": true, ...}`` or ``{"ok": false, "error": msg}``).
-    When one fails or dies the others are ended (by handle) -- they would otherwise wait in a collective for ever --
-    and ``RuntimeError`` carries the first failure's message."""
+    A worker reports through ``work_dir/result_rank<r>.json`` (``{"ok": true, ...}`` or ``{"ok": false, "error": msg}``);
+    its process id is in ``work_dir/pids.json``.  The workers are fresh children in sessions of their own (a Ctrl-C at
+    the terminal reaches this process only), and none outlives this call, whatever way it ends:
+
+    * a rank fails or dies: the others are ended (by handle) -- they would otherwise wait in a collective for ever --
+      and ``WorkerFailure`` carries the first failure's message;
+    * this process is interrupted (``KeyboardInterrupt``; with ``signals_as_interrupt`` also SIGTERM): the interrupt is
+      passed on to the ranks once, they flush what they have and report ``"interrupted": true`` (the reference's worker:
+      pyani_plus/private_cli.py:1889-1894), and after ``grace`` seconds whoever is still there is ended; the results
+      are returned, not raised -- the caller records the partial run;
+    * a rank reports an interrupt of its own (a signal sent to that rank): ranks that exchange data with it
+      (``spec["task"] == "sourmash"``) cannot finish and are ended, independent ranks run to their end;
+    * any other exception here: every child is ended on the way out."""
     work_dir = Path(work_dir)
     work_dir.mkdir(parents=True, exist_ok=True)
     spec = dict(spec)
     spec.setdefault("backend", choose_backend(world))
     spec_file = work_dir / "spec.json"
     spec_file.write_text(json.dumps(spec))
+    for stale in work_dir.glob("result_rank*.json"):  # a resumed run reuses the directory
+        stale.unlink()
     port = free_port()
-    procs = []
-    for rank in range(world):
-        env = dict(os.environ)
-        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))  # fmt: skip
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
-        root = str(Path(__file__).resolve().parent.parent)
-        env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
-        log = (work_dir / f"worker_rank{rank}.log").open("w")
-        procs.append((subprocess.Popen([sys.executable, "-m", "pyani_plus_amd.worker", str(spec_file)], env=env, stdout=log,
-                                       stderr=subprocess.STDOUT), log))  # fmt: skip
-    t0 = time.monotonic()
-    failed = None
-    while True:
-        codes = [p.poll() for p, _ in procs]
-        if all(c is not None for c in codes):
-            break
-        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad and failed is None:
-            failed = bad[0]
-            deadline = time.monotonic() + 5.0  # let the others report the failure themselves if they can
-        if failed is not None and time.monotonic() > deadline or (timeout is not None and time.monotonic() - t0 > timeout):
-            for p, _ in procs:
-                if p.poll() is None:
-                    p.kill()
-        time.sleep(poll)
-    for _, log in procs:
-        log.close()
+    procs: list[tuple[subprocess.Popen, object]] = []
+    exchanging = spec.get("task") == "sourmash"  # ranks that take part in a collective
+    interrupted_here = False
+    try:
+        for rank in range(world):
+            env = dict(os.environ)
+            env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))  # fmt: skip
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+            root = str(Path(__file__).resolve().parent.parent)
+            env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
+            log = (work_dir / f"worker_rank{rank}.log").open("w")
+            procs.append((subprocess.Popen([sys.executable, "-m", "pyani_plus_amd.worker", str(spec_file)], env=env, stdout=log,
+                                           stderr=subprocess.STDOUT, start_new_session=True, preexec_fn=_die_with_parent), log))  # fmt: skip
+        (work_dir / "pids.json").write_text(json.dumps([p.pid for p, _ in procs]))
+        t0 = time.monotonic()
+        deadline = None  # when the ranks still running are ended
+
+        def rank_interrupted(rank: int) -> bool:
+            rfile = work_dir / f"result_rank{rank}.json"
+            try:
+                return bool(json.loads(rfile.read_text()).get("interrupted")) if rfile.is_file() else False
+            except ValueError:
+                return False
+
+        while True:
+            try:
+                codes = [p.poll() for p, _ in procs]
+                if all(c is not None for c in codes):
+                    break
+                now = time.monotonic()
+                if deadline is None:
+                    if any(c not in (None, 0) for c in codes):
+                        deadline = now + 5.0  # let the others report the failure themselves if they can
+                    elif exchanging and any(c == 0 and rank_interrupted(r) for r, c in enumerate(codes)):
+                        deadline = now + 5.0  # its peers wait for it in a collective
+                if (deadline is not None and now > deadline) or (timeout is not None and now - t0 > timeout):
+                    for p, _ in procs:
+                        if p.poll() is None:
+                            p.kill()
+                time.sleep(poll)
+            except KeyboardInterrupt:
+                if interrupted_here:
+                    raise  # a second interrupt: give up at once (the children are ended on the way out)
+                interrupted_here = True
+                for p, _ in procs:
+                    if p.poll() is None:
+                        p.send_signal(signal.SIGINT)
+                deadline = time.monotonic() + grace
+    finally:
+        for p, log in procs:
+            if p.poll() is None:
+                p.kill()
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:  # pragma: no cover - a process that does not die on SIGKILL
+                pass
+            log.close()
     results = []
     for rank, (p, _) in enumerate(procs):
         rfile = work_dir / f"result_rank{rank}.json"
-        res = json.loads(rfile.read_text()) if rfile.is_file() else {"ok": False, "error": None}
+        try:
+            res = json.loads(rfile.read_text()) if rfile.is_file() else {"ok": False, "error": None}
+        except ValueError:
+            res = {"ok": False, "error": None}
         res["returncode"] = p.returncode
         results.append(res)
-    errors = [r for r in results if not r.get("ok") or r["returncode"] != 0]
+    any_interrupt = interrupted_here or any(r.get("interrupted") for r in results)
+    if any_interrupt:
+        for r in results:  # a rank ended while it waited for an interrupted peer (or for too long after the interrupt)
+            if not r.get("ok") and not r.get("error"):
+                r.update(ok=True, interrupted=True, ended_by_parent=True)
+    errors = [r for r in results if not r.get("ok") or (r["returncode"] != 0 and not r.get("ended_by_parent"))]
     if errors:
         # a rank's own message first; a rank that was killed while waiting for a failed peer has none
         told = [r["error"] for r in errors if r.get("error")]

@@ -208,8 +208,14 @@ def compute_fastani_hip(  # noqa: PLR0913
         n = arena.n_genomes
         out = (np.zeros(n, dtype=np.uint32), np.zeros((n, n), dtype=np.uint32), np.zeros((n, n), dtype=np.float64))
         query_idx = [index[q] for q in queries]
-        # batches of consecutive genome indices that hold at most `query_batch` queries each
-        batches: list[list[int]] = [query_idx[i : i + max(1, int(query_batch))] for i in range(0, len(query_idx), max(1, int(query_batch)))]
+        # batches of CONSECUTIVE genome indices, at most `query_batch` queries each: a batch is mapped as a range of query
+        # genomes, so it ends where the queries leave a gap (a subject that is not among the queries sits between them)
+        batches: list[list[int]] = []
+        for i in query_idx:
+            if batches and batches[-1][-1] + 1 == i and len(batches[-1]) < max(1, int(query_batch)):
+                batches[-1].append(i)
+            else:
+                batches.append([i])
         for b, batch in enumerate(batches):
             total, matched, ident_sum = engine.fragani(
                 dev, arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize, ref_range=ref_range,

@@ -109,8 +109,9 @@ def resolve_device(spread_key: int | None = None) -> int:
     * unset -- ``LOCAL_RANK`` (ranks started by ``pyani_plus_amd.launch`` or ``torch.distributed.run``) modulo the
       number of devices, else device 0.
 
-    Counting devices does not initialise the GPU; an index beyond the last device is an error of the caller's
-    environment and is reported by ``HipEngine``."""
+    Meant for the process that goes on to compute (counting the devices may bring up the HIP runtime: a parent that only
+    starts workers counts them in a child process, ``launch.visible_devices``); an index beyond the last device is an
+    error of the caller's environment and is reported by ``HipEngine``."""
     import os
 
     want = os.environ.get(DEVICE_ENV, "").strip().lower()

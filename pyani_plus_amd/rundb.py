@@ -550,11 +550,13 @@ def _file_cost(path: Path) -> int:
 
 
 def _sharded_sourmash_tiles(logger, fasta: Path, fasta_names: list[Path], config: Configuration, cache_dir: Path, tmp_dir: Path,
-                            gpus: int, engine_factory: str | None):
+                            gpus: int, engine_factory: str | None, columns: list[str] | None = None):
     """The multi-GPU form of "sketch everything, compare everything" (DESIGN.md section 6): ``gpus`` fresh worker
     processes (``launch.launch_workers`` -- started before this process has touched a GPU), each sketching a
     length-balanced share of the files, ONE all-gather of the sketches, each rank evaluating all queries against its
-    own genomes as subject columns.  Returns (metadata per file in file order, the ranks' tile files)."""
+    own genomes as subject columns (``columns``, checksums: only those of them -- what a resumed run still needs).
+    Returns (metadata per file in file order, the ranks' tile files, the ranks' reports); None when the ranks were
+    interrupted (their columns need every rank's sketches: there is nothing partial to keep)."""
     from . import launch
     from .distributed import shard_bounds_by_cost
 
@@ -566,10 +568,14 @@ def _sharded_sourmash_tiles(logger, fasta: Path, fasta_names: list[Path], config
     }  # fmt: skip
     if engine_factory:
         spec["engine_factory"] = engine_factory
+    if columns is not None:
+        spec["columns"] = list(columns)
     try:
         results = launch.launch_workers(gpus, spec, work_dir)
     except launch.WorkerFailure as err:
         sourmash_hip.log_sys_exit(logger, str(err))
+    if any(r.get("interrupted") for r in results):
+        return None
     meta = [m for r in results for m in r["meta"]]
     assert [m["path"] for m in meta] == [str(p) for p in fasta_names]
     return meta, [Path(r["tile"]) for r in results if r.get("tile")], results
@@ -632,7 +638,10 @@ def run_sourmash_hip(  # noqa: PLR0913
     # PYANI_HIP_FORCE_WORKERS=1 sends even one GPU's worth of work through a worker process (RCCL with world size 1):
     # the multi-GPU code path on a single-GPU box
     if gpus > 1 or os.environ.get("PYANI_HIP_FORCE_WORKERS") == "1":
-        meta, tile_files, _results = _sharded_sourmash_tiles(logger, fasta, fasta_names, config, cache_dir, tmp_dir, gpus, engine_factory)
+        sharded = _sharded_sourmash_tiles(logger, fasta, fasta_names, config, cache_dir, tmp_dir, gpus, engine_factory)
+        if sharded is None:  # the genomes' checksums come from the ranks: no run has been recorded yet
+            sourmash_hip.log_sys_exit(logger, "Interrupted before the sketches were exchanged; no run was recorded")
+        meta, tile_files, _results = sharded
         for filename, m in zip(fasta_names, meta):
             if m["md5"] in seen:
                 _duplicate_md5_exit(logger, m["md5"], [seen[m["md5"]], filename])
@@ -744,6 +753,8 @@ def _compute_missing(logger, conn, session, run: Run, cache_dir: Path, tmp_dir: 
         mark("pairs_and_column_file")
         import_json_comparisons(logger, conn, json_file)
         mark("import_column_file")
+        if run.status == "Worker interrupted":
+            break
     return None
 
 
@@ -751,6 +762,13 @@ def _finish_run(logger, conn, session, run: Run, direct, mark) -> Run:
     """Completion test, matrix cache, status "Done" (pyani_plus/public_cli.py:302-324)."""
     n = len(run.fasta_hashes)
     done = count_run_comparisons(conn, run) if direct is None else direct[0]
+    if done != n * n and run.status == "Worker interrupted":
+        # the reference's worker ends with return code 0 after an interrupt, its partial results recorded and the run
+        # marked (pyani_plus/private_cli.py:1889-1902); ``resume`` completes such a run
+        logger.warning("Interrupted: %d of %d^2=%d %s comparisons recorded; the run can be resumed", done, n, n * n, run.configuration.method)
+        session.commit()
+        conn.close()
+        return run
     if done != n * n:
         sourmash_hip.log_sys_exit(logger, f"Only have {done} of {n}^2={n * n} {run.configuration.method} comparisons needed")
     if direct is None or direct[5] is False:  # JSON route, or a resumed run that only holds some columns in memory
@@ -823,6 +841,29 @@ def resume(database: Path | str, *, run_id: int | None = None, cache: Path | Non
         return _finish_run(logger, conn, session, run, direct, mark)
     cache_dir = Path(tempfile.mkdtemp(prefix="pyani_hip_cache_")) if cache is None else Path(cache)
     cache_dir.mkdir(parents=True, exist_ok=True)
+    gpus = max(1, min(int(gpus), n))
+    if gpus > 1 and count_run_comparisons(conn, run) != n * n:
+        # the same executor as the run itself (pyani_plus/public_cli.py:243-261 re-runs the missing columns through the
+        # workflow they came from): worker processes, one all-gather, and each rank's tile cut down to the missing columns
+        columns = _incomplete_columns(conn, run)
+        logger.info("%d subject columns to compute on %d worker processes", len(columns), gpus)
+        run.status = "Running"
+        session.commit()
+        names = [fasta / a.fasta_filename for a in sorted(run.fasta_hashes, key=lambda a: a.fasta_filename)]
+        sharded = _sharded_sourmash_tiles(logger, fasta, names, config, cache_dir, tmp_dir, gpus, engine_factory, columns=columns)
+        if sharded is None:
+            run.status = "Worker interrupted"
+            return _finish_run(logger, conn, session, run, None, mark)
+        meta, tile_files, _results = sharded
+        recorded = {a.fasta_filename: a.genome_hash for a in run.fasta_hashes}
+        for m in meta:  # the files must still be the ones the run was made from
+            if recorded[Path(m["path"]).name] != m["md5"]:
+                sourmash_hip.log_sys_exit(
+                    logger, f"run-id {run_id} used {m['path']} with MD5 {recorded[Path(m['path']).name]} but the file now has MD5 {m['md5']}"
+                )
+        for tile_file in tile_files:
+            import_tile(logger, conn, run, tile_file)
+        return _finish_run(logger, conn, session, run, None, mark)
     direct = _compute_missing(logger, conn, session, run, cache_dir, tmp_dir, engine, ingest, mark)
     return _finish_run(logger, conn, session, run, direct, mark)
 
@@ -926,7 +967,7 @@ def export_run(database: Path | str, outdir: Path, *, run_id: int | None = None,
 
 # ------------------------------------------------------------------ the fragment-ANI run (pyani_plus/public_cli.py:502-554)
 def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, engine, gpus: int, engine_factory: str | None,
-                             ingest: str = "json", mark=None):
+                             ingest: str = "json", mark=None, query_batch: int | None = None):
     """The incomplete subject columns of a ``fastANI-hip`` run: in this process (one call per run of missing columns; a
     new run is one call for all of them), or as reference ranges of ``pa_fragani`` spread over ``gpus`` worker
     processes -- the reference's own one-process-per-column layout (pyani_plus/public_cli.py:236-261) with a GPU per
@@ -986,20 +1027,29 @@ def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, eng
         }  # fmt: skip
         if engine_factory:
             spec["engine_factory"] = engine_factory
+        if query_batch:
+            spec["query_batch"] = int(query_batch)
         try:
             results = launch.launch_workers(gpus, spec, work_dir)
         except launch.WorkerFailure as err:
             sourmash_hip.log_sys_exit(logger, str(err))
         mark("workers")
-        for r in results:
+        for rank, r in enumerate(results):
             if r.get("interrupted"):
                 run.status = "Worker interrupted"
             if direct:
-                for tile in r.get("tiles") or []:
+                for tile in r.get("tiles") or sorted(str(t) for t in work_dir.glob(f"{fastani_hip.METHOD}.rank_{rank}.tile_*.npz")):
                     _cfg, queries, subjects, ident, cov, null, aln, sim = wire.load_tile(Path(tile), with_proxies=True)
                     blocks.append((queries, subjects, ident, aln, sim, cov, null))
-            elif r.get("json"):
-                import_json_comparisons(logger, conn, Path(r["json"]))
+            else:
+                # the rank's column file: a complete JSON document after every finished query batch, also when the rank
+                # was interrupted (or ended by this process while it waited) and reported nothing about it
+                c0, c1 = column_ranges[rank]
+                json_file = Path(r["json"]) if r.get("json") else work_dir / f"{fastani_hip.METHOD}.run_{run.run_id}.columns_{c0 + 1}_{c1}.json"
+                if c0 != c1 and json_file.is_file():
+                    import_json_comparisons(logger, conn, json_file)
+        if run.status == "Worker interrupted":
+            session.commit()
     else:
         if engine is None and engine_factory:  # the workers' engine, when their work has shrunk to one process's worth
             import importlib
@@ -1011,14 +1061,21 @@ def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, eng
             status = fastani_hip.compute_fastani_hip(
                 logger, tmp_dir, session, run, json_file, fasta_dir, hash_to_filename, {v: k for k, v in hash_to_filename.items()},
                 query_hashes, "", engine=engine, subject_range=(a, b), on_block=(lambda *blk: blocks.append(blk)) if direct else None,
+                **({"query_batch": int(query_batch)} if query_batch else {}),
             )  # fmt: skip
             if status:
                 sourmash_hip.log_sys_exit(logger, f"Column worker failed with return code {status}")
             if not direct:
                 import_json_comparisons(logger, conn, json_file)
+            if run.status == "Worker interrupted":
+                break
         mark("worker")
     if not direct:
         mark("import_column_files")
+        return None
+    if run.status == "Worker interrupted":  # whatever blocks arrived go in as they are; the run stays partial
+        for queries, subjects, ident, aln, sim, cov, null in blocks:
+            ingest_matrices(conn, run, queries, subjects, ident, cov, null, aln_length=aln, sim_errors=sim)
         return None
     whole = done == 0 and sum(len(b[0]) * len(b[1]) for b in blocks) == n * n
     if whole:  # a new run: one square, rows in index order, matrix cache from memory
@@ -1053,6 +1110,7 @@ def run_fastani_hip(  # noqa: PLR0913
     engine_factory: str | None = None,
     timings: dict | None = None,
     ingest: str = "json",
+    query_batch: int | None = None,
 ) -> Run:
     """FASTA directory -> database with all N^2 fragment-ANI comparisons and cached matrices: counterpart of
     ``pyani-plus fastani <fasta> -d <db> --create-db`` (pyani_plus/public_cli.py:502-554) with one in-process call --
@@ -1092,5 +1150,77 @@ def run_fastani_hip(  # noqa: PLR0913
     tmp_dir.mkdir(parents=True, exist_ok=True)
     if ingest not in {"json", "direct"}:
         sourmash_hip.log_sys_exit(logger, f"ingest must be 'json' or 'direct', not {ingest!r}")
-    direct = _compute_missing_fastani(logger, conn, session, run, tmp_dir, engine, gpus, engine_factory, ingest, mark)
+    direct = _compute_missing_fastani(logger, conn, session, run, tmp_dir, engine, gpus, engine_factory, ingest, mark, query_batch)
     return _finish_run(logger, conn, session, run, direct, mark)
+
+
+# ------------------------------------------------------------------ the driver as a process
+def main(argv: list[str] | None = None) -> int:
+    """``python -m pyani_plus_amd.rundb {sourmash,fastani,resume,export-run} ...``: the run driver as a process of its own,
+    with SIGINT and SIGTERM arriving as ``KeyboardInterrupt`` the way the reference's worker command arranges it
+    (pyani_plus/private_cli.py:816-823), so that ``scancel`` / ``kill`` leave the finished batches recorded and the run
+    marked "Worker interrupted" exactly as Ctrl-C does.  Only what the drivers above take as arguments; the reference's
+    Typer front end is out of scope."""
+    import argparse
+
+    from . import launch
+
+    parser = argparse.ArgumentParser(prog="python -m pyani_plus_amd.rundb", description=main.__doc__)
+    sub = parser.add_subparsers(dest="command", required=True)
+
+    def common(p, *, run_options: bool) -> None:
+        p.add_argument("--database", "-d", required=True, type=Path)
+        p.add_argument("--temp", type=Path, default=None)
+        p.add_argument("--gpus", type=int, default=1)
+        p.add_argument("--ingest", choices=("json", "direct"), default="json")
+        p.add_argument("--engine-factory", default=None, help="module:callable that makes the engine (tests)")
+        p.add_argument("--verbose", "-v", action="store_true")
+        if run_options:
+            p.add_argument("fasta", type=Path)
+            p.add_argument("--name", default=None)
+
+    p_s = sub.add_parser("sourmash", help="FASTA directory -> all N^2 sourmash-hip comparisons")
+    common(p_s, run_options=True)
+    p_s.add_argument("--cache", type=Path, default=None)
+    p_s.add_argument("--kmersize", type=int, default=sourmash_hip.KMER_SIZE)
+    p_s.add_argument("--scaled", type=int, default=sourmash_hip.SCALED)
+    p_f = sub.add_parser("fastani", help="FASTA directory -> all N^2 fastANI-hip comparisons")
+    common(p_f, run_options=True)
+    p_f.add_argument("--kmersize", type=int, default=None)
+    p_f.add_argument("--fragsize", type=int, default=None)
+    p_f.add_argument("--minmatch", type=float, default=None)
+    p_f.add_argument("--query-batch", type=int, default=None)
+    p_r = sub.add_parser("resume", help="complete a partial run")
+    common(p_r, run_options=False)
+    p_r.add_argument("--run-id", type=int, default=None)
+    p_r.add_argument("--cache", type=Path, default=None)
+    p_e = sub.add_parser("export-run", help="long form and matrices of a run as TSV files")
+    p_e.add_argument("--database", "-d", required=True, type=Path)
+    p_e.add_argument("--outdir", "-o", required=True, type=Path)
+    p_e.add_argument("--run-id", type=int, default=None)
+    p_e.add_argument("--label", choices=("md5", "filename", "stem"), default="stem")
+    p_e.add_argument("--verbose", "-v", action="store_true")
+    args = parser.parse_args(argv)
+    logging.basicConfig(level=logging.DEBUG if args.verbose else logging.INFO, format="%(levelname)s %(message)s")
+    logger = logging.getLogger("pyani_plus_amd")
+    with launch.signals_as_interrupt():
+        if args.command == "sourmash":
+            run = run_sourmash_hip(args.fasta, args.database, cache=args.cache, name=args.name, kmersize=args.kmersize, scaled=args.scaled,
+                                   temp=args.temp, logger=logger, ingest=args.ingest, gpus=args.gpus, engine_factory=args.engine_factory)
+        elif args.command == "fastani":
+            run = run_fastani_hip(args.fasta, args.database, name=args.name, kmersize=args.kmersize, fragsize=args.fragsize,
+                                  minmatch=args.minmatch, temp=args.temp, logger=logger, ingest=args.ingest, gpus=args.gpus,
+                                  engine_factory=args.engine_factory, query_batch=args.query_batch)
+        elif args.command == "resume":
+            run = resume(args.database, run_id=args.run_id, cache=args.cache, temp=args.temp, logger=logger, ingest=args.ingest,
+                         gpus=args.gpus, engine_factory=args.engine_factory)
+        else:
+            for path in export_run(args.database, args.outdir, run_id=args.run_id, label=args.label, logger=logger):
+                print(path)
+            return 0
+    logger.info("run-id %d: %s", run.run_id, run.status)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -12,7 +12,10 @@ worker per GPU instead of one per subject column:
   of subject columns and writes the reference's JSON column file for them; no collective at all.
 
 The rank reports through ``result_rank<r>.json`` next to the spec; a failure carries the message the reference
-would have ended the worker with (``log_sys_exit``).
+would have ended the worker with (``log_sys_exit``).  SIGINT and SIGTERM both arrive as ``KeyboardInterrupt``
+(pyani_plus/private_cli.py:816-823): a fragment-ANI rank keeps the query batches it has finished in its column file and
+reports ``"interrupted": true`` with exit code 0 (private_cli.py:1889-1902); a sketch rank has nothing partial to keep
+(its columns need every rank's sketches) and reports the interrupt.
 """
 
 from __future__ import annotations
@@ -105,8 +108,15 @@ def sourmash_rank(spec: dict, rank: int, world: int, dist, torch, logger: loggin
         c = counts.cpu().numpy().view(np.uint32)
         ident, cov, null = ani_host(c, sizes, sizes[g0:g1], kmersize)
         sourmash_hip.check_self_comparisons(order, order[g0:g1], ident, null)
-        tile_file = Path(spec["work_dir"]) / f"{sourmash_hip.METHOD}.rank_{rank}.tile.npz"
-        wire.save_tile(tile_file, config, order, order[g0:g1], ident, cov, null)
+        subjects = order[g0:g1]
+        if spec.get("columns") is not None:  # a resumed run: only the subject columns it still needs leave the rank
+            wanted = set(spec["columns"])
+            keep = [i for i, h in enumerate(subjects) if h in wanted]
+            subjects = [subjects[i] for i in keep]
+            ident, cov, null = ident[:, keep], cov[:, keep], null[:, keep]
+        if subjects:
+            tile_file = Path(spec["work_dir"]) / f"{sourmash_hip.METHOD}.rank_{rank}.tile.npz"
+            wire.save_tile(tile_file, config, order, subjects, np.ascontiguousarray(ident), np.ascontiguousarray(cov), np.ascontiguousarray(null))
     return {"ok": True, "meta": meta, "tile": str(tile_file) if tile_file else None, "device": str(getattr(engine, "device", "test engine")),
             "backend": backend}  # fmt: skip
 
@@ -137,7 +147,7 @@ def fastani_rank(spec: dict, rank: int, world: int, dist, torch, logger: logging
     status = fastani_hip.compute_fastani_hip(
         logger, Path(spec["work_dir"]), session, run, json_file, Path(spec["fasta_dir"]), hash_to_filename,
         {v: k for k, v in hash_to_filename.items()}, query_hashes, "", engine=engine, subject_range=(c0, c1),
-        on_block=keep_tile if spec.get("tiles") else None,
+        on_block=keep_tile if spec.get("tiles") else None, **({"query_batch": int(spec["query_batch"])} if spec.get("query_batch") else {}),
     )  # fmt: skip
     if status:
         return {"ok": False, "error": f"Column worker failed with return code {status}"}
@@ -149,6 +159,11 @@ TASKS = {"sourmash": sourmash_rank, "fastani": fastani_rank}
 
 
 def main(argv: list[str]) -> int:
+    import signal
+
+    # Ctrl-C and a scheduler's SIGTERM alike end the work through KeyboardInterrupt (pyani_plus/private_cli.py:816-823)
+    signal.signal(signal.SIGINT, signal.default_int_handler)
+    signal.signal(signal.SIGTERM, signal.default_int_handler)
     spec_file = Path(argv[1])
     spec = json.loads(spec_file.read_text())
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,6 +172,7 @@ def main(argv: list[str]) -> int:
     logger = logging.getLogger("pyani_plus_amd.worker")
     result: dict
     dist = None
+    needs_group = False
     try:
         import torch
         import torch.distributed as dist
@@ -179,16 +195,25 @@ def main(argv: list[str]) -> int:
                 if sys.exc_info()[0] is None:
                     dist.barrier()
                     dist.destroy_process_group()
+    except KeyboardInterrupt:  # outside the column worker's own handling: nothing partial to keep
+        logger.error("Interrupted")  # noqa: TRY400
+        result = {"ok": True, "interrupted": True}
     except SystemExit as err:  # log_sys_exit: the worker's own error message
         result = {"ok": False, "error": str(err.code) if err.code not in (None, 0) else "worker exited"}
     except Exception as err:  # noqa: BLE001
         traceback.print_exc()
         result = {"ok": False, "error": f"{type(err).__name__}: {err}"}
-    result_file.write_text(json.dumps(result))
+    signal.signal(signal.SIGINT, signal.SIG_IGN)  # the report is written whatever arrives now
+    signal.signal(signal.SIGTERM, signal.SIG_IGN)
+    tmp = result_file.with_suffix(".json.part")
+    tmp.write_text(json.dumps(result))
+    tmp.replace(result_file)  # the parent never reads half a report
     sys.stdout.flush()
     sys.stderr.flush()
     if not result.get("ok"):
         os._exit(1)  # peers may be blocked in a collective with this rank: leave without waiting for them
+    if result.get("interrupted") and needs_group:
+        os._exit(0)  # likewise: no barrier, no orderly shutdown of a process group whose peers are stuck
     return 0
 
 

@@ -110,3 +110,16 @@ class OracleEngine:
                     matched[q, r] = m
                     ident_sum[q, r] = ani * m
         return total, matched, ident_sum
+
+
+class SlowOracleEngine(OracleEngine):
+    """``OracleEngine`` whose fragment-ANI calls take at least ``PYANI_TEST_FRAGANI_SLEEP`` seconds each (default 1.5):
+    the interrupt tests need query batches that last long enough to be interrupted between them."""
+
+    def fragani(self, *args, **kwargs):
+        import os
+        import time
+
+        out = super().fragani(*args, **kwargs)
+        time.sleep(float(os.environ.get("PYANI_TEST_FRAGANI_SLEEP", "1.5")))
+        return out

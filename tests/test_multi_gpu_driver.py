@@ -175,6 +175,39 @@ def test_resume_completes_a_partial_run_without_recomputing_finished_columns(tmp
         rundb.resume(db, engine=OracleEngine())
 
 
+def test_resume_on_worker_processes_computes_the_missing_columns_only(tmp_path, monkeypatch):
+    """``resume(..., gpus=2)`` of a ``sourmash-hip`` run goes through the executor the run itself uses -- worker processes,
+    one all-gather -- and the ranks hand back the missing subject columns only (the reference re-runs the missing
+    columns through the workflow they came from, /root/reference/pyani_plus/public_cli.py:243-261)."""
+    monkeypatch.setenv("PYANI_HIP_DIST_BACKEND", "gloo")
+    lengths = [30_000, 4_000, 52_000, 21_000, 33_000, 9_000]
+    _write_genomes(tmp_path / "in", lengths)
+    db = tmp_path / "run.sqlite"
+    rundb.run_sourmash_hip(tmp_path / "in", db, cache=tmp_path / "cache", scaled=50, kmersize=21, engine=OracleEngine(), temp=tmp_path / "t")
+    full = _dump(db)
+    hashes = sorted(g[0] for g in full["genomes"])
+    missing = [hashes[0], hashes[2], hashes[5]]
+    conn = sqlite3.connect(db)
+    conn.execute("DELETE FROM comparisons WHERE subject_hash IN (?, ?, ?)", missing)
+    conn.execute("UPDATE runs SET status='Worker interrupted', df_identity=NULL, df_cov_query=NULL, df_aln_length=NULL, df_sim_errors=NULL, df_hadamard=NULL")
+    conn.commit()
+    conn.close()
+    run = rundb.resume(db, cache=tmp_path / "cache", temp=tmp_path / "t2", gpus=2, engine_factory=FACTORY)
+    assert run.status == "Done" and _dump(db) == full
+    # what left the ranks: the three missing columns and nothing else
+    from pyani_plus_amd import wire
+
+    columns = []
+    for tile in sorted((tmp_path / "t2" / "sourmash-hip.workers").glob("*.tile.npz")):
+        _cfg, queries, subjects, *_ = wire.load_tile(tile)
+        assert len(queries) == len(lengths)
+        columns += list(subjects)
+    assert sorted(columns) == sorted(missing)
+    # a complete run is left alone, with or without workers
+    assert rundb.resume(db, cache=tmp_path / "cache", temp=tmp_path / "t3", gpus=2, engine_factory=FACTORY).status == "Done"
+    assert not (tmp_path / "t3" / "sourmash-hip.workers").exists()
+
+
 def test_resume_of_a_partial_fastani_run(tmp_path):
     name = "viral_example"
     db = tmp_path / "f.sqlite"
