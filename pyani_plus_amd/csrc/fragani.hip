@@ -169,10 +169,15 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     uint32_t *__restrict__ out_wpos, uint32_t *__restrict__ out_contig, uint32_t n_tiles) {
   static_assert(K >= 8 && K <= 16, "both k-mer registers are 32-bit");
   constexpr int kWords = (K + 7) / 8;
-  __shared__ uint64_t s_lo[kWords][256];
-  __shared__ uint32_t s_hi[kWords][256];
+  // the first-multiply tables; once the hashes are there, the same memory holds the winnowing's suffix-minimum positions
+  constexpr int kTabBytes = kWords * 256 * 12 > kTile * 2 ? kWords * 256 * 12 : kTile * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char s_tab_raw[kTabBytes];
+  uint64_t (*s_lo)[256] = reinterpret_cast<uint64_t (*)[256]>(s_tab_raw);
+  uint32_t (*s_hi)[256] = reinterpret_cast<uint32_t (*)[256]>(s_tab_raw + kWords * 256 * 8);
+  uint16_t *s_sufp = reinterpret_cast<uint16_t *>(s_tab_raw);  // [kTile], after the hashing
   __shared__ uint32_t s_h[kTile];
   __shared__ int32_t s_mp[kTile];
+  uint32_t *s_sufh = reinterpret_cast<uint32_t *>(s_mp);  // [kTile] suffix minima until the window minima are all known
   __shared__ uint32_t s_scan[kThreads / 64];
   __shared__ uint32_t s_tile, s_before;
   const uint32_t tid = threadIdx.x;
@@ -190,6 +195,7 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
   __syncthreads();
 
   // ---- both-strand hashes of the kPPT k-mers starting at p0 .. p0+kPPT-1
+  uint32_t own[kPPT];  // the thread's hashes stay in registers for the winnowing
   {
     uint64_t bases = 0, bad = ~0ULL;  // bit j of `bad`: position p0+j is not a usable base
     if (p0 >= 0 && (uint64_t)p0 < arena_bases) {
@@ -233,27 +239,28 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
         if (hs[0] != hs[1]) h = hs[0] < hs[1] ? hs[0] : hs[1];
       }
       s_h[tid * kPPT + j] = h;
+      own[j] = h;
     }
   }
   __syncthreads();
 
-  // ---- winnowing minimum (rightmost on ties) for every position that can be asked about.  A window of w >= 9
-  // positions ending at x = 8 tid + j is the thread's own positions up to x (running minimum in registers), the whole
-  // groups of eight to the left of them (one minimum per group, computed once), and the tail of the group the window
-  // starts in: about 10 LDS reads per position instead of w.
-  __shared__ uint32_t s_gh[kThreads];
-  __shared__ uint16_t s_gp[kThreads];
+  // ---- winnowing minimum (rightmost on ties) for every position that can be asked about, from minima over the
+  // groups of eight positions a thread owns (a sliding minimum in two pieces): SUFFIX minima of every group go to LDS
+  // (position y: the minimum of y .. end of its group), prefix minima of the own group stay in registers.  A window of
+  // w >= 9 positions ending at x = 8 tid + j is then the own prefix up to j, the whole groups to the left of it (their
+  // suffix minimum at the group's first position), and the suffix minimum at the window's first position in the group
+  // it starts in: three or four LDS reads per position for w = 24 instead of seventeen.
   {
-    const int x7 = (int)tid * kPPT + kPPT - 1;
-    uint32_t bh = s_h[x7];
-    int bp = x7;
+    uint32_t bh = own[kPPT - 1];
+    uint32_t bp = tid * kPPT + kPPT - 1;
+    s_sufh[bp] = bh;
+    s_sufp[bp] = (uint16_t)bp;
 #pragma unroll
-    for (int y = x7 - 1; y > x7 - kPPT; --y) {
-      const uint32_t hy = s_h[y];
-      if (hy < bh) { bh = hy; bp = y; }
+    for (int j = kPPT - 2; j >= 0; --j) {  // right to left, strictly smaller wins: the rightmost of equal hashes stays
+      if (own[j] < bh) { bh = own[j]; bp = tid * kPPT + (uint32_t)j; }
+      s_sufh[tid * kPPT + j] = bh;
+      s_sufp[tid * kPPT + j] = (uint16_t)bp;
     }
-    s_gh[tid] = bh;
-    s_gp[tid] = (uint16_t)bp;
   }
   __syncthreads();
   uint32_t c = 0;
@@ -271,10 +278,16 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
   }
   uint32_t local[kPPT];
   uint32_t cidx[kPPT];
+  int32_t mpv[kPPT];     // position of the window minimum (tile coordinates), -1: no window ends here
+  uint32_t besth[kPPT];  // its hash
+  uint32_t pre_h = kSkip;  // minimum of the own positions 0 .. j, the rightmost of equal ones
+  int pre_p = 0;
 #pragma unroll
   for (int j = 0; j < kPPT; ++j) {
     const int x = (int)tid * kPPT + j;
+    if (own[j] <= pre_h) { pre_h = own[j]; pre_p = x; }
     int32_t mp = -1;
+    uint32_t best = 0;
     local[j] = 0; cidx[j] = 0;
     if (have_c && x >= kHalo / 2) {
       const uint64_t pos = (uint64_t)(p0 + j);
@@ -285,24 +298,20 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
         c_next = c + 1 < n_contigs ? contig_start[c + 1] : ~0ULL;
       }
       const uint64_t loc = pos - c_beg;
-      if (loc < c_len && loc + 1 >= (uint64_t)w && s_h[x] != kSkip) {
-        uint32_t best = s_h[x];
-        mp = x;
+      if (loc < c_len && loc + 1 >= (uint64_t)w && own[j] != kSkip) {
         if (w > kPPT) {
-          const int a = x - w + 1, ga = a / kPPT;  // a >= 1: x >= kHalo / 2 and w <= 64
-          for (int y = x - 1; y >= (int)tid * kPPT; --y) {  // the thread's own positions left of x
-            const uint32_t hy = s_h[y];
-            if (hy < best) { best = hy; mp = y; }
-          }
+          const int a = x - w + 1, ga = a / kPPT;  // a >= 1: x >= kHalo / 2 and w <= 64; ga < tid
+          best = pre_h;
+          mp = pre_p;
           for (int g = (int)tid - 1; g > ga; --g) {
-            const uint32_t hg = s_gh[g];
-            if (hg < best) { best = hg; mp = s_gp[g]; }
+            const uint32_t hg = s_sufh[g * kPPT];
+            if (hg < best) { best = hg; mp = s_sufp[g * kPPT]; }
           }
-          for (int y = ga * kPPT + kPPT - 1; y >= a; --y) {
-            const uint32_t hy = s_h[y];
-            if (hy < best) { best = hy; mp = y; }
-          }
+          const uint32_t ha = s_sufh[a];
+          if (ha < best) { best = ha; mp = s_sufp[a]; }
         } else {
+          best = own[j];
+          mp = x;
           for (int y = x - 1; y > x - w; --y) {
             const uint32_t hy = s_h[y];
             if (hy < best) { best = hy; mp = y; }
@@ -312,8 +321,12 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
         cidx[j] = c;
       }
     }
-    s_mp[x] = mp;
+    mpv[j] = mp;
+    besth[j] = best;
   }
+  __syncthreads();  // the suffix minima have been read: their memory takes the window minima
+#pragma unroll
+  for (int j = 0; j < kPPT; ++j) s_mp[tid * kPPT + j] = mpv[j];
   __syncthreads();
 
   // ---- a minimizer is recorded when it differs from the previous usable window's
@@ -381,8 +394,7 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
   for (int j = 0; j < kPPT; ++j) {
     if (!((flags >> j) & 1u)) continue;
     if (o < cap) {  // a run that overflows the estimate is repeated with the exact size
-      const int x = (int)tid * kPPT + j;
-      out_hash[o] = s_h[s_mp[x]];
+      out_hash[o] = besth[j];
       out_wpos[o] = local[j] - (uint32_t)w + 1u;
       out_contig[o] = cidx[j];
     }
