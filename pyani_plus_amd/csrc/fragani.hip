@@ -1010,6 +1010,7 @@ struct EvalShared {
   uint32_t *hw;        // [kHitCap] window id of each staged hit
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
   uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
+  uint16_t *prev;      // [kRefCap] 1 + stretch position of the same hash earlier in the stretch, 0: none
   uint16_t *qt;        // [kQtBuckets] the fragment's sketch bucketed by the top bits of the hash: first rank (10 bits) | hashes in the bucket (6 bits)
 };
 constexpr uint32_t kQtBits = 9, kQtBuckets = 1u << kQtBits, kQtShift = 32u - kQtBits;
@@ -1023,7 +1024,7 @@ __host__ __device__ inline uint32_t eval_tab_words(uint32_t s_cap, uint32_t ref_
   return ((t > c ? t : c) + 3u) & ~3u;
 }
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
-  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + hit_cap * 6u + ref_cap * 2u + 2u * kQtBuckets;
+  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + hit_cap * 6u + ref_cap * 4u + 2u * kQtBuckets;
 }
 // The arrays whose length is known at compile time come first, so that their addresses are constants of the kernel
 // (immediate offsets of the LDS instructions, no registers); the fragment's sketch and the tables follow.
@@ -1035,7 +1036,8 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   sh.hw = reinterpret_cast<uint32_t *>(sh.qt + kQtBuckets);
   sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
   sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are multiples of 64: everything stays on 16-byte boundaries
-  sh.qh = reinterpret_cast<uint32_t *>(sh.ref_w + kRefCap);
+  sh.prev = sh.ref_w + kRefCap;
+  sh.qh = reinterpret_cast<uint32_t *>(sh.prev + kRefCap);
   sh.cnt = sh.qh + s_cap;  // s_cap is a multiple of 64: the tables start on a 16-byte boundary
   sh.tab = sh.cnt;
   return sh;
@@ -1421,10 +1423,10 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         const uint32_t n = min(m1 - base, kRefCap);
         constexpr int kPer = (int)(kRefCap / 64u);
         uint32_t hh[kPer];
-        int32_t pp[kPer];
+        uint32_t dup_q = 0;  // bit q: the lane's q-th entry repeats a hash met earlier in the stretch
         const uint32_t wbase = mini_wpos[base];
         __syncthreads();
-        // the stretch: hashes and duplicate links into registers, window ids (relative to the first) into LDS
+        // the stretch: hashes into registers, window ids (relative to the first) and duplicate links into LDS
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
           const uint32_t x = (uint32_t)q * 64u + lane;
@@ -1433,7 +1435,10 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           const uint32_t h = mini_hash[t], dw = mini_wpos[t] - wbase;
           const int32_t pv = prev_same[t];
           hh[q] = in ? h : 0u;
-          pp[q] = in ? pv : -1;
+          // the same hash earlier in the stretch (position + 1): a window keeps this occurrence only if it starts after that one
+          const uint32_t p1 = (in && pv >= (int32_t)base) ? (uint32_t)(pv - (int32_t)base) + 1u : 0u;
+          sh.prev[x] = (uint16_t)p1;
+          dup_q |= (p1 ? 1u : 0u) << q;
           sh.ref_w[x] = (uint16_t)((dw > 0xfffeu || !in) ? 0xffffu : dw);  // 0xffff: far beyond any window of this stretch
         }
         __syncthreads();
@@ -1614,7 +1619,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             uint32_t xs = 0, xw = 0;
             bool it_on = false;
             // the begin of item t: the first lane whose run ends past t (the run ends do not decrease over the lanes)
-            auto item_setup = [&](uint32_t pass, bool window_ids_in_lds) {
+            auto item_setup = [&](uint32_t pass) {
               const uint32_t t = pass * 64u + lane;
               it_on = t < n_items;
               uint32_t src = 0;
@@ -1642,15 +1647,14 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
               if (it_on) {
                 // the positions the state stands for: from where entry xw - 1 comes in (or the begin becomes active) to where
                 // entry xw would come in (or the next begin becomes active, or the slide ends)
-                uint32_t w_in = 0xffffu, w_out = 0xffffu;
-                if (window_ids_in_lds) { w_in = sh.ref_w[xw - 1u]; w_out = xw < n ? (uint32_t)sh.ref_w[xw] : 0xffffu; }
+                uint32_t w_in = sh.ref_w[xw - 1u], w_out = xw < n ? (uint32_t)sh.ref_w[xw] : 0xffffu;
                 w_in = w_in == 0xffffu ? mini_wpos[base + xw - 1u] : wbase + w_in;  // (0xffff: more than 65 534 window ids past the stretch's first)
                 w_out = w_out == 0xffffu ? (base + xw < m1 ? mini_wpos[base + xw] : 0xffffffffu) : wbase + w_out;
                 p_first = w_in + 1u > wp_s + count_windows ? w_in + 1u - count_windows : wp_s;
                 p_last = min(we_s, w_out) - count_windows;
               }
             };
-            item_setup(0u, true);  // (the window ids in LDS make way for the duplicate links below)
+            item_setup(0u);
           constexpr uint32_t kW = kRefCap / 32u;  // words per half row; stretch position q * 64 + lane is bit (lane & 31) of word 2 q + (lane >> 5)
           constexpr uint32_t kRow = 2u * kW;
           const uint32_t n_coarse = s / kCoarse + 1u;  // the last row stands at a rank >= s: r + c(r) >= s holds there
@@ -1660,8 +1664,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             uint4 *t4 = reinterpret_cast<uint4 *>(sh.tab);
             for (uint32_t i = lane; i < n_coarse * kRow / 4u; i += 64) t4[i] = make_uint4(0u, 0u, 0u, 0u);  // kRow is a multiple of 4
           }
-          uint16_t *prev16 = sh.ref_w;  // [kRefCap] the window ends are known: the array now takes the duplicate links
-          uint32_t dup_q = 0;
+          const uint16_t *prev16 = sh.prev;
           // word of an entry's bit inside a row (the matching half comes second)
           auto col_of = [&](int q) -> uint32_t { return 2u * (uint32_t)q + (lane >> 5) + (((match_q >> q) & 1u) ? kW : 0u); };
 #pragma unroll
@@ -1669,10 +1672,6 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             const uint32_t x = (uint32_t)q * 64u + lane;
             const uint32_t r = rank[q];
             const bool valid = (x < n_rank) & (r < s);  // inside the used part and below some hash of the fragment: in the rows from r on
-            // the same hash earlier in the stretch (position + 1): a window keeps this occurrence only if it starts after that one
-            const uint32_t p1 = (x < n_rank && pp[q] >= (int32_t)base) ? (uint32_t)(pp[q] - (int32_t)base) + 1u : 0u;
-            prev16[x] = (uint16_t)p1;
-            dup_q |= (p1 ? 1u : 0u) << q;
             rank[q] = valid ? r : 0xffffffffu;
           }
           const bool any_dup = __any(dup_q != 0u);
@@ -1709,7 +1708,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           prefix_or_rows(bc, n_coarse);
           PA_CUT(7);  // coarse table
             for (uint32_t pass = 0; pass * 64u < n_items && !(pass && cut == 21); ++pass) {
-              if (pass) item_setup(pass, false);
+              if (pass) item_setup(pass);
               // the lane's window as a mask over the stretch positions
               uint32_t wm[kW];
               {
@@ -1896,7 +1895,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       if (!handled) {
         // valid runs before the first break of the chunk extend the carried candidate
         const uint64_t head = bm_all ? vm & ((1ULL << __builtin_ctzll(bm_all)) - 1ULL) : vm;
-        if (head && have_cur) cur_ce = max(cur_ce, (uint32_t)__shfl(ce_i, 63 - __builtin_clzll(head), 64));
+        if (head && have_cur) cur_ce = max(cur_ce, (uint32_t)__builtin_amdgcn_readlane((int)ce_i, 63 - __builtin_clzll(head)));
       }
       while (bm && n_list < kListCap) {
         const int bit = __builtin_ctzll(bm);
@@ -1905,16 +1904,17 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         if (have_cur) list_current();
         const uint64_t upto = bm ? ((1ULL << __builtin_ctzll(bm)) - 1ULL) : ~0ULL;
         const uint64_t mine = vm & upto & ~((1ULL << bit) - 1ULL);  // the valid runs of this group inside the chunk
-        cur_c = __shfl(c_i, bit, 64);
-        cur_cs = __shfl(cs_i, bit, 64);
-        cur_fw = __shfl(ce_i, bit, 64);  // window id of the first hit of the candidate's first run
-        cur_ce = __shfl(ce_i, 63 - __builtin_clzll(mine), 64);
+        // (uniform lane numbers: v_readlane puts the values into scalar registers, where the scan's state belongs)
+        cur_c = (uint32_t)__builtin_amdgcn_readlane((int)c_i, bit);
+        cur_cs = (uint32_t)__builtin_amdgcn_readlane((int)cs_i, bit);
+        cur_fw = (uint32_t)__builtin_amdgcn_readlane((int)ce_i, bit);  // window id of the first hit of the candidate's first run
+        cur_ce = (uint32_t)__builtin_amdgcn_readlane((int)ce_i, 63 - __builtin_clzll(mine));
         have_cur = true;
       }
       if (!bm) {  // the chunk is done
         const int last = 63 - __builtin_clzll(vm);
-        prev_c = __shfl(c_i, last, 64);
-        prev_ce = __shfl(ce_i, last, 64);
+        prev_c = (uint32_t)__builtin_amdgcn_readlane((int)c_i, last);
+        prev_ce = (uint32_t)__builtin_amdgcn_readlane((int)ce_i, last);
         have_prev = true;
         handled = 0;
         chunk += 64;
