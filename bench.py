@@ -313,6 +313,25 @@ def also_long_kmer(engine, arena, args, n_total, lengths) -> dict:
     }
 
 
+def pair_tile_balance(sizes, bounds) -> dict:
+    """How evenly the PAIR phase is spread when rank r evaluates all queries against its own genomes as subject
+    columns, from the sketch sizes: dictionary inserts = the rank's own postings; merge-cost
+    model of its tile, sum over (query, own subject) of |S_q| + |S_s| = n_own * sum|S| + N * own postings (SURVEY.md
+    section 8d counts a pair as its two sketches); subject columns.  Each as max over ranks / mean over ranks."""
+    sizes = [int(x) for x in sizes]
+    n, total = len(sizes), sum(sizes)
+    own = [sum(sizes[a:b]) for a, b in bounds]
+    cols = [b - a for a, b in bounds]
+    model = [c * total + n * o for c, o in zip(cols, own)]
+
+    def spread(values):
+        mean = sum(values) / len(values)
+        return max(values) / mean if mean > 0 else None
+
+    return {"dictionary_inserts_max_over_mean": spread(own), "pair_cost_model_max_over_mean": spread(model),
+            "subject_columns_max_over_mean": spread(cols), "own_postings_by_rank": own, "subject_columns_by_rank": cols}
+
+
 def also_mixed(engine, args) -> dict:
     """BASELINE configs[4]: 2 000 genomes of 100 kb - 10 Mb on one GPU (its 8-GPU tiling is the driver's to run)."""
     import oracle
@@ -346,13 +365,17 @@ def also_mixed(engine, args) -> dict:
     if not np.array_equal(counts[:64, :64].cpu().numpy().view(np.uint32), ocounts):
         raise SystemExit("PARITY FAILURE (mixed lengths): pair counts differ from the oracle")
     # how evenly would the 8-GPU shards of this set be loaded: hash cost ~ bases per shard
-    loads = [sum(lengths[a:b]) for a, b in shard_bounds_by_cost(lengths, 8)]
+    bounds8 = shard_bounds_by_cost(lengths, 8)
+    loads = [sum(lengths[a:b]) for a, b in bounds8]
+    tiles = pair_tile_balance(sk.sizes(), bounds8)
     del arena
     return {
         "workload": f"{n} synthetic genomes, log-uniform 100 kb-10 Mb ({sum(lengths) / 1e9:.2f} Gb), k={args.kmer} scaled={args.scaled} (BASELINE configs[4] on one GPU)",
         "ms_per_step": sec * 1e3, "pairs_per_s": n * n / sec, "steps": 3,
-        "shard_balance": {"shards": 8, "bases_max_over_mean": max(loads) / (sum(loads) / len(loads)),
-                          "note": "length-balanced contiguous shards (distributed.shard_bounds_by_cost); hashing cost is proportional to bases"},
+        "shard_balance": {"shards": 8, "bases_max_over_mean": max(loads) / (sum(loads) / len(loads)), "pair_tiles": tiles,
+                          "note": "length-balanced contiguous shards (distributed.shard_bounds_by_cost); hashing cost is proportional to bases; "
+                                  "pair_tiles: the pair phase of rank r = all queries x its own genomes, priced from the sketch sizes "
+                                  "(a rank's postings follow its bases, its column count does not: short genomes mean many columns)"},
         "parity": "sketches of the shortest, median and longest genome equal the oracle; a 64x64 count block equals the oracle and a 256x256 block equals the merge kernel",
     }
 
@@ -374,7 +397,6 @@ def also_n10000(engine, args) -> dict:
         return sk, counts, engine.ani(counts, sk, args.kmer)
 
     sec, (sk, counts, ani) = _time_steps(torch, step, 2)
-    del ani
     engine.prof_enable(True)
     engine.prof_reset()
     step()
@@ -401,10 +423,52 @@ def also_n10000(engine, args) -> dict:
     sub = [flat[int(off[g]) : int(off[g + 1])].cpu().numpy().view(np.uint64) for g in rows]
     if not np.array_equal(counts[n - 24 :, n - 24 :].cpu().numpy().view(np.uint32), oracle.pair_counts(sub)):
         raise SystemExit(f"PARITY FAILURE (N={n}): the last 24x24 count block differs from the oracle")
-    del arena, counts
+    # T_e2e with the bit-identical transform at this size too (packed genomes in pinned host memory -> f64
+    # identity and cov_query in host memory; the counts come back and glibc's pow runs on the host threads)
+    strict = None
+    if not args.no_pcie:
+        from pyani_plus_amd.engine import PinnedArena, ani_host, mask_runs
+
+        h_packed = torch.empty(arena.packed.shape, dtype=arena.packed.dtype, pin_memory=True)
+        h_packed.copy_(arena.packed)
+        h_mask = arena.mask.cpu()
+        run_start, run_len = mask_runs(h_mask.numpy().view(np.uint32), int(arena.genome_start[-1]))
+        del h_mask
+        pinned = PinnedArena(h_packed, run_start, run_len, np.ascontiguousarray(arena.genome_start, dtype=np.uint64))
+        h_counts = torch.empty((n, n), dtype=torch.int32, pin_memory=True)
+        h_ident, h_cov, h_null = np.empty((n, n)), np.empty((n, n)), np.empty((n, n), dtype=np.uint8)
+        runs, pows = [], []
+        for it in range(3):  # the first pass warms the buffers of the streamed upload up
+            arena.packed.zero_()
+            arena.mask.zero_()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _dev, sk3 = engine.sketch_streamed(pinned, args.kmer, args.scaled, arena=arena)
+            c3 = engine.pair_counts(sk3)
+            h_counts.copy_(c3, non_blocking=True)
+            sizes3 = sk3.sizes()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            ani_host(h_counts.numpy().view(np.uint32), sizes3, sizes3, args.kmer, symmetric=True, out=(h_ident, h_cov, h_null))
+            t1 = time.perf_counter()
+            if it:
+                runs.append(t1 - t0)
+                pows.append(t1 - tp)
+        if not torch.equal(c3, counts):
+            raise SystemExit(f"PARITY FAILURE (N={n}): streamed and resident pair counts differ")
+        nul = h_null.view(np.bool_)
+        d_ident = ani[0][-64:, -64:].cpu().numpy()
+        if not (np.array_equal(np.isnan(d_ident), nul[-64:, -64:]) and np.allclose(d_ident[~nul[-64:, -64:]], h_ident[-64:, -64:][~nul[-64:, -64:]], rtol=2.3e-16, atol=0)):
+            raise SystemExit(f"PARITY FAILURE (N={n}): device-pow and host-libm identities differ by more than 1 ulp")
+        mean = sum(runs) / len(runs)
+        strict = {"ms_per_step": mean * 1e3, "pairs_per_s": n * n / mean, "runs": len(runs), "host_pow_ms": sum(pows) / len(pows) * 1e3,
+                  "non_null_pairs": int((~nul).sum()), "h2d_bytes": int(h_packed.numel() * 4 + 16 * len(run_start)), "d2h_bytes": int(h_counts.numel() * 4),
+                  "ani_transform": "host glibc pow on host threads (pa_ani_host): bit-identical to the reference's doubles"}
+        del h_packed, h_counts, h_ident, h_cov, h_null, pinned
+    del arena, counts, ani
     return {
         "workload": f"{n} synthetic {args.length / 1e6:g} Mb genomes, k={args.kmer} scaled={args.scaled} on one GPU (BASELINE configs[2]'s set; its 8-GPU form is --gpus 8)",
-        "ms_per_step": sec * 1e3, "pairs_per_s": n * n / sec, "steps": 2, "phases_ms_per_step": phases,
+        "ms_per_step": sec * 1e3, "pairs_per_s": n * n / sec, "steps": 2, "phases_ms_per_step": phases, "t_e2e": {"strict": strict},
         "pair_phase": "tile pairs on and above the diagonal of the 5 x 5 tile grid are evaluated, the rest mirrored (|A n B| = |B n A|)",
         "parity": "sketches of 3 genomes equal the oracle; counts across the 2 048-column tile boundary (a block below the tile diagonal, i.e. mirrored) "
         "equal the merge kernel; the last 24x24 block equals the oracle",
@@ -746,6 +810,7 @@ def run_rank(args) -> None:
             "shard_balance": {
                 "busy_ms_per_step_by_rank": rank_busy,
                 "max_over_mean": max(rank_busy) / (sum(rank_busy) / len(rank_busy)) if sum(rank_busy) > 0 else None,
+                "pair_tiles": pair_tile_balance(sk.sizes(), bounds) if sk is not None and getattr(sk, "n", 0) == n_total else None,
             },
             "device": engine.device_info()["name"],
             "reference_tools": reference_tools_probe(),

@@ -275,6 +275,10 @@ PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
  * is taken over instead of being rebuilt; PA_E_INVALID when there is no such call.  fastANI itself rebuilds the
  * reference's index in every process. */
 #define PA_FRAGANI_REUSE_INDEX 1u
+/* PA_FRAGANI_COLUMNS_ONLY: h_matched and h_ident_sum hold n_genomes rows of (ref1 - ref0) entries -- the columns of the
+ * reference range and nothing else --, so that a worker asked for one subject column (the reference's layout: one
+ * process per column, pyani_plus/public_cli.py:236-261) keeps O(n) results in host memory instead of an n x n matrix. */
+#define PA_FRAGANI_COLUMNS_ONLY 2u
 PA_API int pa_fragani_ex(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                   const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
                   uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t qry0, uint32_t qry1,

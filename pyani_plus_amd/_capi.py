@@ -21,6 +21,7 @@ PA_E_CAPACITY = -4
 PA_E_IO = -6
 PA_SIG_UNHANDLED = 1
 PA_FRAGANI_REUSE_INDEX = 1
+PA_FRAGANI_COLUMNS_ONLY = 2
 PA_PAIRS_AUTO, PA_PAIRS_BITROW, PA_PAIRS_MERGE, PA_PAIRS_BITROW_HASH = 0, 1, 2, 3
 PA_ALIGN_BASES = 64
 PROF_PHASES = {"kmer_hash": 0, "sketch_sort": 1, "pair_dict": 2, "pair_count": 3, "ani": 4, "frag_index": 5, "frag_seed": 6, "frag_map": 7}

@@ -2143,7 +2143,10 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   PA_REQUIRE(c && d_packed && d_mask && h_total_frags && h_matched && h_ident_sum, "pa_fragani: null argument");
   PA_REQUIRE(ref0 <= ref1 && ref1 <= n_genomes, "pa_fragani: reference range [%u,%u) outside [0,%u)", ref0, ref1, n_genomes);
   PA_REQUIRE(qry0 <= qry1 && qry1 <= n_genomes, "pa_fragani: query range [%u,%u) outside [0,%u)", qry0, qry1, n_genomes);
-  PA_REQUIRE((flags & ~(uint32_t)PA_FRAGANI_REUSE_INDEX) == 0, "pa_fragani: unknown flags 0x%x", flags);
+  PA_REQUIRE((flags & ~(uint32_t)(PA_FRAGANI_REUSE_INDEX | PA_FRAGANI_COLUMNS_ONLY)) == 0, "pa_fragani: unknown flags 0x%x", flags);
+  // the row length of the two result matrices on the host, and the first column they hold
+  const uint32_t out_cols = (flags & PA_FRAGANI_COLUMNS_ONLY) ? ref1 - ref0 : n_genomes;
+  const uint32_t out_col0 = (flags & PA_FRAGANI_COLUMNS_ONLY) ? ref0 : 0u;
   PA_REQUIRE(frag_len >= 100 && frag_len <= 0xffffu, "pa_fragani: fragLen %u outside [100, 65535]", frag_len);
   PA_HIP(hipSetDevice(c->device));
   const int w = window_size_for((int)k, (int)frag_len);
@@ -2162,7 +2165,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     for (uint32_t ci = 0; ci < n_contigs; ++ci) any_frags += h_contig_len[ci] / frag_len;
     if (reuse && any_frags == 0) {
       for (uint32_t g = 0; g < n_genomes; ++g) h_total_frags[g] = 0;
-      for (uint64_t i = (uint64_t)qry0 * n_genomes; i < (uint64_t)qry1 * n_genomes; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
+      for (uint64_t i = (uint64_t)qry0 * out_cols; i < (uint64_t)qry1 * out_cols; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
       return PA_OK;
     }
   }
@@ -2215,7 +2218,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   }
   const uint64_t total_bins = contig_bin_off[n_contigs];
   const uint32_t n_frags = (uint32_t)frag_contig.size();
-  for (uint64_t i = (uint64_t)qry0 * n_genomes; i < (uint64_t)qry1 * n_genomes; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
+  for (uint64_t i = (uint64_t)qry0 * out_cols; i < (uint64_t)qry1 * out_cols; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
   auto remember_index = [&](int which_buf) {
     W.index_packed = d_packed; W.index_arena_bases = arena_bases; W.index_contigs = n_contigs; W.index_genomes = n_genomes;
     W.index_k = k; W.index_frag_len = frag_len; W.index_m = m; W.index_which = which_buf;
@@ -2563,10 +2566,17 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.ident_tab.as<double>(), W.matched.as<uint32_t>(), W.ident_sum.as<double>());
     PA_HIP(hipGetLastError());
     prof.reset();
-    PA_HIP(hipMemcpyAsync(h_matched + (uint64_t)g0 * n_genomes, W.matched.p, (uint64_t)nq * n_genomes * 4,
-                          hipMemcpyDeviceToHost, c->stream));
-    PA_HIP(hipMemcpyAsync(h_ident_sum + (uint64_t)g0 * n_genomes, W.ident_sum.p, (uint64_t)nq * n_genomes * 8,
-                          hipMemcpyDeviceToHost, c->stream));
+    if (out_cols == n_genomes) {
+      PA_HIP(hipMemcpyAsync(h_matched + (uint64_t)g0 * n_genomes, W.matched.p, (uint64_t)nq * n_genomes * 4,
+                            hipMemcpyDeviceToHost, c->stream));
+      PA_HIP(hipMemcpyAsync(h_ident_sum + (uint64_t)g0 * n_genomes, W.ident_sum.p, (uint64_t)nq * n_genomes * 8,
+                            hipMemcpyDeviceToHost, c->stream));
+    } else if (out_cols) {  // the columns of the reference range only
+      PA_HIP(hipMemcpy2DAsync(h_matched + (uint64_t)g0 * out_cols, (size_t)out_cols * 4, W.matched.as<uint32_t>() + out_col0,
+                              (size_t)n_genomes * 4, (size_t)out_cols * 4, nq, hipMemcpyDeviceToHost, c->stream));
+      PA_HIP(hipMemcpy2DAsync(h_ident_sum + (uint64_t)g0 * out_cols, (size_t)out_cols * 8, W.ident_sum.as<double>() + out_col0,
+                              (size_t)n_genomes * 8, (size_t)out_cols * 8, nq, hipMemcpyDeviceToHost, c->stream));
+    }
     PA_HIP(hipStreamSynchronize(c->stream));
     g0 = g1;
   }

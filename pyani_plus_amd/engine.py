@@ -468,32 +468,35 @@ class HipEngine:
 
     # -- fastANI-style fragment ANI (BASELINE configs[3])
     def fragani(self, arena: DeviceArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000, ref_range=None,
-                query_range=None, reuse_index: bool = False, out=None):
+                query_range=None, reuse_index: bool = False, out=None, columns_only: bool = False):
         """All ordered genome pairs: (total_frags[n], matched[n, n], ident_sum[n, n]) as numpy arrays;
         ANI(q, r) = ident_sum / matched (percent), rows = query.  ``ref_range`` = (r0, r1) maps the queries against
         those reference genomes only (the other columns stay 0); ``query_range`` = (q0, q1) maps those query genomes
         only and leaves the other rows of ``out`` = (total, matched, ident_sum) as they are; ``reuse_index``: the
-        previous call was on this very arena with the same k and fragment length, take over its reference index."""
+        previous call was on this very arena with the same k and fragment length, take over its reference index;
+        ``columns_only``: the two matrices are [n, r1 - r0] -- the columns of the reference range and nothing else."""
         n = arena.n_genomes
         r0, r1 = ref_range if ref_range is not None else (0, n)
         q0, q1 = query_range if query_range is not None else (0, n)
+        cols = int(r1) - int(r0) if columns_only else n
         cs = np.ascontiguousarray(contig_start, dtype=np.uint64)
         cl = np.ascontiguousarray(contig_len, dtype=np.uint32)
         cg = np.ascontiguousarray(contig_genome, dtype=np.uint32)
         if out is None:
             total = np.zeros(n, dtype=np.uint32)
-            matched = np.zeros((n, n), dtype=np.uint32)
-            ident_sum = np.zeros((n, n), dtype=np.float64)
+            matched = np.zeros((n, cols), dtype=np.uint32)
+            ident_sum = np.zeros((n, cols), dtype=np.float64)
         else:
             total, matched, ident_sum = out
-            assert total.shape == (n,) and matched.shape == (n, n) == ident_sum.shape
+            assert total.shape == (n,) and matched.shape == (n, cols) == ident_sum.shape
             assert total.dtype == np.uint32 and matched.dtype == np.uint32 and ident_sum.dtype == np.float64
             assert matched.flags.c_contiguous and ident_sum.flags.c_contiguous
+        flags = (_capi.PA_FRAGANI_REUSE_INDEX if reuse_index else 0) | (_capi.PA_FRAGANI_COLUMNS_ONLY if columns_only else 0)
         check(
             self.lib.pa_fragani_ex(
                 self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,
                 cg.ctypes.data, len(cs), n, k, frag_len, int(q0), int(q1), int(r0), int(r1),
-                _capi.PA_FRAGANI_REUSE_INDEX if reuse_index else 0, total.ctypes.data, matched.ctypes.data, ident_sum.ctypes.data,
+                flags, total.ctypes.data, matched.ctypes.data, ident_sum.ctypes.data,
             ),  # fmt: skip
             "pa_fragani",
         )

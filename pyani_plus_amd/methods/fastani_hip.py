@@ -116,17 +116,18 @@ def round_sig6(values: np.ndarray) -> np.ndarray:
     return out
 
 
-def comparison_block(total, matched, ident_sum, lengths, rows, cols, fragsize: int, minmatch: float):
+def comparison_block(total, matched, ident_sum, lengths, rows, cols, fragsize: int, minmatch: float, col0: int = 0):
     """The five fields of the fastANI worker (private_cli.py:1066-1098) for a block of query rows x subject columns
     as arrays: (identity f64, aln_length i64, sim_errors i64, cov_query f64, is_null bool); the array form of
-    ``comparison_entry``.  A pair fastANI would print no line for is NULL in all four."""
+    ``comparison_entry``.  A pair fastANI would print no line for is NULL in all four.  ``col0``: the genome whose
+    column is the first of ``matched`` / ``ident_sum`` (result matrices that hold a range of subject columns only)."""
     rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
-    m = matched[np.ix_(rows, cols)].astype(np.int64)
+    m = matched[np.ix_(rows, cols - col0)].astype(np.int64)
     frags = total[rows].astype(np.int64)[:, None]
     shorter = np.minimum(lengths[rows].astype(np.int64)[:, None], lengths[cols].astype(np.int64)[None, :])
     reported = (frags > 0) & (m > 0) & (m * int(fragsize) >= float(minmatch) * shorter)
     with np.errstate(invalid="ignore", divide="ignore"):
-        ani = np.where(m > 0, ident_sum[np.ix_(rows, cols)] / np.maximum(m, 1), np.nan)
+        ani = np.where(m > 0, ident_sum[np.ix_(rows, cols - col0)] / np.maximum(m, 1), np.nan)
         cov = np.where(reported, m / np.maximum(frags, 1), np.nan)
     identity = np.where(reported, round_sig6(np.where(reported, ani, np.nan)) / 100.0, np.nan)
     aln = np.where(reported, int(fragsize) * m, 0)
@@ -206,7 +207,11 @@ def compute_fastani_hip(  # noqa: PLR0913
         arena, dev = load_genomes_for_fragani([Path(fasta_dir) / hash_to_filename[h] for h in genomes], engine)
         lengths = mappable_lengths(arena.contig_len, arena.contig_genome, arena.n_genomes, fragsize)
         n = arena.n_genomes
-        out = (np.zeros(n, dtype=np.uint32), np.zeros((n, n), dtype=np.uint32), np.zeros((n, n), dtype=np.float64))
+        # a contiguous range of subject columns (one column in the reference's process layout) comes back as exactly
+        # those columns: O(n) numbers in host memory for a column, not an n x n matrix
+        width = ref_range[1] - ref_range[0] if ref_range is not None else n
+        col0 = ref_range[0] if ref_range is not None else 0
+        out = (np.zeros(n, dtype=np.uint32), np.zeros((n, width), dtype=np.uint32), np.zeros((n, width), dtype=np.float64))
         query_idx = [index[q] for q in queries]
         # batches of CONSECUTIVE genome indices, at most `query_batch` queries each: a batch is mapped as a range of query
         # genomes, so it ends where the queries leave a gap (a subject that is not among the queries sits between them)
@@ -219,9 +224,9 @@ def compute_fastani_hip(  # noqa: PLR0913
         for b, batch in enumerate(batches):
             total, matched, ident_sum = engine.fragani(
                 dev, arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize, ref_range=ref_range,
-                query_range=(batch[0], batch[-1] + 1), reuse_index=b > 0, out=out,
+                query_range=(batch[0], batch[-1] + 1), reuse_index=b > 0, out=out, columns_only=ref_range is not None,
             )  # fmt: skip
-            ident, aln, sim, cov, null = comparison_block(total, matched, ident_sum, lengths, batch, sub_idx, fragsize, minmatch)
+            ident, aln, sim, cov, null = comparison_block(total, matched, ident_sum, lengths, batch, sub_idx, fragsize, minmatch, col0=col0)
             if on_block is not None:
                 on_block([genomes[i] for i in batch], subjects, ident, aln, sim, cov, null)
             try:  # the column file grows by one batch of queries (a complete JSON document after each)

@@ -83,7 +83,7 @@ class OracleEngine:
 
 
     def fragani(self, arena: HostArena, contig_start, contig_len, contig_genome, k: int = 16, frag_len: int = 3000, ref_range=None,
-                query_range=None, reuse_index: bool = False, out=None):
+                query_range=None, reuse_index: bool = False, out=None, columns_only: bool = False):
         """Fragment ANI of every ordered pair through the oracle: (total[n], matched[n, n], ident_sum[n, n])."""
         self.fragani_calls = getattr(self, "fragani_calls", [])
         self.fragani_calls.append({"ref_range": ref_range, "query_range": query_range, "reuse_index": reuse_index})
@@ -95,8 +95,9 @@ class OracleEngine:
             contigs[int(g)].append(text[int(start) - g0 : int(start) - g0 + int(length)])
         r0, r1 = (0, n) if ref_range is None else ref_range
         q0, q1 = (0, n) if query_range is None else query_range
+        c0, width = (r0, r1 - r0) if columns_only else (0, n)
         if out is None:
-            out = (np.zeros(n, dtype=np.uint32), np.zeros((n, n), dtype=np.uint32), np.zeros((n, n), dtype=np.float64))
+            out = (np.zeros(n, dtype=np.uint32), np.zeros((n, width), dtype=np.uint32), np.zeros((n, width), dtype=np.float64))
         total, matched, ident_sum = out
         for q in range(n):
             total[q] = sum(len(c) // frag_len for c in contigs[q])
@@ -107,8 +108,8 @@ class OracleEngine:
                 ani, m, t = oracle.fragani_pair(contigs[q], contigs[r], k, frag_len, 0.0)
                 assert t == total[q]
                 if m:
-                    matched[q, r] = m
-                    ident_sum[q, r] = ani * m
+                    matched[q, r - c0] = m
+                    ident_sum[q, r - c0] = ani * m
         return total, matched, ident_sum
 
 

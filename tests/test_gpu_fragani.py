@@ -395,3 +395,21 @@ def test_reuse_index_when_no_contig_holds_a_fragment(engine):
     again = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG, query_range=(2, 3), reuse_index=True)
     for total, matched, ident_sum in (first, again):
         assert not total.any() and not matched.any() and not ident_sum.any()
+
+
+def test_columns_only_results_equal_the_square_ones(engine):
+    """``PA_FRAGANI_COLUMNS_ONLY``: a range of subject columns comes back as [n, r1 - r0] arrays (what a one-column worker
+    keeps in host memory), equal to those columns of the n x n result; query batches fill their own rows."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    texts, _contigs = _random_genomes(19)
+    arena = pack_genomes(texts)
+    dev = engine.upload(arena)
+    n = len(texts)
+    total, matched, ident_sum = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    for r0, r1 in ((0, 1), (1, 4), (4, 5), (0, n)):
+        out = (np.zeros(n, dtype=np.uint32), np.full((n, r1 - r0), 7, dtype=np.uint32), np.full((n, r1 - r0), 7.0))
+        for b, (q0, q1) in enumerate(((0, 2), (2, n))):
+            t, m, s = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG, ref_range=(r0, r1),
+                                     query_range=(q0, q1), reuse_index=b > 0, out=out, columns_only=True)
+        assert np.array_equal(t, total) and np.array_equal(m, matched[:, r0:r1]) and np.array_equal(s, ident_sum[:, r0:r1])

@@ -17,7 +17,10 @@ cd /tmp && export TMPDIR=/tmp
 [ -f "$OUT/../counters_available.txt" ] || rocprofv3 -L > "$OUT/../counters_available.txt" 2>&1
 run_pass() {  # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 "$SCRIPT" "${ARGS[@]}" > "$OUT/$name.log" 2>&1
+  # counters for the kernel under study only: with every dispatch of the run counted (the generator of the synthetic genomes
+  # alone launches thousands) the profiler segfaults once counter instances x dispatches pass some size -- at 1 000
+  # genomes every TCC counter and any two SQ counters did, one SQ counter or GRBM_GUI_ACTIVE did not (round 4)
+  rocprofv3 --pmc "$@" --kernel-include-regex "$FILTER" --kernel-trace --output-format csv -d "$OUT/$name" -- python3 "$SCRIPT" "${ARGS[@]}" > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 ARGS=("$@")
