@@ -1285,9 +1285,34 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
 
   PA_CUT(1);  // staging, sort, bucket table
   int32_t best_shared = -1;
-  uint32_t best_c = 0xffffffffu, best_p = 0;
+  // the best mapping so far: contig; first position of its first and last position of its last optimal state as far as
+  // evaluated (best_last), the last position the optimum can extend to (best_lmax, see extend_optimum), and what the
+  // extension would start from
+  uint32_t best_c = 0xffffffffu, best_first = 0, best_last = 0, best_lmax = 0, best_eb = 0, best_ee = 0, best_we = 0;
   uint32_t half0 = 1;
   while (2u * half0 <= s) half0 *= 2u;
+
+  // The states right after the last EVALUATED state with the most shared minimizers (same begin, one more minimizer taken
+  // in each, none of them matching a hash of the fragment) share as many or fewer: while they share as many, the optimum
+  // extends over them.  One cooperative evaluation per state, from HBM -- asked for only when the mapping position could
+  // change something (below): `last` = the optimum's last position so far, the state it comes from = minimizers
+  // [eb, ee) of contig c, `we` = the window ids below which the begin's widest window stays.  Returns the exact last position.
+  auto extend_optimum = [&](uint32_t c, uint32_t eb, uint32_t ee, uint32_t we, int32_t value, uint32_t last) -> uint32_t {
+    const uint32_t m1 = contig_mini_off[c + 1];
+    const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
+    const uint32_t e_last = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, we);
+    for (uint32_t e = ee + 1u; e <= e_last; ++e) {
+      PA_STAT(14, 1);  // states evaluated after the optimum
+      __syncthreads();
+      for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
+      if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
+      __syncthreads();
+      if ((int32_t)eval_window_coop(eb, e) != value) break;
+      const uint32_t w_out = e < m1 ? mini_wpos[e] : 0xffffffffu;  // the first minimizer past the window
+      last = min(we, w_out) - count_windows;
+    }
+    return last;
+  };
 
   // ---- L2, the exact slide (oracle/fragani_oracle.c, L2 rule 2).  The window at position i of the candidate's contig
   // holds the minimizers of the reference windows [i, i + count_windows): from b = the last minimizer recorded at or
@@ -1819,29 +1844,36 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       }
     }
     if (c_best < 0) return;
-    // The states right after the last evaluated state with the most shared minimizers (same begin, one more minimizer taken
-    // in each) share as many or fewer: while they share as many, the optimum extends over them.  Only where the position
-    // can matter: the candidate is reported, and wins or ties with the best so far.
+    // The mapping position is (first position of the first optimal state + last position of the last one) / 2, and the
+    // last optimal state may be one of the unevaluated states after the last evaluated one (extend_optimum).  The position
+    // decides two things only: the reference bin of the final mapping, and ties between candidates that share equally
+    // many minimizers on one contig.  So the optimum is extended only where the span of positions it could end at
+    // ([c_last, c_lmax]: at most the rest of its begin's states, a dozen window ids) leaves one of the two open.
+    uint32_t c_lmax = c_last, c_we = 0;
     if (c_best >= floor_bar && c_best >= best_shared && cut != 20) {  // (cut 20..23: timing experiments, results wrong)
       const uint32_t wp_after = c_last_b + 1u < m1 ? mini_wpos[c_last_b + 1u] : 0xffffffffu;
-      const uint32_t we = min(wp_after - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
-      if (c_last + count_windows < we) {  // the state is not the begin's last
-        const uint32_t e_last = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, we);
-        for (uint32_t e = c_last_e + 1u; e <= e_last; ++e) {
-          PA_STAT(14, 1);  // states evaluated after the optimum
-          __syncthreads();
-          for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
-          if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
-          __syncthreads();
-          if ((int32_t)eval_window_coop(c_last_b, e) != c_best) break;
-          const uint32_t w_out = e < m1 ? mini_wpos[e] : 0xffffffffu;  // the first minimizer past the window
-          c_last = min(we, w_out) - count_windows;
-        }
+      c_we = min(wp_after - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
+      if (c_last + count_windows < c_we) c_lmax = c_we - count_windows;  // the state is not the begin's last
+    }
+    bool take;
+    if (c_best != best_shared) {
+      take = c_best > best_shared;
+    } else if (c != best_c) {
+      take = c < best_c;
+    } else {  // the smaller position wins
+      if ((c_first + c_lmax) / 2u < (best_first + best_last) / 2u) {
+        take = true;
+      } else if ((c_first + c_last) / 2u >= (best_first + best_lmax) / 2u) {
+        take = false;
+      } else {  // the spans overlap: both positions exactly
+        if (c_lmax != c_last) c_last = c_lmax = extend_optimum(c, c_last_b, c_last_e, c_we, c_best, c_last);
+        if (best_lmax != best_last) best_last = best_lmax = extend_optimum(best_c, best_eb, best_ee, best_we, best_shared, best_last);
+        take = (c_first + c_last) / 2u < (best_first + best_last) / 2u;
       }
     }
-    const uint32_t pos = (c_first + c_last) / 2u;
-    if (c_best > best_shared || (c_best == best_shared && (c < best_c || (c == best_c && pos < best_p)))) {
-      best_shared = c_best; best_c = c; best_p = pos;
+    if (take) {
+      best_shared = c_best; best_c = c; best_first = c_first; best_last = c_last; best_lmax = c_lmax;
+      best_eb = c_last_b; best_ee = c_last_e; best_we = c_we;
     }
   };
 
@@ -1930,11 +1962,16 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     __syncthreads();
   }
 
-  if (best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s] && lane == 0) {
-    const uint64_t jq = ((uint64_t)best_shared << 30) / s;
-    const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
-    const uint64_t bin = contig_bin_off[best_c] + best_p / (frag_len - 20u);  // fastANI buckets the reference by fragLen - 20
-    atomicMax(&table[(uint64_t)frag_genome_local[f] * table_stride + bin], packed);
+  if (best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s]) {
+    // fastANI buckets the reference by fragLen - 20; the optimum is extended when that could move the mapping to the next bin
+    if ((best_first + best_last) / 2u / (frag_len - 20u) != (best_first + best_lmax) / 2u / (frag_len - 20u))
+      best_last = extend_optimum(best_c, best_eb, best_ee, best_we, best_shared, best_last);
+    if (lane == 0) {
+      const uint64_t jq = ((uint64_t)best_shared << 30) / s;
+      const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
+      const uint64_t bin = contig_bin_off[best_c] + (best_first + best_last) / 2u / (frag_len - 20u);
+      atomicMax(&table[(uint64_t)frag_genome_local[f] * table_stride + bin], packed);
+    }
   }
 }
 
