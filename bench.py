@@ -568,6 +568,8 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
             "definition": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / (GRBM_GUI_ACTIVE / 8); salu_busy = SQ_INSTS_SALU / CUs / (GRBM_GUI_ACTIVE / 8) "
             "(one scalar unit per CU); the two pipes issue side by side, so the busier one is the fraction of the issue roof",
             "source": mc.get("source", "no counter passes committed"), "avg_ms_per_run": map_ms, "share_of_run": map_ms / (sec * 1e3),
+            "counted_fetch_bytes_per_dispatch": mc.get("fetch_bytes_per_dispatch_as_counted"), "counted_write_bytes_per_dispatch": mc.get("write_bytes_per_dispatch"),
+            "counted_bytes_note": "the kernel's results are a few MB per dispatch; the counted writes are its register spills (scratch memory)",
         }
         bc = (counters or {}).get("bucket_hits_kernel", {})
         out["roofline_seeding"] = {

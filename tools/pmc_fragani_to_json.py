@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """profiles/fragani_counters.json from the summaries of the rocprofv3 counter passes on the fragment-ANI kernels
-(tools/pmc_passes.sh <tag> <kernel> tools/bench_fragani.py 300 -> gpurun_out/<tag>_pmc/summary.txt, copied to
-profiles/).  bench.py copies these figures into `also.fragment_ani.roofline*`, labelled as coming from these passes.
+(tools/pmc_passes.sh <tag> <kernel> tools/bench_fragani.py 1000 0 interleaved 78 -> gpurun_out/<tag>_pmc/summary.txt,
+copied to profiles/: the benchmark's 1 000 genomes, one batch of 2^17 query fragments per repetition).  bench.py copies
+these figures into `also.fragment_ani.roofline*`, labelled as coming from these passes.
 
-    python tools/pmc_fragani_to_json.py profiles/r03_pmc_map_segments_summary.txt profiles/r03_pmc_bucket_hits_summary.txt \
-        <seed hits per bucket_hits dispatch>
+    python tools/pmc_fragani_to_json.py profiles/r04_pmc_map_segments_summary.txt profiles/r04_pmc_bucket_hits_summary.txt \
+        <seed hits per bucket_hits dispatch> [workload label]
 """
 import json
 import re
@@ -29,17 +30,21 @@ def parse(path: Path) -> dict:
 def main() -> None:
     map_file, bucket_file = Path(sys.argv[1]), Path(sys.argv[2])
     hits_per_dispatch = float(sys.argv[3]) if len(sys.argv) > 3 else None
+    what = sys.argv[4] if len(sys.argv) > 4 else "tools/bench_fragani.py 1000 0 interleaved 78 (the benchmark's 1 000 genomes, one batch of 2^17 query fragments)"
     m, b = parse(map_file), parse(bucket_file)
     cycles = m["GRBM_GUI_ACTIVE"] / XCDS
     out = {
         "map_segments_kernel": {
-            "source": f"rocprofv3 --pmc passes of tools/bench_fragani.py 300 ({map_file.name}); not measured inside this run",
+            "source": f"rocprofv3 --pmc passes of {what} ({map_file.name}); not measured inside this run",
             "valu_busy": m["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / cycles,
             "salu_busy": m["SQ_INSTS_SALU"] / CUS / cycles,
             "valu_instructions": m["SQ_INSTS_VALU"], "salu_instructions": m["SQ_INSTS_SALU"],
             "wait_share": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
             "waves_per_simd": m["SQ_WAVE_CYCLES"] * 4 / SIMDS / cycles,  # SQ_* cycle counters are in quad-cycles
             "avg_ms_per_dispatch": m["duration_ms"],
+            # the kernel's own results are a few MB per dispatch: what FETCH_SIZE / WRITE_SIZE count beyond the stretches it
+            # reads is its register spill traffic (scratch memory, 72 bytes per lane in round 4)
+            "fetch_bytes_per_dispatch_as_counted": m.get("FETCH_SIZE", 0.0) * 1024, "write_bytes_per_dispatch": m.get("WRITE_SIZE", 0.0) * 1024,
         },
     }
     cyc_b = b["GRBM_GUI_ACTIVE"] / XCDS
@@ -49,7 +54,7 @@ def main() -> None:
     fetch = b["FETCH_SIZE"] * 1024 * 2
     write = b["WRITE_SIZE"] * 1024
     entry = {
-        "source": f"rocprofv3 --pmc passes of tools/bench_fragani.py 300 ({bucket_file.name}); FETCH_SIZE as counted and doubled (the gfx950 rule is "
+        "source": f"rocprofv3 --pmc passes of {what} ({bucket_file.name}); FETCH_SIZE as counted and doubled (the gfx950 rule is "
         "calibrated for wide streaming reads only); not measured inside this run",
         "fetch_bytes_per_dispatch_as_counted": fetch / 2, "write_bytes_per_dispatch": write, "avg_ms_per_dispatch": b["duration_ms"],
         "counter_gbs": (fetch / 2 + write) / (b["duration_ms"] * 1e-3) / 1e9,

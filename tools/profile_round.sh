@@ -13,10 +13,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/${TAG}
 echo "fragani stats rc=$?"
 cd "$ROOT"
 bash tools/pmc_passes.sh ${TAG}_hash kmer_hash tools/pmc_hash.py 1000
-bash tools/pmc_passes.sh ${TAG}_fragmap map_segments tools/bench_fragani.py 300 0
-bash tools/pmc_passes.sh ${TAG}_bucket bucket_hits tools/bench_fragani.py 300 0
+# the fragment-ANI kernels at the benchmark's 1 000 genomes, one batch of 2^17 query fragments (78 query genomes) per repetition
+bash tools/pmc_passes.sh ${TAG}_fragmap "map_segments_kernel<320u, true>" tools/bench_fragani.py 1000 0 interleaved 78
+bash tools/pmc_passes.sh ${TAG}_bucket bucket_hits tools/bench_fragani.py 1000 0 interleaved 78
 # seed hits per bucket_hits dispatch of that run (the denominator of its bytes per hit)
-PA_FRAGANI_TRACE=1 python3 tools/bench_fragani.py 300 0 2>&1 | grep "seed hits" > gpurun_out/${TAG}_fragani300_trace.txt
+PA_FRAGANI_TRACE=1 python3 tools/bench_fragani.py 1000 0 interleaved 78 2>&1 | grep "seed hits" | head -1 > gpurun_out/${TAG}_fragani1000_onebatch_trace.txt
 for d in gpurun_out/${TAG}_stats_bench gpurun_out/${TAG}_stats_fragani; do
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then
