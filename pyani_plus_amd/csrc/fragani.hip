@@ -1007,6 +1007,7 @@ struct EvalShared {
   uint32_t *tab;       //   the same memory: the bit tables of the windowed evaluation (eval_tab_words)
   uint32_t *matched;   // [kQMax / 32] bitset over query ranks (cooperative evaluation of one over-long window)
   uint32_t *cand;      // [4 * 8] candidates of the L1 scan waiting for their evaluation: contig, first and last start, first hit
+  uint32_t *scan;      // [16] the L1 scan's state while the candidates it has listed are evaluated
   uint32_t *hw;        // [kHitCap] window id of each staged hit
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
   uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
@@ -1024,7 +1025,7 @@ __host__ __device__ inline uint32_t eval_tab_words(uint32_t s_cap, uint32_t ref_
   return ((t > c ? t : c) + 3u) & ~3u;
 }
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
-  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + hit_cap * 6u + ref_cap * 4u + 2u * kQtBuckets;
+  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + 64u + hit_cap * 6u + ref_cap * 4u + 2u * kQtBuckets;
 }
 // The arrays whose length is known at compile time come first, so that their addresses are constants of the kernel
 // (immediate offsets of the LDS instructions, no registers); the fragment's sketch and the tables follow.
@@ -1032,7 +1033,8 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   EvalShared sh;
   sh.matched = base;
   sh.cand = sh.matched + kQMax / 32;
-  sh.qt = reinterpret_cast<uint16_t *>(sh.cand + 32);
+  sh.scan = sh.cand + 32;
+  sh.qt = reinterpret_cast<uint16_t *>(sh.scan + 16);
   sh.hw = reinterpret_cast<uint32_t *>(sh.qt + kQtBuckets);
   sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
   sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are multiples of 64: everything stays on 16-byte boundaries
@@ -1297,7 +1299,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // extends over them.  One cooperative evaluation per state, from HBM -- asked for only when the mapping position could
   // change something (below): `last` = the optimum's last position so far, the state it comes from = minimizers
   // [eb, ee) of contig c, `we` = the window ids below which the begin's widest window stays.  Returns the exact last position.
-  auto extend_optimum = [&](uint32_t c, uint32_t eb, uint32_t ee, uint32_t we, int32_t value, uint32_t last) -> uint32_t {
+  auto extend_optimum = [&](uint32_t c, uint32_t eb, uint32_t ee, uint32_t we, int32_t value, uint32_t last) __attribute__((always_inline)) -> uint32_t {
     const uint32_t m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
     const uint32_t e_last = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, we);
@@ -1328,7 +1330,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // over (query rank x stretch position), and every lane finds, by two short searches over rows of those tables, how many
   // of the fragment's smallest hashes lie in the bottom-s of the union with its own window and how many of them the window
   // holds.  Begins none of whose windows can hold as many seed hits as the best so far shares are never evaluated.
-  auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) {
+  auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) __attribute__((always_inline)) {
     PA_CUT(2);  // L1 only
     const uint32_t m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
@@ -1890,7 +1892,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   bool have_cur = false, have_prev = false;
   uint32_t cur_c = 0, cur_cs = 0, cur_ce = 0, cur_fw = 0, prev_c = 0, prev_ce = 0;
   uint64_t handled = 0;
-  for (uint32_t chunk = 0;;) {
+  uint32_t chunk = 0;
+  for (;;) {
     const bool tail = chunk >= nh;  // one more turn after the last chunk lists the candidate still open
     uint32_t n_list = 0;
     auto list_current = [&]() {
@@ -1952,13 +1955,27 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         chunk += 64;
       }
     }
+    // The scan's state sits in LDS while the listed candidates are evaluated: kept in registers across the evaluation --
+    // the register-hungriest part of the kernel -- it was spilled to scratch memory (HBM traffic, and a wait) at every turn.
+    if (lane == 0) {
+      sh.scan[0] = chunk; sh.scan[1] = (have_cur ? 1u : 0u) | (have_prev ? 2u : 0u) | (tail ? 4u : 0u);
+      sh.scan[2] = cur_c; sh.scan[3] = cur_cs; sh.scan[4] = cur_ce; sh.scan[5] = cur_fw; sh.scan[6] = prev_c; sh.scan[7] = prev_ce;
+      sh.scan[8] = (uint32_t)handled; sh.scan[9] = (uint32_t)(handled >> 32); sh.scan[10] = n_list;
+    }
     __syncthreads();
-    for (uint32_t t = 0; t < n_list; ++t) {
+    for (uint32_t t = 0; t < sh.scan[10]; ++t) {
       const uint4 cand = reinterpret_cast<const uint4 *>(sh.cand)[t];
       process_candidate((uint32_t)__builtin_amdgcn_readfirstlane((int)cand.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)cand.y),
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)cand.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)cand.w));
     }
-    if (tail) break;
+    __syncthreads();
+    {
+      const uint32_t flags1 = sh.scan[1];
+      chunk = sh.scan[0]; have_cur = flags1 & 1u; have_prev = (flags1 >> 1) & 1u;
+      cur_c = sh.scan[2]; cur_cs = sh.scan[3]; cur_ce = sh.scan[4]; cur_fw = sh.scan[5]; prev_c = sh.scan[6]; prev_ce = sh.scan[7];
+      handled = ((uint64_t)sh.scan[9] << 32) | sh.scan[8];
+      if (flags1 & 4u) break;
+    }
     __syncthreads();
   }
 
