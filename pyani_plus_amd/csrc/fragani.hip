@@ -1007,7 +1007,7 @@ struct EvalShared {
   uint32_t *tab;       //   the same memory: the bit tables of the windowed evaluation (eval_tab_words)
   uint32_t *matched;   // [kQMax / 32] bitset over query ranks (cooperative evaluation of one over-long window)
   uint32_t *cand;      // [4 * 8] candidates of the L1 scan waiting for their evaluation: contig, first and last start, first hit
-  uint32_t *scan;      // [16] the L1 scan's state while the candidates it has listed are evaluated
+  uint32_t *scan;      // [24] the L1 scan's state while the candidates it has listed are evaluated [0..10], the best mapping so far [16..23]
   uint32_t *hw;        // [kHitCap] window id of each staged hit
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
   uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
@@ -1025,7 +1025,7 @@ __host__ __device__ inline uint32_t eval_tab_words(uint32_t s_cap, uint32_t ref_
   return ((t > c ? t : c) + 3u) & ~3u;
 }
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
-  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + 64u + hit_cap * 6u + ref_cap * 4u + 2u * kQtBuckets;
+  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + 96u + hit_cap * 6u + ref_cap * 4u + 2u * kQtBuckets;
 }
 // The arrays whose length is known at compile time come first, so that their addresses are constants of the kernel
 // (immediate offsets of the LDS instructions, no registers); the fragment's sketch and the tables follow.
@@ -1034,7 +1034,7 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   sh.matched = base;
   sh.cand = sh.matched + kQMax / 32;
   sh.scan = sh.cand + 32;
-  sh.qt = reinterpret_cast<uint16_t *>(sh.scan + 16);
+  sh.qt = reinterpret_cast<uint16_t *>(sh.scan + 24);
   sh.hw = reinterpret_cast<uint32_t *>(sh.qt + kQtBuckets);
   sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
   sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are multiples of 64: everything stays on 16-byte boundaries
@@ -1286,11 +1286,15 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   };
 
   PA_CUT(1);  // staging, sort, bucket table
-  int32_t best_shared = -1;
-  // the best mapping so far: contig; first position of its first and last position of its last optimal state as far as
-  // evaluated (best_last), the last position the optimum can extend to (best_lmax, see extend_optimum), and what the
-  // extension would start from
-  uint32_t best_c = 0xffffffffu, best_first = 0, best_last = 0, best_lmax = 0, best_eb = 0, best_ee = 0, best_we = 0;
+  // The best mapping so far lives in LDS (sh.scan[16..23]: it is looked at once per candidate, and eight values kept in
+  // registers across the whole kernel were eight spills): shared minimizers; contig; first position of its first and
+  // last position of its last optimal state as far as evaluated (last), the last position the optimum can extend to
+  // (lmax, see extend_optimum), and what the extension would start from (begin, end, window-id bound).
+  enum { kBestShared = 16, kBestC, kBestFirst, kBestLast, kBestLmax, kBestEb, kBestEe, kBestWe };
+  if (lane == 0) {
+    sh.scan[kBestShared] = 0xffffffffu;  // -1
+    sh.scan[kBestC] = 0xffffffffu;
+  }
   uint32_t half0 = 1;
   while (2u * half0 <= s) half0 *= 2u;
 
@@ -1332,6 +1336,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // holds.  Begins none of whose windows can hold as many seed hits as the best so far shares are never evaluated.
   auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) __attribute__((always_inline)) {
     PA_CUT(2);  // L1 only
+    const int32_t best_shared = (int32_t)__builtin_amdgcn_readfirstlane((int)sh.scan[kBestShared]);  // (fixed while this candidate is evaluated)
     const uint32_t m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
     // first begin: through the bucket index, the bucket itself searched by the whole wave (two memory round trips
@@ -1858,25 +1863,34 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       if (c_last + count_windows < c_we) c_lmax = c_we - count_windows;  // the state is not the begin's last
     }
     bool take;
+    const uint32_t best_c = sh.scan[kBestC];
     if (c_best != best_shared) {
       take = c_best > best_shared;
     } else if (c != best_c) {
       take = c < best_c;
     } else {  // the smaller position wins
+      const uint32_t best_first = sh.scan[kBestFirst], best_lmax = sh.scan[kBestLmax];
+      uint32_t best_last = sh.scan[kBestLast];
       if ((c_first + c_lmax) / 2u < (best_first + best_last) / 2u) {
         take = true;
       } else if ((c_first + c_last) / 2u >= (best_first + best_lmax) / 2u) {
         take = false;
       } else {  // the spans overlap: both positions exactly
         if (c_lmax != c_last) c_last = c_lmax = extend_optimum(c, c_last_b, c_last_e, c_we, c_best, c_last);
-        if (best_lmax != best_last) best_last = best_lmax = extend_optimum(best_c, best_eb, best_ee, best_we, best_shared, best_last);
+        if (best_lmax != best_last) {
+          best_last = extend_optimum(best_c, sh.scan[kBestEb], sh.scan[kBestEe], sh.scan[kBestWe], best_shared, best_last);
+          __syncthreads();
+          if (lane == 0) sh.scan[kBestLast] = sh.scan[kBestLmax] = best_last;
+        }
         take = (c_first + c_last) / 2u < (best_first + best_last) / 2u;
       }
     }
-    if (take) {
-      best_shared = c_best; best_c = c; best_first = c_first; best_last = c_last; best_lmax = c_lmax;
-      best_eb = c_last_b; best_ee = c_last_e; best_we = c_we;
+    __syncthreads();
+    if (take && lane == 0) {
+      sh.scan[kBestShared] = (uint32_t)c_best; sh.scan[kBestC] = c; sh.scan[kBestFirst] = c_first; sh.scan[kBestLast] = c_last;
+      sh.scan[kBestLmax] = c_lmax; sh.scan[kBestEb] = c_last_b; sh.scan[kBestEe] = c_last_e; sh.scan[kBestWe] = c_we;
     }
+    __syncthreads();
   };
 
   // ---- L1: run a is valid when hits a .. a+mh-1 share a contig and span < frag_len window ids; its candidate range
@@ -1979,10 +1993,14 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     __syncthreads();
   }
 
+  __syncthreads();
+  const int32_t best_shared = (int32_t)sh.scan[kBestShared];
   if (best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s]) {
+    const uint32_t best_c = sh.scan[kBestC], best_first = sh.scan[kBestFirst], best_lmax = sh.scan[kBestLmax];
+    uint32_t best_last = sh.scan[kBestLast];
     // fastANI buckets the reference by fragLen - 20; the optimum is extended when that could move the mapping to the next bin
     if ((best_first + best_last) / 2u / (frag_len - 20u) != (best_first + best_lmax) / 2u / (frag_len - 20u))
-      best_last = extend_optimum(best_c, best_eb, best_ee, best_we, best_shared, best_last);
+      best_last = extend_optimum(best_c, sh.scan[kBestEb], sh.scan[kBestEe], sh.scan[kBestWe], best_shared, best_last);
     if (lane == 0) {
       const uint64_t jq = ((uint64_t)best_shared << 30) / s;
       const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
