@@ -413,3 +413,49 @@ def test_columns_only_results_equal_the_square_ones(engine):
             t, m, s = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG, ref_range=(r0, r1),
                                      query_range=(q0, q1), reuse_index=b > 0, out=out, columns_only=True)
         assert np.array_equal(t, total) and np.array_equal(m, matched[:, r0:r1]) and np.array_equal(s, ident_sum[:, r0:r1])
+
+
+def test_contigs_that_end_right_after_their_last_fragment(engine):
+    """The slide ends when the window's end reaches the first minimizer at or past rangeEnd + fragLen -- or the contig's
+    end: a fragment that ends within a few residues of its contig's end cannot be mapped at its own position (the
+    reference's MIBY01000011 pin).  Contigs of f fragments plus 0 .. 120 residues, against themselves and against
+    mutated copies whose contigs end elsewhere: same integers as the oracle."""
+    rng = np.random.default_rng(404)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    root = rng.choice(acgt, size=200_000)
+    tails = [0, 1, 2, 5, 17, 23, 38, 39, 40, 41, 64, 120]
+    contigs_a, contigs_b, pos = [], [], 0
+    for i, r in enumerate(tails):
+        n = 3_000 * (1 + i % 3) + r
+        seq = root[pos : pos + n + 200]
+        contigs_a.append(seq[:n].tobytes())
+        mutated = seq.copy()
+        hit = rng.random(mutated.size) < 0.01
+        mutated[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+        contigs_b.append(mutated[: n + (7 * i) % 200].tobytes())  # the copy's contig ends somewhere else
+        pos += n + 200
+    contig_lists = [contigs_a, contigs_b, [b"".join(contigs_a)]]
+    texts = [b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(cs)) for cs in contig_lists]
+    total, matched, _ = _check_against_oracle(engine, texts, contig_lists)
+    # nearly every fragment maps onto its own genome; the last fragment of a contig that ends with it (tails 0 and 1 here)
+    # may find no window at all before the slide ends
+    assert total[0] - 3 <= matched[0, 0] <= total[0]
+    _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
+
+
+def test_a_long_run_of_n_inside_a_contig(engine):
+    """70 kb of N in the middle of a contig: the window ids of neighbouring minimizers are more than 65 535 apart (the
+    mapping kernel keeps them as 16-bit offsets inside a stretch), windows near the gap hold next to nothing."""
+    rng = np.random.default_rng(505)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    left, right = rng.choice(acgt, size=12_000), rng.choice(acgt, size=15_000)
+    gap = np.full(70_000, ord("N"), dtype=np.uint8)
+    a = np.concatenate([left, gap, right])
+    b = a.copy()
+    hit = (rng.random(b.size) < 0.02) & (b != ord("N"))
+    b[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+    c = np.concatenate([left, right])  # the same sequence without the gap
+    genomes = [a.tobytes(), b.tobytes(), c.tobytes()]
+    texts = [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)]
+    total, matched, _ = _check_against_oracle(engine, texts, [[g] for g in genomes])
+    assert matched[2, 0] > 0 and matched[0, 2] > 0
