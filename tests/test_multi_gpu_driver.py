@@ -316,6 +316,40 @@ def test_fastani_worker_flushes_every_query_batch_and_keeps_them_on_interrupt(tm
     assert json.loads(whole.read_text()) == json.loads(batched.read_text())
 
 
+def test_fastani_query_batches_end_where_the_queries_leave_a_gap(tmp_path):
+    """A subject that is not among the queries sits between them in the sorted genome list: a batch is mapped as a RANGE
+    of genomes, so it ends at the gap instead of spanning the subject (whose rows would be computed and thrown away);
+    and a one-column call gets that column only back from the engine (O(n) results, not n x n)."""
+    import json
+
+    from tests.test_host_logic import _make_run, _Session
+
+    name = "viral_example"
+    _scaled, genomes = FIXTURE_SETS[name]
+    run = _make_run(GOLDEN / name, genomes, 300, method=fastani_hip.METHOD)
+    tool = fastani_hip.get_fastani_hip()
+    run.configuration.program, run.configuration.version = tool.exe_path.stem, tool.version
+    run.configuration.fragsize, run.configuration.kmersize, run.configuration.minmatch = 3000, 16, 0.2
+    hash_to_filename = dict(genomes)
+    ordered = sorted(hash_to_filename)
+    subject = ordered[1]  # the middle genome: the two queries are genomes 0 and 2
+    queries = {h: 1000 for h in ordered if h != subject}
+    eng = OracleEngine()
+    out = tmp_path / "gap.json"
+    assert fastani_hip.compute_fastani_hip(LOGGER, tmp_path, _Session(), run, out, GOLDEN / name, hash_to_filename, {}, queries, subject,
+                                           engine=eng) == 0
+    assert [c["query_range"] for c in eng.fragani_calls] == [(0, 1), (2, 3)]  # not (0, 3)
+    assert all(c["ref_range"] == (1, 2) for c in eng.fragani_calls)
+    rows = json.loads(out.read_text())["comparisons"]
+    assert [(r["query_hash"], r["subject_hash"]) for r in rows] == [(ordered[0], subject), (ordered[2], subject)]
+    # the same two rows as in the all-vs-all column file
+    whole = tmp_path / "whole.json"
+    assert fastani_hip.compute_fastani_hip(LOGGER, tmp_path, _Session(), run, whole, GOLDEN / name, hash_to_filename, {},
+                                           {h: 1000 for h in ordered}, "", engine=OracleEngine()) == 0
+    want = {(r["query_hash"], r["subject_hash"]): r for r in json.loads(whole.read_text())["comparisons"]}
+    assert all(want[(r["query_hash"], r["subject_hash"])] == r for r in rows)
+
+
 def test_fastani_rows_as_arrays_equal_the_row_by_row_form_and_json_dumps(tmp_path):
     """The worker's vectorised rows (``comparison_block``) against the per-row statement of the reference's mapping
     (``comparison_entry``, pyani_plus/private_cli.py:1066-1098), and the natively written six-key rows against
