@@ -17,21 +17,27 @@
  *                      window, slid over EVERY position of the candidate range: the window at position i
  *                      holds the minimizers of the reference windows [i, i + count_windows) -- the one
  *                      still active at i included --; the slide ends when the window's end reaches the
- *                      first minimizer at or past rangeEnd + fragLen; identity = 1 + ln(2J/(1+J))/k
- *   per fragment     : best window; kept when the upper confidence bound of its identity >= 80 %
- *   per genome pair  : one best fragment per reference bin; ANI = mean identity of the kept
- *                      fragments, reported when kept / total >= minFraction.
+ *                      first minimizer at or past rangeEnd + fragLen; identity = 1 + ln(2J/(1+J))/k;
+ *                      position of a window = the window id of its first minimizer, position of a
+ *                      candidate = the mean of the first and the last window with the most shared minimizers
+ *   per fragment     : every candidate whose upper confidence bound of the identity is >= 80 % is a mapping;
+ *                      the fragment keeps the one of highest identity, the LAST of them (in contig, position
+ *                      order) when several share it -- fastANI sorts the mappings by (fragment, identity) and
+ *                      lets each overwrite the one before
+ *   per genome pair  : one best fragment per reference bin; ANI = mean identity of the kept fragments --
+ *                      float identities, summed in float in (contig, bin) order, as fastANI holds them --,
+ *                      reported when kept / total >= minFraction.
  *
- * PARITY STATUS: pinned on the self and near-identical rows, tolerance on the distant ones.  The reference holds 25
- * output rows for 7 small inputs (tests/fixtures/{viral,bacterial}_example/intermediates/fastANI/, files
- * all_vs_X.fastani) and three more pins in its tests (tests/test_self_vs_self.py:90-91 and 121-122,
- * tests/test_coverage.py:143-160); nothing pins the internals.  The choices below that are this restatement's own are
- * marked RESTATEMENT and can be switched at run time (tests/tools/fragani_bisect.py scores every variant against the
- * rows and pins: profiles/r04_fragani_bisect.md).  With the defaults -- what the HIP path implements bit for bit --:
- *   all 9 viral rows, all 7 self rows, MIBY01000005 == 100, MIBY01000011 == 99.9953 and the k = 15 matrices print
- *   exactly as fastANI printed them (six significant digits); the 99.99 % pair is within 0.0001 percentage points;
- *   the 83 - 86 % pairs are within 0.0707 percentage points and 0.71 % of the fragments; total fragments exact.
- * tests/test_fragani_oracle.py asserts exactly that.
+ * PARITY STATUS: pinned on every fastANI value the reference holds.  These are 25 output rows for 7 small inputs
+ * (tests/fixtures/{viral,bacterial}_example/intermediates/fastANI/, files all_vs_X.fastani) and three more pins in its
+ * tests (tests/test_self_vs_self.py:90-91 and 121-122, tests/test_coverage.py:143-160); nothing pins the internals.  The
+ * choices below that are this restatement's own are marked RESTATEMENT and can be switched at run time
+ * (tests/tools/fragani_bisect.py scores every variant against the rows and pins: profiles/r04_fragani_bisect.md).  With
+ * the defaults -- what the HIP path implements bit for bit -- ALL 25 rows (identity as printed, six significant digits;
+ * kept fragments; total fragments), MIBY01000005 == 100, MIBY01000011 == 99.9953 and the k = 15 matrices come out exactly
+ * as fastANI wrote them.  tests/test_fragani_oracle.py asserts exactly that.  Not pinned by any of those values, and
+ * switched off: Mashmap's cut of the 0.001 % most frequent minimizers from the seed look-up (OPT_FREQ; it changes none
+ * of the 25 rows).
  */
 #include <math.h>
 #ifdef _OPENMP
@@ -46,10 +52,10 @@
 uint64_t orc_murmur3_h1(const uint8_t *data, uint32_t len, uint32_t seed);
 
 /* ------------------------------------------------------------------ variant switches
- * The five RESTATEMENT choices can be switched at run time so that tools/fragani_bisect.py can measure, on
+ * The RESTATEMENT choices can be switched at run time so that tools/fragani_bisect.py can measure, on
  * the reference's 25 fastANI rows, what each of them costs (table in profiles/ and DESIGN.md).  The defaults
  * are the variant the HIP path implements. */
-enum { OPT_WINDOW_RULE = 0, OPT_BIN_RULE = 1, OPT_L2_RULE = 2, OPT_CONF = 3, OPT_L2_POS = 4, OPT_L2_STOP = 5, OPT_COUNT = 6 };
+enum { OPT_WINDOW_RULE = 0, OPT_BIN_RULE = 1, OPT_L2_RULE = 2, OPT_CONF = 3, OPT_L2_POS = 4, OPT_L2_STOP = 5, OPT_TIE = 6, OPT_FREQ = 7, OPT_FLOAT = 8, OPT_COUNT = 9 };
 static double g_opt[OPT_COUNT] = {
     1.0, /* OPT_WINDOW_RULE: 0 = sketch sizes 10, 60, 110, ... (round 1); 1 = 1, 2, 5, 10, 20, 30, ... (Mashmap's list) */
     1.0, /* OPT_BIN_RULE:    0 = (pos + fragLen/2) / fragLen (round 1); 1 = pos / (fragLen - 20) (fastANI's bucket) */
@@ -58,10 +64,18 @@ static double g_opt[OPT_COUNT] = {
                                   every position i holds the minimizers of the reference windows [i, i + count_windows) -- the one still
                                   active at i included --, and the slide ends when the window's end reaches the candidate's last end */
     0.9, /* OPT_CONF:        confidence level of the identity bounds */
-    1.0, /* OPT_L2_POS:      (rule 2) position of a window: 0 = window id of its first minimizer, 1 = the positions i it stands for (first to last),
+    0.0, /* OPT_L2_POS:      (rule 2) position of a window: 0 = window id of its first minimizer, 1 = the positions i it stands for (first to last),
                                   2 = the first position i it stands for (where the slide arrives at it) */
     0.0, /* OPT_L2_STOP:     (rule 2) 0 = the slide ends when the window's end reaches the first minimizer at or past rangeEnd + fragLen;
                                   1 = it also ends past position rangeEnd; 2 = past rangeEnd only (no end rule) */
+    1.0, /* OPT_TIE:         (rule 2) candidates of one fragment with the same number of shared minimizers: 0 = the first one (lowest contig, then
+                                  lowest position) is the fragment's mapping; 1 = the last one; 2 = the one that fastANI's
+                                  `std::sort by (fragment, identity)`, then `the last of a fragment's run`, ends up with: libstdc++'s
+                                  introsort restated below, run over every kept candidate of the query genome in the order fastANI emits them */
+    0.0, /* OPT_FREQ:        seed hits: 0 = every reference occurrence of a query minimizer; 1 = Mashmap's frequency cut: occurrences of the
+                                  0.001 % most frequent reference minimizers are not looked up */
+    1.0, /* OPT_FLOAT:       0 = identities and their mean in double; 1 = in float, as fastANI holds them (float Jaccard, float Mash distance,
+                                  float identity, float running sum in (contig, bin) order) */
 };
 ORC_API void orc_fragani_set_option(int which, double value) { if (which >= 0 && which < OPT_COUNT) g_opt[which] = value; }
 ORC_API double orc_fragani_get_option(int which) { return (which >= 0 && which < OPT_COUNT) ? g_opt[which] : NAN; }
@@ -106,8 +120,20 @@ static double md_lower_bound(double d, int s, int k) {
   return j2md((double)x / s, k);
 }
 
+/* OPT_FLOAT 1: the identity as fastANI holds it -- Mashmap's j2md takes the Jaccard estimate as a float and returns a
+ * float (the division 2j / (1 + j) has a float denominator, the logarithm is double), and nucIdentity = 100 * (1 - mash_dist)
+ * is float arithmetic */
+static float identity_f(int shared, int s, int k) {
+  const float j = (float)(1.0 * shared / s);
+  float d;
+  if (j == 0) d = 1.0f; else if (j == 1) d = 0.0f; else d = (float)((-1.0 / k) * log(2.0 * j / (1 + j)));
+  return 100 * (1 - d);
+}
+
 /* identity (percent) of `shared` common minimizers out of a sketch of s */
-ORC_API double orc_fragani_identity(int shared, int s, int k) { return 100.0 * (1.0 - j2md((double)shared / s, k)); }
+ORC_API double orc_fragani_identity(int shared, int s, int k) {
+  return g_opt[OPT_FLOAT] != 0.0 ? (double)identity_f(shared, s, k) : 100.0 * (1.0 - j2md((double)shared / s, k));
+}
 
 /* smallest `shared` whose upper-bound identity reaches the cut-off (s+1 if none) */
 ORC_API int orc_fragani_min_shared(int s, int k) {
@@ -300,7 +326,7 @@ typedef struct { int32_t frag, ref_seq, ref_pos, shared, s; } FragMap;
 /* The reference genome's index: its minimizers in position order and in hash order.  fastANI builds it once per
  * process and maps every query of its --ql list against it (the reference's worker: one process per subject column
  * and batch of 500 queries, pyani_plus/private_cli.py:1029-1063). */
-typedef struct { MiniVec rpos; Mini *rhash; } RefIndex;
+typedef struct { MiniVec rpos; Mini *rhash; int64_t freq_threshold; } RefIndex;
 
 static void ref_index_free(RefIndex *ix) { free(ix->rpos.v); free(ix->rhash); ix->rpos.v = NULL; ix->rhash = NULL; }
 
@@ -313,7 +339,105 @@ static int ref_index_build(RefIndex *ix, const uint8_t *r_seq, const uint64_t *r
   if (!ix->rhash) { ref_index_free(ix); return -1; }
   memcpy(ix->rhash, ix->rpos.v, sizeof(Mini) * ix->rpos.n);
   qsort(ix->rhash, ix->rpos.n, sizeof(Mini), cmp_hash);
+  /* Mashmap's frequency cut (OPT_FREQ 1): walk the histogram of occurrence counts from the most frequent minimizers down; the
+   * threshold is the count reached while the number of distinct minimizers passed stays at or below 0.001 % of all distinct ones;
+   * minimizers occurring >= threshold times give no seed hits. */
+  ix->freq_threshold = INT64_MAX;
+  if (g_opt[OPT_FREQ] != 0.0 && ix->rpos.n) {
+    const size_t n = ix->rpos.n;
+    uint32_t *counts = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    if (!counts) { ref_index_free(ix); return -1; }
+    size_t uniq = 0;
+    for (size_t i = 0; i < n;) { size_t j = i; while (j < n && ix->rhash[j].hash == ix->rhash[i].hash) ++j; counts[uniq++] = (uint32_t)(j - i); i = j; }
+    qsort(counts, uniq, sizeof(uint32_t), cmp_u32);
+    const int64_t to_ignore = (int64_t)((float)uniq * 0.001f / 100);
+    int64_t sum = 0;
+    for (size_t i = uniq; i > 0;) { /* one histogram bar = a run of equal counts */
+      size_t j = i; while (j > 0 && counts[j - 1] == counts[i - 1]) --j;
+      sum += (int64_t)(i - j);
+      if (sum < to_ignore) ix->freq_threshold = counts[i - 1];
+      else { if (sum == to_ignore) ix->freq_threshold = counts[i - 1]; break; }
+      i = j;
+    }
+    free(counts);
+  }
   return 0;
+}
+
+/* ------------------------------------------------------------------ libstdc++'s std::sort, restated
+ * fastANI keeps, per query fragment, the last element of the fragment's run after `std::sort(all mappings, by (genome, fragment,
+ * identity))`; which of several candidates with the SAME identity that is depends on the sort itself, which is not stable.  This is
+ * the algorithm of libstdc++ (GCC >= 4.9, bits/stl_algo.h: __introsort_loop with a median-of-three pivot moved to the front and an
+ * unguarded Hoare partition, ranges of at most 16 left to one final insertion sort, heap sort once the depth limit 2*floor(log2 n) is
+ * used up), element moves included, so that equal elements end up where they do there. */
+static int fm_less(const FragMap *a, const FragMap *b) { return a->frag != b->frag ? a->frag < b->frag : a->shared < b->shared; }
+static void fm_swap(FragMap *a, FragMap *b) { const FragMap t = *a; *a = *b; *b = t; }
+static void fm_adjust_heap(FragMap *first, int64_t hole, int64_t len, FragMap value) {
+  const int64_t top = hole;
+  int64_t child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (fm_less(&first[child], &first[child - 1])) --child;
+    first[hole] = first[child]; hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); first[hole] = first[child - 1]; hole = child - 1; }
+  int64_t parent = (hole - 1) / 2;
+  while (hole > top && fm_less(&first[parent], &value)) { first[hole] = first[parent]; hole = parent; parent = (hole - 1) / 2; }
+  first[hole] = value;
+}
+static void fm_heap_sort(FragMap *first, FragMap *last) { /* std::partial_sort(first, last, last) */
+  const int64_t len = last - first;
+  if (len >= 2)
+    for (int64_t parent = (len - 2) / 2;; --parent) { fm_adjust_heap(first, parent, len, first[parent]); if (parent == 0) break; }
+  while (last - first > 1) { --last; const FragMap value = *last; *last = *first; fm_adjust_heap(first, 0, last - first, value); }
+}
+static void fm_median_to_first(FragMap *result, FragMap *a, FragMap *b, FragMap *c) {
+  if (fm_less(a, b)) {
+    if (fm_less(b, c)) fm_swap(result, b); else if (fm_less(a, c)) fm_swap(result, c); else fm_swap(result, a);
+  } else if (fm_less(a, c)) fm_swap(result, a);
+  else if (fm_less(b, c)) fm_swap(result, c);
+  else fm_swap(result, b);
+}
+static void fm_introsort_loop(FragMap *first, FragMap *last, int depth) {
+  while (last - first > 16) {
+    if (depth == 0) { fm_heap_sort(first, last); return; }
+    --depth;
+    fm_median_to_first(first, first + 1, first + (last - first) / 2, last - 1);
+    FragMap *lo = first + 1, *hi = last;
+    for (;;) {
+      while (fm_less(lo, first)) ++lo;
+      --hi;
+      while (fm_less(first, hi)) --hi;
+      if (!(lo < hi)) break;
+      fm_swap(lo, hi);
+      ++lo;
+    }
+    fm_introsort_loop(lo, last, depth);
+    last = lo;
+  }
+}
+static void fm_unguarded_linear_insert(FragMap *last) {
+  const FragMap value = *last;
+  FragMap *next = last - 1;
+  while (fm_less(&value, next)) { *last = *next; last = next; --next; }
+  *last = value;
+}
+static void fm_insertion_sort(FragMap *first, FragMap *last) {
+  if (first == last) return;
+  for (FragMap *i = first + 1; i != last; ++i) {
+    if (fm_less(i, first)) { const FragMap value = *i; memmove(first + 1, first, (size_t)(i - first) * sizeof(FragMap)); *first = value; }
+    else fm_unguarded_linear_insert(i);
+  }
+}
+static void fm_std_sort(FragMap *first, FragMap *last) {
+  if (first == last) return;
+  int lg = 0;
+  for (int64_t n = last - first; n > 1; n >>= 1) ++lg;
+  fm_introsort_loop(first, last, 2 * lg);
+  if (last - first > 16) {
+    fm_insertion_sort(first, first + 16);
+    for (FragMap *i = first + 16; i != last; ++i) fm_unguarded_linear_insert(i);
+  } else fm_insertion_sort(first, last);
 }
 
 static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_t q_contigs, const RefIndex *ix, int k,
@@ -325,6 +449,7 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
   for (uint32_t c = 0; c < q_contigs; ++c) total += (int)((q_off[c + 1] - q_off[c]) / (uint64_t)frag_len);
   FragMap *maps = (FragMap *)malloc(sizeof(FragMap) * (size_t)(total ? total : 1));
   int n_maps = 0, frag_id = 0;
+  FragMap *emit = NULL; size_t n_emit = 0, emit_cap = 0; /* OPT_TIE 2: every kept candidate, in fastANI's order */
   MiniVec qm = {0, 0, 0};
   Mini *hits = NULL; size_t hits_cap = 0;
   uint32_t *winh = NULL; size_t win_cap = 0;
@@ -363,6 +488,10 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
       size_t nh = 0; /* seed hits: every reference occurrence of every query hash */
       for (int i = 0; i < s; ++i) {
         size_t p = lower_bound_hash(rhash, rpos.n, qh[i]);
+        if (ix->freq_threshold != INT64_MAX) {
+          size_t e = p; while (e < rpos.n && rhash[e].hash == qh[i]) ++e;
+          if ((int64_t)(e - p) >= ix->freq_threshold) continue;
+        }
         while (p < rpos.n && rhash[p].hash == qh[i]) {
           if (nh == hits_cap) { hits_cap = hits_cap ? hits_cap * 2 : 1024; hits = (Mini *)realloc(hits, hits_cap * sizeof(Mini)); }
           hits[nh++] = rhash[p++];
@@ -433,7 +562,12 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
           }
           if (c_best < 0) continue;
           const int64_t pos = (c_first + c_last) / 2;
-          if (c_best > best_shared || (c_best == best_shared && (cseq < best_seq || (cseq == best_seq && pos < best_pos)))) {
+          if (g_opt[OPT_TIE] == 2.0 && c_best >= orc_fragani_min_shared(s, k)) {
+            if (n_emit == emit_cap) { emit_cap = emit_cap ? emit_cap * 2 : 4096; emit = (FragMap *)realloc(emit, emit_cap * sizeof(FragMap)); }
+            const FragMap m = {frag_id, cseq, (int32_t)pos, c_best, s};
+            emit[n_emit++] = m;
+          }
+          if (c_best > best_shared || (c_best == best_shared && (g_opt[OPT_TIE] != 0.0 || cseq < best_seq || (cseq == best_seq && pos < best_pos)))) {
             best_shared = c_best; best_seq = cseq; best_pos = pos;
           }
         }
@@ -491,12 +625,18 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
       }
       free(cands);
       free(qh);
-      if (best_shared >= 0 && best_shared >= orc_fragani_min_shared(s, k)) {
+      if (!(g_opt[OPT_TIE] == 2.0 && g_opt[OPT_L2_RULE] == 2.0) && best_shared >= 0 && best_shared >= orc_fragani_min_shared(s, k)) {
         FragMap m = {frag_id, best_seq, (int32_t)best_pos, best_shared, s};
         maps[n_maps++] = m;
       }
     }
   }
+  if (g_opt[OPT_TIE] == 2.0 && g_opt[OPT_L2_RULE] == 2.0) {
+    fm_std_sort(emit, emit + n_emit);
+    for (size_t i = 0; i < n_emit; ++i)
+      if (i + 1 == n_emit || emit[i + 1].frag != emit[i].frag) maps[n_maps++] = emit[i];
+  }
+  free(emit);
   free(qm.v); free(qall.v); free(hits); free(winh);
   *maps_out = maps; *n_maps_out = n_maps; *total_out = total;
   return 0;
@@ -592,12 +732,13 @@ static void reduce_pair(FragMap *maps, int n, int total, const uint64_t *q_off, 
   for (int i = 0; i < n; ++i)
     maps[i].ref_pos = g_opt[OPT_BIN_RULE] == 0.0 ? (maps[i].ref_pos + frag_len / 2) / frag_len : maps[i].ref_pos / (frag_len - 20);
   qsort(maps, (size_t)n, sizeof(FragMap), cmp_bin);
-  double sum = 0.0; int matched = 0;
+  double sum = 0.0; float sum_f = 0.0f; int matched = 0;
   for (int i = 0; i < n;) {
     int best = i, j = i + 1;
     for (; j < n && maps[j].ref_seq == maps[i].ref_seq && maps[j].ref_pos == maps[i].ref_pos; ++j)
       if ((int64_t)maps[j].shared * maps[best].s > (int64_t)maps[best].shared * maps[j].s) best = j;
-    sum += orc_fragani_identity(maps[best].shared, maps[best].s, k);
+    if (g_opt[OPT_FLOAT] != 0.0) { sum_f += identity_f(maps[best].shared, maps[best].s, k); sum = (double)sum_f; }
+    else sum += orc_fragani_identity(maps[best].shared, maps[best].s, k);
     ++matched;
     i = j;
   }
@@ -607,5 +748,6 @@ static void reduce_pair(FragMap *maps, int n, int total, const uint64_t *q_off, 
   for (uint32_t c = 0; c < q_contigs; ++c) if (q_off[c + 1] - q_off[c] >= (uint64_t)frag_len) len_q += q_off[c + 1] - q_off[c];
   for (uint32_t c = 0; c < r_contigs; ++c) if (r_off[c + 1] - r_off[c] >= (uint64_t)frag_len) len_r += r_off[c + 1] - r_off[c];
   const double shorter = (double)(len_q < len_r ? len_q : len_r);
-  *ani_out = (matched > 0 && total > 0 && (double)matched * frag_len >= min_fraction * shorter) ? sum / matched : NAN;
+  const double mean = g_opt[OPT_FLOAT] != 0.0 ? (double)(sum_f / (float)matched) : sum / matched;
+  *ani_out = (matched > 0 && total > 0 && (double)matched * frag_len >= min_fraction * shorter) ? mean : NAN;
 }

@@ -189,7 +189,7 @@ def _load_frag() -> C.CDLL:
     return lib
 
 
-FRAGANI_OPTIONS = {"window_rule": 0, "bin_rule": 1, "l2_rule": 2, "conf": 3, "l2_pos": 4, "l2_stop": 5}
+FRAGANI_OPTIONS = {"window_rule": 0, "bin_rule": 1, "l2_rule": 2, "conf": 3, "l2_pos": 4, "l2_stop": 5, "tie": 6, "freq": 7, "float": 8}
 
 
 def fragani_set_option(name: str, value: float) -> None:

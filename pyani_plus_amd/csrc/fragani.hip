@@ -1286,11 +1286,10 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   };
 
   PA_CUT(1);  // staging, sort, bucket table
-  // The best mapping so far lives in LDS (sh.scan[16..23]: it is looked at once per candidate, and eight values kept in
-  // registers across the whole kernel were eight spills): shared minimizers; contig; first position of its first and
-  // last position of its last optimal state as far as evaluated (last), the last position the optimum can extend to
-  // (lmax, see extend_optimum), and what the extension would start from (begin, end, window-id bound).
-  enum { kBestShared = 16, kBestC, kBestFirst, kBestLast, kBestLmax, kBestEb, kBestEe, kBestWe };
+  // The best mapping so far lives in LDS (sh.scan[16..19]: it is looked at once per candidate, and values kept in
+  // registers across the whole kernel were spills): shared minimizers; contig; window ids of the first minimizers of its
+  // first and of its last optimal state.
+  enum { kBestShared = 16, kBestC, kBestFirst, kBestLast };
   if (lane == 0) {
     sh.scan[kBestShared] = 0xffffffffu;  // -1
     sh.scan[kBestC] = 0xffffffffu;
@@ -1298,35 +1297,14 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   uint32_t half0 = 1;
   while (2u * half0 <= s) half0 *= 2u;
 
-  // The states right after the last EVALUATED state with the most shared minimizers (same begin, one more minimizer taken
-  // in each, none of them matching a hash of the fragment) share as many or fewer: while they share as many, the optimum
-  // extends over them.  One cooperative evaluation per state, from HBM -- asked for only when the mapping position could
-  // change something (below): `last` = the optimum's last position so far, the state it comes from = minimizers
-  // [eb, ee) of contig c, `we` = the window ids below which the begin's widest window stays.  Returns the exact last position.
-  auto extend_optimum = [&](uint32_t c, uint32_t eb, uint32_t ee, uint32_t we, int32_t value, uint32_t last) __attribute__((always_inline)) -> uint32_t {
-    const uint32_t m1 = contig_mini_off[c + 1];
-    const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
-    const uint32_t e_last = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, we);
-    for (uint32_t e = ee + 1u; e <= e_last; ++e) {
-      PA_STAT(14, 1);  // states evaluated after the optimum
-      __syncthreads();
-      for (uint32_t i = lane; i <= s; i += 64) sh.cnt[i] = 0;  // the cooperative form counts in the memory of the tables
-      if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
-      __syncthreads();
-      if ((int32_t)eval_window_coop(eb, e) != value) break;
-      const uint32_t w_out = e < m1 ? mini_wpos[e] : 0xffffffffu;  // the first minimizer past the window
-      last = min(we, w_out) - count_windows;
-    }
-    return last;
-  };
-
   // ---- L2, the exact slide (oracle/fragani_oracle.c, L2 rule 2).  The window at position i of the candidate's contig
   // holds the minimizers of the reference windows [i, i + count_windows): from b = the last minimizer recorded at or
   // before i (still active in window i) to e = the first one recorded at or after i + count_windows.  The slide starts
   // at the first minimizer of the candidate range and ends as soon as e reaches the first minimizer at or past
   // rangeEnd + fragLen (or the contig's end): positions up to i_max = (window id of the minimizer before that) -
-  // count_windows.  A STATE is a maximal run of positions with the same (b, e); per candidate the mapping position is
-  // the mean of the first position of the first and the last position of the last state with the most shared minimizers.
+  // count_windows.  A STATE is a maximal run of positions with the same (b, e); its position is the window id of its first
+  // minimizer b (Mashmap's), and per candidate the mapping position is the mean of the positions of the first and of the
+  // last state with the most shared minimizers.
   // One lane per begin b, as a group of 64 begins is taken up: its states are the ends e from "first minimizer at or
   // after P[b] + count_windows" to "first at or after min(P[b+1] - 1, i_max) + count_windows", usually one or two.  In a
   // round the states of the group's pending begins are spread over the lanes in slide order (up to 64 of them: ITEMS),
@@ -1405,7 +1383,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     if (b_lo >= b_hi) return;
     PA_STAT(2, 1);  // candidates with begins
     int32_t c_best = -1;
-    uint32_t c_first = 0, c_last = 0, c_last_b = 0, c_last_e = 0;  // c_last_b/e: begin and end of the state c_last comes from
+    uint32_t c_first = 0, c_last = 0;
     const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
     // A begin matters only if one of its windows can hold min_shared minimizers of the fragment (less is never reported)
     // and reach the best so far.  The group holding the candidate's first seed hit goes first -- for a true mapping the
@@ -1506,21 +1484,21 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             hi_known = xe_hi < n || at_end;
           }
         }
-        uint32_t f_shared = 0, p_first = 0, p_last = 0;
+        uint32_t f_shared = 0, p_state = 0;  // p_state: the position of the lane's state = the window id of its begin
         bool counted = false;  // the lane holds the exact value of a state (a window found out of reach of the bar is done, but not counted)
         uint32_t taken = 0;
         bool complete = false;  // the begin's last state is behind it
-        // fold the evaluated states into the candidate's optimum: most shared; first position of the first and last
-        // position of the last state that has it (the lanes hold the states in slide order)
-        auto fold_items = [&](uint32_t item_b, uint32_t item_e) {  // the lane's state: minimizers [item_b, item_e)
+        // fold the evaluated states into the candidate's optimum: most shared; position of the first and of the last
+        // state that has it (the lanes hold the states in slide order; the groups of a candidate do not come in that order).
+        // The states that are not evaluated -- reached by taking in a minimizer the fragment does not hold -- share as many
+        // as the state before them or fewer and have that state's begin, hence its position: they change neither.
+        auto fold_items = [&]() {
           const uint64_t dm = __ballot(counted);
           const int32_t group_best = (int32_t)pa_dev::wave_max_dpp(counted ? f_shared + 1u : 0u) - 1;
           if (dm && group_best >= c_best) {
             const uint64_t top_items = __ballot(counted && (int32_t)f_shared == group_best);
-            const int last_lane = 63 - __builtin_clzll(top_items);
-            const uint32_t w_first = __shfl(p_first, __builtin_ctzll(top_items), 64), w_last = __shfl(p_last, last_lane, 64);
-            const uint32_t l_b = __shfl(item_b, last_lane, 64), l_e = __shfl(item_e, last_lane, 64);
-            if (group_best > c_best || w_last > c_last) { c_last = w_last; c_last_b = l_b; c_last_e = l_e; }
+            const uint32_t w_first = __shfl(p_state, __builtin_ctzll(top_items), 64), w_last = __shfl(p_state, 63 - __builtin_clzll(top_items), 64);
+            c_last = group_best > c_best ? w_last : max(c_last, w_last);
             c_first = group_best > c_best ? w_first : min(c_first, w_first);
             c_best = group_best;
           }
@@ -1538,18 +1516,15 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;    // (the rounds keep their bitmap of matching entries there)
             __syncthreads();
             const uint32_t v = eval_window_coop(base, e_abs);
-            const uint32_t w_in = mini_wpos[e_abs - 1u];                                  // the last minimizer the window holds
-            const uint32_t w_out = e_abs < m1 ? mini_wpos[e_abs] : 0xffffffffu;           // the first one past it
             if (lane == first_lane) {
               f_shared = v;
               counted = true;
-              p_first = w_in + 1u > wp0 + count_windows ? w_in + 1u - count_windows : wp0;
-              p_last = min(we0, w_out) - count_windows;
+              p_state = wp0;
               e_next = e_abs + 1u;
             }
           }
           complete = lane == first_lane && e_abs + 1u > e_last;
-          fold_items(base, e_abs);
+          fold_items();
         } else {
           // ---- ranks of the lane's kPer minimizers among the fragment's hashes, for the part of the stretch that some
           // window of the pending begins reaches: the binary searches advance together, one halving step for all of them at
@@ -1672,19 +1647,9 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
               const int src_addr = (int)(min(src, 63u) << 2);
               const uint32_t packed = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)(((b - base) & 0x3ffu) | (xa << 10)));
               const uint32_t off_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)off);
-              const uint32_t wp_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)wp);
-              const uint32_t we_s = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)w_end);
+              p_state = (uint32_t)__builtin_amdgcn_ds_bpermute(src_addr, (int)wp);  // the state's position: its begin's window id
               xs = it_on ? (packed & 0x3ffu) : 0u;                  // the window: stretch entries [xs, xw)
               xw = it_on ? (packed >> 10) + (t - off_s) : 0u;
-              if (it_on) {
-                // the positions the state stands for: from where entry xw - 1 comes in (or the begin becomes active) to where
-                // entry xw would come in (or the next begin becomes active, or the slide ends)
-                uint32_t w_in = sh.ref_w[xw - 1u], w_out = xw < n ? (uint32_t)sh.ref_w[xw] : 0xffffu;
-                w_in = w_in == 0xffffu ? mini_wpos[base + xw - 1u] : wbase + w_in;  // (0xffff: more than 65 534 window ids past the stretch's first)
-                w_out = w_out == 0xffffu ? (base + xw < m1 ? mini_wpos[base + xw] : 0xffffffffu) : wbase + w_out;
-                p_first = w_in + 1u > wp_s + count_windows ? w_in + 1u - count_windows : wp_s;
-                p_last = min(we_s, w_out) - count_windows;
-              }
             };
             item_setup(0u);
           constexpr uint32_t kW = kRefCap / 32u;  // words per half row; stretch position q * 64 + lane is bit (lane & 31) of word 2 q + (lane >> 5)
@@ -1835,7 +1800,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
                 if (now) { f_shared = c; unresolved = false; }
               }
               __syncthreads();
-              fold_items(base + xs, base + xw);
+              fold_items();
             }
           }
         }
@@ -1851,44 +1816,12 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       }
     }
     if (c_best < 0) return;
-    // The mapping position is (first position of the first optimal state + last position of the last one) / 2, and the
-    // last optimal state may be one of the unevaluated states after the last evaluated one (extend_optimum).  The position
-    // decides two things only: the reference bin of the final mapping, and ties between candidates that share equally
-    // many minimizers on one contig.  So the optimum is extended only where the span of positions it could end at
-    // ([c_last, c_lmax]: at most the rest of its begin's states, a dozen window ids) leaves one of the two open.
-    uint32_t c_lmax = c_last, c_we = 0;
-    if (c_best >= floor_bar && c_best >= best_shared && cut != 20) {  // (cut 20..23: timing experiments, results wrong)
-      const uint32_t wp_after = c_last_b + 1u < m1 ? mini_wpos[c_last_b + 1u] : 0xffffffffu;
-      c_we = min(wp_after - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
-      if (c_last + count_windows < c_we) c_lmax = c_we - count_windows;  // the state is not the begin's last
-    }
-    bool take;
-    const uint32_t best_c = sh.scan[kBestC];
-    if (c_best != best_shared) {
-      take = c_best > best_shared;
-    } else if (c != best_c) {
-      take = c < best_c;
-    } else {  // the smaller position wins
-      const uint32_t best_first = sh.scan[kBestFirst], best_lmax = sh.scan[kBestLmax];
-      uint32_t best_last = sh.scan[kBestLast];
-      if ((c_first + c_lmax) / 2u < (best_first + best_last) / 2u) {
-        take = true;
-      } else if ((c_first + c_last) / 2u >= (best_first + best_lmax) / 2u) {
-        take = false;
-      } else {  // the spans overlap: both positions exactly
-        if (c_lmax != c_last) c_last = c_lmax = extend_optimum(c, c_last_b, c_last_e, c_we, c_best, c_last);
-        if (best_lmax != best_last) {
-          best_last = extend_optimum(best_c, sh.scan[kBestEb], sh.scan[kBestEe], sh.scan[kBestWe], best_shared, best_last);
-          __syncthreads();
-          if (lane == 0) sh.scan[kBestLast] = sh.scan[kBestLmax] = best_last;
-        }
-        take = (c_first + c_last) / 2u < (best_first + best_last) / 2u;
-      }
-    }
+    // fastANI keeps every candidate as a mapping, orders a fragment's mappings by identity and lets each overwrite the one
+    // before: of several candidates that share equally many minimizers the LAST one -- the candidates come in (contig,
+    // position) order -- is the fragment's mapping.
     __syncthreads();
-    if (take && lane == 0) {
+    if (c_best >= best_shared && lane == 0) {
       sh.scan[kBestShared] = (uint32_t)c_best; sh.scan[kBestC] = c; sh.scan[kBestFirst] = c_first; sh.scan[kBestLast] = c_last;
-      sh.scan[kBestLmax] = c_lmax; sh.scan[kBestEb] = c_last_b; sh.scan[kBestEe] = c_last_e; sh.scan[kBestWe] = c_we;
     }
     __syncthreads();
   };
@@ -1995,47 +1928,48 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
 
   __syncthreads();
   const int32_t best_shared = (int32_t)sh.scan[kBestShared];
-  if (best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s]) {
-    const uint32_t best_c = sh.scan[kBestC], best_first = sh.scan[kBestFirst], best_lmax = sh.scan[kBestLmax];
-    uint32_t best_last = sh.scan[kBestLast];
-    // fastANI buckets the reference by fragLen - 20; the optimum is extended when that could move the mapping to the next bin
-    if ((best_first + best_last) / 2u / (frag_len - 20u) != (best_first + best_lmax) / 2u / (frag_len - 20u))
-      best_last = extend_optimum(best_c, sh.scan[kBestEb], sh.scan[kBestEe], sh.scan[kBestWe], best_shared, best_last);
-    if (lane == 0) {
-      const uint64_t jq = ((uint64_t)best_shared << 30) / s;
-      const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
-      const uint64_t bin = contig_bin_off[best_c] + (best_first + best_last) / 2u / (frag_len - 20u);
-      atomicMax(&table[(uint64_t)frag_genome_local[f] * table_stride + bin], packed);
-    }
+  if (lane == 0 && best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s]) {
+    // fastANI buckets the reference by fragLen - 20
+    const uint64_t jq = ((uint64_t)best_shared << 30) / s;
+    const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
+    const uint64_t bin = contig_bin_off[sh.scan[kBestC]] + (sh.scan[kBestFirst] + sh.scan[kBestLast]) / 2u / (frag_len - 20u);
+    atomicMax(&table[(uint64_t)frag_genome_local[f] * table_stride + bin], packed);
   }
 }
 
 // ============================================================== 5. per-pair reduction
-// one wave per (query of the batch, reference genome): kept fragments and the sum of their identities
+// One wave per (query of the batch, reference genome): kept fragments and the sum of their identities.  fastANI holds the
+// identities as floats and adds them up in a float, in (contig, bin) order; a float sum depends on its order, so the wave
+// adds in exactly that order: 64 bins per load, then one addition per kept bin through a scalar loop over the wave.
 __global__ __launch_bounds__(64) void reduce_pairs_kernel(const unsigned long long *__restrict__ table,
                                                           uint64_t table_stride,
                                                           const uint32_t *__restrict__ genome_bin_off,
-                                                          uint32_t n_genomes, const double *__restrict__ ident_tab,
+                                                          uint32_t n_genomes, const float *__restrict__ ident_tab,
                                                           uint32_t *__restrict__ matched, double *__restrict__ ident_sum) {
   const uint32_t lane = threadIdx.x;
   const uint32_t q = blockIdx.x / n_genomes, r = blockIdx.x % n_genomes;
   const uint32_t b0 = genome_bin_off[r], b1 = genome_bin_off[r + 1];
   uint32_t cnt = 0;
-  double sum = 0.0;
-  for (uint32_t bidx = b0 + lane; bidx < b1; bidx += 64) {
-    const unsigned long long v = table[(uint64_t)q * table_stride + bidx];
+  float sum = 0.0f;
+  for (uint32_t base = b0; base < b1; base += 64) {
+    const uint32_t bidx = base + lane;
+    const unsigned long long v = bidx < b1 ? table[(uint64_t)q * table_stride + bidx] : 0ull;
+    float id = 0.0f;
     if (v) {
       const uint32_t shared = (uint32_t)(v >> 16) & 0xffffu, s = (uint32_t)v & 0xffffu;
-      sum += ident_tab[(uint64_t)s * (kQMax + 1) + shared];
-      ++cnt;
+      id = ident_tab[(uint64_t)s * (kQMax + 1) + shared];
+    }
+    uint64_t kept = __ballot(v != 0ull);
+    cnt += (uint32_t)__popcll(kept);
+    while (kept) {
+      const int l = __builtin_ctzll(kept);
+      kept &= kept - 1;
+      sum = __fadd_rn(sum, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, id), l)));
     }
   }
-  cnt = wave_sum(cnt);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
   if (lane == 0) {
     matched[(uint64_t)q * n_genomes + r] = cnt;
-    ident_sum[(uint64_t)q * n_genomes + r] = sum;
+    ident_sum[(uint64_t)q * n_genomes + r] = (double)sum;
   }
 }
 
@@ -2172,8 +2106,16 @@ int pa_fragani_tables(uint32_t k, uint32_t s_max, uint32_t *h_min_hits, uint32_t
   return PA_OK;
 }
 
+// fastANI holds the Jaccard estimate, the Mash distance and the identity as floats (Mashmap's j2md takes and returns a
+// float, and nucIdentity = 100 * (1 - mash_dist) is float arithmetic): the value here is that float, widened.
 double pa_fragani_identity(uint32_t shared, uint32_t s, uint32_t k) {
-  return s ? 100.0 * (1.0 - j2md((double)shared / s, (int)k)) : 0.0;
+  if (!s) return 0.0;
+  const float j = (float)(1.0 * shared / s);
+  float d;
+  if (j == 0) d = 1.0f;
+  else if (j == 1) d = 0.0f;
+  else d = (float)((-1.0 / (int)k) * std::log(2.0 * j / (1 + j)));
+  return (double)(100 * (1 - d));
 }
 
 int pa_fragani_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
@@ -2340,9 +2282,9 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   {
     std::vector<uint32_t> mh(kQMax + 1), ms(kQMax + 1);
     PA_TRY(pa_fragani_tables(k, kQMax, mh.data(), ms.data()));
-    std::vector<double> ident((uint64_t)(kQMax + 1) * (kQMax + 1), 0.0);
+    std::vector<float> ident((uint64_t)(kQMax + 1) * (kQMax + 1), 0.0f);
     for (uint32_t s = 1; s <= (uint32_t)kQMax; ++s)
-      for (uint32_t x = 0; x <= s; ++x) ident[(uint64_t)s * (kQMax + 1) + x] = pa_fragani_identity(x, s, k);
+      for (uint32_t x = 0; x <= s; ++x) ident[(uint64_t)s * (kQMax + 1) + x] = (float)pa_fragani_identity(x, s, k);
     PA_TRY(upload(c, W.tab_min_hits, mh));
     PA_TRY(upload(c, W.tab_min_shared, ms));
     PA_TRY(upload(c, W.ident_tab, ident));
@@ -2635,7 +2577,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_TRY(W.ident_sum.reserve((uint64_t)nq * n_genomes * 8));
     hipLaunchKernelGGL(reduce_pairs_kernel, dim3(nq * n_genomes), dim3(64), 0, c->stream,
                        W.table.as<unsigned long long>(), total_bins, W.genome_bin_off.as<uint32_t>(), n_genomes,
-                       W.ident_tab.as<double>(), W.matched.as<uint32_t>(), W.ident_sum.as<double>());
+                       W.ident_tab.as<float>(), W.matched.as<uint32_t>(), W.ident_sum.as<double>());
     PA_HIP(hipGetLastError());
     prof.reset();
     if (out_cols == n_genomes) {

@@ -19,8 +19,9 @@ Where the reference runs ``fastANI --ql <queries> -r <subject> -o out --fragLen 
     sim_errors = total - matched
     cov_query  = matched / total
 
-Parity with fastANI itself is tolerance-only (oracle/fragani_oracle.c; the tolerance on the reference's 25
-fixture rows is stated in tests/test_fragani_oracle.py and DESIGN.md 4.5).
+Parity with fastANI itself: every value the reference holds -- its 25 fixture rows and the pins of its tests -- comes
+out exactly, the identity to the six digits fastANI prints (oracle/fragani_oracle.c, tests/test_fragani_oracle.py,
+DESIGN.md 2 and 4.5).
 """
 
 from __future__ import annotations
@@ -50,6 +51,15 @@ def fastani_print_round(ani_percent: float) -> float:
     (``82.9124``, ``99.9953``, ``100``).  The reference parses that text (pyani_plus/methods/fastani.py:98-120),
     so the stored identity carries exactly those digits."""
     return float(f"{ani_percent:.6g}")
+
+
+def fastani_mean(ident_sum, matched):
+    """The ANI of a pair as fastANI computes it: the float sum of the kept fragments' identities (``ident_sum`` holds that
+    float, widened) divided by their number IN FLOAT.  NaN where nothing was kept."""
+    ident_sum, matched = np.asarray(ident_sum), np.asarray(matched)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mean = ident_sum.astype(np.float32) / matched.astype(np.float32)
+    return np.where(matched > 0, mean.astype(np.float64), np.nan)
 
 
 def mappable_lengths(contig_len, contig_genome, n_genomes: int, fragsize: int) -> np.ndarray:
@@ -86,7 +96,7 @@ def fragment_ani_matrices(fasta_files: list[Path], *, kmersize: int, fragsize: i
     arena, dev = load_genomes_for_fragani(fasta_files, eng)
     total, matched, ident_sum = eng.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, kmersize, fragsize, ref_range=ref_range)
     with np.errstate(invalid="ignore", divide="ignore"):
-        ani = np.where(matched > 0, ident_sum / np.maximum(matched, 1), np.nan)
+        ani = fastani_mean(ident_sum, matched)
     return total, matched, ani, mappable_lengths(arena.contig_len, arena.contig_genome, arena.n_genomes, fragsize)
 
 
@@ -127,7 +137,7 @@ def comparison_block(total, matched, ident_sum, lengths, rows, cols, fragsize: i
     shorter = np.minimum(lengths[rows].astype(np.int64)[:, None], lengths[cols].astype(np.int64)[None, :])
     reported = (frags > 0) & (m > 0) & (m * int(fragsize) >= float(minmatch) * shorter)
     with np.errstate(invalid="ignore", divide="ignore"):
-        ani = np.where(m > 0, ident_sum[np.ix_(rows, cols - col0)] / np.maximum(m, 1), np.nan)
+        ani = fastani_mean(ident_sum[np.ix_(rows, cols - col0)], m)
         cov = np.where(reported, m / np.maximum(frags, 1), np.nan)
     identity = np.where(reported, round_sig6(np.where(reported, ani, np.nan)) / 100.0, np.nan)
     aln = np.where(reported, int(fragsize) * m, 0)

@@ -48,6 +48,13 @@ def _random_genomes(seed: int):
     return texts, contig_lists
 
 
+def mean_f(ident_sum, matched) -> float:
+    """the pair's ANI as fastANI computes it: float sum / float count (pyani_plus_amd.methods.fastani_hip.fastani_mean)"""
+    from pyani_plus_amd.methods.fastani_hip import fastani_mean
+
+    return float(fastani_mean(ident_sum, matched))
+
+
 def test_parameters_match_oracle(engine):
     from pyani_plus_amd import _capi
 
@@ -117,7 +124,7 @@ def _check_against_oracle(engine, texts, contig_lists, frag=FRAG, k=K):
             assert total[q] == t
             assert matched[q, r] == m, (q, r, matched[q, r], m)
             if m:
-                assert abs(ident_sum[q, r] / m - ani) <= 1e-9 * ani  # same doubles, summation order differs
+                assert mean_f(ident_sum[q, r], m) == ani  # the same float sum in the same order, the same float division
             else:
                 assert math.isnan(ani) and ident_sum[q, r] == 0.0
     return total, matched, ident_sum
@@ -260,7 +267,7 @@ def test_whole_batch_sort_with_unlisted_pairs(engine, monkeypatch):
                         continue
                     assert matched[q, r] == m, (sort_max, ref_range, q, r, matched[q, r], m)
                     if m:
-                        assert abs(ident_sum[q, r] / m - ani) <= 1e-9 * ani
+                        assert mean_f(ident_sum[q, r], m) == ani
     assert want[1, 1][1] > 0 and want[2, 1][1] > 0 and want[0, 1][1] == 0
 
 
@@ -298,11 +305,11 @@ def test_viral_fixture_rows(engine):
     for q, r, ani, m, t in fixture_rows("viral_example"):
         qi, ri = names.index(q), names.index(r)
         assert total[qi] == t and int(matched[qi, ri]) == m
-        assert printed(ident_sum[qi, ri] / matched[qi, ri]) == ani, (q, r)  # as fastANI prints it: six significant digits
+        assert printed(mean_f(ident_sum[qi, ri], matched[qi, ri])) == ani, (q, r)  # as fastANI prints it: six significant digits
 
 
 def test_bacterial_fixture_rows(engine):
-    """All 16 bacterial fastANI rows on the GPU (the CPU oracle is only asked for two pairs here)."""
+    """All 16 bacterial fastANI rows on the GPU, each exactly as fastANI wrote it (the CPU oracle is only asked for two pairs here)."""
     from pyani_plus_amd.engine import load_fasta_files
 
     files = sorted((GOLDEN / "bacterial_example").glob("*.gz"))
@@ -311,10 +318,10 @@ def test_bacterial_fixture_rows(engine):
     names = [p.name for p in files]
     for q, r, ani, m, t in fixture_rows("bacterial_example"):
         qi, ri = names.index(q), names.index(r)
-        bacterial_row_bounds(q, r, ani, m, t, ident_sum[qi, ri] / matched[qi, ri], int(matched[qi, ri]), int(total[qi]))
+        bacterial_row_bounds(q, r, ani, m, t, mean_f(ident_sum[qi, ri], matched[qi, ri]), int(matched[qi, ri]), int(total[qi]))
     for qi, ri in ((1, 0), (0, 2)):
         ani, m, t = oracle.fragani_pair(contigs_of(files[qi]), contigs_of(files[ri]), K, FRAG, 0.0)
-        assert matched[qi, ri] == m and abs(ident_sum[qi, ri] / m - ani) <= 1e-9 * ani
+        assert matched[qi, ri] == m and mean_f(ident_sum[qi, ri], m) == ani
 
 
 def test_plugin_column_matches_reference_matrices(engine, tmp_path):
