@@ -501,7 +501,9 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
             engine.prof_reset()
     sec = min(times[1:])
     prof = engine.prof_get()
-    ani = np.where(matched > 0, ident_sum / np.maximum(matched, 1), np.nan)
+    from pyani_plus_amd.methods.fastani_hip import fastani_mean
+
+    ani = fastani_mean(ident_sum, matched)  # fastANI's own mean: a float sum by a float count
     # against itself a genome keeps (nearly) every fragment: fastANI's own self rows read 1820/1825, 1346/1347, ...,
     # because fragments can compete for one reference bucket of fragLen - 20 positions
     if not np.all(np.diag(matched) >= 0.99 * total):

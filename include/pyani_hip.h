@@ -256,11 +256,12 @@ PA_API int pa_ani_mash(pa_ctx *ctx, const uint32_t *d_common, const uint32_t *d_
  * h_contig_genome[i] = owning genome, in arena order (pa_fasta_records / the packers' layout).
  * Outputs (host): h_total_frags[g] = sum over g's contigs of floor(len/fragLen) (the last column of a
  * fastANI line); h_matched[q*n+r] = kept (orthologous) fragments, h_ident_sum[q*n+r] = sum of their
- * identities in percent, so ANI(q,r) = sum/matched, reported by fastANI when matched/total >= minFraction
- * (pyani_plus/methods/fastani.py:98-120 parses exactly these three numbers).
+ * identities in percent -- fastANI's own sum: float identities added in a float in (contig, bin) order, widened to
+ * double here --, so ANI(q,r) = (float)sum / (float)matched IN FLOAT is the number fastANI prints, reported when
+ * matched/total >= minFraction (pyani_plus/methods/fastani.py:98-120 parses exactly these three numbers).
  * Only the reference genomes [ref0, ref1) are mapped against (columns outside stay 0): the reference's worker is
  * called once per subject column (pyani_plus/private_cli.py:976-1063), and a column costs one column's mappings.
- * Algorithm and its tolerance-only parity: oracle/fragani_oracle.c.  k from 8 to 16 (fastANI itself stops at 16); fragLen in
+ * Algorithm and its parity (every fastANI value the reference holds, exactly): oracle/fragani_oracle.c.  k from 8 to 16 (fastANI itself stops at 16); fragLen in
  * [100, 65535]; contigs listed genome by genome, at most 65535 per genome and 2^20-1 in all; at most 2^20-1
  * fragments per genome.  The workspace (about 12 GB for 1000 x 5 Mb genomes) stays in the context. */
 PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,

@@ -3,8 +3,9 @@
 // Replaces one `fastANI --ql queries -r subject --fragLen F -k K --minFraction M` process per
 // subject column (pyani_plus/private_cli.py:1044-1063) by an all-vs-all device pipeline.  The
 // algorithm is the restatement pinned in oracle/fragani_oracle.c (published fastANI / Mashmap
-// method; tolerance-only parity with the reference's 25 fixture rows); every integer this file
-// produces (minimizers, per-fragment shared counts, kept fragments) equals the oracle's.
+// method; it reproduces the reference's 25 fixture rows and test pins exactly); every number this
+// file produces (minimizers, per-fragment shared counts, kept fragments, the float sums of the
+// identities) equals the oracle's.
 //
 //   1. minimizer_kernel   both-strand 32-bit murmur of every K-mer (first multiply by LDS table,
 //                         as in kmer_hash.hip), winnowing minimum over w positions from an LDS tile,
@@ -16,10 +17,11 @@
 //   4. seed hits           every posting of every sketch hash -> (fragment, ref contig, window id),
 //                         bucketed by reference genome; one wave per (fragment, reference genome)
 //                         segment then orders its hits in registers, applies the L1 run test and
-//                         evaluates the winnowed-MinHash Jaccard at the window starts the hits imply
-//                         (bit tables over query rank x reference position in LDS, no per-window sort)
+//                         slides the fragment over every candidate range: the winnowed-MinHash Jaccard
+//                         of every window that could be the optimum (bit tables over query rank x
+//                         reference position in LDS, no per-window sort); of equally good candidates the last
 //   5. one best fragment per reference bin by atomicMax on (J, shared, s); per pair the kept
-//      fragments and the sum of their identities.
+//      fragments and the float sum of their float identities in bin order (fastANI's arithmetic).
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>

@@ -109,8 +109,22 @@ class OracleEngine:
                 assert t == total[q]
                 if m:
                     matched[q, r - c0] = m
-                    ident_sum[q, r - c0] = ani * m
+                    ident_sum[q, r - c0] = _float_sum_with_mean(ani, m)
         return total, matched, ident_sum
+
+
+def _float_sum_with_mean(ani: float, m: int) -> float:
+    """A float whose float quotient by ``m`` is the oracle's (float) mean: what the library's ``ident_sum`` holds."""
+    want, mf = np.float32(ani), np.float32(m)
+    guess = want * mf
+    up = down = guess
+    for _ in range(4):  # (the oracle's mean IS such a quotient: the sum is within a few float steps of mean x count)
+        if up / mf == want:
+            return float(up)
+        if down / mf == want:
+            return float(down)
+        up, down = np.nextafter(up, np.float32(np.inf)), np.nextafter(down, np.float32(-np.inf))
+    return float(guess)
 
 
 class SlowOracleEngine(OracleEngine):

@@ -9,8 +9,9 @@ path (``rundb.run_fastani_hip`` -> ``compute_fastani_hip`` -> JSON column -> dat
 
 fastANI itself is a third-party binary whose source is not in the reference tree; with the exact slide of round 4
  the MIBY pins are reproduced EXACTLY -- identities equal to the reference's constants, coverage
-fractions, fragment totals and the NULL pattern too --; the bacterial proxy matrices within 0.075 percentage points
-and 1 % of the fragments (the distant pairs; the self and 99.99 % pairs are exact or one fragment off).
+fractions, fragment totals and the NULL pattern too --; and with the last three choices settled (position of a window,
+the last of equally good candidates, float sums) the bacterial proxy matrices are exact as well: every aln_length, every
+sim_errors, identity x coverage to the digits the matrix file holds.
 
 Each check runs twice: on the CPU with the oracle-backed stand-in engine, and (``-m gpu``) on the device.
 """
@@ -106,10 +107,10 @@ def _bacterial_column_checks(rows, labels, want, stems, columns, total_frags):
             continue
         t = total_frags[stems[q]]
         assert e["aln_length"] % 3000 == 0
-        assert abs(e["aln_length"] - aln[qi, si]) <= 3000 * 0.01 * t + 1e-9, (stems[q], stems[s], e["aln_length"], aln[qi, si])
-        assert abs(e["sim_errors"] - err[qi, si]) <= 0.01 * t + 1e-9, (stems[q], stems[s])
+        assert e["aln_length"] == aln[qi, si], (stems[q], stems[s], e["aln_length"], aln[qi, si])
+        assert e["sim_errors"] == err[qi, si], (stems[q], stems[s])
         assert e["aln_length"] // 3000 + e["sim_errors"] == t  # matched + unmatched = all fragments, exactly
-        assert abs(e["identity"] * e["cov_query"] - had[qi, si]) <= 0.00075 + 0.01, (stems[q], stems[s])
+        assert abs(e["identity"] * e["cov_query"] - had[qi, si]) <= 1e-9, (stems[q], stems[s], e["identity"] * e["cov_query"], had[qi, si])
 
 
 def test_bacterial_proxy_matrices(engine, tmp_path):

@@ -1,5 +1,5 @@
 """GPU: the fastANI-style fragment-ANI path against its oracle (exact integers) and, through the
-oracle, against the reference's fastANI fixtures (stated tolerance, tests/test_fragani_oracle.py)."""
+oracle, against the reference's fastANI fixtures (every row exactly as fastANI wrote it, tests/test_fragani_oracle.py)."""
 
 from __future__ import annotations
 
@@ -326,7 +326,7 @@ def test_bacterial_fixture_rows(engine):
 
 def test_plugin_column_matches_reference_matrices(engine, tmp_path):
     """compute_fastani_hip -> JSON column vs the reference's fastANI matrices for the viral set
-    (identity within the ANI tolerance, aln_length / sim_errors / cov_query from kept fragments)."""
+    (identity to the digits the matrix file holds, aln_length / sim_errors / cov_query from kept fragments)."""
     import json
     import logging
 

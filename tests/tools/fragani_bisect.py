@@ -22,18 +22,24 @@ from tests.helpers import GOLDEN, read_fasta_bytes  # noqa: E402
 
 K, FRAG = 16, 3000
 
+OLD = {"tie": 0, "float": 0}  # rounds 1-3 and the first half of round 4: the first of equally good candidates, double sums
 VARIANTS = {
-    "round 1: seed-implied starts, sketch list 10,60,.., bins (pos+L/2)/L": {"window_rule": 0, "bin_rule": 0, "l2_rule": 0},
-    "seed-implied starts, window 24, bins pos/(L-20)": {"l2_rule": 0},
-    "rounds 2-3: slide over reference minimizer starts": {"l2_rule": 1},
-    "exact slide, ends with the window's end; position = first minimizer": {"l2_rule": 2, "l2_pos": 0, "l2_stop": 0},
-    "ADOPTED: exact slide, ends with the window's end; position = the positions a state stands for": {"l2_rule": 2, "l2_pos": 1, "l2_stop": 0},
-    "exact slide, ends with the window's end; position = where the slide arrives at a state": {"l2_rule": 2, "l2_pos": 2, "l2_stop": 0},
-    "exact slide, ends with the window's end or past rangeEnd; position = first minimizer": {"l2_rule": 2, "l2_pos": 0, "l2_stop": 1},
-    "exact slide, ends past rangeEnd only; position = first minimizer": {"l2_rule": 2, "l2_pos": 0, "l2_stop": 2},
-    "exact slide, ends with the window's end; position = first minimizer; confidence 0.75": {"l2_rule": 2, "l2_pos": 0, "conf": 0.75},
+    "round 1: seed-implied starts, sketch list 10,60,.., bins (pos+L/2)/L": {"window_rule": 0, "bin_rule": 0, "l2_rule": 0, **OLD},
+    "seed-implied starts, window 24, bins pos/(L-20)": {"l2_rule": 0, **OLD},
+    "rounds 2-3: slide over reference minimizer starts": {"l2_rule": 1, **OLD},
+    "exact slide; position = first minimizer; first candidate on ties; double sums": {"l2_pos": 0, **OLD},
+    "exact slide; position = the positions a state stands for; first candidate on ties; double sums (round 4, first half)": {"l2_pos": 1, **OLD},
+    "exact slide; position = where the slide arrives at a state; first candidate on ties; double sums": {"l2_pos": 2, **OLD},
+    "exact slide, ends with the window's end or past rangeEnd; first candidate on ties; double sums": {"l2_stop": 1, **OLD},
+    "exact slide, ends past rangeEnd only; first candidate on ties; double sums": {"l2_stop": 2, **OLD},
+    "exact slide; confidence 0.75; first candidate on ties; double sums": {"conf": 0.75, **OLD},
+    "exact slide; position = the positions a state stands for; LAST candidate on ties; double sums": {"l2_pos": 1, "tie": 1, "float": 0},
+    "exact slide; position = first minimizer; LAST candidate on ties; double sums": {"tie": 1, "float": 0},
+    "exact slide; position = first minimizer; the candidate libstdc++'s std::sort leaves last; float sums": {"tie": 2},
+    "exact slide; position = first minimizer; last candidate on ties; float sums; Mashmap's frequency cut of the seeds": {"freq": 1},
+    "ADOPTED: exact slide; position = first minimizer; LAST candidate on ties; float identities summed in float": {},
 }
-DEFAULTS = {"window_rule": 1, "bin_rule": 1, "l2_rule": 2, "conf": 0.9, "l2_pos": 1, "l2_stop": 0}
+DEFAULTS = {"window_rule": 1, "bin_rule": 1, "l2_rule": 2, "conf": 0.9, "l2_pos": 0, "l2_stop": 0, "tie": 1, "freq": 0, "float": 1}
 
 
 def contigs_of(path):
@@ -116,6 +122,7 @@ def main():
             say(f"* all rows: max |dANI| {max(abs(x[2]) for x in res):.4f}, mean {sum(abs(x[2]) for x in res) / len(res):.4f}; "
                 f"max |d matched| / total {max(abs(x[3]) / x[4] for x in res) * 100:.2f} %, mean "
                 f"{sum(abs(x[3]) / x[4] for x in res) / len(res) * 100:.2f} %; totals exact: {all(x[5] for x in res)}")
+            say(f"* rows exactly as fastANI wrote them (identity as printed, kept, total): {sum(1 for x in res if x[2] == 0.0 and x[3] == 0 and x[5])} of {len(res)}")
             say(f"* self rows: {sum(1 for x in self_rows if x[2] == 0.0)} of {len(self_rows)} print as fastANI's; signed dANI "
                 + ", ".join(f"{x[2]:+.4f}" for x in self_rows))
             say(f"* other rows: mean signed dANI {sum(x[2] for x in other) / max(1, len(other)):+.4f}")

@@ -38,7 +38,9 @@ for rep in range(2):
     total, matched, ident_sum = eng.fragani(arena, starts, lens, genome, k, frag, query_range=(0, n_query))
     dt = time.perf_counter() - t0
     print(f"rep {rep}: {n_query}x{n} pairs in {dt:.3f} s -> {n_query * n / dt:.3e} pairs/s", {k: round(v[0], 1) for k, v in eng.prof_get().items() if k.startswith("frag")}, flush=True)
-ani = np.where(matched > 0, ident_sum / np.maximum(matched, 1), np.nan)
+from pyani_plus_amd.methods.fastani_hip import fastani_mean  # noqa: E402
+
+ani = fastani_mean(ident_sum, matched)
 related = ~np.isnan(ani)
 print("fragments per genome", int(total[0]), "pairs with mappings", int(related.sum()), "ANI range", float(np.nanmin(ani)), float(np.nanmax(ani)))
 assert np.all(np.diag(matched)[:n_query] >= 0.99 * total[:n_query])
