@@ -1802,6 +1802,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
                 if (now) { f_shared = c; unresolved = false; }
               }
               __syncthreads();
+              PA_STAT(14, __popcll(__ballot(counted)));  // windows whose exact value was found
+              PA_STAT(15, __popcll(__ballot(counted && (int32_t)f_shared >= max(max(c_best, best_shared), floor_bar))));  // ... at or above the bar
               fold_items();
             }
           }
@@ -2570,8 +2572,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         PA_HIP(hipMemcpy(st, W.run_g.p, 64, hipMemcpyDeviceToHost));
         fprintf(stderr, "pa_fragani: map stats: %u segments at L1 with %u hits, %u candidates, %u groups, %u begins past the bound, "
                         "%u rounds, %u stretch entries, %u windows evaluated, %u fine passes, %u cooperative, %u begins in rounds, "
-                        "%u begins finished, %u rounds without items, %u second passes, %u states evaluated after the optimum\n",
-                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14]);
+                        "%u begins finished, %u rounds without items, %u second passes, %u windows with an exact value, %u of them at or above the bar\n",
+                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15]);
       }
 #endif
     }
