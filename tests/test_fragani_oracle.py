@@ -160,3 +160,19 @@ def test_min_fraction_and_unrelated_genomes():
     ani, m, t = oracle.fragani_pair([a + c], [a], min_fraction=0.2)  # 10 of 100 fragments, but all of the 30 kb reference
     assert t == 100 and m == 10 and ani > 99.9
     assert oracle.fragani_pair([a[:2999]], [a])[2] == 0  # shorter than one fragment
+
+
+def test_fastani_mean_is_a_float_quotient():
+    """Where the product forms a pair's ANI (methods/fastani_hip.fastani_mean): the library's float sum by the float count,
+    in float -- the oracle's own mean, so that the six printed digits are fastANI's."""
+    from pyani_plus_amd.methods.fastani_hip import fastani_mean, fastani_print_round
+
+    small = contigs_of(GOLDEN / "MIBY01000011.fasta")
+    ani, m, _t = oracle.fragani_pair(small, small, K, FRAG, 0.2)
+    maps, _ = oracle.fragani_map(small, small, K, FRAG)
+    total = np.float32(0)
+    for shared, s_ in zip(maps["shared"], maps["s"]):  # (one contig: fragment order is bin order)
+        total = total + np.float32(oracle.fragani_identity(int(shared), int(s_), K))
+    assert float(fastani_mean(float(total), m)) == ani and fastani_print_round(ani) == 99.9953
+    got = fastani_mean(np.array([[float(total), 0.0]]), np.array([[m, 0]], dtype=np.uint32))
+    assert got.shape == (1, 2) and got[0, 0] == ani and np.isnan(got[0, 1])
