@@ -12,7 +12,11 @@
  *   reference sketch : winnowed minimizers; k-mer hash = min over both strands of the low 32 bits of
  *                      MurmurHash3_x64_128(seed 42); window w from the p-value bound below
  *   query            : non-overlapping fragments of fragLen per contig (remainder dropped)
- *   L1               : reference ranges holding >= m shared minimizers within fragLen
+ *   seeds            : every reference occurrence of every minimizer of the fragment -- but for the most frequent
+ *                      reference minimizers (Mashmap's cut: as many bars of the histogram of occurrence counts, from
+ *                      the top, as stay within 0.001 % of the distinct minimizers; fastANI logs "ignore minimizers
+ *                      occurring >= N times during lookup")
+ *   L1               : reference ranges holding >= m seed hits within fragLen
  *   L2               : winnowed-MinHash Jaccard J of the fragment against a fragment-sized reference
  *                      window, slid over EVERY position of the candidate range: the window at position i
  *                      holds the minimizers of the reference windows [i, i + count_windows) -- the one
@@ -35,9 +39,9 @@
  * (tests/tools/fragani_bisect.py scores every variant against the rows and pins: profiles/r04_fragani_bisect.md).  With
  * the defaults -- what the HIP path implements bit for bit -- ALL 25 rows (identity as printed, six significant digits;
  * kept fragments; total fragments), MIBY01000005 == 100, MIBY01000011 == 99.9953 and the k = 15 matrices come out exactly
- * as fastANI wrote them.  tests/test_fragani_oracle.py asserts exactly that.  Not pinned by any of those values, and
- * switched off: Mashmap's cut of the 0.001 % most frequent minimizers from the seed look-up (OPT_FREQ; it changes none
- * of the 25 rows).
+ * as fastANI wrote them.  tests/test_fragani_oracle.py asserts exactly that.  Not pinned by any of those values --
+ * it changes none of the 25 rows -- and applied because fastANI does: the frequency cut of the seeds (OPT_FREQ; the
+ * bacterial fixtures lose the seeds of 2 to 4 minimizers each: thresholds 26, 56, 26 and 21 occurrences).
  */
 #include <math.h>
 #ifdef _OPENMP
@@ -72,8 +76,9 @@ static double g_opt[OPT_COUNT] = {
                                   lowest position) is the fragment's mapping; 1 = the last one; 2 = the one that fastANI's
                                   `std::sort by (fragment, identity)`, then `the last of a fragment's run`, ends up with: libstdc++'s
                                   introsort restated below, run over every kept candidate of the query genome in the order fastANI emits them */
-    0.0, /* OPT_FREQ:        seed hits: 0 = every reference occurrence of a query minimizer; 1 = Mashmap's frequency cut: occurrences of the
-                                  0.001 % most frequent reference minimizers are not looked up */
+    1.0, /* OPT_FREQ:        seed hits: 0 = every reference occurrence of a query minimizer; 1 = Mashmap's frequency cut: occurrences of the
+                                  0.001 % most frequent reference minimizers are not looked up (fastANI logs the threshold it finds: "ignore
+                                  minimizers occurring >= N times during lookup") */
     1.0, /* OPT_FLOAT:       0 = identities and their mean in double; 1 = in float, as fastANI holds them (float Jaccard, float Mash distance,
                                   float identity, float running sum in (contig, bin) order) */
 };

@@ -488,6 +488,81 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
   }
 }
 
+// ---- Mashmap's frequency cut of the seed look-up (fastANI logs it: "ignore minimizers occurring >= N times during
+// lookup").  The reference sketch of a fastANI process is ONE genome; the minimizers it holds are counted per hash, and
+// the most frequent ones -- as many bars of the histogram of counts, from the top, as stay within 0.001 % of the distinct
+// minimizers -- give no seed hits.  Here the postings of a hash are ordered by arena position, so the occurrences of a
+// hash in one genome are a RUN of its list: a run of c >= 2 is counted into its genome's histogram (c >= kFreqBins - 1:
+// listed exactly instead), the host walks the histograms (a few KB per genome), and the runs at or above their genome's
+// threshold are taken out of the posting lists -- everything after the index sees lists that never held them.  The
+// minimizers themselves stay where they are: the L2 windows hold every minimizer, as fastANI's do.
+constexpr uint32_t kFreqBins = 256;
+__device__ __forceinline__ uint32_t posting_run_length(const uint32_t *__restrict__ heads, const uint16_t *__restrict__ post_genome,
+                                                       uint32_t i, uint32_t m) {
+  const uint16_t g = post_genome[i];
+  uint32_t j = i + 1;
+  while (j < m && !heads[j] && post_genome[j] == g) ++j;
+  return j - i;
+}
+__global__ __launch_bounds__(kThreads) void posting_run_hist_kernel(const uint32_t *__restrict__ heads,
+                                                                    const uint16_t *__restrict__ post_genome, uint32_t m,
+                                                                    uint32_t *__restrict__ hist /* [genomes][kFreqBins] */,
+                                                                    uint32_t *__restrict__ dups /* [genomes] */,
+                                                                    uint2 *__restrict__ over, uint32_t over_cap,
+                                                                    uint32_t *__restrict__ over_n) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= m) return;
+  const uint16_t g = post_genome[i];
+  if (!heads[i] && post_genome[i - 1] == g) return;  // inside a run
+  if (i + 1 >= m || heads[i + 1] || post_genome[i + 1] != g) return;  // a run of one: the common case, counted by difference
+  const uint32_t c = posting_run_length(heads, post_genome, i, m);
+  atomicAdd(&dups[g], c - 1u);
+  if (c < kFreqBins - 1u) {
+    atomicAdd(&hist[(uint64_t)g * kFreqBins + c], 1u);
+  } else {
+    atomicAdd(&hist[(uint64_t)g * kFreqBins + kFreqBins - 1u], 1u);
+    const uint32_t at = atomicAdd(over_n, 1u);
+    if (at < over_cap) over[at] = make_uint2(g, c);
+  }
+}
+// keep[] (all ones on entry) = 0 for the postings of runs at or above their genome's threshold: the thread of a run's first
+// posting measures the run and, where it is cut, clears its flags (one thread per run: a run costs its length once)
+__global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint32_t *__restrict__ heads,
+                                                                     const uint32_t *__restrict__ ids_before,
+                                                                     const uint16_t *__restrict__ post_genome, uint32_t m,
+                                                                     const uint32_t *__restrict__ threshold,
+                                                                     uint32_t *__restrict__ keep, uint8_t *__restrict__ hash_cut) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= m) return;
+  const uint16_t g = post_genome[i];
+  if (!heads[i] && post_genome[i - 1] == g) return;  // inside a run
+  const uint32_t thr = threshold[g];
+  if (thr == 0xffffffffu) return;
+  const uint32_t c = posting_run_length(heads, post_genome, i, m);
+  if (c >= thr) {
+    for (uint32_t j = i; j < i + c; ++j) keep[j] = 0u;
+    // the hash (dense id: hashes before this posting's, plus one where it is its hash's first) has lost seed hits somewhere:
+    // its matches in an L2 window are no longer all among the seed hits (the mapping kernel's bounds allow for them)
+    uint32_t first = i;
+    while (!heads[first]) --first;
+    hash_cut[ids_before[first]] = 1;
+  }
+}
+__global__ __launch_bounds__(kThreads) void posting_compact_kernel(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ at,
+                                                                   const uint64_t *__restrict__ post_cw,
+                                                                   const uint16_t *__restrict__ post_genome, uint32_t m,
+                                                                   uint64_t *__restrict__ cw_out, uint16_t *__restrict__ g_out) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < m && keep[i]) { cw_out[at[i]] = post_cw[i]; g_out[at[i]] = post_genome[i]; }
+}
+__global__ __launch_bounds__(kThreads) void posting_starts_kernel(uint32_t *__restrict__ post_start, uint32_t n_ids,
+                                                                  const uint32_t *__restrict__ at, uint32_t m, uint32_t kept) {
+  const uint32_t id = blockIdx.x * kThreads + threadIdx.x;
+  if (id > n_ids) return;
+  const uint32_t old = post_start[id];
+  post_start[id] = old < m ? at[old] : kept;
+}
+
 // Keys ordered in registers (a segment's hits by (contig, window id) in the mapping kernel, a fragment's minimizers by
 // hash below): E keys per lane, element e = lane * E + q, bitonic network over 64 E elements.  Strides of E and more exchange between lanes (ds_bpermute, no LDS memory, no barrier),
 // the strides below E between the registers of a lane.  Missing elements are keys above any real one.  Key = uint32_t
@@ -556,7 +631,8 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const uint32_t *__restrict__ mini_wpos, const uint32_t *__restrict__ mini_id, const uint32_t *__restrict__ post_start,
     uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos /* posting list length */,
     uint32_t *__restrict__ q_id /* first posting */, uint32_t *__restrict__ q_s,
-    uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow, uint32_t *__restrict__ max_hits) {
+    uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow, uint32_t *__restrict__ max_hits,
+    const uint8_t *__restrict__ hash_cut, uint32_t *__restrict__ q_cut /* hashes of the sketch that lost seed hits to the frequency cut */) {
   __shared__ uint64_t s_key[kThreads / 64][kQMax];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * (kThreads / 64) + wave;
@@ -596,7 +672,7 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
   __builtin_amdgcn_wave_barrier();
   if (!active) return;
   // keep the first entry of every hash run (smallest slice index = smallest window id)
-  uint32_t s = 0, hits = 0;
+  uint32_t s = 0, hits = 0, cut_hashes = 0;
   for (uint32_t base = 0; base < n; base += 64) {
     const uint32_t i = base + lane;
     bool keep = false;
@@ -617,12 +693,15 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
       q_pos[(uint64_t)f * kQMax + o] = cnt;
       q_id[(uint64_t)f * kQMax + o] = lo;
       hits += cnt;
+      cut_hashes += hash_cut[id];
     }
     s += __popcll(bal);
   }
   hits = wave_sum(hits);
+  cut_hashes = wave_sum(cut_hashes);
   if (lane == 0) {
     q_s[f] = s;
+    q_cut[f] = cut_hashes;
     hit_count[f] = hits;
     // running maxima of the batch; look first, most fragments do not raise them
     if (hits > __builtin_nontemporal_load(max_hits)) atomicMax(max_hits, hits);
@@ -1058,11 +1137,12 @@ __device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t i
 // One record per listed segment: what a mapping wave needs before it can load anything else -- where the hits are, the
 // fragment, its sketch size, the seed hits a run needs, the first contig of the reference genome -- gathered by one
 // thread per segment, so that the wave starts with one scalar load instead of a chain of five dependent ones.
-// Two uint4: {first hit, hits, fragment, sketch size} {hits a run needs, first contig, 0, 0}; sketch size 0 = nothing to do.
+// Two uint4: {first hit, hits, fragment, sketch size} {hits a run needs, first contig, hashes of the sketch that lost seed hits to the
+// frequency cut, 0}; sketch size 0 = nothing to do.
 __global__ __launch_bounds__(kThreads) void segment_records_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh, uint32_t n_segs,
-    const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ contig_genome,
-    const uint32_t *__restrict__ genome_first_contig, uint4 *__restrict__ rec) {
+    const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ q_cut, const uint32_t *__restrict__ tab_min_hits,
+    const uint32_t *__restrict__ contig_genome, const uint32_t *__restrict__ genome_first_contig, uint4 *__restrict__ rec) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n_segs) return;
   const uint32_t a0 = seg_a0[i], nh = seg_nh[i];
@@ -1073,7 +1153,7 @@ __global__ __launch_bounds__(kThreads) void segment_records_kernel(
   if (nh < mh) s = 0;  // chance matches with unrelated genomes: fewer seed hits than any L1 run needs
   const uint32_t hc_base = genome_first_contig[contig_genome[(uint32_t)(key >> 24) & 0xfffffu]];
   rec[2 * (uint64_t)i] = make_uint4(a0, nh, f, s);
-  rec[2 * (uint64_t)i + 1] = make_uint4(mh, hc_base, 0u, 0u);
+  rec[2 * (uint64_t)i + 1] = make_uint4(mh, hc_base, q_cut[f], 0u);
 }
 
 // the segment's hits from the hit array into LDS, in order: window id and contig (relative to the genome's first)
@@ -1149,6 +1229,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
 #endif
   const uint4 rec0 = seg_rec[2 * (uint64_t)blockIdx.x], rec1 = seg_rec[2 * (uint64_t)blockIdx.x + 1];  // segment_records_kernel
   const uint32_t a0 = rec0.x, nh = rec0.y, f = rec0.z, s = rec0.w, mh = rec1.x;
+  const int32_t unseeded = (int32_t)rec1.z;  // hashes of the sketch whose reference occurrences are not all seed hits (frequency cut)
   if (s == 0) return;  // no sketch, or fewer seed hits than any L1 run needs
   PA_STAT(0, 1);   // segments that reach L1
   PA_STAT(1, nh);  // their seed hits
@@ -1406,8 +1487,11 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       const uint32_t wp = has ? mini_wpos[b] : 0u;
       const uint32_t wp_next = (has && b + 1u < m1) ? mini_wpos[b + 1u] : 0xffffffffu;
       const uint32_t w_end = min(wp_next - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
-      int32_t bar = c_best > best_shared ? c_best : best_shared;  // what a window must reach to matter (ties matter)
+      // what a window must reach to matter (ties matter) -- in SEED HITS: a window shares no more than the seed hits it holds
+      // plus the sketch's hashes that the frequency cut took out of the seeds (nearly always none)
+      int32_t bar = c_best > best_shared ? c_best : best_shared;
       if (bar < floor_bar) bar = floor_bar;
+      bar -= unseeded;
       // A window with `bar` of the candidate's hits ends after the bar-th hit and does not begin after the bar-th hit
       // from the end: groups without such a begin are passed over before any counting
       if (bar > 0) {
@@ -1415,8 +1499,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         const uint32_t w_after = HW(h_lo + (uint32_t)bar - 1u), w_upto = HW(h_hi - (uint32_t)bar);
         if (!__any(has && w_end > w_after && wp <= w_upto)) continue;
       }
-      // Seed hits inside the begin's widest window: every occurrence of every query hash is a hit, so no window shares
-      // more.  Only "at least b of them" is ever asked: with i0 = the first hit at or after the begin, that is "hit
+      // Seed hits inside the begin's widest window: every occurrence of every query hash is a hit (but for the hashes the
+      // frequency cut took out: `unseeded`, allowed for in the bar), so no window shares more.  Only "at least b of them" is ever asked: with i0 = the first hit at or after the begin, that is "hit
       // i0 + b - 1 exists and lies before the window's end" -- one search and one read instead of two searches.
       const uint32_t i0 = hit_lower_bound_w(h_lo, h_hi, wp, h_steps);
       auto holds_hits = [&](int32_t b) -> bool {
@@ -1815,6 +1899,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         {
           int32_t bar2 = c_best > best_shared ? c_best : best_shared;
           if (bar2 < floor_bar) bar2 = floor_bar;
+          bar2 -= unseeded;
           pending = pending && (bar2 > 0 ? holds_hits(bar2) : true);
         }
       }
@@ -1990,7 +2075,7 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first, post_g, seg_rec;
+      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs;
   // the reference index (stages 1 and 2) of the last pa_fragani(_ex) call, for PA_FRAGANI_REUSE_INDEX
   bool index_valid = false;
   const void *index_packed = nullptr;
@@ -2003,7 +2088,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -2013,6 +2098,85 @@ struct FragWork {
 FragWork &frag_work(pa_ctx *c) {
   if (!c->frag_work) c->frag_work = new FragWork();
   return *static_cast<FragWork *>(c->frag_work);
+}
+
+// Mashmap's frequency cut (see posting_run_hist_kernel): thresholds per reference genome on the host, from the histograms
+// of the run lengths; the runs at or above them leave the posting lists.  `heads`: 1 at the first posting of every hash,
+// `ids_before`: the hashes before a posting's own (the scan of `heads`); `scratch`: 2 m words, free at this point.
+int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const uint32_t *d_ids_before, uint32_t *scratch, uint32_t m,
+                          uint32_t n_ids, const uint32_t *h_contig_genome, uint32_t n_contigs, uint32_t n_genomes) {
+  uint32_t *scratch_a = scratch, *scratch_b = scratch + m;
+  PA_TRY(W.hash_cut.reserve((uint64_t)n_ids + 16));
+  PA_HIP(hipMemsetAsync(W.hash_cut.p, 0, (uint64_t)n_ids + 1, c->stream));
+  if (const char *v = getenv("PA_FRAGANI_NO_FREQ_CUT")) { if (atoi(v)) return PA_OK; }  // tools: the seeds as rounds 1-4 looked them up
+  constexpr uint32_t kOverCap = 1u << 20;
+  std::vector<uint32_t> threshold(n_genomes, 0xffffffffu);
+  bool any = false;
+  {
+    const uint64_t hist_words = (uint64_t)n_genomes * kFreqBins + n_genomes + 1;  // histograms, duplicate counts, overflow cursor
+    PA_TRY(W.run_hist.reserve(hist_words * 4));
+    PA_TRY(W.long_runs.reserve((uint64_t)kOverCap * 8));
+    uint32_t *d_hist = W.run_hist.as<uint32_t>(), *d_dups = d_hist + (uint64_t)n_genomes * kFreqBins, *d_over_n = d_dups + n_genomes;
+    PA_HIP(hipMemsetAsync(d_hist, 0, hist_words * 4, c->stream));
+    hipLaunchKernelGGL(posting_run_hist_kernel, dim3(ceil_div_u64(m, kThreads)), dim3(kThreads), 0, c->stream, d_heads,
+                       W.post_g.as<uint16_t>(), m, d_hist, d_dups, W.long_runs.as<uint2>(), kOverCap, d_over_n);
+    std::vector<uint32_t> h((size_t)hist_words);
+    PA_HIP(hipMemcpyAsync(h.data(), d_hist, hist_words * 4, hipMemcpyDeviceToHost, c->stream));
+    PA_HIP(hipStreamSynchronize(c->stream));
+    const uint32_t n_over = h[hist_words - 1];
+    PA_REQUIRE(n_over <= kOverCap, "pa_fragani: %u (minimizer, genome) pairs with %u or more occurrences", n_over, kFreqBins - 1);
+    std::vector<uint2> h_over(n_over);
+    if (n_over) PA_HIP(hipMemcpy(h_over.data(), W.long_runs.p, (size_t)n_over * 8, hipMemcpyDeviceToHost));
+    // minimizers per genome: its contigs' shares of the minimizer array
+    std::vector<uint32_t> cmo(n_contigs + 1);
+    PA_HIP(hipMemcpy(cmo.data(), W.contig_mini_off.p, (size_t)(n_contigs + 1) * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> n_min(n_genomes, 0);
+    for (uint32_t ci = 0; ci < n_contigs; ++ci) n_min[h_contig_genome[ci]] += cmo[ci + 1] - cmo[ci];
+    std::vector<std::vector<uint32_t>> long_runs(n_genomes);
+    for (const uint2 &e : h_over) long_runs[e.x].push_back(e.y);
+    for (uint32_t g = 0; g < n_genomes; ++g) {
+      const uint32_t *bars = h.data() + (uint64_t)g * kFreqBins;
+      const uint64_t uniq = n_min[g] - h[(uint64_t)n_genomes * kFreqBins + g];
+      const int64_t to_ignore = (int64_t)((float)uniq * 0.001f / 100);
+      // the bars from the most frequent minimizers down: (count, distinct minimizers with that count)
+      std::vector<std::pair<uint32_t, uint64_t>> top;
+      std::sort(long_runs[g].begin(), long_runs[g].end(), std::greater<uint32_t>());
+      for (uint32_t v : long_runs[g]) { if (!top.empty() && top.back().first == v) ++top.back().second; else top.push_back({v, 1}); }
+      uint64_t repeated = long_runs[g].size();
+      for (uint32_t cnt = kFreqBins - 2; cnt >= 2; --cnt) if (bars[cnt]) { top.push_back({cnt, bars[cnt]}); repeated += bars[cnt]; }
+      if (uniq > repeated) top.push_back({1u, uniq - repeated});
+      int64_t sum = 0;
+      for (const auto &bar : top) {
+        sum += (int64_t)bar.second;
+        if (sum < to_ignore) threshold[g] = bar.first;
+        else { if (sum == to_ignore) threshold[g] = bar.first; break; }
+      }
+      any = any || threshold[g] != 0xffffffffu;
+    }
+  }
+  if (!any) return PA_OK;
+  // take the runs out: flags, their prefix sums, the postings moved into the workspace's second pair of arrays (which then
+  // change places with the first), the lists' bounds rewritten
+  PA_TRY(upload(c, W.run_hist, threshold));  // (the histograms are on the host by now)
+  PA_TRY(W.post_cw2.reserve((uint64_t)m * 8));
+  PA_TRY(W.post_g2.reserve((uint64_t)m * 2 + 16));
+  const uint32_t gm = ceil_div_u64(m, kThreads);
+  PA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch_a), 1, m, c->stream));
+  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before, W.post_g.as<uint16_t>(), m,
+                     W.run_hist.as<uint32_t>(), scratch_a, W.hash_cut.as<uint8_t>());
+  PA_TRY(pa_exclusive_scan_u32(c, scratch_a, scratch_b, m, W.scalars.as<uint64_t>()));
+  PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  const uint32_t kept = (uint32_t)c->h_pinned[0];
+  if (kept != m) {
+    hipLaunchKernelGGL(posting_compact_kernel, dim3(gm), dim3(kThreads), 0, c->stream, scratch_a, scratch_b, W.post_cw.as<uint64_t>(),
+                       W.post_g.as<uint16_t>(), m, W.post_cw2.as<uint64_t>(), W.post_g2.as<uint16_t>());
+    hipLaunchKernelGGL(posting_starts_kernel, dim3(ceil_div_u64((uint64_t)n_ids + 1, kThreads)), dim3(kThreads), 0, c->stream,
+                       W.post_start.as<uint32_t>(), n_ids, scratch_b, m, kept);
+    std::swap(W.post_cw, W.post_cw2);
+    std::swap(W.post_g, W.post_g2);
+  }
+  return PA_OK;
 }
 
 template <int K>
@@ -2277,6 +2441,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
                        W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>(), W.contig_mini_off.as<uint32_t>(), n_contigs);
     W.index_ids = n_ids;
+    PA_TRY(cut_frequent_postings(c, W, d_flags, d_pos, reinterpret_cast<uint32_t *>(keys[1 - which]), m, n_ids, h_contig_genome, n_contigs, n_genomes));
   }
   const uint32_t *d_sorted_idx = vals[which];
   // the index (minimizers, bucket index, dictionary, postings) is complete: a later call may take it over
@@ -2324,7 +2489,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   }
   PA_TRY(upload(c, W.genome_first_contig, gfc));
   PA_HIP(hipStreamSynchronize(c->stream));
-  static const bool trace = getenv("PA_FRAGANI_TRACE") != nullptr;  // per-batch sizes on stderr
+  const bool trace = getenv("PA_FRAGANI_TRACE") != nullptr;  // per-batch sizes on stderr
   static const bool force_sorted = [] {
     const char *v = getenv("PA_FRAGANI_HITS");
     return v && v[0] == 's';
@@ -2354,6 +2519,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_TRY(W.q_pos.reserve((uint64_t)nf * kQMax * 4));
     PA_TRY(W.q_id.reserve((uint64_t)nf * kQMax * 4));
     PA_TRY(W.q_s.reserve((uint64_t)nf * 4));
+    PA_TRY(W.q_cut.reserve((uint64_t)nf * 4));
     PA_TRY(W.hit_count.reserve((uint64_t)nf * 4));
     PA_TRY(W.hit_off.reserve((uint64_t)nf * 4));
     const uint32_t gw = ceil_div_u64(nf, kThreads / 64);
@@ -2363,7 +2529,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
                        W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),
-                       W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits);
+                       W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits,
+                       W.hash_cut.as<uint8_t>(), W.q_cut.as<uint32_t>());
     PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipMemcpyAsync(c->h_pinned + 1, d_max_hits, 8, hipMemcpyDeviceToHost, c->stream));
@@ -2376,6 +2543,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
       prof.reset();
       continue;  // the same g0 again
     }
+    if (trace) fprintf(stderr, "pa_fragani: batch of genomes %u..%u: %u fragments, %llu seed hits\n", g0, g1, nf, (unsigned long long)n_hits);
     PA_REQUIRE(n_hits < (1ULL << 31), "pa_fragani: %llu seed hits for the fragments of genome %u alone (limit 2^31); highly "
                "repetitive input", (unsigned long long)n_hits, g0);
     PA_TRY(W.table.reserve((uint64_t)nq * total_bins * 8));
@@ -2526,7 +2694,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         constexpr bool kAll = decltype(all_staged)::value;
         PA_TRY(W.seg_rec.reserve((uint64_t)count * 32));
         hipLaunchKernelGGL(segment_records_kernel, dim3(ceil_div_u64(count, kThreads)), dim3(kThreads), 0, c->stream, hk[hw],
-                           list_a0, list_nh, count, W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(),
+                           list_a0, list_nh, count, W.q_s.as<uint32_t>(), W.q_cut.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(),
                            W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(), W.seg_rec.as<uint4>());
 #define PA_MAP_CASE(CAP)                                                                                                  \
   case CAP:                                                                                                               \

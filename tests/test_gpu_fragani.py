@@ -466,3 +466,79 @@ def test_a_long_run_of_n_inside_a_contig(engine):
     texts = [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)]
     total, matched, _ = _check_against_oracle(engine, texts, [[g] for g in genomes])
     assert matched[2, 0] > 0 and matched[0, 2] > 0
+
+
+def _expected_seed_hits(genomes: list[bytes], k: int, frag: int, cut: bool) -> int:
+    """Seed hits of an all-vs-all run, counted independently of the library: per fragment the distinct minimizer hashes of its
+    slice of the genome's minimizers, per reference genome the occurrences of each -- none where Mashmap's frequency cut
+    applies (occurrences >= the genome's threshold; the oracle's ref_index_build restated in numpy)."""
+    w = oracle.fragani_window_size(k, frag)
+    cw = frag - (w - 1) - (k - 1)
+    minis = [oracle.fragani_minimizers(g, k, w) for g in genomes]
+    tables = []
+    for h, _p in minis:
+        u, cnt = np.unique(h, return_counts=True)
+        thr = np.iinfo(np.int64).max
+        if cut and len(u):
+            to_ignore = int(np.float32(len(u)) * np.float32(0.001) / np.float32(100))
+            bars, sizes = np.unique(cnt, return_counts=True)
+            total = 0
+            for c, n in zip(bars[::-1].tolist(), sizes[::-1].tolist()):
+                total += n
+                if total < to_ignore:
+                    thr = c
+                else:
+                    if total == to_ignore:
+                        thr = c
+                    break
+        tables.append(dict(zip(u[cnt < thr].tolist(), cnt[cnt < thr].tolist())))
+    hits = 0
+    for (h, p), g in zip(minis, genomes):
+        for f in range(len(g) // frag):
+            start = f * frag
+            b, e = int(np.searchsorted(p, start)), int(np.searchsorted(p, start + cw))
+            b0 = b - 1 if b > 0 and not (b < len(p) and p[b] == start) else b
+            for x in np.unique(h[b0:e]).tolist():
+                hits += sum(t.get(x, 0) for t in tables)
+    return hits
+
+
+def test_frequency_cut_of_the_seeds(engine, monkeypatch, capfd):
+    """Mashmap's cut of the most frequent reference minimizers from the seed look-up (fastANI logs "ignore minimizers
+    occurring >= N times during lookup"): per reference genome, as many bars of the histogram of occurrence counts, from the
+    top, as stay within 0.001 % of its distinct minimizers.  A 1.4 Mb genome holds an (ACC)n array whose one minimizer occurs
+    ~300 times: above the threshold, it gives no seed hits -- the number of seed hits the library reports equals the count
+    made here from the oracle's minimizers, with the cut and (PA_FRAGANI_NO_FREQ_CUT=1) without; the results equal the
+    oracle's, which applies the same cut."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n: int) -> bytes:
+        return rng.choice(acgt, size=n).tobytes()
+
+    big = rnd(700_000) + b"ACC" * 300 + rnd(2_000) + b"AGG" * 200 + rnd(700_000)
+    part = np.frombuffer(big[680_000:722_000], dtype=np.uint8).copy()
+    hit = rng.random(part.size) < 0.02
+    part[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+    genomes = [big, part.tobytes(), rnd(20_000)]
+    arena = pack_genomes([b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)])
+    monkeypatch.setenv("PA_FRAGANI_TRACE", "1")
+    seen = {}
+    for no_cut in ("0", "1"):
+        monkeypatch.setenv("PA_FRAGANI_NO_FREQ_CUT", no_cut)
+        capfd.readouterr()
+        total, matched, ident_sum = engine.fragani(engine.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+        err = capfd.readouterr().err
+        seen[no_cut] = sum(int(line.split(" fragments, ")[1].split(" seed hits")[0]) for line in err.splitlines() if "batch of genomes" in line)
+        if no_cut == "0":
+            for q in range(3):
+                for r in range(3):
+                    ani, m, t = oracle.fragani_pair([genomes[q]], [genomes[r]], K, FRAG, 0.0)
+                    assert (int(total[q]), int(matched[q, r])) == (t, m), (q, r)
+                    assert m == 0 or mean_f(ident_sum[q, r], m) == ani
+            assert matched[1, 0] >= 12 and matched[0, 0] >= total[0] - 2
+    assert seen["0"] == _expected_seed_hits(genomes, K, FRAG, cut=True)
+    assert seen["1"] == _expected_seed_hits(genomes, K, FRAG, cut=False)
+    assert seen["1"] - seen["0"] > 500  # the array's minimizer, ~290 occurrences in the big genome, in the sketches of two fragments

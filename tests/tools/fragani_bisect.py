@@ -22,7 +22,7 @@ from tests.helpers import GOLDEN, read_fasta_bytes  # noqa: E402
 
 K, FRAG = 16, 3000
 
-OLD = {"tie": 0, "float": 0}  # rounds 1-3 and the first half of round 4: the first of equally good candidates, double sums
+OLD = {"tie": 0, "float": 0, "freq": 0}  # rounds 1-3 and the first half of round 4: the first of equally good candidates, double sums, every occurrence a seed
 VARIANTS = {
     "round 1: seed-implied starts, sketch list 10,60,.., bins (pos+L/2)/L": {"window_rule": 0, "bin_rule": 0, "l2_rule": 0, **OLD},
     "seed-implied starts, window 24, bins pos/(L-20)": {"l2_rule": 0, **OLD},
@@ -33,13 +33,13 @@ VARIANTS = {
     "exact slide, ends with the window's end or past rangeEnd; first candidate on ties; double sums": {"l2_stop": 1, **OLD},
     "exact slide, ends past rangeEnd only; first candidate on ties; double sums": {"l2_stop": 2, **OLD},
     "exact slide; confidence 0.75; first candidate on ties; double sums": {"conf": 0.75, **OLD},
-    "exact slide; position = the positions a state stands for; LAST candidate on ties; double sums": {"l2_pos": 1, "tie": 1, "float": 0},
-    "exact slide; position = first minimizer; LAST candidate on ties; double sums": {"tie": 1, "float": 0},
-    "exact slide; position = first minimizer; the candidate libstdc++'s std::sort leaves last; float sums": {"tie": 2},
-    "exact slide; position = first minimizer; last candidate on ties; float sums; Mashmap's frequency cut of the seeds": {"freq": 1},
-    "ADOPTED: exact slide; position = first minimizer; LAST candidate on ties; float identities summed in float": {},
+    "exact slide; position = the positions a state stands for; LAST candidate on ties; double sums": {"l2_pos": 1, "tie": 1, "float": 0, "freq": 0},
+    "exact slide; position = first minimizer; LAST candidate on ties; double sums": {"tie": 1, "float": 0, "freq": 0},
+    "exact slide; position = first minimizer; the candidate libstdc++'s std::sort leaves last; float sums": {"tie": 2, "freq": 0},
+    "exact slide; position = first minimizer; last candidate on ties; float sums; every occurrence a seed (no frequency cut)": {"freq": 0},
+    "ADOPTED: exact slide; position = first minimizer; LAST candidate on ties; float identities summed in float; Mashmap's frequency cut of the seeds": {},
 }
-DEFAULTS = {"window_rule": 1, "bin_rule": 1, "l2_rule": 2, "conf": 0.9, "l2_pos": 0, "l2_stop": 0, "tie": 1, "freq": 0, "float": 1}
+DEFAULTS = {"window_rule": 1, "bin_rule": 1, "l2_rule": 2, "conf": 0.9, "l2_pos": 0, "l2_stop": 0, "tie": 1, "freq": 1, "float": 1}
 
 
 def contigs_of(path):
