@@ -460,30 +460,16 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
   uint32_t *winh = NULL; size_t win_cap = 0;
   const int64_t count_windows = (int64_t)frag_len - (w - 1) - (k - 1);
 
-  /* RESTATEMENT: a fragment is not re-sketched.  Its sketch is the slice of its genome's minimizers
-   * whose window ids lie in the fragment, plus the one recorded last before it unless a new one is
-   * recorded exactly at the fragment's first window -- on sequence without skipped k-mers this is
-   * exactly what sketching the fragment alone gives (tests/test_fragani_oracle.py checks that). */
-  MiniVec qall = {0, 0, 0};
-  for (uint32_t c = 0; c < q_contigs; ++c)
-    if (add_minimizers(&qall, q_seq + q_off[c], (int64_t)(q_off[c + 1] - q_off[c]), k, w, (int32_t)c)) return -1;
+  /* A fragment is sketched on its own, as fastANI does it (winnowing restarts at the fragment's first residue).  The HIP
+   * path takes the fragment's sketch as a slice of its genome's minimizers instead -- the ones recorded at the fragment's
+   * window ids, plus the one recorded last before them unless a new one is recorded at the fragment's first window at
+   * which any is selected (the window of the first used k-mer at or after the fragment's w-th) -- which is the same set
+   * (tests/test_fragani_oracle.py checks that, runs of N and reverse-palindromic k-mers at the fragments' starts included). */
   for (uint32_t c = 0; c < q_contigs; ++c) {
     const int64_t clen = (int64_t)(q_off[c + 1] - q_off[c]);
     for (int64_t f = 0; f < clen / frag_len; ++f, ++frag_id) {
       qm.n = 0;
-      {
-        const int64_t p = f * frag_len;
-        const size_t b = lower_bound_pos(qall.v, qall.n, (int32_t)c, p);
-        const size_t e = lower_bound_pos(qall.v, qall.n, (int32_t)c, p + count_windows);
-        const int fresh = b < qall.n && qall.v[b].seq == (int32_t)c && (int64_t)qall.v[b].wpos == p;
-        const size_t b0 = (!fresh && b > 0 && qall.v[b - 1].seq == (int32_t)c) ? b - 1 : b;
-        for (size_t t = b0; t < e; ++t) {
-          Mini m = qall.v[t];
-          m.seq = 0;
-          m.wpos = (int64_t)m.wpos > p ? (int32_t)(m.wpos - p) : 0;
-          if (mv_push(&qm, m)) return -1;
-        }
-      }
+      if (add_minimizers(&qm, q_seq + q_off[c] + f * frag_len, frag_len, k, w, 0)) return -1;
       uint32_t *qh = (uint32_t *)malloc(sizeof(uint32_t) * (qm.n ? qm.n : 1));
       for (size_t i = 0; i < qm.n; ++i) qh[i] = qm.v[i].hash;
       qsort(qh, qm.n, sizeof(uint32_t), cmp_u32);
@@ -642,7 +628,7 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
       if (i + 1 == n_emit || emit[i + 1].frag != emit[i].frag) maps[n_maps++] = emit[i];
   }
   free(emit);
-  free(qm.v); free(qall.v); free(hits); free(winh);
+  free(qm.v); free(hits); free(winh);
   *maps_out = maps; *n_maps_out = n_maps; *total_out = total;
   return 0;
 }

@@ -12,8 +12,9 @@
 //                         ordered compaction -> minimizers (hash, window id, contig) per contig
 //   2. radix sort by hash -> dense hash ids, postings, "same hash earlier in this contig" links
 //   3. query_sketch_kernel a fragment's sketch is a SLICE of its genome's minimizers (window ids
-//                         inside the fragment + the one still active at its first window): sort,
-//                         de-duplicate in LDS, no re-hashing
+//                         inside the fragment + the one still active at the first window at which the
+//                         fragment, sketched alone as fastANI does it, selects any): sort, de-duplicate
+//                         in LDS, no re-hashing
 //   4. seed hits           every posting of every sketch hash -> (fragment, ref contig, window id),
 //                         bucketed by reference genome; one wave per (fragment, reference genome)
 //                         segment then orders its hits in registers, applies the L1 run test and
@@ -623,8 +624,42 @@ __device__ __forceinline__ void bitonic_sort_lanes(Key (&k)[E], uint32_t lane) {
   }
 }
 // ============================================================== 3. fragment sketches
+// fastANI sketches a fragment on its own: winnowing restarts at the fragment's first residue, and the first minimizer is
+// selected at the window of the first USED k-mer at or after the fragment's w-th.  Here a fragment's sketch is a slice of its
+// genome's minimizers, and that window is all the slice needs to know: d = the windows at the fragment's start at which
+// nothing is selected = the k-mers from the w-th on that hold an invalid residue or equal their own reverse complement
+// (both strands hash alike), 0 nearly always; count_windows when no k-mer of the fragment is used from there on.  The
+// wave looks at 64 windows at a time, one k-mer per lane.  (x0: arena position of the fragment's w-th k-mer.)
+__device__ __forceinline__ uint32_t windows_without_selection(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask,
+                                                              uint64_t arena_bases, uint64_t x0, uint32_t k, uint32_t count_windows,
+                                                              uint32_t lane) {
+  const uint32_t k_mask = k == 16u ? 0xffffffffu : ((1u << (2u * k)) - 1u);
+  const uint64_t nw = arena_bases >> 4, nm = arena_bases >> 5;
+  for (uint32_t base = 0; base < count_windows; base += 64) {
+    const uint32_t d = base + lane;
+    bool used = false;
+    if (d < count_windows) {
+      const uint64_t x = x0 + d, wi = x >> 4, mi = x >> 5;
+      const uint64_t w0 = wi < nw ? packed[wi] : 0u, w1 = wi + 1 < nw ? packed[wi + 1] : 0u;
+      const uint32_t fwd = (uint32_t)(((w1 << 32) | w0) >> (2u * ((uint32_t)x & 15u))) & k_mask;  // base j in bits 2j, 2j+1
+      const uint64_t m0 = mi < nm ? mask[mi] : 0xffffffffu, m1 = mi + 1 < nm ? mask[mi + 1] : 0xffffffffu;
+      const uint32_t bad = (uint32_t)(((m1 << 32) | m0) >> ((uint32_t)x & 31u)) & ((1u << k) - 1u);
+      // the reverse complement in the same layout: the 2-bit groups in reverse order, complemented
+      uint32_t r = __brev(fwd);
+      r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+      const uint32_t rc = (r >> (32u - 2u * k)) ^ k_mask;
+      used = bad == 0u && rc != fwd;
+    }
+    const uint64_t any = __ballot(used);
+    if (any) return base + (uint32_t)__builtin_ctzll(any);
+  }
+  return count_windows;
+}
+
 // one wave per fragment: slice of the contig's minimizers, sorted by (hash, slice index), first of each hash kept
 __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
+    const uint64_t *__restrict__ contig_start, uint32_t k, uint32_t w,
     const uint32_t *__restrict__ frag_contig, const uint32_t *__restrict__ frag_no, uint32_t n_frags, uint32_t frag_len,
     uint32_t count_windows, const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
@@ -646,9 +681,12 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
     const uint32_t b = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p);
     const uint32_t e = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p + count_windows);
-    const bool fresh = b < m1 && mini_wpos[b] == p;
+    // the minimizer recorded last before the fragment belongs to its sketch unless a new one is recorded by the first
+    // window at which the fragment, sketched alone, selects any
+    const uint32_t d = windows_without_selection(packed, mask, arena_bases, contig_start[c] + p + w - 1u, k, count_windows, lane);
+    const bool fresh = b < m1 && mini_wpos[b] <= p + d;
     b0 = (!fresh && b > m0) ? b - 1 : b;
-    n = e - b0;
+    n = d < count_windows ? e - b0 : 0u;  // (no used k-mer from the w-th on: no sketch)
     if (n > (uint32_t)kQMax) { if (lane == 0) atomicAdd(overflow, 1u); n = kQMax; }
   }
   // the slice's (hash, slice index) keys ordered in registers, E = 1, 2, 4 or 8 per lane by the size of the slice, and
@@ -2525,7 +2563,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     const uint32_t gw = ceil_div_u64(nf, kThreads / 64);
     PA_HIP(hipMemsetAsync(d_max_hits, 0, 8, c->stream));  // [0] most hits, [1] longest sketch of a fragment
     prof.emplace(c, PA_PROF_FRAG_SEED);
-    hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, W.frag_contig.as<uint32_t>(),
+    hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, d_packed, d_mask, arena_bases,
+                       W.contig_start.as<uint64_t>(), k, (uint32_t)w, W.frag_contig.as<uint32_t>(),
                        W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
                        W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),

@@ -61,19 +61,45 @@ def test_parameters():
     assert oracle.fragani_kmer_hash(b"ACGTTGCATGCATGCA") == oracle.fragani_kmer_hash(b"TGCATGCATGCAACGT")  # strand-symmetric
 
 
+def fragment_slice(gh: np.ndarray, gp: np.ndarray, seq: bytes, f: int, k: int, w: int, frag: int) -> np.ndarray:
+    """The HIP path's sketch of fragment f (query_sketch_kernel): the genome's minimizers recorded at the fragment's window ids,
+    plus the one recorded last before them unless a new one is recorded by the first window of the fragment at which any is
+    selected -- the window of the first USED k-mer at or after the fragment's w-th (d windows in: 0 unless that k-mer holds
+    an N or is its own reverse complement).  No used k-mer from there to the fragment's end: no sketch."""
+    cw = frag - (w - 1) - (k - 1)
+    p = f * frag
+    d = 0
+    while d < cw and oracle.fragani_kmer_hash(seq[p + w - 1 + d : p + w - 1 + d + k]) == 0xFFFFFFFF:
+        d += 1
+    if d == cw:
+        return gh[:0]
+    b, e = int(np.searchsorted(gp, p)), int(np.searchsorted(gp, p + cw))
+    fresh = b < e and gp[b] <= p + d
+    return gh[b - 1 if not fresh and b > 0 else b : e]
+
+
 def test_minimizers_of_a_fragment_are_a_slice_of_the_genome_minimizers():
-    """The HIP path never re-sketches fragments: a fragment's sketch is the genome's minimizers whose
-    window ids fall in the fragment, plus the one still active at its first window."""
-    seq = contigs_of(GOLDEN / "viral_example" / "OP073605.fasta")[0]
+    """The HIP path never re-sketches fragments (fastANI does, and so does the oracle): a fragment's sketch is a slice of its
+    genome's minimizers.  Same hashes in the same order -- on a fixture, and where winnowing restarted at the fragment's first
+    residue could differ: runs of N across and inside fragment starts, reverse-palindromic k-mers at a fragment's w-th
+    position (no minimizer is selected at that window), a fragment of N only."""
     w = oracle.fragani_window_size(K, FRAG)
-    gh, gp = oracle.fragani_minimizers(seq, K, w)
-    cw = FRAG - (w - 1) - (K - 1)
-    for f in range(len(seq) // FRAG):
-        fh, fp = oracle.fragani_minimizers(seq[f * FRAG : (f + 1) * FRAG], K, w)
-        b, e = int(np.searchsorted(gp, f * FRAG)), int(np.searchsorted(gp, f * FRAG + cw))
-        b0 = b - 1 if b > 0 and (b == len(gp) or gp[b] > f * FRAG) else b
-        assert np.array_equal(fh, gh[b0:e])
-        assert np.array_equal(fp, np.maximum(gp[b0:e] - f * FRAG, 0))
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    synth = bytearray(rng.choice(letters, size=12 * FRAG + 700).tobytes())
+    pal = b"ACGTACGTACGTACGT"  # its own reverse complement: both strands hash alike, the k-mer is not used
+    synth[1 * FRAG + w - 1 : 1 * FRAG + w - 1 + K] = pal
+    synth[2 * FRAG + w - 1 : 2 * FRAG + w + 1 + K] = b"AC" + pal  # ... and the two k-mers after it (period 2 of the palindrome's own shift)
+    synth[3 * FRAG - 40 : 3 * FRAG + 90] = b"N" * 130             # a run of N across a fragment's start
+    synth[4 * FRAG + 10 : 4 * FRAG + 30] = b"N" * 20              # ... inside its first window
+    synth[5 * FRAG - 5 : 7 * FRAG + 3] = b"N" * (2 * FRAG + 8)     # fragments 5 and 6 hold nothing usable (6: N only)
+    synth[8 * FRAG + 2900 : 9 * FRAG] = b"N" * 100                # N at a fragment's end
+    for seq in (contigs_of(GOLDEN / "viral_example" / "OP073605.fasta")[0], bytes(synth)):
+        gh, gp = oracle.fragani_minimizers(seq, K, w)
+        for f in range(len(seq) // FRAG):
+            fh, _fp = oracle.fragani_minimizers(seq[f * FRAG : (f + 1) * FRAG], K, w)
+            assert np.array_equal(fh, fragment_slice(gh, gp, seq, f, K, w, FRAG)), f
+    assert len(oracle.fragani_minimizers(bytes(synth[6 * FRAG : 7 * FRAG]), K, w)[0]) == 0
 
 
 def test_viral_rows_print_as_fastani_does():

@@ -542,3 +542,34 @@ def test_frequency_cut_of_the_seeds(engine, monkeypatch, capfd):
     assert seen["0"] == _expected_seed_hits(genomes, K, FRAG, cut=True)
     assert seen["1"] == _expected_seed_hits(genomes, K, FRAG, cut=False)
     assert seen["1"] - seen["0"] > 500  # the array's minimizer, ~290 occurrences in the big genome, in the sketches of two fragments
+
+
+def test_fragment_sketches_where_winnowing_restarted_at_the_fragment_could_differ(engine):
+    """fastANI sketches every fragment on its own; the device takes a slice of the genome's minimizers.  Same mappings as the
+    oracle (which sketches the fragments on their own) where the two could differ: runs of N across a fragment's start,
+    inside its first window and over whole fragments, reverse-palindromic k-mers at a fragment's w-th position."""
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    w = oracle.fragani_window_size(K, FRAG)
+    base = rng.choice(letters, size=14 * FRAG + 700)
+    pal = np.frombuffer(b"ACGTACGTACGTACGT", dtype=np.uint8)
+
+    def variant(rate: float, with_gaps: bool) -> bytes:
+        g = base.copy()
+        hit = rng.random(g.size) < rate
+        g[hit] = letters[rng.integers(0, 4, size=int(hit.sum()))]
+        g = bytearray(g.tobytes())
+        if with_gaps:
+            g[1 * FRAG + w - 1 : 1 * FRAG + w - 1 + K] = pal.tobytes()
+            g[2 * FRAG + w - 1 : 2 * FRAG + w + 1 + K] = b"AC" + pal.tobytes()
+            g[3 * FRAG - 40 : 3 * FRAG + 90] = b"N" * 130
+            g[4 * FRAG + 10 : 4 * FRAG + 30] = b"N" * 20
+            g[5 * FRAG - 5 : 7 * FRAG + 3] = b"N" * (2 * FRAG + 8)
+            g[8 * FRAG + 2900 : 9 * FRAG] = b"N" * 100
+            g[10 * FRAG : 10 * FRAG + w + K + 40] = b"N" * (w + K + 40)
+        return bytes(g)
+
+    genomes = [variant(0.0, True), variant(0.01, False), variant(0.03, True)]
+    texts = [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)]
+    total, matched, _ = _check_against_oracle(engine, texts, [[g] for g in genomes])
+    assert total.tolist() == [14, 14, 14] and matched[1, 1] == 14 and 10 <= matched[0, 1] <= 12 and matched[0, 0] <= 12
