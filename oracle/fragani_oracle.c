@@ -208,31 +208,24 @@ static int mv_push(MiniVec *a, Mini m) {
   return 0;
 }
 
-static int base2(uint8_t c) {
-  switch (c) {
-    case 'A': case 'a': return 0; case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2; case 'T': case 't': return 3;
-    default: return -1;
-  }
-}
-
 #define SKIP_HASH 0xffffffffu
 
-/* Canonical-by-hash k-mer hash of the k residues at s, or SKIP_HASH when the k-mer is not used:
- * RESTATEMENT: k-mers holding a non-ACGT residue are skipped (fastANI hashes the raw characters;
- * the 2-bit arena of the HIP path cannot represent them), as are k-mers whose two strands hash alike
- * (fastANI does the same) and the 2^-32 case of a hash equal to the SKIP marker. */
+/* Canonical-by-hash k-mer hash of the k residues at s, or SKIP_HASH when the k-mer is not used: fastANI upper-cases the
+ * sequence, hashes the k characters AS THEY ARE and their reverse complement (A<->T, C<->G, anything else left in place),
+ * takes the smaller hash and passes over k-mers whose two strands hash alike -- reverse palindromes, runs of N.  No residue
+ * is special: a k-mer holding an N is a k-mer.  (RESTATEMENT: the 2^-32 case of a hash equal to the SKIP marker is passed
+ * over too.  The HIP path keeps two bits per residue and one "not ACGT" bit: there every such residue is an N.) */
 ORC_API uint32_t orc_fragani_kmer_hash(const uint8_t *s, int k) {
-  static const char up[4] = {'A', 'C', 'G', 'T'};
   uint8_t f[32], r[32];
   for (int j = 0; j < k; ++j) {
-    const int c = base2(s[j]);
-    if (c < 0) return SKIP_HASH;
-    f[j] = (uint8_t)up[c];
-    r[k - 1 - j] = (uint8_t)up[3 - c];
+    uint8_t c = s[j];
+    if (c >= 'a' && c <= 'z') c = (uint8_t)(c - 'a' + 'A');
+    f[j] = c;
+    switch (c) { case 'A': c = 'T'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; case 'T': c = 'A'; break; default: break; }
+    r[k - 1 - j] = c;
   }
   const uint32_t hf = (uint32_t)orc_murmur3_h1(f, (uint32_t)k, 42), hb = (uint32_t)orc_murmur3_h1(r, (uint32_t)k, 42);
-  if (hf == hb) return SKIP_HASH;
+  if (hf == hb || (hf < hb ? hf : hb) == SKIP_HASH) return SKIP_HASH;
   return hf < hb ? hf : hb;
 }
 

@@ -164,6 +164,38 @@ constexpr uint32_t kLookSpinLimit = 1u << 24;
 // for a chained scan: the first tile of a run waits for the last tile of the run before it, which its workgroup
 // reaches last, so the workgroups execute one after the other: 34 s.)
 
+// A k-mer that holds residues other than A, C, G, T: fastANI hashes the characters as they are (upper-cased; the reverse
+// complement leaves what it does not know in place), so such a k-mer is a k-mer like any other -- only a k-mer equal to its
+// own reverse complement (a run of N, for one) is passed over, as every k-mer whose two strands hash alike is.  The packed
+// arena keeps two bits per residue and one "not ACGT" bit: every such residue is taken to be 'N' (by far the commonest).
+// Rare, and off the hot path: the bytes are put together one by one, the two multiplies of MurmurHash3 done in full.
+// `codes`: residue j in bits 2j, 2j+1; `bad`: bit j set = residue j is not ACGT.  Returns kSkip when the strands hash alike.
+template <int K>
+__device__ __forceinline__ uint32_t hash_kmer_with_unknowns(uint32_t codes, uint32_t bad) {
+  constexpr int kWords = (K + 7) / 8;
+  uint32_t hs[2];
+#pragma unroll
+  for (int strand = 0; strand < 2; ++strand) {
+    uint64_t P[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < kWords; ++q) {
+      uint64_t word = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int j = 8 * q + t;  // byte j of the strand's text
+        if (j >= K) break;
+        const int src = strand ? K - 1 - j : j;
+        const uint32_t code = ((codes >> (2 * src)) & 3u) ^ (strand ? 3u : 0u);
+        const uint32_t ch = ((bad >> src) & 1u) ? (uint32_t)'N' : (0x54474341u >> (8 * code)) & 0xffu;  // "ACGT"
+        word |= (uint64_t)ch << (8 * t);
+      }
+      P[q] = word * ((q & 1) ? kC2 : kC1);
+    }
+    hs[strand] = (uint32_t)murmur3_from_products<K>(P);
+  }
+  return hs[0] == hs[1] ? kSkip : (hs[0] < hs[1] ? hs[0] : hs[1]);
+}
+
 template <int K>
 __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
@@ -245,6 +277,58 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
       own[j] = h;
     }
   }
+  uint32_t c = 0;
+  bool have_c = false;
+  // the contig of the thread's first position, and its bounds in registers: they change at a contig boundary only
+  // (asking contig_start again for every position was a load, and a wait, per position)
+  uint64_t c_beg = 0, c_next = ~0ULL;
+  uint32_t c_len = 0;
+  if (p0 >= 0 && (uint64_t)p0 < arena_bases) {
+    c = contig_of(contig_start, n_contigs, (uint64_t)p0);
+    have_c = true;
+    c_beg = contig_start[c];
+    c_len = contig_len[c];
+    c_next = c + 1 < n_contigs ? contig_start[c + 1] : ~0ULL;
+  }
+  // Residues other than ACGT in a k-mer -- or the padding between contigs, marked the same way: a k-mer that starts in it
+  // or runs into it is none.  Few threads ever come here, and it shows nowhere else only if nothing here looks like the
+  // hot path: held across the loop above, the residues and mask bits cost the sixteen hashes their registers; a second
+  // search through the contigs' starts was merged with every thread's own one (a quarter of the kernel's time, measured
+  // variant by variant) -- so the mask words are asked for again (they are in the cache), the residues only by the threads
+  // that need them, and the k-mer's contig is found by walking on from the thread's.
+  if (have_c) {
+    constexpr uint32_t kMask = (K == 16) ? 0xffffffffu : ((1u << (2 * K)) - 1u);
+    constexpr uint64_t kBadMask = (1ULL << K) - 1;
+    const uint64_t mi = (uint64_t)p0 >> 5, nm = arena_bases >> 5;
+    const uint64_t m0 = mask[mi], m1 = mi + 1 < nm ? mask[mi + 1] : 0xffffffffu;
+    const uint64_t bad = ((m1 << 32) | m0) >> ((uint32_t)p0 & 31u);  // (bits past the two words: never reached by 8 + 16 residues)
+    uint32_t unknowns = 0;  // bit j: the k-mer at p0 + j holds a residue that is not ACGT
+#pragma unroll
+    for (int j = 0; j < kPPT; ++j) unknowns |= (((bad >> j) & kBadMask) != 0 ? 1u : 0u) << j;
+    if (__builtin_expect(unknowns != 0u, 0)) {
+      const uint64_t wi = (uint64_t)p0 >> 4, nw = arena_bases >> 4;
+      const uint64_t w0 = packed[wi], w1 = wi + 1 < nw ? packed[wi + 1] : 0u;
+      const uint64_t bases = ((w1 << 32) | w0) >> (2 * ((uint32_t)p0 & 15u));
+      uint64_t beg = c_beg, next = c_next;
+      uint32_t cc = c, len = c_len;
+#pragma unroll 1  // one copy of the code, the thread's positions one after the other; the registers take the results from LDS
+      for (uint32_t rest = unknowns; rest; rest &= rest - 1u) {
+        const int j = __builtin_ctz(rest);
+        const uint64_t pos = (uint64_t)(p0 + j);
+        if (pos >= arena_bases) break;
+        while (pos >= next) {  // into the next contig
+          ++cc;
+          beg = next;
+          len = contig_len[cc];
+          next = cc + 1 < n_contigs ? contig_start[cc + 1] : ~0ULL;
+        }
+        if (pos - beg + K > len) continue;
+        s_h[tid * kPPT + j] = hash_kmer_with_unknowns<K>((uint32_t)(bases >> (2 * j)) & kMask, (uint32_t)((bad >> j) & kBadMask));
+      }
+#pragma unroll
+      for (int j = 0; j < kPPT; ++j) own[j] = s_h[tid * kPPT + j];
+    }
+  }
   __syncthreads();
 
   // ---- winnowing minimum (rightmost on ties) for every position that can be asked about, from minima over the
@@ -266,19 +350,6 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     }
   }
   __syncthreads();
-  uint32_t c = 0;
-  bool have_c = false;
-  // the contig of the thread's first position, and its bounds in registers: they change at a contig boundary only
-  // (asking contig_start again for every position was a load, and a wait, per position)
-  uint64_t c_beg = 0, c_next = ~0ULL;
-  uint32_t c_len = 0;
-  if (p0 >= 0 && (uint64_t)p0 < arena_bases) {
-    c = contig_of(contig_start, n_contigs, (uint64_t)p0);
-    have_c = true;
-    c_beg = contig_start[c];
-    c_len = contig_len[c];
-    c_next = c + 1 < n_contigs ? contig_start[c + 1] : ~0ULL;
-  }
   uint32_t local[kPPT];
   uint32_t cidx[kPPT];
   int32_t mpv[kPPT];     // position of the window minimum (tile coordinates), -1: no window ends here
@@ -498,6 +569,7 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
 // threshold are taken out of the posting lists -- everything after the index sees lists that never held them.  The
 // minimizers themselves stay where they are: the L2 windows hold every minimizer, as fastANI's do.
 constexpr uint32_t kFreqBins = 256;
+constexpr uint32_t kCutBits = 24;  // bit set of the hashes that lost seed hits: one bit per value of the hash's top kCutBits bits
 __device__ __forceinline__ uint32_t posting_run_length(const uint32_t *__restrict__ heads, const uint16_t *__restrict__ post_genome,
                                                        uint32_t i, uint32_t m) {
   const uint16_t g = post_genome[i];
@@ -529,10 +601,10 @@ __global__ __launch_bounds__(kThreads) void posting_run_hist_kernel(const uint32
 // keep[] (all ones on entry) = 0 for the postings of runs at or above their genome's threshold: the thread of a run's first
 // posting measures the run and, where it is cut, clears its flags (one thread per run: a run costs its length once)
 __global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint32_t *__restrict__ heads,
-                                                                     const uint32_t *__restrict__ ids_before,
+                                                                     const uint64_t *__restrict__ sorted_keys,
                                                                      const uint16_t *__restrict__ post_genome, uint32_t m,
                                                                      const uint32_t *__restrict__ threshold,
-                                                                     uint32_t *__restrict__ keep, uint8_t *__restrict__ hash_cut) {
+                                                                     uint32_t *__restrict__ keep, uint32_t *__restrict__ hash_cut) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= m) return;
   const uint16_t g = post_genome[i];
@@ -542,11 +614,12 @@ __global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint3
   const uint32_t c = posting_run_length(heads, post_genome, i, m);
   if (c >= thr) {
     for (uint32_t j = i; j < i + c; ++j) keep[j] = 0u;
-    // the hash (dense id: hashes before this posting's, plus one where it is its hash's first) has lost seed hits somewhere:
-    // its matches in an L2 window are no longer all among the seed hits (the mapping kernel's bounds allow for them)
-    uint32_t first = i;
-    while (!heads[first]) --first;
-    hash_cut[ids_before[first]] = 1;
+    // the hash has lost seed hits somewhere: its matches in an L2 window are no longer all among the seed hits (the mapping
+    // kernel's bounds allow for them).  Marked in a bit set over the top kCutBits bits of the hash (2 MB: it stays in the L2
+    // while every minimizer of every fragment asks it; a hash that merely shares its top bits with a cut one -- 3 in 10 000 --
+    // loosens a bound by one, no more)
+    const uint32_t h = (uint32_t)sorted_keys[i];
+    atomicOr(&hash_cut[h >> (32u - kCutBits + 5u)], 1u << ((h >> (32u - kCutBits)) & 31u));
   }
 }
 __global__ __launch_bounds__(kThreads) void posting_compact_kernel(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ at,
@@ -627,47 +700,55 @@ __device__ __forceinline__ void bitonic_sort_lanes(Key (&k)[E], uint32_t lane) {
 // fastANI sketches a fragment on its own: winnowing restarts at the fragment's first residue, and the first minimizer is
 // selected at the window of the first USED k-mer at or after the fragment's w-th.  Here a fragment's sketch is a slice of its
 // genome's minimizers, and that window is all the slice needs to know: d = the windows at the fragment's start at which
-// nothing is selected = the k-mers from the w-th on that hold an invalid residue or equal their own reverse complement
-// (both strands hash alike), 0 nearly always; count_windows when no k-mer of the fragment is used from there on.  The
-// wave looks at 64 windows at a time, one k-mer per lane.  (x0: arena position of the fragment's w-th k-mer.)
-__device__ __forceinline__ uint32_t windows_without_selection(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask,
-                                                              uint64_t arena_bases, uint64_t x0, uint32_t k, uint32_t count_windows,
-                                                              uint32_t lane) {
+// nothing is selected = the k-mers from the w-th on that equal their own reverse complement (both strands hash alike; a
+// residue that is not ACGT counts as the N it is hashed as, and stays where it is in the reverse complement: a run of N is
+// such a k-mer), 0 nearly always; count_windows when no k-mer of the fragment is used from there on.
+// One thread per fragment of the batch (the answer is in the first k-mer nearly always; the wave that builds the sketch
+// would only wait for it).  (x0: arena position of the fragment's w-th k-mer.)
+__global__ __launch_bounds__(kThreads) void windows_without_selection_kernel(
+    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
+    const uint64_t *__restrict__ contig_start, uint32_t k, uint32_t w, const uint32_t *__restrict__ frag_contig,
+    const uint32_t *__restrict__ frag_no, uint32_t n_frags, uint32_t frag_len, uint32_t count_windows,
+    uint32_t *__restrict__ frag_d) {
+  const uint32_t f = blockIdx.x * kThreads + threadIdx.x;
+  if (f >= n_frags) return;
+  const uint64_t x0 = contig_start[frag_contig[f]] + (uint64_t)frag_no[f] * frag_len + w - 1u;
   const uint32_t k_mask = k == 16u ? 0xffffffffu : ((1u << (2u * k)) - 1u);
   const uint64_t nw = arena_bases >> 4, nm = arena_bases >> 5;
-  for (uint32_t base = 0; base < count_windows; base += 64) {
-    const uint32_t d = base + lane;
-    bool used = false;
-    if (d < count_windows) {
-      const uint64_t x = x0 + d, wi = x >> 4, mi = x >> 5;
-      const uint64_t w0 = wi < nw ? packed[wi] : 0u, w1 = wi + 1 < nw ? packed[wi + 1] : 0u;
-      const uint32_t fwd = (uint32_t)(((w1 << 32) | w0) >> (2u * ((uint32_t)x & 15u))) & k_mask;  // base j in bits 2j, 2j+1
-      const uint64_t m0 = mi < nm ? mask[mi] : 0xffffffffu, m1 = mi + 1 < nm ? mask[mi + 1] : 0xffffffffu;
-      const uint32_t bad = (uint32_t)(((m1 << 32) | m0) >> ((uint32_t)x & 31u)) & ((1u << k) - 1u);
-      // the reverse complement in the same layout: the 2-bit groups in reverse order, complemented
-      uint32_t r = __brev(fwd);
-      r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
-      const uint32_t rc = (r >> (32u - 2u * k)) ^ k_mask;
-      used = bad == 0u && rc != fwd;
-    }
-    const uint64_t any = __ballot(used);
-    if (any) return base + (uint32_t)__builtin_ctzll(any);
+  uint32_t d = 0;
+  for (; d < count_windows; ++d) {
+    const uint64_t x = x0 + d, wi = x >> 4, mi = x >> 5;
+    const uint64_t w0 = wi < nw ? packed[wi] : 0u, w1 = wi + 1 < nw ? packed[wi + 1] : 0u;
+    const uint32_t fwd = (uint32_t)(((w1 << 32) | w0) >> (2u * ((uint32_t)x & 15u))) & k_mask;  // base j in bits 2j, 2j+1
+    const uint64_t m0 = mi < nm ? mask[mi] : 0xffffffffu, m1 = mi + 1 < nm ? mask[mi + 1] : 0xffffffffu;
+    const uint32_t bad = (uint32_t)(((m1 << 32) | m0) >> ((uint32_t)x & 31u)) & ((1u << k) - 1u);
+    // the reverse complement in the same layout: the 2-bit groups in reverse order, complemented; the unknown residues
+    // in reverse order, as they are
+    uint32_t r = __brev(fwd);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    const uint32_t rc = (r >> (32u - 2u * k)) ^ k_mask;
+    const uint32_t rbad = __brev(bad) >> (32u - k);
+    uint32_t known = ~bad & 0xffffu;  // one bit per residue -> two
+    known = (known | (known << 8)) & 0x00ff00ffu;
+    known = (known | (known << 4)) & 0x0f0f0f0fu;
+    known = (known | (known << 2)) & 0x33333333u;
+    known = (known | (known << 1)) & 0x55555555u;
+    known |= known << 1;
+    if (!(bad == rbad && ((fwd ^ rc) & known & k_mask) == 0u)) break;  // a used k-mer
   }
-  return count_windows;
+  frag_d[f] = d;
 }
 
 // one wave per fragment: slice of the contig's minimizers, sorted by (hash, slice index), first of each hash kept
 __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
-    const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
-    const uint64_t *__restrict__ contig_start, uint32_t k, uint32_t w,
-    const uint32_t *__restrict__ frag_contig, const uint32_t *__restrict__ frag_no, uint32_t n_frags, uint32_t frag_len,
+    const uint32_t *__restrict__ frag_d, const uint32_t *__restrict__ frag_contig, const uint32_t *__restrict__ frag_no, uint32_t n_frags, uint32_t frag_len,
     uint32_t count_windows, const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const uint32_t *__restrict__ mini_id, const uint32_t *__restrict__ post_start,
     uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos /* posting list length */,
     uint32_t *__restrict__ q_id /* first posting */, uint32_t *__restrict__ q_s,
     uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow, uint32_t *__restrict__ max_hits,
-    const uint8_t *__restrict__ hash_cut, uint32_t *__restrict__ q_cut /* hashes of the sketch that lost seed hits to the frequency cut */) {
+    const uint32_t *__restrict__ hash_cut, uint32_t *__restrict__ q_cut /* hashes of the sketch that lost seed hits to the frequency cut */) {
   __shared__ uint64_t s_key[kThreads / 64][kQMax];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * (kThreads / 64) + wave;
@@ -683,7 +764,7 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const uint32_t e = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, p + count_windows);
     // the minimizer recorded last before the fragment belongs to its sketch unless a new one is recorded by the first
     // window at which the fragment, sketched alone, selects any
-    const uint32_t d = windows_without_selection(packed, mask, arena_bases, contig_start[c] + p + w - 1u, k, count_windows, lane);
+    const uint32_t d = frag_d[f];  // windows_without_selection_kernel
     const bool fresh = b < m1 && mini_wpos[b] <= p + d;
     b0 = (!fresh && b > m0) ? b - 1 : b;
     n = d < count_windows ? e - b0 : 0u;  // (no used k-mer from the w-th on: no sketch)
@@ -731,7 +812,7 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
       q_pos[(uint64_t)f * kQMax + o] = cnt;
       q_id[(uint64_t)f * kQMax + o] = lo;
       hits += cnt;
-      cut_hashes += hash_cut[id];
+      cut_hashes += (hash_cut[h >> (32u - kCutBits + 5u)] >> ((h >> (32u - kCutBits)) & 31u)) & 1u;
     }
     s += __popcll(bal);
   }
@@ -2113,7 +2194,7 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs;
+      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d;
   // the reference index (stages 1 and 2) of the last pa_fragani(_ex) call, for PA_FRAGANI_REUSE_INDEX
   bool index_valid = false;
   const void *index_packed = nullptr;
@@ -2126,7 +2207,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -2140,12 +2221,12 @@ FragWork &frag_work(pa_ctx *c) {
 
 // Mashmap's frequency cut (see posting_run_hist_kernel): thresholds per reference genome on the host, from the histograms
 // of the run lengths; the runs at or above them leave the posting lists.  `heads`: 1 at the first posting of every hash,
-// `ids_before`: the hashes before a posting's own (the scan of `heads`); `scratch`: 2 m words, free at this point.
-int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const uint32_t *d_ids_before, uint32_t *scratch, uint32_t m,
+// `sorted_keys`: the postings' hashes (low words); `scratch`: 2 m words, free at this point.
+int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const uint64_t *d_sorted_keys, uint32_t *scratch, uint32_t m,
                           uint32_t n_ids, const uint32_t *h_contig_genome, uint32_t n_contigs, uint32_t n_genomes) {
   uint32_t *scratch_a = scratch, *scratch_b = scratch + m;
-  PA_TRY(W.hash_cut.reserve((uint64_t)n_ids + 16));
-  PA_HIP(hipMemsetAsync(W.hash_cut.p, 0, (uint64_t)n_ids + 1, c->stream));
+  PA_TRY(W.hash_cut.reserve((1ull << kCutBits) / 8));
+  PA_HIP(hipMemsetAsync(W.hash_cut.p, 0, (1ull << kCutBits) / 8, c->stream));
   if (const char *v = getenv("PA_FRAGANI_NO_FREQ_CUT")) { if (atoi(v)) return PA_OK; }  // tools: the seeds as rounds 1-4 looked them up
   constexpr uint32_t kOverCap = 1u << 20;
   std::vector<uint32_t> threshold(n_genomes, 0xffffffffu);
@@ -2200,8 +2281,8 @@ int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const
   PA_TRY(W.post_g2.reserve((uint64_t)m * 2 + 16));
   const uint32_t gm = ceil_div_u64(m, kThreads);
   PA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch_a), 1, m, c->stream));
-  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before, W.post_g.as<uint16_t>(), m,
-                     W.run_hist.as<uint32_t>(), scratch_a, W.hash_cut.as<uint8_t>());
+  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_sorted_keys, W.post_g.as<uint16_t>(), m,
+                     W.run_hist.as<uint32_t>(), scratch_a, W.hash_cut.as<uint32_t>());
   PA_TRY(pa_exclusive_scan_u32(c, scratch_a, scratch_b, m, W.scalars.as<uint64_t>()));
   PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
   PA_HIP(hipStreamSynchronize(c->stream));
@@ -2479,7 +2560,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
                        W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>(), W.contig_mini_off.as<uint32_t>(), n_contigs);
     W.index_ids = n_ids;
-    PA_TRY(cut_frequent_postings(c, W, d_flags, d_pos, reinterpret_cast<uint32_t *>(keys[1 - which]), m, n_ids, h_contig_genome, n_contigs, n_genomes));
+    PA_TRY(cut_frequent_postings(c, W, d_flags, keys[which], reinterpret_cast<uint32_t *>(keys[1 - which]), m, n_ids, h_contig_genome, n_contigs, n_genomes));
   }
   const uint32_t *d_sorted_idx = vals[which];
   // the index (minimizers, bucket index, dictionary, postings) is complete: a later call may take it over
@@ -2563,13 +2644,16 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     const uint32_t gw = ceil_div_u64(nf, kThreads / 64);
     PA_HIP(hipMemsetAsync(d_max_hits, 0, 8, c->stream));  // [0] most hits, [1] longest sketch of a fragment
     prof.emplace(c, PA_PROF_FRAG_SEED);
-    hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, d_packed, d_mask, arena_bases,
-                       W.contig_start.as<uint64_t>(), k, (uint32_t)w, W.frag_contig.as<uint32_t>(),
+    PA_TRY(W.frag_d.reserve((uint64_t)nf * 4));
+    hipLaunchKernelGGL(windows_without_selection_kernel, dim3(ceil_div_u64(nf, kThreads)), dim3(kThreads), 0, c->stream, d_packed, d_mask,
+                       arena_bases, W.contig_start.as<uint64_t>(), k, (uint32_t)w, W.frag_contig.as<uint32_t>(), W.frag_no.as<uint32_t>(),
+                       nf, frag_len, count_windows, W.frag_d.as<uint32_t>());
+    hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, W.frag_d.as<uint32_t>(), W.frag_contig.as<uint32_t>(),
                        W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
                        W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),
                        W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits,
-                       W.hash_cut.as<uint8_t>(), W.q_cut.as<uint32_t>());
+                       W.hash_cut.as<uint32_t>(), W.q_cut.as<uint32_t>());
     PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipMemcpyAsync(c->h_pinned + 1, d_max_hits, 8, hipMemcpyDeviceToHost, c->stream));

@@ -57,7 +57,12 @@ def test_parameters():
     want = np.float32(100) * (np.float32(1) - np.float32((-1.0 / 16) * math.log(2.0 * 0.5 / float(np.float32(1) + np.float32(0.5)))))
     assert oracle.fragani_identity(100, 200, 16) == float(want)
     assert oracle.fragani_identity(7, 240, 16) == float(np.float32(oracle.fragani_identity(7, 240, 16)))
-    assert oracle.fragani_kmer_hash(b"ACGTACGTACGTACGN") == 0xFFFFFFFF  # non-ACGT -> skipped
+    # fastANI hashes the characters as they are: a k-mer holding an N is a k-mer (its reverse complement keeps the N in
+    # place); only k-mers whose two strands hash alike are passed over -- reverse palindromes, runs of N
+    assert oracle.fragani_kmer_hash(b"ACGTACGTACGTACGN") not in (0xFFFFFFFF, oracle.fragani_kmer_hash(b"ACGTACGTACGTACGA"))
+    assert oracle.fragani_kmer_hash(b"ACGTACGTACGTACGN") == oracle.fragani_kmer_hash(b"NCGTACGTACGTACGT") == oracle.fragani_kmer_hash(b"acgtacgtacgtacgn")
+    assert oracle.fragani_kmer_hash(b"N" * 16) == 0xFFFFFFFF and oracle.fragani_kmer_hash(b"ACGTACGTACGTACGT") == 0xFFFFFFFF
+    assert oracle.fragani_kmer_hash(b"ACGTNNNNNNNNACGT") == 0xFFFFFFFF  # its own reverse complement, the N in place
     assert oracle.fragani_kmer_hash(b"ACGTTGCATGCATGCA") == oracle.fragani_kmer_hash(b"TGCATGCATGCAACGT")  # strand-symmetric
 
 
