@@ -10,7 +10,8 @@
  * This file restates the published algorithm (Jain et al. 2018, Nat. Commun. 9:5114, and the Mashmap
  * winnowed-MinHash mapper it embeds, Jain et al. 2017):
  *   reference sketch : winnowed minimizers; k-mer hash = min over both strands of the low 32 bits of
- *                      MurmurHash3_x64_128(seed 42); window w from the p-value bound below
+ *                      MurmurHash3_x64_128(seed 42) of the upper-cased characters as they are (no residue is
+ *                      special; k-mers whose strands hash alike are passed over); window w from the p-value bound below
  *   query            : non-overlapping fragments of fragLen per contig (remainder dropped)
  *   seeds            : every reference occurrence of every minimizer of the fragment -- but for the most frequent
  *                      reference minimizers (Mashmap's cut: as many bars of the histogram of occurrence counts, from
