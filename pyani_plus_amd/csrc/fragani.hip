@@ -624,10 +624,12 @@ __global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint3
 }
 __global__ __launch_bounds__(kThreads) void posting_compact_kernel(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ at,
                                                                    const uint64_t *__restrict__ post_cw,
-                                                                   const uint16_t *__restrict__ post_genome, uint32_t m,
-                                                                   uint64_t *__restrict__ cw_out, uint16_t *__restrict__ g_out) {
+                                                                   const uint16_t *__restrict__ post_genome,
+                                                                   const uint32_t *__restrict__ sorted_idx, uint32_t m,
+                                                                   uint64_t *__restrict__ cw_out, uint16_t *__restrict__ g_out,
+                                                                   uint32_t *__restrict__ idx_out) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-  if (i < m && keep[i]) { cw_out[at[i]] = post_cw[i]; g_out[at[i]] = post_genome[i]; }
+  if (i < m && keep[i]) { cw_out[at[i]] = post_cw[i]; g_out[at[i]] = post_genome[i]; idx_out[at[i]] = sorted_idx[i]; }
 }
 __global__ __launch_bounds__(kThreads) void posting_starts_kernel(uint32_t *__restrict__ post_start, uint32_t n_ids,
                                                                   const uint32_t *__restrict__ at, uint32_t m, uint32_t kept) {
@@ -2221,8 +2223,10 @@ FragWork &frag_work(pa_ctx *c) {
 
 // Mashmap's frequency cut (see posting_run_hist_kernel): thresholds per reference genome on the host, from the histograms
 // of the run lengths; the runs at or above them leave the posting lists.  `heads`: 1 at the first posting of every hash,
-// `sorted_keys`: the postings' hashes (low words); `scratch`: 2 m words, free at this point.
-int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const uint64_t *d_sorted_keys, uint32_t *scratch, uint32_t m,
+// `sorted_keys`: the postings' hashes (low words), `sorted_idx`: their minimizers, `idx_spare`: m words; `scratch`: 2 m words,
+// free at this point.
+int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const uint64_t *d_sorted_keys, uint32_t *d_sorted_idx,
+                          uint32_t *d_idx_spare, uint32_t *scratch, uint32_t m,
                           uint32_t n_ids, const uint32_t *h_contig_genome, uint32_t n_contigs, uint32_t n_genomes) {
   uint32_t *scratch_a = scratch, *scratch_b = scratch + m;
   PA_TRY(W.hash_cut.reserve((1ull << kCutBits) / 8));
@@ -2289,11 +2293,13 @@ int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const
   const uint32_t kept = (uint32_t)c->h_pinned[0];
   if (kept != m) {
     hipLaunchKernelGGL(posting_compact_kernel, dim3(gm), dim3(kThreads), 0, c->stream, scratch_a, scratch_b, W.post_cw.as<uint64_t>(),
-                       W.post_g.as<uint16_t>(), m, W.post_cw2.as<uint64_t>(), W.post_g2.as<uint16_t>());
+                       W.post_g.as<uint16_t>(), d_sorted_idx, m, W.post_cw2.as<uint64_t>(), W.post_g2.as<uint16_t>(), d_idx_spare);
     hipLaunchKernelGGL(posting_starts_kernel, dim3(ceil_div_u64((uint64_t)n_ids + 1, kThreads)), dim3(kThreads), 0, c->stream,
                        W.post_start.as<uint32_t>(), n_ids, scratch_b, m, kept);
     std::swap(W.post_cw, W.post_cw2);
     std::swap(W.post_g, W.post_g2);
+    // (the postings' minimizer indices -- what the path for more than 8 192 genomes reads -- go back where they are looked for)
+    PA_HIP(hipMemcpyAsync(d_sorted_idx, d_idx_spare, (uint64_t)kept * 4, hipMemcpyDeviceToDevice, c->stream));
   }
   return PA_OK;
 }
@@ -2560,7 +2566,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
                        W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>(), W.contig_mini_off.as<uint32_t>(), n_contigs);
     W.index_ids = n_ids;
-    PA_TRY(cut_frequent_postings(c, W, d_flags, keys[which], reinterpret_cast<uint32_t *>(keys[1 - which]), m, n_ids, h_contig_genome, n_contigs, n_genomes));
+    PA_TRY(cut_frequent_postings(c, W, d_flags, keys[which], vals[which], vals[1 - which], reinterpret_cast<uint32_t *>(keys[1 - which]), m, n_ids, h_contig_genome, n_contigs, n_genomes));
   }
   const uint32_t *d_sorted_idx = vals[which];
   // the index (minimizers, bucket index, dictionary, postings) is complete: a later call may take it over
@@ -2609,7 +2615,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   PA_TRY(upload(c, W.genome_first_contig, gfc));
   PA_HIP(hipStreamSynchronize(c->stream));
   const bool trace = getenv("PA_FRAGANI_TRACE") != nullptr;  // per-batch sizes on stderr
-  static const bool force_sorted = [] {
+  const bool force_sorted = [] {  // PA_FRAGANI_HITS=sorted: the path of more than 8 192 genomes, for any number (tests)
     const char *v = getenv("PA_FRAGANI_HITS");
     return v && v[0] == 's';
   }();

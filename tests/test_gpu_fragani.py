@@ -573,3 +573,39 @@ def test_fragment_sketches_where_winnowing_restarted_at_the_fragment_could_diffe
     texts = [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)]
     total, matched, _ = _check_against_oracle(engine, texts, [[g] for g in genomes])
     assert total.tolist() == [14, 14, 14] and matched[1, 1] == 14 and 10 <= matched[0, 1] <= 12 and matched[0, 0] <= 12
+
+
+def test_the_path_for_more_than_8192_genomes(engine, monkeypatch):
+    """Beyond 8 192 genomes there is no LDS counter per reference genome: every fragment's hits are written out, sorted as a
+    whole and cut into segments by head flags (`PA_FRAGANI_HITS=sorted` takes that path for any number of genomes).  Same
+    results as the oracle and as the bucketed path: random genomes, the viral fixture, a repeat family, runs of N, and the
+    bacterial fixture, whose posting lists lose their most frequent minimizers (the frequency cut moves the postings and
+    the minimizer indices this path reads)."""
+    from pyani_plus_amd.engine import load_fasta_files, pack_genomes
+
+    texts, contig_lists = _random_genomes(7)
+    bucketed = _check_against_oracle(engine, texts, contig_lists)
+    files = sorted((GOLDEN / "bacterial_example").glob("*.gz"))
+    infos, arena = load_fasta_files(files)
+    dev = engine.upload(arena)
+    want = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    monkeypatch.setenv("PA_FRAGANI_HITS", "sorted")
+    got = _check_against_oracle(engine, texts, contig_lists)
+    for a, b in zip(bucketed, got):
+        assert np.array_equal(a, b)
+    got = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    names = [p.name for p in files]
+    for q, r, ani, m, t in fixture_rows("bacterial_example"):
+        qi, ri = names.index(q), names.index(r)
+        bacterial_row_bounds(q, r, ani, m, t, mean_f(got[2][qi, ri], got[1][qi, ri]), int(got[1][qi, ri]), int(got[0][qi]))
+    rng = np.random.default_rng(41)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = rng.choice(letters, size=3_000).tobytes()
+    g0 = rng.choice(letters, size=6_000).tobytes() + unit * 5 + b"N" * 3_500 + rng.choice(letters, size=6_000).tobytes()
+    g1 = bytearray(g0)
+    for i in rng.integers(0, len(g1), size=300):
+        g1[i] = ord("ACGT"[int(rng.integers(0, 4))])
+    genomes = [g0, bytes(g1)]
+    _check_against_oracle(engine, [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)], [[g] for g in genomes])
