@@ -569,7 +569,6 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
 // threshold are taken out of the posting lists -- everything after the index sees lists that never held them.  The
 // minimizers themselves stay where they are: the L2 windows hold every minimizer, as fastANI's do.
 constexpr uint32_t kFreqBins = 256;
-constexpr uint32_t kCutBits = 24;  // bit set of the hashes that lost seed hits: one bit per value of the hash's top kCutBits bits
 __device__ __forceinline__ uint32_t posting_run_length(const uint32_t *__restrict__ heads, const uint16_t *__restrict__ post_genome,
                                                        uint32_t i, uint32_t m) {
   const uint16_t g = post_genome[i];
@@ -601,10 +600,12 @@ __global__ __launch_bounds__(kThreads) void posting_run_hist_kernel(const uint32
 // keep[] (all ones on entry) = 0 for the postings of runs at or above their genome's threshold: the thread of a run's first
 // posting measures the run and, where it is cut, clears its flags (one thread per run: a run costs its length once)
 __global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint32_t *__restrict__ heads,
-                                                                     const uint64_t *__restrict__ sorted_keys,
+                                                                     const uint32_t *__restrict__ ids_before,
+                                                                     const uint32_t *__restrict__ sorted_idx,
                                                                      const uint16_t *__restrict__ post_genome, uint32_t m,
                                                                      const uint32_t *__restrict__ threshold,
-                                                                     uint32_t *__restrict__ keep, uint32_t *__restrict__ hash_cut) {
+                                                                     uint32_t *__restrict__ keep, uint32_t *__restrict__ hash_cut,
+                                                                     uint32_t *__restrict__ mini_id) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= m) return;
   const uint16_t g = post_genome[i];
@@ -615,11 +616,16 @@ __global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint3
   if (c >= thr) {
     for (uint32_t j = i; j < i + c; ++j) keep[j] = 0u;
     // the hash has lost seed hits somewhere: its matches in an L2 window are no longer all among the seed hits (the mapping
-    // kernel's bounds allow for them).  Marked in a bit set over the top kCutBits bits of the hash (2 MB: it stays in the L2
-    // while every minimizer of every fragment asks it; a hash that merely shares its top bits with a cut one -- 3 in 10 000 --
-    // loosens a bound by one, no more)
-    const uint32_t h = (uint32_t)sorted_keys[i];
-    atomicOr(&hash_cut[h >> (32u - kCutBits + 5u)], 1u << ((h >> (32u - kCutBits)) & 31u));
+    // kernel's bounds allow for them).  Every minimizer that has this hash -- in whatever genome: it is the QUERY's
+    // minimizers that are asked -- carries the mark in the top bit of its hash id, which the sketch kernel reads anyway; the
+    // first of the hash's cut runs to get here (a bit per hash says so) marks them all.
+    uint32_t first = i;
+    while (!heads[first]) --first;
+    const uint32_t id = ids_before[first];  // the hashes before this posting's own = its dense id
+    if (!((atomicOr(&hash_cut[id >> 5], 1u << (id & 31u)) >> (id & 31u)) & 1u)) {
+      uint32_t j = first;
+      do { mini_id[sorted_idx[j]] |= 0x80000000u; ++j; } while (j < m && !heads[j]);
+    }
   }
 }
 __global__ __launch_bounds__(kThreads) void posting_compact_kernel(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ at,
@@ -750,7 +756,7 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos /* posting list length */,
     uint32_t *__restrict__ q_id /* first posting */, uint32_t *__restrict__ q_s,
     uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow, uint32_t *__restrict__ max_hits,
-    const uint32_t *__restrict__ hash_cut, uint32_t *__restrict__ q_cut /* hashes of the sketch that lost seed hits to the frequency cut */) {
+    uint32_t *__restrict__ q_cut /* hashes of the sketch that lost seed hits to the frequency cut */) {
   __shared__ uint64_t s_key[kThreads / 64][kQMax];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * (kThreads / 64) + wave;
@@ -806,7 +812,7 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const uint64_t bal = __ballot(keep);
     if (keep) {
       const uint32_t o = s + __popcll(bal & ((1ULL << lane) - 1ULL));
-      const uint32_t g = b0 + idx, id = mini_id[g];
+      const uint32_t g = b0 + idx, id_and_mark = mini_id[g], id = id_and_mark & 0x7fffffffu;  // top bit: the hash lost seed hits to the frequency cut
       // the minimizer's posting list as (first posting, length): the seeding kernels then go straight to the postings
       // instead of through two more dependent, uncoalesced reads of post_start per list
       const uint32_t lo = post_start[id], cnt = post_start[id + 1] - lo;
@@ -814,7 +820,7 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
       q_pos[(uint64_t)f * kQMax + o] = cnt;
       q_id[(uint64_t)f * kQMax + o] = lo;
       hits += cnt;
-      cut_hashes += (hash_cut[h >> (32u - kCutBits + 5u)] >> ((h >> (32u - kCutBits)) & 31u)) & 1u;
+      cut_hashes += id_and_mark >> 31;
     }
     s += __popcll(bal);
   }
@@ -2223,14 +2229,14 @@ FragWork &frag_work(pa_ctx *c) {
 
 // Mashmap's frequency cut (see posting_run_hist_kernel): thresholds per reference genome on the host, from the histograms
 // of the run lengths; the runs at or above them leave the posting lists.  `heads`: 1 at the first posting of every hash,
-// `sorted_keys`: the postings' hashes (low words), `sorted_idx`: their minimizers, `idx_spare`: m words; `scratch`: 2 m words,
+// `ids_before`: the hashes before a posting's own (the scan of `heads`), `sorted_idx`: the postings' minimizers, `idx_spare`: m words; `scratch`: 2 m words,
 // free at this point.
-int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const uint64_t *d_sorted_keys, uint32_t *d_sorted_idx,
+int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const uint32_t *d_ids_before, uint32_t *d_sorted_idx,
                           uint32_t *d_idx_spare, uint32_t *scratch, uint32_t m,
                           uint32_t n_ids, const uint32_t *h_contig_genome, uint32_t n_contigs, uint32_t n_genomes) {
   uint32_t *scratch_a = scratch, *scratch_b = scratch + m;
-  PA_TRY(W.hash_cut.reserve((1ull << kCutBits) / 8));
-  PA_HIP(hipMemsetAsync(W.hash_cut.p, 0, (1ull << kCutBits) / 8, c->stream));
+  PA_TRY(W.hash_cut.reserve(((uint64_t)n_ids / 32 + 2) * 4));
+  PA_HIP(hipMemsetAsync(W.hash_cut.p, 0, ((uint64_t)n_ids / 32 + 2) * 4, c->stream));
   if (const char *v = getenv("PA_FRAGANI_NO_FREQ_CUT")) { if (atoi(v)) return PA_OK; }  // tools: the seeds as rounds 1-4 looked them up
   constexpr uint32_t kOverCap = 1u << 20;
   std::vector<uint32_t> threshold(n_genomes, 0xffffffffu);
@@ -2285,8 +2291,8 @@ int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const
   PA_TRY(W.post_g2.reserve((uint64_t)m * 2 + 16));
   const uint32_t gm = ceil_div_u64(m, kThreads);
   PA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch_a), 1, m, c->stream));
-  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_sorted_keys, W.post_g.as<uint16_t>(), m,
-                     W.run_hist.as<uint32_t>(), scratch_a, W.hash_cut.as<uint32_t>());
+  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before, d_sorted_idx,
+                     W.post_g.as<uint16_t>(), m, W.run_hist.as<uint32_t>(), scratch_a, W.hash_cut.as<uint32_t>(), W.mini_id.as<uint32_t>());
   PA_TRY(pa_exclusive_scan_u32(c, scratch_a, scratch_b, m, W.scalars.as<uint64_t>()));
   PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
   PA_HIP(hipStreamSynchronize(c->stream));
@@ -2559,6 +2565,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipStreamSynchronize(c->stream));
     const uint32_t n_ids = (uint32_t)c->h_pinned[0];
+    PA_REQUIRE(n_ids < (1u << 31), "pa_fragani: %u distinct minimizer hashes (limit 2^31)", n_ids);
     PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
     PA_HIP(hipMemsetAsync(W.prev_same.p, 0xff, (uint64_t)m * 4, c->stream));  // -1: no earlier occurrence
     hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
@@ -2566,7 +2573,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
                        W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>(), W.contig_mini_off.as<uint32_t>(), n_contigs);
     W.index_ids = n_ids;
-    PA_TRY(cut_frequent_postings(c, W, d_flags, keys[which], vals[which], vals[1 - which], reinterpret_cast<uint32_t *>(keys[1 - which]), m, n_ids, h_contig_genome, n_contigs, n_genomes));
+    PA_TRY(cut_frequent_postings(c, W, d_flags, d_pos, vals[which], vals[1 - which], reinterpret_cast<uint32_t *>(keys[1 - which]), m, n_ids, h_contig_genome, n_contigs, n_genomes));
   }
   const uint32_t *d_sorted_idx = vals[which];
   // the index (minimizers, bucket index, dictionary, postings) is complete: a later call may take it over
@@ -2659,7 +2666,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
                        W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),
                        W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits,
-                       W.hash_cut.as<uint32_t>(), W.q_cut.as<uint32_t>());
+                       W.q_cut.as<uint32_t>());
     PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipMemcpyAsync(c->h_pinned + 1, d_max_hits, 8, hipMemcpyDeviceToHost, c->stream));
