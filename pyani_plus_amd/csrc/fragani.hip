@@ -601,11 +601,9 @@ __global__ __launch_bounds__(kThreads) void posting_run_hist_kernel(const uint32
 // posting measures the run and, where it is cut, clears its flags (one thread per run: a run costs its length once)
 __global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint32_t *__restrict__ heads,
                                                                      const uint32_t *__restrict__ ids_before,
-                                                                     const uint32_t *__restrict__ sorted_idx,
                                                                      const uint16_t *__restrict__ post_genome, uint32_t m,
                                                                      const uint32_t *__restrict__ threshold,
-                                                                     uint32_t *__restrict__ keep, uint32_t *__restrict__ hash_cut,
-                                                                     uint32_t *__restrict__ mini_id) {
+                                                                     uint32_t *__restrict__ keep, uint32_t *__restrict__ hash_cut) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= m) return;
   const uint16_t g = post_genome[i];
@@ -616,17 +614,23 @@ __global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint3
   if (c >= thr) {
     for (uint32_t j = i; j < i + c; ++j) keep[j] = 0u;
     // the hash has lost seed hits somewhere: its matches in an L2 window are no longer all among the seed hits (the mapping
-    // kernel's bounds allow for them).  Every minimizer that has this hash -- in whatever genome: it is the QUERY's
-    // minimizers that are asked -- carries the mark in the top bit of its hash id, which the sketch kernel reads anyway; the
-    // first of the hash's cut runs to get here (a bit per hash says so) marks them all.
-    uint32_t first = i;
-    while (!heads[first]) --first;
-    const uint32_t id = ids_before[first];  // the hashes before this posting's own = its dense id
-    if (!((atomicOr(&hash_cut[id >> 5], 1u << (id & 31u)) >> (id & 31u)) & 1u)) {
-      uint32_t j = first;
-      do { mini_id[sorted_idx[j]] |= 0x80000000u; ++j; } while (j < m && !heads[j]);
-    }
+    // kernel's bounds allow for them).  A bit per hash (dense id: the hashes before this posting's own, plus one where it
+    // is its hash's first) says so; mark_cut_minimizers_kernel hands it on to the minimizers.
+    const uint32_t id = ids_before[i] + heads[i] - 1u;
+    atomicOr(&hash_cut[id >> 5], 1u << (id & 31u));
   }
+}
+// Every minimizer whose hash lost seed hits -- in whatever genome: it is the QUERY's minimizers that are asked -- carries
+// the mark in the top bit of its hash id, which the sketch kernel reads anyway.  One thread per posting.
+__global__ __launch_bounds__(kThreads) void mark_cut_minimizers_kernel(const uint32_t *__restrict__ heads,
+                                                                       const uint32_t *__restrict__ ids_before,
+                                                                       const uint32_t *__restrict__ sorted_idx, uint32_t m,
+                                                                       const uint32_t *__restrict__ hash_cut,
+                                                                       uint32_t *__restrict__ mini_id) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t id = ids_before[i] + heads[i] - 1u;
+  if ((hash_cut[id >> 5] >> (id & 31u)) & 1u) mini_id[sorted_idx[i]] |= 0x80000000u;
 }
 __global__ __launch_bounds__(kThreads) void posting_compact_kernel(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ at,
                                                                    const uint64_t *__restrict__ post_cw,
@@ -2291,8 +2295,10 @@ int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const
   PA_TRY(W.post_g2.reserve((uint64_t)m * 2 + 16));
   const uint32_t gm = ceil_div_u64(m, kThreads);
   PA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch_a), 1, m, c->stream));
-  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before, d_sorted_idx,
-                     W.post_g.as<uint16_t>(), m, W.run_hist.as<uint32_t>(), scratch_a, W.hash_cut.as<uint32_t>(), W.mini_id.as<uint32_t>());
+  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before,
+                     W.post_g.as<uint16_t>(), m, W.run_hist.as<uint32_t>(), scratch_a, W.hash_cut.as<uint32_t>());
+  hipLaunchKernelGGL(mark_cut_minimizers_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before, d_sorted_idx, m,
+                     W.hash_cut.as<uint32_t>(), W.mini_id.as<uint32_t>());
   PA_TRY(pa_exclusive_scan_u32(c, scratch_a, scratch_b, m, W.scalars.as<uint64_t>()));
   PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
   PA_HIP(hipStreamSynchronize(c->stream));
