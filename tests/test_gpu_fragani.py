@@ -36,6 +36,8 @@ def _random_genomes(seed: int):
         seq[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
         if g == 2:
             seq[5_000:5_040] = ord("N")  # a run of N inside a fragment
+        if g == 3:  # single unknown residues: inside a contig, as a contig's first and as a contig's last residue
+            seq[[1_234, 7_000, 7_000 + 3_100 - 1, 13_099 + 777, 13_099 + 778, 30_000]] = ord("N")
         contigs, pos = [], 0
         for n in cuts:
             contigs.append(seq[pos : pos + n].tobytes())
