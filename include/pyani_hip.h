@@ -262,8 +262,8 @@ PA_API int pa_ani_mash(pa_ctx *ctx, const uint32_t *d_common, const uint32_t *d_
  * Only the reference genomes [ref0, ref1) are mapped against (columns outside stay 0): the reference's worker is
  * called once per subject column (pyani_plus/private_cli.py:976-1063), and a column costs one column's mappings.
  * Algorithm and its parity (every fastANI value the reference holds, exactly): oracle/fragani_oracle.c.  k from 8 to 16 (fastANI itself stops at 16); fragLen in
- * [100, 65535]; contigs listed genome by genome, at most 65535 per genome and 2^20-1 in all; at most 2^20-1
- * fragments per genome.  The workspace (about 12 GB for 1000 x 5 Mb genomes) stays in the context. */
+ * [100, 65535]; at most 65535 genomes; contigs listed genome by genome, at most 65535 per genome and 2^20-1 in all;
+ * at most 2^20-1 fragments per genome.  The workspace (about 12 GB for 1000 x 5 Mb genomes) stays in the context. */
 PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
                uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t ref0, uint32_t ref1,

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
   const uint32_t pg = contig_genome[mc];
   const uint64_t key = keys[i];
   post_cw[i] = ((uint64_t)pg << 44) | ((uint64_t)mc << 24) | (uint32_t)(key >> 32);  // the window id rode along in the sort key
-  post_genome[i] = (uint16_t)pg;  // used by the bucketed seeding only, which needs n_genomes <= 8192
+  post_genome[i] = (uint16_t)pg;  // (the bucketed seeding and the frequency cut read this; at most 65 535 genomes)
   if (flags[i]) post_start[id] = i;
   if (i == m - 1) post_start[n_ids] = m;
   // "the same hash earlier in this contig": rare (repeats inside a contig), and the array has been filled with -1
@@ -2462,6 +2462,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   PA_REQUIRE(c && d_packed && d_mask && h_total_frags && h_matched && h_ident_sum, "pa_fragani: null argument");
   PA_REQUIRE(ref0 <= ref1 && ref1 <= n_genomes, "pa_fragani: reference range [%u,%u) outside [0,%u)", ref0, ref1, n_genomes);
   PA_REQUIRE(qry0 <= qry1 && qry1 <= n_genomes, "pa_fragani: query range [%u,%u) outside [0,%u)", qry0, qry1, n_genomes);
+  PA_REQUIRE(n_genomes <= 0xffffu, "pa_fragani: %u genomes (limit 65 535: a posting names its genome in 16 bits)", n_genomes);
   PA_REQUIRE((flags & ~(uint32_t)(PA_FRAGANI_REUSE_INDEX | PA_FRAGANI_COLUMNS_ONLY)) == 0, "pa_fragani: unknown flags 0x%x", flags);
   // the row length of the two result matrices on the host, and the first column they hold
   const uint32_t out_cols = (flags & PA_FRAGANI_COLUMNS_ONLY) ? ref1 - ref0 : n_genomes;
