@@ -780,7 +780,29 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const bool fresh = b < m1 && mini_wpos[b] <= p + d;
     b0 = (!fresh && b > m0) ? b - 1 : b;
     n = d < count_windows ? e - b0 : 0u;  // (no used k-mer from the w-th on: no sketch)
-    if (n > (uint32_t)kQMax) { if (lane == 0) atomicAdd(overflow, 1u); n = kQMax; }
+  }
+  // A slice of more than kQMax minimizers is low-complexity sequence: inside a homopolymer run or an array of a short
+  // unit every window records its (rightmost) minimum anew -- one minimizer per position, all with the same hash.  Runs of
+  // equal hashes are taken as one entry each on the way in (the sketch is the set of hashes); only a slice that still
+  // holds more than kQMax entries is refused.
+  const bool long_slice = n > (uint32_t)kQMax;  // (uniform: one fragment per wave)
+  if (long_slice) {
+    uint32_t o = 0, carry = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+      const uint32_t e = base + lane;
+      const uint32_t h = e < n ? mini_hash[b0 + e] : 0u;
+      uint32_t before = (uint32_t)__shfl_up((int)h, 1, 64);
+      if (lane == 0) before = carry;
+      const bool keep = e < n && (e == 0u || h != before);
+      const uint64_t bal = __ballot(keep);
+      const uint32_t at = o + (uint32_t)__popcll(bal & ((1ULL << lane) - 1ULL));
+      if (keep && at < (uint32_t)kQMax) key[at] = ((uint64_t)h << 16) | e;  // (e <= count_windows <= 65 535)
+      o += (uint32_t)__popcll(bal);
+      carry = (uint32_t)__shfl((int)h, 63, 64);
+    }
+    if (o > (uint32_t)kQMax) { if (lane == 0) atomicAdd(overflow, 1u); o = kQMax; }
+    n = o;
+    __builtin_amdgcn_wave_barrier();
   }
   // the slice's (hash, slice index) keys ordered in registers, E = 1, 2, 4 or 8 per lane by the size of the slice, and
   // left in LDS for the pass below (every wave has its own keys: no barrier between the waves of the workgroup)
@@ -790,8 +812,9 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
-      k[q] = e < n ? (((uint64_t)mini_hash[b0 + e] << 16) | e) : ~0ULL;
+      k[q] = e < n ? (long_slice ? key[e] : (((uint64_t)mini_hash[b0 + e] << 16) | e)) : ~0ULL;
     }
+    __builtin_amdgcn_wave_barrier();  // (a long slice: every lane has its entries before any is overwritten)
     bitonic_sort_lanes<E, uint64_t>(k, lane);
 #pragma unroll
     for (int q = 0; q < E; ++q) key[lane * (uint32_t)E + (uint32_t)q] = k[q];

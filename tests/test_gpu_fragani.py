@@ -611,3 +611,22 @@ def test_the_path_for_more_than_8192_genomes(engine, monkeypatch):
         g1[i] = ord("ACGT"[int(rng.integers(0, 4))])
     genomes = [g0, bytes(g1)]
     _check_against_oracle(engine, [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)], [[g] for g in genomes])
+
+
+def test_low_complexity_fragments(engine):
+    """Inside a homopolymer run or an array of a short unit every window records its minimum anew: a fragment's slice of the
+    genome's minimizers then holds one entry per position (thousands, all of one hash) where its sketch holds one hash.  The
+    sketch kernel takes runs of equal hashes as one entry on the way in; same mappings as the oracle."""
+    rng = np.random.default_rng(8)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n: int) -> bytes:
+        return rng.choice(letters, size=n).tobytes()
+
+    g0 = rnd(6_500) + b"A" * 900 + rnd(4_000) + b"AC" * 700 + rnd(3_100) + b"AAC" * 1_100 + rnd(6_000) + b"T" * 3_200 + rnd(5_000)
+    g1 = bytearray(g0)
+    for i in rng.integers(0, len(g1), size=400):
+        g1[i] = ord("ACGT"[int(rng.integers(0, 4))])
+    genomes = [g0, bytes(g1), rnd(9_000)]
+    total, matched, _ = _check_against_oracle(engine, [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)], [[g] for g in genomes])
+    assert matched[0, 1] >= total[0] - 3 and matched[0, 2] == 0

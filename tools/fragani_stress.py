@@ -3,7 +3,10 @@
 broken it before -- repeats (tandem and dispersed), runs of N and single N, contigs shorter than a fragment, contigs that end
 with their last fragment, lower case, several k and fragment lengths.
 
-    python tools/fragani_stress.py [cases=200] [seed=1]
+    python tools/fragani_stress.py [cases=200] [seed=1] [big]
+
+`big`: genomes of 1.4 to 3 Mb with arrays of short repeats and homopolymer runs, so that Mashmap's frequency cut of the seeds
+is active (it needs 100 000 distinct minimizers before it ignores one), and a small mutated excerpt as the second genome.
 
 Prints one line per failing case (and stops after ten); exit code 1 if any.  Needs a GPU; the oracle is the checker."""
 import sys
@@ -57,15 +60,40 @@ def make_case(rng):
     return k, frag, genomes
 
 
+def make_big_case(rng):
+    n = int(rng.integers(1_400_000, 3_000_000))
+    g = bytearray(rng.choice(ACGT, size=n).tobytes())
+    arrays = []
+    for _ in range(int(rng.integers(1, 6))):
+        unit = rng.choice(ACGT, size=int(rng.integers(1, 5))).tobytes()
+        copies = int(rng.integers(60, 400))
+        at = int(rng.integers(10_000, len(g) - 10_000))
+        g[at:at] = unit * copies
+        arrays.append(at)
+    for _ in range(int(rng.integers(0, 3))):  # a dispersed family: one 1.2 kb element at 30 to 60 places
+        el = rng.choice(ACGT, size=1_200).tobytes()
+        for _ in range(int(rng.integers(30, 60))):
+            at = int(rng.integers(0, len(g)))
+            g[at:at] = el
+    big = bytes(g)
+    around = arrays[int(rng.integers(0, len(arrays)))]
+    lo = max(0, around - int(rng.integers(6_000, 30_000)))
+    part = np.frombuffer(big[lo : lo + int(rng.integers(30_000, 90_000))], dtype=np.uint8).copy()
+    hit = rng.random(part.size) < float(rng.choice([0.0, 0.01, 0.05, 0.1]))
+    part[hit] = ACGT[rng.integers(0, 4, size=int(hit.sum()))]
+    return 16, 3000, [[big], [part.tobytes()]]
+
+
 def main() -> int:
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     rng = np.random.default_rng(seed)
     eng = HipEngine(0)
     bad = 0
     t0 = time.time()
     for case in range(cases):
-        k, frag, genomes = make_case(rng)
+        k, frag, genomes = make_big_case(rng) if big else make_case(rng)
         if oracle.fragani_window_size(k, frag) > 64:
             continue
         texts = [b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs)) for contigs in genomes]
