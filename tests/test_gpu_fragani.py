@@ -630,3 +630,31 @@ def test_low_complexity_fragments(engine):
     genomes = [g0, bytes(g1), rnd(9_000)]
     total, matched, _ = _check_against_oracle(engine, [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)], [[g] for g in genomes])
     assert matched[0, 1] >= total[0] - 3 and matched[0, 2] == 0
+
+
+def test_random_genome_sets(engine):
+    """Forty random genome sets of tools/fragani_stress.py (repeats, runs of N, short and exactly-ending contigs, lower case,
+    four k and four fragment lengths): every ordered pair, device against oracle."""
+    import importlib.util
+    from pathlib import Path
+
+    from pyani_plus_amd.engine import pack_genomes
+
+    spec = importlib.util.spec_from_file_location("fragani_stress", Path(__file__).resolve().parent.parent / "tools" / "fragani_stress.py")
+    stress = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stress)
+    rng = np.random.default_rng(2024)
+    pairs = 0
+    for _case in range(40):
+        k, frag, genomes = stress.make_case(rng)
+        if oracle.fragani_window_size(k, frag) > 64:
+            continue
+        arena = pack_genomes([b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs)) for contigs in genomes])
+        total, matched, ident_sum = engine.fragani(engine.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, k, frag)
+        for q in range(len(genomes)):
+            for r in range(len(genomes)):
+                ani, m, t = oracle.fragani_pair(genomes[q], genomes[r], k, frag, 0.0)
+                assert (int(total[q]), int(matched[q, r])) == (t, m), (_case, k, frag, q, r)
+                assert m == 0 or mean_f(ident_sum[q, r], m) == ani, (_case, k, frag, q, r)
+                pairs += 1
+    assert pairs > 300
