@@ -2559,7 +2559,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     }
     genome_bin_off[n_genomes] = contig_bin_off[n_contigs];
   }
-  const uint64_t total_bins = contig_bin_off[n_contigs];
+  const uint32_t bin_base = genome_bin_off[ref0];
+  const uint64_t range_bins = std::max<uint32_t>(genome_bin_off[ref1] - bin_base, 1u);  // bins of the reference genomes asked for
   const uint32_t n_frags = (uint32_t)frag_contig.size();
   for (uint64_t i = (uint64_t)qry0 * out_cols; i < (uint64_t)qry1 * out_cols; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
   auto remember_index = [&](int which_buf) {
@@ -2619,8 +2620,15 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_TRY(upload(c, W.tab_min_hits, mh));
     PA_TRY(upload(c, W.tab_min_shared, ms));
     PA_TRY(upload(c, W.ident_tab, ident));
-    PA_TRY(upload(c, W.contig_bin_off, contig_bin_off));
-    PA_TRY(upload(c, W.genome_bin_off, genome_bin_off));
+    // The table of best fragments per reference bin holds the bins of the reference range only (a worker asked for one
+    // subject column keeps 1 700 bins per query genome instead of 1.7 million): bin numbers relative to the range's first;
+    // genomes outside it get an empty run of bins, so the reduction gives them nothing, as an all-zero table did.
+    std::vector<uint32_t> cbo_rel(contig_bin_off.size()), gbo_rel(genome_bin_off.size());
+    for (size_t i = 0; i < contig_bin_off.size(); ++i) cbo_rel[i] = contig_bin_off[i] - std::min(contig_bin_off[i], bin_base);
+    for (size_t g = 0; g < genome_bin_off.size(); ++g)
+      gbo_rel[g] = std::min<uint32_t>(genome_bin_off[g] - std::min(genome_bin_off[g], bin_base), (uint32_t)range_bins);
+    PA_TRY(upload(c, W.contig_bin_off, cbo_rel));
+    PA_TRY(upload(c, W.genome_bin_off, gbo_rel));
     PA_HIP(hipStreamSynchronize(c->stream));
   }
 
@@ -2665,7 +2673,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   for (uint32_t g0 = qry0; g0 < qry1;) {
     uint32_t g1 = g0 + 1;
     while (g1 < qry1 && genome_frag_off[g1 + 1] - genome_frag_off[g0] <= batch_frags &&
-           (uint64_t)(g1 + 1 - g0) * total_bins * 8 <= kMaxTableBytes)
+           (uint64_t)(g1 + 1 - g0) * range_bins * 8 <= kMaxTableBytes)
       ++g1;
     const uint32_t f0 = genome_frag_off[g0], nf = genome_frag_off[g1] - f0, nq = g1 - g0;
     PA_REQUIRE(nf < (1u << 20), "pa_fragani: genome %u alone has %u fragments (limit 2^20)", g0, nf);
@@ -2712,8 +2720,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     if (trace) fprintf(stderr, "pa_fragani: batch of genomes %u..%u: %u fragments, %llu seed hits\n", g0, g1, nf, (unsigned long long)n_hits);
     PA_REQUIRE(n_hits < (1ULL << 31), "pa_fragani: %llu seed hits for the fragments of genome %u alone (limit 2^31); highly "
                "repetitive input", (unsigned long long)n_hits, g0);
-    PA_TRY(W.table.reserve((uint64_t)nq * total_bins * 8));
-    PA_HIP(hipMemsetAsync(W.table.p, 0, (uint64_t)nq * total_bins * 8, c->stream));
+    PA_TRY(W.table.reserve((uint64_t)nq * range_bins * 8));
+    PA_HIP(hipMemsetAsync(W.table.p, 0, (uint64_t)nq * range_bins * 8, c->stream));
     if (n_hits) {
       PA_TRY(W.hkeys[0].reserve(n_hits * 8));
       PA_TRY(W.hvals[0].reserve(n_hits * 4));
@@ -2869,7 +2877,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.frag_genome_local.as<uint32_t>(), frag_len, count_windows,                                        \
                        W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),                                  \
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),      \
-                       W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), total_bins, \
+                       W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), range_bins, \
                        W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap, map_cut);                 \
     break;
         switch (ref_cap) {
@@ -2914,7 +2922,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_TRY(W.matched.reserve((uint64_t)nq * n_genomes * 4));
     PA_TRY(W.ident_sum.reserve((uint64_t)nq * n_genomes * 8));
     hipLaunchKernelGGL(reduce_pairs_kernel, dim3(nq * n_genomes), dim3(64), 0, c->stream,
-                       W.table.as<unsigned long long>(), total_bins, W.genome_bin_off.as<uint32_t>(), n_genomes,
+                       W.table.as<unsigned long long>(), range_bins, W.genome_bin_off.as<uint32_t>(), n_genomes,
                        W.ident_tab.as<float>(), W.matched.as<uint32_t>(), W.ident_sum.as<double>());
     PA_HIP(hipGetLastError());
     prof.reset();
