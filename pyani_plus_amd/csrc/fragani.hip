@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
       bad = ((m1 << 32) | m0) >> ((uint32_t)p0 & 31u);
       if ((uint32_t)p0 & 31u) bad |= ~0ULL << (64 - ((uint32_t)p0 & 31u));  // beyond the two mask words: unusable
     }
-    constexpr uint32_t kMask = (K == 16) ? 0xffffffffu : ((1u << (2 * K)) - 1u);
+    constexpr uint32_t kMask = (K == 16) ? 0xffffffffu : (uint32_t)((1ull << (2 * K)) - 1ull);
     constexpr uint64_t kBadMask = (1ULL << K) - 1;
     uint32_t fm = 0, fl = 0;
 #pragma unroll
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
   // variant by variant) -- so the mask words are asked for again (they are in the cache), the residues only by the threads
   // that need them, and the k-mer's contig is found by walking on from the thread's.
   if (have_c) {
-    constexpr uint32_t kMask = (K == 16) ? 0xffffffffu : ((1u << (2 * K)) - 1u);
+    constexpr uint32_t kMask = (K == 16) ? 0xffffffffu : (uint32_t)((1ull << (2 * K)) - 1ull);
     constexpr uint64_t kBadMask = (1ULL << K) - 1;
     const uint64_t mi = (uint64_t)p0 >> 5, nm = arena_bases >> 5;
     const uint64_t m0 = mask[mi], m1 = mi + 1 < nm ? mask[mi + 1] : 0xffffffffu;
@@ -502,10 +502,36 @@ __global__ __launch_bounds__(kThreads) void bucket_index_kernel(const uint32_t *
 // ============================================================== 2. dictionary of minimizer hashes
 // Sort key of a minimizer: its hash in the low word -- the only bits the radix passes look at -- and its window id as a
 // passenger in the high word, so that the posting build reads it in posting order instead of gathering it.
+// (`base`: the first minimizer the dictionary holds -- those of the reference genomes asked for; values = minimizer indices)
 __global__ __launch_bounds__(kThreads) void mini_keys_kernel(const uint32_t *__restrict__ hash, const uint32_t *__restrict__ wpos,
-                                                             uint32_t m, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                                                             uint32_t base, uint32_t m, uint64_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ vals) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-  if (i < m) { keys[i] = ((uint64_t)wpos[i] << 32) | hash[i]; vals[i] = i; }
+  if (i < m) { keys[i] = ((uint64_t)wpos[base + i] << 32) | hash[base + i]; vals[i] = base + i; }
+}
+// Where the dictionary holds the reference range's minimizers only, a query minimizer finds its hash by value: an open
+// table of {hash, first posting, postings | mark of the frequency cut << 31, -} entries, 16 bytes each, at least two slots
+// per hash, linear probing -- one load per look-up where a search through the sorted hashes and the list bounds were eight
+// (19 ms per batch against 1 for 125 of 1 000 genomes).  The slot comes from the hash multiplied by the golden-ratio
+// constant: a minimizer's hash is the MINIMUM of a window of hashes, and minima crowd at the low end -- slotted by their top
+// bits they filled the table's first tenth and every probe walked through it (28 s for twenty genomes).
+__device__ __forceinline__ uint32_t lookup_slot(uint32_t h, uint32_t table_bits) { return (h * 0x9e3779b1u) >> (32u - table_bits); }
+__global__ __launch_bounds__(kThreads) void lookup_insert_kernel(const uint32_t *__restrict__ uniq_hash,
+                                                                 const uint32_t *__restrict__ post_start,
+                                                                 const uint32_t *__restrict__ hash_cut, uint32_t n_ids,
+                                                                 uint32_t table_bits, uint4 *__restrict__ table) {
+  const uint32_t id = blockIdx.x * kThreads + threadIdx.x;
+  if (id >= n_ids) return;
+  const uint32_t h = uniq_hash[id], lo = post_start[id], cnt = post_start[id + 1] - lo;
+  const uint32_t mark = (hash_cut[id >> 5] >> (id & 31u)) & 1u;
+  const uint32_t mask = (1u << table_bits) - 1u;
+  unsigned long long *words = reinterpret_cast<unsigned long long *>(table);
+  for (uint32_t slot = lookup_slot(h, table_bits);; slot = (slot + 1u) & mask) {
+    if (atomicCAS(&words[2ull * slot], ~0ULL, ((unsigned long long)lo << 32) | h) == ~0ULL) {
+      table[slot].z = cnt | (mark << 31);
+      return;
+    }
+  }
 }
 __global__ __launch_bounds__(kThreads) void key_heads_kernel(const uint64_t *__restrict__ keys, uint32_t m,
                                                              uint32_t *__restrict__ flags) {
@@ -523,7 +549,8 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
                                                             const uint32_t *__restrict__ contig_genome,
                                                             uint64_t *__restrict__ post_cw,
                                                             uint16_t *__restrict__ post_genome,
-                                                            const uint32_t *__restrict__ contig_mini_off, uint32_t n_contigs) {
+                                                            const uint32_t *__restrict__ contig_mini_off, uint32_t n_contigs,
+                                                            uint32_t *__restrict__ uniq_hash) {
   // the contig of the posting before this one comes from the thread before it (LDS) instead of a second random read
   __shared__ uint32_t s_contig[kThreads];
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
@@ -550,7 +577,7 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
   const uint64_t key = keys[i];
   post_cw[i] = ((uint64_t)pg << 44) | ((uint64_t)mc << 24) | (uint32_t)(key >> 32);  // the window id rode along in the sort key
   post_genome[i] = (uint16_t)pg;  // (the bucketed seeding and the frequency cut read this; at most 65 535 genomes)
-  if (flags[i]) post_start[id] = i;
+  if (flags[i]) { post_start[id] = i; uniq_hash[id] = (uint32_t)key; }
   if (i == m - 1) post_start[n_ids] = m;
   // "the same hash earlier in this contig": rare (repeats inside a contig), and the array has been filled with -1
   if (i > 0 && (uint32_t)key == (uint32_t)keys[i - 1]) {
@@ -760,7 +787,8 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     uint32_t *__restrict__ q_hash, uint32_t *__restrict__ q_pos /* posting list length */,
     uint32_t *__restrict__ q_id /* first posting */, uint32_t *__restrict__ q_s,
     uint32_t *__restrict__ hit_count, uint32_t *__restrict__ overflow, uint32_t *__restrict__ max_hits,
-    uint32_t *__restrict__ q_cut /* hashes of the sketch that lost seed hits to the frequency cut */) {
+    uint32_t *__restrict__ q_cut /* hashes of the sketch that lost seed hits to the frequency cut */,
+    const uint4 *__restrict__ lookup /* null: every minimizer knows its hash id */, uint32_t lookup_bits) {
   __shared__ uint64_t s_key[kThreads / 64][kQMax];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t f = blockIdx.x * (kThreads / 64) + wave;
@@ -839,15 +867,27 @@ __global__ __launch_bounds__(kThreads) void query_sketch_kernel(
     const uint64_t bal = __ballot(keep);
     if (keep) {
       const uint32_t o = s + __popcll(bal & ((1ULL << lane) - 1ULL));
-      const uint32_t g = b0 + idx, id_and_mark = mini_id[g], id = id_and_mark & 0x7fffffffu;  // top bit: the hash lost seed hits to the frequency cut
       // the minimizer's posting list as (first posting, length): the seeding kernels then go straight to the postings
       // instead of through two more dependent, uncoalesced reads of post_start per list
-      const uint32_t lo = post_start[id], cnt = post_start[id + 1] - lo;
+      uint32_t lo = 0, cnt = 0, mark = 0;  // (a hash the dictionary does not hold: an empty list)
+      if (lookup) {  // the dictionary of the reference range only: by the hash's value
+        const uint32_t mask = (1u << lookup_bits) - 1u;
+        for (uint32_t slot = lookup_slot(h, lookup_bits);; slot = (slot + 1u) & mask) {
+          const uint4 entry = lookup[slot];
+          if (entry.y == 0xffffffffu) break;  // an empty slot: not there
+          if (entry.x == h) { lo = entry.y; cnt = entry.z & 0x7fffffffu; mark = entry.z >> 31; break; }
+        }
+      } else {
+        const uint32_t id_and_mark = mini_id[b0 + idx], id = id_and_mark & 0x7fffffffu;  // top bit: the hash lost seed hits to the frequency cut
+        lo = post_start[id];
+        cnt = post_start[id + 1] - lo;
+        mark = id_and_mark >> 31;
+      }
       q_hash[(uint64_t)f * kQMax + o] = h;
       q_pos[(uint64_t)f * kQMax + o] = cnt;
       q_id[(uint64_t)f * kQMax + o] = lo;
       hits += cnt;
-      cut_hashes += id_and_mark >> 31;
+      cut_hashes += mark;
     }
     s += __popcll(bal);
   }
@@ -2229,12 +2269,14 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d;
+      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at;
   // the reference index (stages 1 and 2) of the last pa_fragani(_ex) call, for PA_FRAGANI_REUSE_INDEX
   bool index_valid = false;
   const void *index_packed = nullptr;
   uint64_t index_arena_bases = 0;
   uint32_t index_contigs = 0, index_genomes = 0, index_k = 0, index_frag_len = 0, index_m = 0, index_ids = 0;
+  uint32_t index_ref0 = 0, index_ref1 = 0;  // the reference genomes whose minimizers the dictionary holds
+  uint32_t index_lookup_bits = 10;          // log2 of the slots of the look-up table by hash value (such a dictionary only)
   int index_which = 0;
   ~FragWork() {
     DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
@@ -2242,7 +2284,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -2514,8 +2556,10 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   }
   if (reuse) {
     PA_REQUIRE(W.index_valid && W.index_packed == (const void *)d_packed && W.index_arena_bases == arena_bases &&
-                   W.index_contigs == n_contigs && W.index_genomes == n_genomes && W.index_k == k && W.index_frag_len == frag_len,
-               "pa_fragani: PA_FRAGANI_REUSE_INDEX without a preceding call on the same arena, contigs, k and fragLen");
+                   W.index_contigs == n_contigs && W.index_genomes == n_genomes && W.index_k == k && W.index_frag_len == frag_len &&
+                   W.index_ref0 <= ref0 && ref1 <= W.index_ref1,
+               "pa_fragani: PA_FRAGANI_REUSE_INDEX without a preceding call on the same arena, contigs, k and fragLen whose "
+               "reference range holds this one");
   }
   W.index_valid = false;  // until this call has passed stage 2 (or taken it over)
   prof.emplace(c, PA_PROF_FRAG_INDEX);
@@ -2563,9 +2607,11 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   const uint64_t range_bins = std::max<uint32_t>(genome_bin_off[ref1] - bin_base, 1u);  // bins of the reference genomes asked for
   const uint32_t n_frags = (uint32_t)frag_contig.size();
   for (uint64_t i = (uint64_t)qry0 * out_cols; i < (uint64_t)qry1 * out_cols; ++i) { h_matched[i] = 0; h_ident_sum[i] = 0.0; }
+  const uint32_t dict_ref0 = ref0, dict_ref1 = ref1;  // the reference genomes a dictionary built by this call holds
   auto remember_index = [&](int which_buf) {
     W.index_packed = d_packed; W.index_arena_bases = arena_bases; W.index_contigs = n_contigs; W.index_genomes = n_genomes;
     W.index_k = k; W.index_frag_len = frag_len; W.index_m = m; W.index_which = which_buf;
+    if (!reuse) { W.index_ref0 = dict_ref0; W.index_ref1 = dict_ref1; }
     W.index_valid = true;
   };
   if (m == 0 || n_frags == 0) {  // nothing to map (and nothing a later call could not take over)
@@ -2576,35 +2622,72 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   }
 
   // ---- 2. dictionary of minimizer hashes: ids, postings, same-hash links
-  for (int b = 0; b < 2; ++b) { PA_TRY(W.keys[b].reserve((uint64_t)m * 8)); PA_TRY(W.vals[b].reserve((uint64_t)m * 4)); }
-  PA_TRY(W.flags.reserve((uint64_t)m * 8 + 64));
+  // The dictionary holds the minimizers of the REFERENCE genomes asked for (a worker asked for one subject column sorts
+  // and lists one genome's minimizers, and its seed-hit arrays are that small too); the query genomes' minimizers find
+  // their hashes in it by value.  With every genome a reference the minimizers know their hash ids themselves.
+  const bool restricted = reuse ? !(W.index_ref0 == 0 && W.index_ref1 == n_genomes) : !(ref0 == 0 && ref1 == n_genomes);
+  uint32_t m_lo = 0, m_hi = m;
+  if (!reuse && restricted) {
+    uint32_t c_lo = 0, c_hi = n_contigs;  // the contigs of the reference range (contigs are listed genome by genome)
+    while (c_lo < n_contigs && h_contig_genome[c_lo] < ref0) ++c_lo;
+    c_hi = c_lo;
+    while (c_hi < n_contigs && h_contig_genome[c_hi] < ref1) ++c_hi;
+    PA_HIP(hipMemcpy(&m_lo, W.contig_mini_off.as<uint32_t>() + c_lo, 4, hipMemcpyDeviceToHost));
+    PA_HIP(hipMemcpy(&m_hi, W.contig_mini_off.as<uint32_t>() + c_hi, 4, hipMemcpyDeviceToHost));
+  }
+  const uint32_t md = m_hi - m_lo;  // minimizers in the dictionary
+  const uint64_t md_room = std::max<uint32_t>(md, 1u);
+  for (int b = 0; b < 2; ++b) { PA_TRY(W.keys[b].reserve(md_room * 8)); PA_TRY(W.vals[b].reserve(md_room * 4)); }
+  PA_TRY(W.flags.reserve(md_room * 8 + 64));
   PA_TRY(W.mini_id.reserve((uint64_t)m * 4));
   PA_TRY(W.prev_same.reserve((uint64_t)m * 4));
-  PA_TRY(W.post_cw.reserve((uint64_t)m * 8));
-  PA_TRY(W.post_g.reserve((uint64_t)m * 2 + 16));
+  PA_TRY(W.post_cw.reserve(md_room * 8));
+  PA_TRY(W.post_g.reserve(md_room * 2 + 16));
   uint64_t *keys[2] = {W.keys[0].as<uint64_t>(), W.keys[1].as<uint64_t>()};
   uint32_t *vals[2] = {W.vals[0].as<uint32_t>(), W.vals[1].as<uint32_t>()};
   int which = reuse ? W.index_which : 0;
   if (!reuse) {
-    const uint32_t gm = ceil_div_u64(m, kThreads);
-    hipLaunchKernelGGL(mini_keys_kernel, dim3(gm), dim3(kThreads), 0, c->stream, W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), m,
-                       keys[0], vals[0]);
-    PA_TRY(pa_radix_sort_pairs(c, keys, vals, m, 0, 32, false, &which));
-    uint32_t *d_flags = W.flags.as<uint32_t>(), *d_pos = d_flags + m;
-    hipLaunchKernelGGL(key_heads_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], m, d_flags);
-    PA_TRY(pa_exclusive_scan_u32(c, d_flags, d_pos, m, W.scalars.as<uint64_t>()));
-    PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
-    PA_HIP(hipStreamSynchronize(c->stream));
-    const uint32_t n_ids = (uint32_t)c->h_pinned[0];
-    PA_REQUIRE(n_ids < (1u << 31), "pa_fragani: %u distinct minimizer hashes (limit 2^31)", n_ids);
-    PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
     PA_HIP(hipMemsetAsync(W.prev_same.p, 0xff, (uint64_t)m * 4, c->stream));  // -1: no earlier occurrence
-    hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, m,
-                       n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
-                       W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
-                       W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>(), W.contig_mini_off.as<uint32_t>(), n_contigs);
+    uint32_t n_ids = 0;
+    if (md) {
+      const uint32_t gm = ceil_div_u64(md, kThreads);
+      hipLaunchKernelGGL(mini_keys_kernel, dim3(gm), dim3(kThreads), 0, c->stream, W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(),
+                         m_lo, md, keys[0], vals[0]);
+      PA_TRY(pa_radix_sort_pairs(c, keys, vals, md, 0, 32, false, &which));
+      uint32_t *d_flags = W.flags.as<uint32_t>(), *d_pos = d_flags + md;
+      hipLaunchKernelGGL(key_heads_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], md, d_flags);
+      PA_TRY(pa_exclusive_scan_u32(c, d_flags, d_pos, md, W.scalars.as<uint64_t>()));
+      PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
+      PA_HIP(hipStreamSynchronize(c->stream));
+      n_ids = (uint32_t)c->h_pinned[0];
+      PA_REQUIRE(n_ids < (1u << 31), "pa_fragani: %u distinct minimizer hashes (limit 2^31)", n_ids);
+      PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
+      PA_TRY(W.uniq_hash.reserve((uint64_t)(n_ids + 2) * 4));
+      hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, md,
+                         n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
+                         W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
+                         W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>(), W.contig_mini_off.as<uint32_t>(), n_contigs,
+                         W.uniq_hash.as<uint32_t>());
+      PA_TRY(cut_frequent_postings(c, W, d_flags, d_pos, vals[which], vals[1 - which], reinterpret_cast<uint32_t *>(keys[1 - which]), md, n_ids,
+                                   h_contig_genome, n_contigs, n_genomes));
+    } else {  // the reference genomes hold no minimizer: an empty dictionary
+      PA_TRY(W.post_start.reserve(16));
+      PA_TRY(W.uniq_hash.reserve(16));
+      PA_TRY(W.hash_cut.reserve(16));
+      PA_HIP(hipMemsetAsync(W.post_start.p, 0, 8, c->stream));
+      PA_HIP(hipMemsetAsync(W.hash_cut.p, 0, 8, c->stream));
+    }
     W.index_ids = n_ids;
-    PA_TRY(cut_frequent_postings(c, W, d_flags, d_pos, vals[which], vals[1 - which], reinterpret_cast<uint32_t *>(keys[1 - which]), m, n_ids, h_contig_genome, n_contigs, n_genomes));
+    if (restricted) {
+      uint32_t bits = 10;
+      while ((1ull << bits) < 2ull * n_ids + 1) ++bits;
+      W.index_lookup_bits = bits;
+      PA_TRY(W.lookup_at.reserve((16ull << bits) + 16));
+      PA_HIP(hipMemsetAsync(W.lookup_at.p, 0xff, 16ull << bits, c->stream));
+      if (n_ids)
+        hipLaunchKernelGGL(lookup_insert_kernel, dim3(ceil_div_u64(n_ids, kThreads)), dim3(kThreads), 0, c->stream, W.uniq_hash.as<uint32_t>(),
+                           W.post_start.as<uint32_t>(), W.hash_cut.as<uint32_t>(), n_ids, bits, W.lookup_at.as<uint4>());
+    }
   }
   const uint32_t *d_sorted_idx = vals[which];
   // the index (minimizers, bucket index, dictionary, postings) is complete: a later call may take it over
@@ -2704,7 +2787,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
                        W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),
                        W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits,
-                       W.q_cut.as<uint32_t>());
+                       W.q_cut.as<uint32_t>(), restricted ? W.lookup_at.as<uint4>() : nullptr, W.index_lookup_bits);
     PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipMemcpyAsync(c->h_pinned + 1, d_max_hits, 8, hipMemcpyDeviceToHost, c->stream));

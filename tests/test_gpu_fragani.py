@@ -658,3 +658,28 @@ def test_random_genome_sets(engine):
                 assert m == 0 or mean_f(ident_sum[q, r], m) == ani, (_case, k, frag, q, r)
                 pairs += 1
     assert pairs > 300
+
+
+def test_one_subject_column_at_a_time(engine):
+    """A worker asked for one subject column builds the dictionary of that genome's minimizers only (the query genomes' find
+    their hashes in it by value) and keeps that genome's bins only: every column of the bacterial fixture -- the frequency cut
+    is active in each -- equals the column of the all-against-all run; so does a range of two.  An index built for a range
+    may be taken over for a range inside it, not for one outside."""
+    from pyani_plus_amd._capi import HipBackendError
+    from pyani_plus_amd.engine import load_fasta_files
+
+    files = sorted((GOLDEN / "bacterial_example").glob("*.gz"))
+    infos, arena = load_fasta_files(files)
+    dev = engine.upload(arena)
+    args = (dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    total, matched, ident_sum = engine.fragani(*args)
+    for r0, r1 in ((0, 1), (1, 2), (2, 3), (3, 4), (1, 3)):
+        t, m, s = engine.fragani(*args, ref_range=(r0, r1), columns_only=True)
+        assert np.array_equal(t, total) and np.array_equal(m, matched[:, r0:r1]) and np.array_equal(s, ident_sum[:, r0:r1]), (r0, r1)
+    # (the last index holds genomes 1 and 2)
+    t, m, s = engine.fragani(*args, ref_range=(2, 3), columns_only=True, reuse_index=True)
+    assert np.array_equal(m, matched[:, 2:3]) and np.array_equal(s, ident_sum[:, 2:3])
+    with pytest.raises(HipBackendError, match="REUSE_INDEX"):
+        engine.fragani(*args, ref_range=(0, 2), reuse_index=True)
+    t, m, s = engine.fragani(*args)  # and back to every genome a reference
+    assert np.array_equal(m, matched) and np.array_equal(s, ident_sum)

@@ -1,10 +1,12 @@
 """Time the fastANI-style fragment-ANI path (BASELINE configs[3]) on synthetic 5 Mb genomes.
 
-    python tools/bench_fragani.py [n_genomes] [0] [interleaved|grouped] [query genomes]
+    python tools/bench_fragani.py [n_genomes] [0] [interleaved|grouped] [query genomes] [reference genomes]
 Prints pairs/s for the all-vs-all device pipeline (the CPU figure and the parity check against the oracle are
 bench.py's `also.fragment_ani` leg and tests/test_gpu_fragani.py).  With a fourth argument only that many query
 genomes are mapped (against the index of all n): 78 of them are one batch of 2^17 fragments -- the form the counter
-passes of rocprofv3 take at the benchmark's 1 000 genomes (one dispatch of every kernel per repetition).
+passes of rocprofv3 take at the benchmark's 1 000 genomes (one dispatch of every kernel per repetition).  With a fifth,
+the queries are mapped against the first that many genomes only, results as columns: 1 = what the reference's worker asks
+for, one subject column (the first repetition includes the allocation of the workspace, as a worker process's only call does).
 """
 import json
 import sys
@@ -20,6 +22,7 @@ from pyani_plus_amd.synth import synth_arena_torch  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 order = sys.argv[3] if len(sys.argv) > 3 else "interleaved"  # "grouped": the genomes of one species next to each other
 n_query = int(sys.argv[4]) if len(sys.argv) > 4 else n
+n_ref = int(sys.argv[5]) if len(sys.argv) > 5 else n
 length, k, frag = 5_000_000, 16, 3000
 eng = HipEngine(0)
 ids = None
@@ -35,14 +38,15 @@ for rep in range(2):
     eng.prof_reset()
     t.cuda.synchronize()
     t0 = time.perf_counter()
-    total, matched, ident_sum = eng.fragani(arena, starts, lens, genome, k, frag, query_range=(0, n_query))
+    total, matched, ident_sum = eng.fragani(arena, starts, lens, genome, k, frag, query_range=(0, n_query),
+                                            ref_range=None if n_ref == n else (0, n_ref), columns_only=n_ref != n)
     dt = time.perf_counter() - t0
-    print(f"rep {rep}: {n_query}x{n} pairs in {dt:.3f} s -> {n_query * n / dt:.3e} pairs/s", {k: round(v[0], 1) for k, v in eng.prof_get().items() if k.startswith("frag")}, flush=True)
+    print(f"rep {rep}: {n_query}x{n_ref} pairs in {dt:.3f} s -> {n_query * n_ref / dt:.3e} pairs/s", {k: round(v[0], 1) for k, v in eng.prof_get().items() if k.startswith("frag")}, flush=True)
 from pyani_plus_amd.methods.fastani_hip import fastani_mean  # noqa: E402
 
 ani = fastani_mean(ident_sum, matched)
 related = ~np.isnan(ani)
 print("fragments per genome", int(total[0]), "pairs with mappings", int(related.sum()), "ANI range", float(np.nanmin(ani)), float(np.nanmax(ani)))
-assert np.all(np.diag(matched)[:n_query] >= 0.99 * total[:n_query])
-out = {"n": n, "query_genomes": n_query, "seconds": dt, "pairs_per_s": n_query * n / dt}
+assert np.all(np.diag(matched)[: min(n_query, n_ref)] >= 0.99 * total[: min(n_query, n_ref)])
+out = {"n": n, "query_genomes": n_query, "reference_genomes": n_ref, "seconds": dt, "pairs_per_s": n_query * n_ref / dt}
 print(json.dumps(out))

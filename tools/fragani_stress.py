@@ -107,6 +107,15 @@ def main() -> int:
                 if (int(total[q]), int(matched[q, r])) != (t, m) or (m and got != ani):
                     print(f"case {case} (k={k} frag={frag}) pair ({q},{r}): device {int(total[q])} {int(matched[q, r])} {got} oracle {t} {m} {ani}", flush=True)
                     bad += 1
+        if n > 1:  # one subject column, and a range of them: the dictionary of those genomes' minimizers only
+            r0 = int(rng.integers(0, n))
+            r1 = int(rng.integers(r0 + 1, n + 1))
+            for a, b in ((r0, r0 + 1), (r0, r1)):
+                t2, m2, s2 = eng.fragani(eng.upload(arena), arena.contig_start, arena.contig_len, arena.contig_genome, k, frag,
+                                         ref_range=(a, b), columns_only=True)
+                if not (np.array_equal(t2, total) and np.array_equal(m2, matched[:, a:b]) and np.array_equal(s2, ident_sum[:, a:b])):
+                    print(f"case {case} (k={k} frag={frag}): columns [{a}, {b}) differ from the all-against-all run", flush=True)
+                    bad += 1
         if bad >= 10:
             break
     print(f"{cases} cases, {bad} differing pairs, {time.time() - t0:.0f} s")
