@@ -260,7 +260,8 @@ PA_API int pa_ani_mash(pa_ctx *ctx, const uint32_t *d_common, const uint32_t *d_
  * double here --, so ANI(q,r) = (float)sum / (float)matched IN FLOAT is the number fastANI prints, reported when
  * matched/total >= minFraction (pyani_plus/methods/fastani.py:98-120 parses exactly these three numbers).
  * Only the reference genomes [ref0, ref1) are mapped against (columns outside stay 0): the reference's worker is
- * called once per subject column (pyani_plus/private_cli.py:976-1063), and a column costs one column's mappings.
+ * called once per subject column (pyani_plus/private_cli.py:976-1063), and a column costs one column: the hash
+ * dictionary, the seed-hit arrays and the table of best fragments hold the reference range only.
  * Algorithm and its parity (every fastANI value the reference holds, exactly): oracle/fragani_oracle.c.  k from 8 to 16 (fastANI itself stops at 16); fragLen in
  * [100, 65535]; at most 65535 genomes; contigs listed genome by genome, at most 65535 per genome and 2^20-1 in all;
  * at most 2^20-1 fragments per genome.  The workspace (about 12 GB for 1000 x 5 Mb genomes) stays in the context. */
@@ -273,7 +274,8 @@ PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
  * after each (pyani_plus/private_cli.py:1029-1101) -- so that an interrupted worker keeps the finished batches.
  * flags: PA_FRAGANI_REUSE_INDEX = the arena, contigs, k and fragLen are exactly those of the previous pa_fragani(_ex)
  * call on this context and the reference index it built (minimizers, dictionary, postings: about a tenth of a run)
- * is taken over instead of being rebuilt; PA_E_INVALID when there is no such call.  fastANI itself rebuilds the
+ * is taken over instead of being rebuilt; PA_E_INVALID when there is no such call, or when that call's reference range
+ * does not hold this one (the dictionary holds the reference range's minimizers).  fastANI itself rebuilds the
  * reference's index in every process. */
 #define PA_FRAGANI_REUSE_INDEX 1u
 /* PA_FRAGANI_COLUMNS_ONLY: h_matched and h_ident_sum hold n_genomes rows of (ref1 - ref0) entries -- the columns of the
