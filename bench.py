@@ -501,6 +501,16 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
             engine.prof_reset()
     sec = min(times[1:])
     prof = engine.prof_get()
+    # one subject column, as the reference's worker asks for it (one process per column): the dictionary, the seed hits and
+    # the bins of that genome only, results as a column
+    col_times = []
+    for _rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        c_total, c_matched, c_sum = engine.fragani(sub, starts, lens, genome, k, frag, ref_range=(0, 1), columns_only=True)
+        col_times.append(time.perf_counter() - t0)
+    if not (np.array_equal(c_total, total) and np.array_equal(c_matched[:, 0], matched[:, 0]) and np.array_equal(c_sum[:, 0], ident_sum[:, 0])):
+        raise SystemExit("PARITY FAILURE (fragment ANI): the subject column computed alone differs from the column of the all-against-all run")
     from pyani_plus_amd.methods.fastani_hip import fastani_mean
 
     ani = fastani_mean(ident_sum, matched)  # fastANI's own mean: a float sum by a float count
@@ -541,6 +551,9 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
         "workload": f"{n} synthetic {args.length / 1e6:g} Mb genomes, fastANI-style fragment ANI k={k} fragLen={frag} (BASELINE configs[3]), all ordered pairs in one pa_fragani call",
         "seconds_per_run": sec, "pairs_per_s": n * n / sec, "runs": 2, "first_run_seconds_incl_workspace_alloc": times[0],
         "pairs_with_mappings": related,
+        "one_subject_column": {"seconds": min(col_times), "pairs_per_s": n / min(col_times),
+                               "what": f"the {n} genomes against genome 0 alone (pa_fragani reference range [0, 1), columns only): what one per-column "
+                               "worker of the reference's layout asks for; equals column 0 of the all-against-all run"},
         "phases_ms_per_run": {name: v[0] / 2 for name, v in prof.items() if name.startswith("frag")},
         "cpu_baseline": {"value": n_q / cpu_sec, "unit": "pairs/s", "cores": cores, "kind": "port", "seconds": cpu_sec,
                          "sample": f"{n_q} query genomes (ten cycles of the {args.species} species: 1 related query in {args.species}, as in the N x N matrix) against "

@@ -633,14 +633,14 @@ def test_low_complexity_fragments(engine):
 
 
 def test_random_genome_sets(engine):
-    """Forty random genome sets of tools/fragani_stress.py (repeats, runs of N, short and exactly-ending contigs, lower case,
+    """Forty random genome sets of tests/tools/fragani_stress.py (repeats, runs of N, short and exactly-ending contigs, lower case,
     four k and four fragment lengths): every ordered pair, device against oracle."""
     import importlib.util
     from pathlib import Path
 
     from pyani_plus_amd.engine import pack_genomes
 
-    spec = importlib.util.spec_from_file_location("fragani_stress", Path(__file__).resolve().parent.parent / "tools" / "fragani_stress.py")
+    spec = importlib.util.spec_from_file_location("fragani_stress", Path(__file__).resolve().parent / "tools" / "fragani_stress.py")
     stress = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(stress)
     rng = np.random.default_rng(2024)

@@ -3,19 +3,20 @@
 broken it before -- repeats (tandem and dispersed), runs of N and single N, contigs shorter than a fragment, contigs that end
 with their last fragment, lower case, several k and fragment lengths.
 
-    python tools/fragani_stress.py [cases=200] [seed=1] [big]
+    python tests/tools/fragani_stress.py [cases=200] [seed=1] [big]
 
 `big`: genomes of 1.4 to 3 Mb with arrays of short repeats and homopolymer runs, so that Mashmap's frequency cut of the seeds
 is active (it needs 100 000 distinct minimizers before it ignores one), and a small mutated excerpt as the second genome.
 
-Prints one line per failing case (and stops after ten); exit code 1 if any.  Needs a GPU; the oracle is the checker."""
+Prints one line per failing case (and stops after ten); exit code 1 if any.  Needs a GPU; the oracle is the checker (test
+infrastructure, like the rest of tests/)."""
 import sys
 import time
 from pathlib import Path
 
 import numpy as np
 
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import oracle  # noqa: E402
 from pyani_plus_amd.engine import HipEngine, pack_genomes  # noqa: E402
 from pyani_plus_amd.methods.fastani_hip import fastani_mean  # noqa: E402
