@@ -2636,13 +2636,15 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_HIP(hipMemcpy(&m_hi, W.contig_mini_off.as<uint32_t>() + c_hi, 4, hipMemcpyDeviceToHost));
   }
   const uint32_t md = m_hi - m_lo;  // minimizers in the dictionary
-  const uint64_t md_room = std::max<uint32_t>(md, 1u);
-  for (int b = 0; b < 2; ++b) { PA_TRY(W.keys[b].reserve(md_room * 8)); PA_TRY(W.vals[b].reserve(md_room * 4)); }
-  PA_TRY(W.flags.reserve(md_room * 8 + 64));
-  PA_TRY(W.mini_id.reserve((uint64_t)m * 4));
-  PA_TRY(W.prev_same.reserve((uint64_t)m * 4));
-  PA_TRY(W.post_cw.reserve(md_room * 8));
-  PA_TRY(W.post_g.reserve(md_room * 2 + 16));
+  if (!reuse) {  // (an index that is taken over stays where it is: asking for room again could move -- and lose -- it)
+    const uint64_t md_room = std::max<uint32_t>(md, 1u);
+    for (int b = 0; b < 2; ++b) { PA_TRY(W.keys[b].reserve(md_room * 8)); PA_TRY(W.vals[b].reserve(md_room * 4)); }
+    PA_TRY(W.flags.reserve(md_room * 8 + 64));
+    PA_TRY(W.mini_id.reserve((uint64_t)m * 4));
+    PA_TRY(W.prev_same.reserve((uint64_t)m * 4));
+    PA_TRY(W.post_cw.reserve(md_room * 8));
+    PA_TRY(W.post_g.reserve(md_room * 2 + 16));
+  }
   uint64_t *keys[2] = {W.keys[0].as<uint64_t>(), W.keys[1].as<uint64_t>()};
   uint32_t *vals[2] = {W.vals[0].as<uint32_t>(), W.vals[1].as<uint32_t>()};
   int which = reuse ? W.index_which : 0;

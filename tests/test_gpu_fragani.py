@@ -683,3 +683,24 @@ def test_one_subject_column_at_a_time(engine):
         engine.fragani(*args, ref_range=(0, 2), reuse_index=True)
     t, m, s = engine.fragani(*args)  # and back to every genome a reference
     assert np.array_equal(m, matched) and np.array_equal(s, ident_sum)
+
+
+def test_query_batches_of_one_subject_column_in_a_fresh_context(engine):
+    """The reference's worker maps its queries in batches against one subject (private_cli.py:1029-1063); here the second
+    batch takes over the index of the first.  In a context of its own -- a worker process's: every buffer exactly as large
+    as the first call made it -- the index must stay where it is (asking for the room of a whole-set dictionary again once
+    moved, and lost, the one-genome dictionary)."""
+    from pyani_plus_amd.engine import HipEngine, load_fasta_files
+
+    files = sorted((GOLDEN / "bacterial_example").glob("*.gz"))
+    infos, arena = load_fasta_files(files)
+    args = (arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    total, matched, ident_sum = engine.fragani(engine.upload(arena), *args)
+    fresh = HipEngine(0)
+    try:
+        dev = fresh.upload(arena)
+        out = fresh.fragani(dev, *args, ref_range=(1, 2), query_range=(0, 2), columns_only=True)
+        out = fresh.fragani(dev, *args, ref_range=(1, 2), query_range=(2, 4), columns_only=True, reuse_index=True, out=out)
+        assert np.array_equal(out[0], total) and np.array_equal(out[1], matched[:, 1:2]) and np.array_equal(out[2], ident_sum[:, 1:2])
+    finally:
+        fresh.close()
