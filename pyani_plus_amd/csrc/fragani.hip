@@ -1675,6 +1675,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
       const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
+      if (gi > 0 && cut == 23) break;  // (timing experiment: the group of the first seed hit only; results wrong)
       const uint32_t sb = b_lo + g * 64u;
       const uint32_t b = sb + lane;
       const bool has = b < b_hi;

@@ -23,7 +23,7 @@ genome = np.arange(n, dtype=np.uint32)
 eng.prof_enable(True)
 names = {10: "segment header + sketch load", 11: "hits loaded, ordered, staged", 1: "staging + sort + bucket table", 2: "L1", 3: "candidate set-up", 4: "seed-hit bounds per group", 5: "stretch loads + window ends",
          6: "ranks", 7: "coarse table", 8: "window masks + coarse search", 9: "fine passes (whole kernel)",
-         21: "whole kernel without second passes", 22: "whole kernel without fine passes"}
+         21: "whole kernel without second passes", 22: "whole kernel without fine passes", 23: "whole kernel, the group of the first seed hit only"}
 prev = 0.0
 cuts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7, 8, 9]
 for cut in cuts:
