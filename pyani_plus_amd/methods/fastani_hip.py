@@ -14,7 +14,9 @@ Where the reference runs ``fastANI --ql <queries> -r <subject> -o out --fragLen 
 ``pa_fragani`` call for all genomes involved and derives the same five fields
 (private_cli.py:1070-1080):
 
-    identity   = ANI / 100            (None when fastANI would print no line)
+    identity   = 0.01 * ANI           (the reference's own product, pyani_plus/methods/fastani.py:113: the same double,
+                                       where ANI / 100 differs in the last place for 4 of the 22 values its fixtures
+                                       hold; None when fastANI would print no line)
     aln_length = round(fragsize * matched)
     sim_errors = total - matched
     cov_query  = matched / total
@@ -108,7 +110,7 @@ def comparison_entry(q: str, s: str, frags: int, matches: int, ani_percent: floa
     return {
         "query_hash": q,
         "subject_hash": s,
-        "identity": fastani_print_round(float(ani_percent)) / 100.0 if reported else None,
+        "identity": 0.01 * fastani_print_round(float(ani_percent)) if reported else None,  # fastani.py:113
         # proxy values, private_cli.py:1072-1080
         "aln_length": round(fragsize * matches) if reported else None,
         "sim_errors": frags - matches if reported else None,
@@ -139,7 +141,7 @@ def comparison_block(total, matched, ident_sum, lengths, rows, cols, fragsize: i
     with np.errstate(invalid="ignore", divide="ignore"):
         ani = fastani_mean(ident_sum[np.ix_(rows, cols - col0)], m)
         cov = np.where(reported, m / np.maximum(frags, 1), np.nan)
-    identity = np.where(reported, round_sig6(np.where(reported, ani, np.nan)) / 100.0, np.nan)
+    identity = np.where(reported, 0.01 * round_sig6(np.where(reported, ani, np.nan)), np.nan)  # fastani.py:113: 0.01 * float(text)
     aln = np.where(reported, int(fragsize) * m, 0)
     err = np.where(reported, frags - m, 0)
     return identity, aln.astype(np.int64), err.astype(np.int64), cov, ~reported

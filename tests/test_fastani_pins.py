@@ -27,7 +27,7 @@ import pytest
 from pyani_plus_amd import rundb
 from tests.helpers import GOLDEN, load_matrix_tsv
 
-PIN_TOL = 1e-12  # identity as a fraction: the six significant digits fastANI prints, nothing more
+PIN_TOL = 0.0  # the stored identity is the reference's own double, 0.01 * float(the text fastANI printed): pyani_plus/methods/fastani.py:113
 SMALL, BOTH, LARGE = "154173fb8e7415ab45532a738572f957", "7b6a6226ce00e52edca15565aa0d270d", "a0efc718e680e34d2f5c8f5d2286ca9c"
 
 
@@ -61,7 +61,7 @@ def test_miby_large_contig_against_itself(engine, tmp_path):
     rundb.run_fastani_hip(indir, tmp_path / "self.sqlite", engine=engine, temp=tmp_path / "t")
     ident, cov, aln, err, _had = _matrices(tmp_path / "self.sqlite")
     assert ident["index"] == ident["columns"] == [LARGE]
-    assert abs(ident["data"][0][0] - 0.999953) <= PIN_TOL  # the point of the pin: not a perfect self hit
+    assert ident["data"][0][0] == 0.999953  # an `==` in the reference too; the point of the pin: not a perfect self hit
     assert cov["data"] == [[1.0]] and aln["data"] == [[18000.0]] and err["data"] == [[0.0]]  # 6 of 6 fragments of 3000
 
 
@@ -95,7 +95,7 @@ def test_miby_coverage_matrices_with_non_default_settings(engine, tmp_path):
             if want_ident[q][s] is None:
                 assert ident["data"][q][s] is None and cov["data"][q][s] is None  # the NULL pattern, exactly
             else:
-                assert abs(ident["data"][q][s] - want_ident[q][s]) <= PIN_TOL, (q, s, ident["data"][q][s])
+                assert ident["data"][q][s] == want_ident[q][s], (q, s, ident["data"][q][s])
                 assert cov["data"][q][s] == want_cov[q][s], (q, s)  # 3/12, 9/12, 12/12: exact
 
 
@@ -158,3 +158,33 @@ def test_bacterial_proxy_matrices(engine, tmp_path):
     rows = {(e["query_hash"], e["subject_hash"]): e for e in json.loads(out.read_text())["comparisons"]}
     assert len(rows) == 4
     _bacterial_column_checks(rows, labels, (aln, err, had), stems, {labels.index("NC_011916")}, total_frags)
+
+
+def test_identity_is_the_reference_double_for_every_value_its_fixtures_hold():
+    """/root/reference/pyani_plus/methods/fastani.py:113 stores ``0.01 * float(text)``.  ``x / 100.0`` is another double for
+    four of the distinct identities the reference's 25 ``.fastani`` rows hold (85.9835, 99.4912, 99.9386, 99.9946): the
+    method must produce the product, bit for bit, in its scalar and in its array form."""
+    from pyani_plus_amd.methods import fastani_hip
+
+    texts = set()
+    for path in sorted(GOLDEN.glob("*/fastANI/all_vs_*.fastani")):
+        for line in path.read_text().splitlines():
+            if line.strip():
+                texts.add(line.split("\t")[2])
+    texts |= {"99.9953", "99.997", "99.9959"}  # the pins of tests/test_self_vs_self.py:121-122 and tests/test_coverage.py:143-160
+    assert len(texts) == 22
+    differing = 0
+    for text in sorted(texts):
+        x = float(text)
+        want = 0.01 * x
+        differing += want != x / 100.0
+        entry = fastani_hip.comparison_entry("q", "s", 10, 10, x, 3000, 0.2, 30000, 30000, {})
+        assert entry["identity"] == want, text
+        total, matched = np.array([10], dtype=np.uint32), np.array([[10]], dtype=np.uint32)
+        # the float sum whose float mean prints as `text`: ten fragments of that identity
+        ident_sum = np.array([[float(np.float32(x) * np.float32(10))]])
+        ident, *_rest = fastani_hip.comparison_block(total, matched, ident_sum, np.array([30000]), [0], [0], 3000, 0.2)
+        if fastani_hip.fastani_print_round(float(fastani_hip.fastani_mean(ident_sum, matched)[0, 0])) == x:
+            assert ident[0, 0] == want, text
+    assert differing >= 4  # the values on which the two expressions part
+    assert PIN_TOL == 0.0

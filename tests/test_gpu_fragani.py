@@ -367,7 +367,7 @@ def test_plugin_column_matches_reference_matrices(engine, tmp_path):
     assert fastani_hip.compute_fastani_hip(logging.getLogger("t"), tmp_path, _S(), run, out, GOLDEN / "viral_example", hash_to_filename, {}, lengths, subject, engine=engine) == 0
     col = json.loads(out.read_text())["comparisons"]
     assert [(e["query_hash"], e["subject_hash"]) for e in col] == [(q, subject) for q in sorted(hash_to_filename)]
-    assert all(abs(e["identity"] - rows[(e["query_hash"], subject)]["identity"]) < 1e-12 for e in col)
+    assert all(e["identity"] == rows[(e["query_hash"], subject)]["identity"] for e in col)
     # a size-asymmetric pair: minFraction is taken of the SHORTER genome (fastANI's rule), not of the query's fragments
     rng = np.random.default_rng(21)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
