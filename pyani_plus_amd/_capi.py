@@ -14,6 +14,10 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "_lib" / "libpyani_hip.so"
+# The same sources built with -DPA_TOOLS: the environment switches that force a rare path, cut a kernel short or select an
+# ablation variant (PA_MAP_CUT, PA_FRAGANI_*, PA_KMER_*, PA_PAIRS_SYMMETRIC, ...) exist in this build only.  tools/ and
+# the tests of those paths load it (``HipEngine(tools=True)``); nothing else does.
+TOOLS_LIB_PATH = _PKG / "_lib" / "libpyani_hip_tools.so"
 
 ABI_VERSION = 3
 PA_OK = 0
@@ -142,29 +146,29 @@ class HipBackendError(RuntimeError):
     """The HIP extension is missing, failed to load, or a call into it failed."""
 
 
-_lib: C.CDLL | None = None
+_libs: dict[bool, C.CDLL] = {}
 
 
 def build_library(force: bool = False) -> Path:
-    """Compile ``libpyani_hip.so`` for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compile ``libpyani_hip.so`` and ``libpyani_hip_tools.so`` for gfx950 with hipcc (cross-compiles without a GPU)."""
     srcdir = _PKG / "csrc"
     cmd = ["make", "-C", str(srcdir), "-j", str(min(8, os.cpu_count() or 1))]
     if force:
         cmd.append("-B")
     proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0 or not LIB_PATH.is_file():
+    if proc.returncode != 0 or not LIB_PATH.is_file() or not TOOLS_LIB_PATH.is_file():
         raise HipBackendError(f"building libpyani_hip.so failed:\n{proc.stdout}\n{proc.stderr}")
     return LIB_PATH
 
 
-def load_library() -> C.CDLL:
-    """Load the shared library and type every symbol of the header; raise loudly if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not LIB_PATH.is_file():
+def load_library(tools: bool = False) -> C.CDLL:
+    """Load the shared library (``tools``: the -DPA_TOOLS build) and type every symbol of the header; raise loudly if absent."""
+    if tools in _libs:
+        return _libs[tools]
+    path = TOOLS_LIB_PATH if tools else LIB_PATH
+    if not path.is_file():
         raise HipBackendError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C pyani_plus_amd/csrc`).  There is no CPU fallback for the compute path."
         )
     # PyTorch's ROCm wheel bundles its own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one
@@ -175,26 +179,26 @@ def load_library() -> C.CDLL:
     except ImportError:  # pragma: no cover - plain ROCm install without torch
         pass
     try:
-        lib = C.CDLL(str(LIB_PATH))
+        lib = C.CDLL(str(path))
     except OSError as err:  # missing ROCm runtime, wrong arch, ...
-        raise HipBackendError(f"cannot load {LIB_PATH}: {err}") from err
+        raise HipBackendError(f"cannot load {path}: {err}") from err
     for name, (restype, argtypes) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as err:
-            raise HipBackendError(f"{LIB_PATH} does not export {name}") from err
+            raise HipBackendError(f"{path} does not export {name}") from err
         fn.restype = restype
         fn.argtypes = argtypes
     if lib.pa_abi_version() != ABI_VERSION:
         raise HipBackendError(f"ABI version mismatch: library reports {lib.pa_abi_version()}, binding expects {ABI_VERSION}")
-    _lib = lib
+    _libs[tools] = lib
     return lib
 
 
-def last_error() -> str:
-    return (load_library().pa_last_error() or b"").decode(errors="replace")
+def last_error(lib: C.CDLL | None = None) -> str:
+    return ((lib or load_library()).pa_last_error() or b"").decode(errors="replace")
 
 
-def check(status: int, what: str) -> None:
+def check(status: int, what: str, lib: C.CDLL | None = None) -> None:
     if status != PA_OK:
-        raise HipBackendError(f"{what} failed with status {status}: {last_error()}")
+        raise HipBackendError(f"{what} failed with status {status}: {last_error(lib)}")

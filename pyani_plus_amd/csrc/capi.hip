@@ -196,7 +196,7 @@ int pa_sketch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const
   // Per-genome candidate regions (expectation + 25 % + 128 slots).  When the longest fits an LDS sort the
   // sketches are finished by sketch_lds.hip; otherwise, or if a region overflows, by the global sort below.
   static const bool force_global = [] {
-    const char *v = getenv("PA_SKETCH_SORT");
+    const char *v = PA_TOOL_ENV("PA_SKETCH_SORT");
     return v && v[0] == 'g';
   }();
   std::vector<uint64_t> region_off(n_genomes + 1, 0);

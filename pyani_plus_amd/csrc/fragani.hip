@@ -1391,6 +1391,19 @@ __device__ __forceinline__ void stage_hits_sorted(const uint64_t *__restrict__ s
   }
 }
 
+// The kernel cut short after a phase (tools/map_cut.py: phase times by difference, results wrong): an argument of the
+// tools build only.
+#ifdef PA_TOOLS
+#define PA_MAP_CUT_PARAM , uint32_t cut
+#define PA_MAP_CUT_ARG , map_cut
+#define PA_CUT(k) do { if (cut == (k)) return; } while (0)
+#define PA_CUT_IS(k) (cut == (k))
+#else
+#define PA_MAP_CUT_PARAM
+#define PA_MAP_CUT_ARG
+#define PA_CUT(k) do { } while (0)
+#define PA_CUT_IS(k) false
+#endif
 // one wave per (fragment, reference genome) segment
 #ifndef PA_MAP_WAVES
 #define PA_MAP_WAVES 4  // waves per SIMD the register allocation aims at: 128 VGPRs, the kernel needs 117 without spilling (80 registers / 6 waves: 0.64 s instead of 0.48 s for the 1 000-genome run)
@@ -1406,7 +1419,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash,
     const uint32_t *__restrict__ mini_wpos, const int32_t *__restrict__ prev_same,
     const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride, unsigned long long *__restrict__ table,
-    uint32_t *__restrict__ run_g, uint32_t s_cap, uint32_t hit_cap, uint32_t cut) {
+    uint32_t *__restrict__ run_g, uint32_t s_cap, uint32_t hit_cap PA_MAP_CUT_PARAM) {
   extern __shared__ uint32_t eval_lds[];
   // the short-segment launch stages up to kHitCapSmall hits, the other one up to kHitCap (what the host passes as hit_cap)
   constexpr uint32_t kStageCap = kAllStaged ? (uint32_t)kHitCapSmall : (uint32_t)kHitCap;
@@ -1414,7 +1427,6 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   const uint32_t lane = threadIdx.x;
   (void)vals;
   if (blockIdx.x >= n_segs) return;
-#define PA_CUT(k) do { if (cut == (k)) return; } while (0)
 #ifdef PA_MAP_STATS  // event counts of the mapping kernel in run_g[0 .. 15] (tools: -DPA_MAP_STATS, PA_FRAGANI_TRACE=1)
 #define PA_STAT(slot, v) do { const uint32_t pa_stat_v = (uint32_t)(v); if (lane == 0) atomicAdd(&run_g[slot], pa_stat_v); } while (0)  // (v may hold a ballot: every lane evaluates it)
 #else
@@ -1675,7 +1687,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
       const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
-      if (gi > 0 && cut == 23) break;  // (timing experiment: the group of the first seed hit only; results wrong)
+      if (gi > 0 && PA_CUT_IS(23)) break;  // (timing experiment: the group of the first seed hit only; results wrong)
       const uint32_t sb = b_lo + g * 64u;
       const uint32_t b = sb + lane;
       const bool has = b < b_hi;
@@ -1703,7 +1715,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         return has & (idx < h_hi) & (HW(min(idx, nh - 1u)) < w_end);
       };
       bool pending = bar > 0 ? holds_hits(bar) : has;
-      if (cut == 4) pending = false;  // seed-hit bounds of every group
+      if (PA_CUT_IS(4)) pending = false;  // seed-hit bounds of every group
       PA_STAT(3, 1);                              // groups of 64 begins
       PA_STAT(4, __popcll(__ballot(pending)));    // begins that pass the seed-hit bound
       uint32_t e_next = 0;  // end (minimizer index) of the begin's next state; 0: none of its states has been evaluated yet
@@ -1985,7 +1997,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
           };
           prefix_or_rows(bc, n_coarse);
           PA_CUT(7);  // coarse table
-            for (uint32_t pass = 0; pass * 64u < n_items && !(pass && cut == 21); ++pass) {
+            for (uint32_t pass = 0; pass * 64u < n_items && !(pass && PA_CUT_IS(21)); ++pass) {
               if (pass) item_setup(pass);
               // the lane's window as a mask over the stretch positions
               uint32_t wm[kW];
@@ -2044,7 +2056,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
               if (bar_now < floor_bar) bar_now = floor_bar;
               const bool in_reach = (int32_t)count_in(bc + g_lo * kRow + kW) >= bar_now;
               counted = it_on && in_reach;
-              bool unresolved = counted && cut != 22;
+              bool unresolved = counted && !PA_CUT_IS(22);
               while (__any(unresolved)) {
                 PA_STAT(8, 1);  // fine passes
                 const uint32_t g_cur = pa_dev::wave_min_dpp(unresolved ? g_lo : 0xffffffffu);
@@ -2307,7 +2319,7 @@ int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const
   uint32_t *scratch_a = scratch, *scratch_b = scratch + m;
   PA_TRY(W.hash_cut.reserve(((uint64_t)n_ids / 32 + 2) * 4));
   PA_HIP(hipMemsetAsync(W.hash_cut.p, 0, ((uint64_t)n_ids / 32 + 2) * 4, c->stream));
-  if (const char *v = getenv("PA_FRAGANI_NO_FREQ_CUT")) { if (atoi(v)) return PA_OK; }  // tools: the seeds as rounds 1-4 looked them up
+  if (const char *v = PA_TOOL_ENV("PA_FRAGANI_NO_FREQ_CUT")) { if (atoi(v)) return PA_OK; }  // tools: the seeds as rounds 1-4 looked them up
   constexpr uint32_t kOverCap = 1u << 20;
   std::vector<uint32_t> threshold(n_genomes, 0xffffffffu);
   bool any = false;
@@ -2391,7 +2403,7 @@ int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint3
   // expected density of winnowed minimizers is 2 / (w + 1); the arrays are sized a quarter above that and the run is
   // repeated with the exact size should a low-complexity data set need more
   uint64_t cap = (uint64_t)((double)arena_bases * 2.5 / (double)(w + 1)) + (1u << 20);
-  if (const char *v = getenv("PA_FRAGANI_MINIMIZER_ROOM")) cap = std::max<uint64_t>(1, strtoull(v, nullptr, 10));  // tests: force the repeat
+  if (const char *v = PA_TOOL_ENV("PA_FRAGANI_MINIMIZER_ROOM")) cap = std::max<uint64_t>(1, strtoull(v, nullptr, 10));  // tests: force the repeat
   for (int attempt = 0; attempt < 2; ++attempt) {
     PA_REQUIRE(cap < (1ULL << 31), "fragment ANI: room for %llu minimizers exceeds the 31-bit index space", (unsigned long long)cap);
     PA_TRY(W.mini_hash.reserve(cap * 4 + 16));
@@ -2723,7 +2735,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   // 1.48 s with 2^16).  A batch whose seed hits do not fit 31-bit indices is halved and started again.
   uint32_t batch_frags = 1u << 17;
   uint64_t hit_limit = 1ULL << 31;
-  if (const char *v = getenv("PA_FRAGANI_BATCH_HITS")) hit_limit = std::max<uint64_t>(1, strtoull(v, nullptr, 10));  // tests: force the halving
+  if (const char *v = PA_TOOL_ENV("PA_FRAGANI_BATCH_HITS")) hit_limit = std::max<uint64_t>(1, strtoull(v, nullptr, 10));  // tests: force the halving
   const uint64_t kMaxTableBytes = 1ULL << 31;
   PA_TRY(W.scalars.reserve(64));
   uint32_t *d_overflow = W.scalars.as<uint32_t>() + 8;
@@ -2745,9 +2757,9 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   }
   PA_TRY(upload(c, W.genome_first_contig, gfc));
   PA_HIP(hipStreamSynchronize(c->stream));
-  const bool trace = getenv("PA_FRAGANI_TRACE") != nullptr;  // per-batch sizes on stderr
+  const bool trace = PA_TOOL_ENV("PA_FRAGANI_TRACE") != nullptr;  // per-batch sizes on stderr
   const bool force_sorted = [] {  // PA_FRAGANI_HITS=sorted: the path of more than 8 192 genomes, for any number (tests)
-    const char *v = getenv("PA_FRAGANI_HITS");
+    const char *v = PA_TOOL_ENV("PA_FRAGANI_HITS");
     return v && v[0] == 's';
   }();
   const bool fields_fit = count_windows <= 0xffffu && most_contigs <= 0xffffu;
@@ -2864,7 +2876,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         PA_TRY(bucket_pass(false));
         presorted = false;
         uint32_t frag_sort_max = kFragSortMax;  // tests: PA_FRAGANI_SORT_MAX=600 sends a 60-copy repeat family down this path
-        if (const char *v = getenv("PA_FRAGANI_SORT_MAX")) frag_sort_max = (uint32_t)std::max(1, atoi(v));
+        if (const char *v = PA_TOOL_ENV("PA_FRAGANI_SORT_MAX")) frag_sort_max = (uint32_t)std::max(1, atoi(v));
         if (n_big && max_big > frag_sort_max) {
           // a repeat family with more hits than one LDS sort takes: order the whole batch by key; the
           // (fragment, genome) slices keep their places because contigs are numbered genome by genome -- provided every
@@ -2947,8 +2959,10 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
 #ifdef PA_MAP_STATS
       PA_HIP(hipMemsetAsync(W.run_g.p, 0, 64, c->stream));
 #endif
-      const char *cut_env = getenv("PA_MAP_CUT");  // tools: the mapping kernel cut short after a phase (timing by difference)
+#ifdef PA_TOOLS
+      const char *cut_env = PA_TOOL_ENV("PA_MAP_CUT");  // tools: the mapping kernel cut short after a phase (timing by difference)
       const uint32_t map_cut = cut_env ? (uint32_t)atoi(cut_env) : 0xffffffffu;
+#endif
       auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap, auto all_staged) -> int {
         if (count == 0) return PA_OK;
         constexpr bool kAll = decltype(all_staged)::value;
@@ -2964,7 +2978,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),                                  \
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),      \
                        W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), range_bins, \
-                       W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap, map_cut);                 \
+                       W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap PA_MAP_CUT_ARG);          \
     break;
         switch (ref_cap) {
           PA_MAP_CASE(256) PA_MAP_CASE(320) PA_MAP_CASE(384) PA_MAP_CASE(448)

@@ -270,7 +270,7 @@ int launch(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, const ui
            uint32_t *d_cand_genome, uint64_t cap, uint64_t *d_count, const uint64_t *d_region_off, uint32_t *d_cursor,
            uint32_t *d_overflow, uint64_t blk0, hipStream_t stream) {
   static const bool arithmetic = [] {
-    const char *v = getenv("PA_KMER_VARIANT");
+    const char *v = PA_TOOL_ENV("PA_KMER_VARIANT");
     return v && v[0] == '0';
   }();
   if constexpr (K == 31)  // the ablation build exists for the benchmarked k only
@@ -602,7 +602,7 @@ int pa_launch_kmer_hash(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_m
                         hipStream_t stream) {
   PA_REQUIRE(n_blocks64 < (1ULL << 32), "arena too large: %llu blocks of 64 bases", (unsigned long long)n_blocks64);
   if (n_blocks64 <= blk0) return PA_OK;
-  const char *long_form = getenv("PA_KMER_LONG");  // "plain": the one-window-per-step form (cross-check, read per launch)
+  const char *long_form = PA_TOOL_ENV("PA_KMER_LONG");  // "plain": the one-window-per-step form (cross-check, read per launch)
   const bool long_plain = long_form && long_form[0] == 'p';
   if (k > 32 && k <= 64 && !long_plain) {
     PA_REQUIRE((blk0 & 63u) == 0, "k-mer hash launch must start at a multiple of 64 blocks, not %llu", (unsigned long long)blk0);

@@ -37,6 +37,18 @@ void pa_set_error(const char *fmt, ...);
     }                           \
   } while (0)
 
+// ---- switches for tools and tests ------------------------------------------
+// Environment variables that force a rare path, cut a kernel short or select an ablation variant exist in
+// libpyani_hip_tools.so only (built with -DPA_TOOLS from the same sources; tools/ and the tests of the rare paths load
+// it).  In the product library the look-up is a null constant: the names are not even in the binary, and a stray variable
+// in a worker's environment cannot change a result.
+#ifdef PA_TOOLS
+#include <cstdlib>
+#define PA_TOOL_ENV(name) getenv(name)
+#else
+#define PA_TOOL_ENV(name) static_cast<const char *>(nullptr)
+#endif
+
 // ---- growable device buffer owned by the context ---------------------------
 struct DevBuf {
   void *p = nullptr;

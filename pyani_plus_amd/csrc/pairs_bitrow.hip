@@ -531,7 +531,7 @@ int pa_pairs_bitrow_hash(pa_ctx *c, const uint64_t *d_hashes, const uint64_t *d_
   PA_REQUIRE(!prepared || ns <= kMaxTileSubjects, "pair phase: a prepared dictionary serves one tile of at most %u subjects",
              kMaxTileSubjects);
   // all-vs-all over several subject tiles: tile j takes the queries of tiles i <= j only, the rest is mirrored
-  static const bool symmetry_off = [] { const char *v = getenv("PA_PAIRS_SYMMETRIC"); return v && v[0] == '0'; }();
+  static const bool symmetry_off = [] { const char *v = PA_TOOL_ENV("PA_PAIRS_SYMMETRIC"); return v && v[0] == '0'; }();
   const bool symmetric = !symmetry_off && q0 == s0 && q1 == s1 && ns > kMaxTileSubjects;
   for (uint32_t t0 = s0; t0 < s1; t0 += kMaxTileSubjects) {
     const uint32_t t1 = (s1 - t0 > kMaxTileSubjects) ? t0 + kMaxTileSubjects : s1;

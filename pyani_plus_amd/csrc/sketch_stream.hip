@@ -173,7 +173,7 @@ int pa_sketch_streamed(pa_ctx *c, const uint32_t *h_packed, const uint64_t *h_ru
 
   // 64 MB of packed bases (2.7e8 positions) per chunk: ~1.2 ms on the bus, ~0.7 ms of hashing
   uint64_t chunk_blocks = (64ull << 20) / 16;
-  if (const char *v = getenv("PA_STREAM_CHUNK_BLOCKS"))  // tests: small chunks, so that windows cross chunk boundaries
+  if (const char *v = PA_TOOL_ENV("PA_STREAM_CHUNK_BLOCKS"))  // tests: small chunks, so that windows cross chunk boundaries
     chunk_blocks = std::max<uint64_t>(64, (strtoull(v, nullptr, 10) + 63) / 64 * 64);
   std::vector<hipEvent_t> arrived;
   int status = PA_OK;

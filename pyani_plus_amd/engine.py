@@ -254,8 +254,11 @@ class DeviceSketches:
 class HipEngine:
     """One HIP context on one GPU.  Raises ``HipBackendError`` when no MI355X is usable."""
 
-    def __init__(self, device: int = 0):
-        self.lib = _capi.load_library()
+    def __init__(self, device: int = 0, *, tools: bool = False):
+        """``tools``: bind the -DPA_TOOLS build of the library (``_capi.TOOLS_LIB_PATH``), in which the environment
+        switches of tools/ and of the rare-path tests exist; the product library ignores them."""
+        self.lib = _capi.load_library(tools)
+        self._check = lambda status, what: check(status, what, self.lib)
         try:
             import torch
         except ImportError as err:  # pragma: no cover
@@ -266,14 +269,14 @@ class HipEngine:
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         ctx = C.c_void_p()
-        check(self.lib.pa_ctx_create(device, C.byref(ctx)), "pa_ctx_create")
+        self._check(self.lib.pa_ctx_create(device, C.byref(ctx)), "pa_ctx_create")
         self.ctx = ctx
         self.use_torch_stream()
 
     # -- plumbing
     def use_torch_stream(self) -> None:
         stream = self.torch.cuda.current_stream(self.device).cuda_stream
-        check(self.lib.pa_ctx_set_stream(self.ctx, C.c_void_p(stream)), "pa_ctx_set_stream")
+        self._check(self.lib.pa_ctx_set_stream(self.ctx, C.c_void_p(stream)), "pa_ctx_set_stream")
 
     def close(self) -> None:
         if getattr(self, "ctx", None):
@@ -289,11 +292,11 @@ class HipEngine:
     def device_info(self) -> dict:
         name = C.create_string_buffer(256)
         cus, mem = C.c_int(0), C.c_uint64(0)
-        check(self.lib.pa_ctx_device_info(self.ctx, name, C.byref(cus), C.byref(mem)), "pa_ctx_device_info")
+        self._check(self.lib.pa_ctx_device_info(self.ctx, name, C.byref(cus), C.byref(mem)), "pa_ctx_device_info")
         return {"name": name.value.decode(), "compute_units": cus.value, "global_mem": mem.value}
 
     def sync(self) -> None:
-        check(self.lib.pa_ctx_sync(self.ctx), "pa_ctx_sync")
+        self._check(self.lib.pa_ctx_sync(self.ctx), "pa_ctx_sync")
 
     # -- data movement
     def upload(self, arena: HostArena) -> DeviceArena:
@@ -326,7 +329,7 @@ class HipEngine:
             t = self.torch
             words = (arena.arena_bases // 64 + 63) // 64
             dirty = t.empty(max(words, 1), dtype=t.int64, device=self.device)
-            check(self.lib.pa_arena_dirty(self.ctx, arena.mask.data_ptr(), arena.arena_bases, dirty.data_ptr()), "pa_arena_dirty")
+            self._check(self.lib.pa_arena_dirty(self.ctx, arena.mask.data_ptr(), arena.arena_bases, dirty.data_ptr()), "pa_arena_dirty")
             arena.dirty = dirty
         return arena.dirty
 
@@ -350,7 +353,7 @@ class HipEngine:
             if st == _capi.PA_E_CAPACITY:
                 cap = int(total.value)
                 continue
-            check(st, "pa_sketch")
+            self._check(st, "pa_sketch")
             return DeviceSketches(hashes, off, n, int(total.value))
         raise HipBackendError("pa_sketch: capacity retry failed")
 
@@ -392,7 +395,7 @@ class HipEngine:
             if st == _capi.PA_E_CAPACITY:
                 cap = int(total.value)
                 continue
-            check(st, "pa_sketch_streamed")
+            self._check(st, "pa_sketch_streamed")
             return arena, DeviceSketches(hashes, off, n, int(total.value))
         raise HipBackendError("pa_sketch_streamed: capacity retry failed")
 
@@ -404,7 +407,7 @@ class HipEngine:
         counts = t.empty((q1 - q0, s1 - s0), dtype=t.int32, device=self.device)
         h_off = sk.offsets_host()  # one small copy per sketch set, cached; the pair phase itself then never waits for the host
         assert h_off.dtype == np.uint64 and len(h_off) == sk.n + 1
-        check(
+        self._check(
             self.lib.pa_pair_counts_ex(
                 self.ctx, sk.hashes.data_ptr(), sk.off.data_ptr(), h_off.ctypes.data, sk.n, q0, q1, s0, s1, counts.data_ptr(), algo,
             ),  # fmt: skip
@@ -415,7 +418,7 @@ class HipEngine:
     def pair_dict_prepare(self, subject_hashes, n_postings: int) -> None:
         """Enqueue the dictionary build of one subject tile from its ``n_postings`` contiguous hashes (multi-GPU
         overlap with the sketch all-gather); the next default-algorithm ``pair_counts`` over that tile uses it."""
-        check(self.lib.pa_pair_dict_prepare(self.ctx, subject_hashes.data_ptr(), int(n_postings)), "pa_pair_dict_prepare")
+        self._check(self.lib.pa_pair_dict_prepare(self.ctx, subject_hashes.data_ptr(), int(n_postings)), "pa_pair_dict_prepare")
 
     def ani(self, counts, sk: DeviceSketches, k: int, q_range=None, s_range=None):
         """Device f64 (identity, cov_query); NaN marks the reference's NULL."""
@@ -424,7 +427,7 @@ class HipEngine:
         s0, s1 = s_range or (0, sk.n)
         ident = t.empty((q1 - q0, s1 - s0), dtype=t.float64, device=self.device)
         cov = t.empty_like(ident)
-        check(
+        self._check(
             self.lib.pa_ani(self.ctx, counts.data_ptr(), sk.off.data_ptr(), q0, q1, s0, s1, k, ident.data_ptr(), cov.data_ptr()),
             "pa_ani",
         )
@@ -438,7 +441,7 @@ class HipEngine:
         off = t.empty(n + 1, dtype=t.int64, device=self.device)
         gs = np.ascontiguousarray(arena.genome_start, dtype=np.uint64)
         total = C.c_uint64(0)
-        check(
+        self._check(
             self.lib.pa_sketch_bottom(
                 self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), self.arena_dirty(arena).data_ptr(), arena.arena_bases,
                 gs.ctypes.data_as(C.POINTER(C.c_uint64)), n, k, m, hashes.data_ptr(), n * m, off.data_ptr(), C.byref(total),
@@ -454,7 +457,7 @@ class HipEngine:
         s0, s1 = s_range or (0, sk.n)
         common = t.empty((q1 - q0, s1 - s0), dtype=t.int32, device=self.device)
         denom = t.empty_like(common)
-        check(
+        self._check(
             self.lib.pa_pair_mash(self.ctx, sk.hashes.data_ptr(), sk.off.data_ptr(), sk.n, q0, q1, s0, s1, m, common.data_ptr(), denom.data_ptr()),
             "pa_pair_mash",
         )
@@ -463,7 +466,7 @@ class HipEngine:
     def ani_mash(self, common, denom, k: int):
         t = self.torch
         out = t.empty(common.shape, dtype=t.float64, device=self.device)
-        check(self.lib.pa_ani_mash(self.ctx, common.data_ptr(), denom.data_ptr(), common.numel(), k, out.data_ptr()), "pa_ani_mash")
+        self._check(self.lib.pa_ani_mash(self.ctx, common.data_ptr(), denom.data_ptr(), common.numel(), k, out.data_ptr()), "pa_ani_mash")
         return out
 
     # -- fastANI-style fragment ANI (BASELINE configs[3])
@@ -492,7 +495,7 @@ class HipEngine:
             assert total.dtype == np.uint32 and matched.dtype == np.uint32 and ident_sum.dtype == np.float64
             assert matched.flags.c_contiguous and ident_sum.flags.c_contiguous
         flags = (_capi.PA_FRAGANI_REUSE_INDEX if reuse_index else 0) | (_capi.PA_FRAGANI_COLUMNS_ONLY if columns_only else 0)
-        check(
+        self._check(
             self.lib.pa_fragani_ex(
                 self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,
                 cg.ctypes.data, len(cs), n, k, frag_len, int(q0), int(q1), int(r0), int(r1),
@@ -512,7 +515,7 @@ class HipEngine:
         wp = np.zeros(cap, dtype=np.uint32)
         ct = np.zeros(cap, dtype=np.uint32)
         n = C.c_uint64(0)
-        check(
+        self._check(
             self.lib.pa_fragani_sketch(
                 self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,
                 cg.ctypes.data, len(cs), arena.n_genomes, k, window, h.ctypes.data, wp.ctypes.data, ct.ctypes.data, cap, C.byref(n),
@@ -524,16 +527,16 @@ class HipEngine:
 
     # -- profiling
     def prof_enable(self, on: bool = True) -> None:
-        check(self.lib.pa_prof_enable(self.ctx, int(on)), "pa_prof_enable")
+        self._check(self.lib.pa_prof_enable(self.ctx, int(on)), "pa_prof_enable")
 
     def prof_reset(self) -> None:
-        check(self.lib.pa_prof_reset(self.ctx), "pa_prof_reset")
+        self._check(self.lib.pa_prof_reset(self.ctx), "pa_prof_reset")
 
     def prof_get(self) -> dict[str, tuple[float, int]]:
         out = {}
         for name, idx in _capi.PROF_PHASES.items():
             ms, n = C.c_double(0), C.c_uint64(0)
-            check(self.lib.pa_prof_get(self.ctx, idx, C.byref(ms), C.byref(n)), "pa_prof_get")
+            self._check(self.lib.pa_prof_get(self.ctx, idx, C.byref(ms), C.byref(n)), "pa_prof_get")
             out[name] = (ms.value, int(n.value))
         return out
 

@@ -25,6 +25,16 @@ def engine():
     eng.close()
 
 
+@pytest.fixture(scope="module")
+def tools_engine():
+    """The -DPA_TOOLS build of the library: the environment switches that force a rare path exist there only."""
+    from pyani_plus_amd.engine import HipEngine
+
+    eng = HipEngine(0, tools=True)
+    yield eng
+    eng.close()
+
+
 def _random_genomes(seed: int):
     rng = np.random.default_rng(seed)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -92,10 +102,11 @@ def test_minimizers_equal_oracle(engine, k, w):
     assert ci == len(arena.contig_start)
 
 
-def test_minimizer_run_is_repeated_when_the_estimate_is_too_small(engine, monkeypatch):
+def test_minimizer_run_is_repeated_when_the_estimate_is_too_small(tools_engine, monkeypatch):
     """The single-pass minimizer kernel writes into arrays sized from the expected density 2 / (w + 1); low-complexity
     sequence (every window of a homopolymer records a new, rightmost, position) needs more, and the run is repeated
     with the exact size.  Forced here by giving the first run room for 100 minimizers."""
+    engine = tools_engine  # the -DPA_TOOLS build: the switch below exists there only
     from pyani_plus_amd.engine import pack_genomes
 
     rng = np.random.default_rng(3)
@@ -181,9 +192,10 @@ def test_reference_of_hundreds_of_contigs(engine):
     assert total[1] == 320  # one fragment per contig of the draft
 
 
-def test_batches_are_halved_when_the_seed_hits_outgrow_their_indices(engine, monkeypatch):
+def test_batches_are_halved_when_the_seed_hits_outgrow_their_indices(tools_engine, monkeypatch):
     """A batch of query genomes whose seed hits pass 2^31 is halved and started again; forced here with a limit of a few
     thousand hits, down to one query genome per batch.  Same integers as the one-batch run and as the oracle."""
+    engine = tools_engine  # the -DPA_TOOLS build: the switch below exists there only
     texts, contig_lists = _random_genomes(31)
     one_batch = _check_against_oracle(engine, texts, contig_lists)
     monkeypatch.setenv("PA_FRAGANI_BATCH_HITS", "3000")
@@ -221,12 +233,13 @@ def test_repeat_families_take_the_long_segment_paths(engine):
     _check_against_oracle(engine, texts[:2], [[g] for g in genomes[:2]])
 
 
-def test_whole_batch_sort_with_unlisted_pairs(engine, monkeypatch):
+def test_whole_batch_sort_with_unlisted_pairs(tools_engine, monkeypatch):
     """The whole-batch radix sort of a repeat family (more hits in one segment than an LDS sort takes) must leave every
     (fragment, genome) slice in place although the bucketing does not write the hits of pairs nobody maps: chance hits of
     an unrelated genome and everything outside the reference range.  A 60-copy repeat genome, a relative, an unrelated
     genome sharing a short stretch (a few seed hits per fragment: below what an L1 run needs) and a reference range;
     once with the real limit (8 192 hits) and once with the limit lowered so that the 8-copy segments take the path too."""
+    engine = tools_engine  # the -DPA_TOOLS build: the switch below exists there only
     from pyani_plus_amd.engine import pack_genomes
 
     rng = np.random.default_rng(212)
@@ -505,13 +518,14 @@ def _expected_seed_hits(genomes: list[bytes], k: int, frag: int, cut: bool) -> i
     return hits
 
 
-def test_frequency_cut_of_the_seeds(engine, monkeypatch, capfd):
+def test_frequency_cut_of_the_seeds(tools_engine, monkeypatch, capfd):
     """Mashmap's cut of the most frequent reference minimizers from the seed look-up (fastANI logs "ignore minimizers
     occurring >= N times during lookup"): per reference genome, as many bars of the histogram of occurrence counts, from the
     top, as stay within 0.001 % of its distinct minimizers.  A 1.4 Mb genome holds an (ACC)n array whose one minimizer occurs
     ~300 times: above the threshold, it gives no seed hits -- the number of seed hits the library reports equals the count
     made here from the oracle's minimizers, with the cut and (PA_FRAGANI_NO_FREQ_CUT=1) without; the results equal the
     oracle's, which applies the same cut."""
+    engine = tools_engine  # the -DPA_TOOLS build: the switch below exists there only
     from pyani_plus_amd.engine import pack_genomes
 
     rng = np.random.default_rng(77)
@@ -577,12 +591,13 @@ def test_fragment_sketches_where_winnowing_restarted_at_the_fragment_could_diffe
     assert total.tolist() == [14, 14, 14] and matched[1, 1] == 14 and 10 <= matched[0, 1] <= 12 and matched[0, 0] <= 12
 
 
-def test_the_path_for_more_than_8192_genomes(engine, monkeypatch):
+def test_the_path_for_more_than_8192_genomes(tools_engine, monkeypatch):
     """Beyond 8 192 genomes there is no LDS counter per reference genome: every fragment's hits are written out, sorted as a
     whole and cut into segments by head flags (`PA_FRAGANI_HITS=sorted` takes that path for any number of genomes).  Same
     results as the oracle and as the bucketed path: random genomes, the viral fixture, a repeat family, runs of N, and the
     bacterial fixture, whose posting lists lose their most frequent minimizers (the frequency cut moves the postings and
     the minimizer indices this path reads)."""
+    engine = tools_engine  # the -DPA_TOOLS build: the switch below exists there only
     from pyani_plus_amd.engine import load_fasta_files, pack_genomes
 
     texts, contig_lists = _random_genomes(7)
@@ -704,3 +719,32 @@ def test_query_batches_of_one_subject_column_in_a_fresh_context(engine):
         assert np.array_equal(out[0], total) and np.array_equal(out[1], matched[:, 1:2]) and np.array_equal(out[2], ident_sum[:, 1:2])
     finally:
         fresh.close()
+
+
+def test_product_library_ignores_the_tool_switches(engine, tools_engine, monkeypatch):
+    """The switches of tools/ and of the rare-path tests live in the -DPA_TOOLS build only: with every one of them set, the
+    product library returns what it returns without them (and what the oracle says); the tools build, with its mapping
+    kernel cut short after L1 by the same environment, maps nothing -- the switches are live there."""
+    from pyani_plus_amd.engine import load_fasta_files
+
+    texts, contig_lists = _random_genomes(11)
+    want = _check_against_oracle(engine, texts, contig_lists)
+    files = sorted((GOLDEN / "bacterial_example").glob("*.gz"))[:2]
+    _infos, arena = load_fasta_files(files)
+    dev = engine.upload(arena)
+    want_b = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    for name, value in (("PA_MAP_CUT", "2"), ("PA_FRAGANI_NO_FREQ_CUT", "1"), ("PA_FRAGANI_HITS", "sorted"), ("PA_FRAGANI_SORT_MAX", "1"),
+                        ("PA_FRAGANI_BATCH_HITS", "1"), ("PA_FRAGANI_MINIMIZER_ROOM", "1"), ("PA_KMER_VARIANT", "0"), ("PA_PAIRS_SYMMETRIC", "0")):
+        monkeypatch.setenv(name, value)
+    got = _check_against_oracle(engine, texts, contig_lists)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
+    got_b = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    for a, b in zip(want_b, got_b):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv("PA_FRAGANI_BATCH_HITS")
+    monkeypatch.delenv("PA_FRAGANI_MINIMIZER_ROOM")
+    monkeypatch.delenv("PA_FRAGANI_SORT_MAX")
+    dev_t = tools_engine.upload(arena)
+    cut_short = tools_engine.fragani(dev_t, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    assert not np.array_equal(cut_short[1], want_b[1])  # PA_MAP_CUT=2 ends the mapping kernel after L1: nothing is mapped

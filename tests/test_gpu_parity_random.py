@@ -25,6 +25,16 @@ def engine():
     eng.close()
 
 
+@pytest.fixture(scope="module")
+def tools_engine():
+    """The -DPA_TOOLS build of the library: the environment switches that force a rare path exist there only."""
+    from pyani_plus_amd.engine import HipEngine
+
+    eng = HipEngine(0, tools=True)
+    yield eng
+    eng.close()
+
+
 def _random_fasta(rng, n_records, max_len, *, lower=False, n_runs=0) -> bytes:
     out = []
     for r in range(n_records):
@@ -236,10 +246,11 @@ def test_full_size_properties_baseline_config(engine):
 
 
 @pytest.mark.parametrize("k", [33, 34, 47, 48, 49, 51, 63, 64])
-def test_two_forms_of_the_long_kmer_kernel_agree(engine, k, monkeypatch):
+def test_two_forms_of_the_long_kmer_kernel_agree(tools_engine, k, monkeypatch):
     """k above 32 has two independent kernels: 64 windows per thread (streams, column order, 128-bit compare on lane
     masks) and one window per thread-step (PA_KMER_LONG=plain).  Same sketches, Ns, lower case, records and all; both
     equal the oracle."""
+    engine = tools_engine  # the -DPA_TOOLS build: the switch below exists there only
     from pyani_plus_amd.engine import pack_genomes
 
     rng = np.random.default_rng(3 * k)
@@ -374,9 +385,10 @@ def test_streamed_sketch_equals_resident_sketch(engine):
 
 
 @pytest.mark.parametrize("k", [31, 51, 64])
-def test_streamed_sketch_windows_across_chunk_boundaries(engine, k, monkeypatch):
+def test_streamed_sketch_windows_across_chunk_boundaries(tools_engine, k, monkeypatch):
     """The hash kernel of chunk c looks back into chunk c - 1 (up to k - 1 positions, 63 for the long-k form): with
     chunks of 64 arena blocks every 4 096th position is such a boundary."""
+    engine = tools_engine  # the -DPA_TOOLS build: the switch below exists there only
     from pyani_plus_amd.engine import pack_genomes
 
     rng = np.random.default_rng(k)

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import json
 import logging
+import os
 import re
 import sqlite3
 from pathlib import Path
@@ -36,6 +37,39 @@ def test_library_exports_every_header_symbol():
     assert lib.pa_abi_version() == 3
     assert lib.pa_max_hash(300) == 61489146912365176 and lib.pa_max_hash(1000) == 18446744073709552
     assert max_hash_for_scaled(1) == 2**64 - 1
+
+
+def test_tool_switches_are_not_in_the_product_library():
+    """The environment switches that force a rare path, cut a kernel short or select an ablation variant are read through
+    ``PA_TOOL_ENV`` and exist in ``libpyani_hip_tools.so`` (-DPA_TOOLS) only: the product library does not hold their names,
+    so no variable in a worker's environment can change what it computes.  Both libraries export the whole header."""
+    names = set()
+    for src in (ROOT / "pyani_plus_amd" / "csrc").glob("*.hip"):
+        text = src.read_text()
+        names |= set(re.findall(r'PA_TOOL_ENV\("([A-Z_]+)"\)', text))
+        # nothing in the kernels' sources reads the environment any other way
+        assert not re.search(r"(?<![A-Za-z_])getenv\(", text), src
+    assert {"PA_MAP_CUT", "PA_FRAGANI_NO_FREQ_CUT", "PA_KMER_VARIANT", "PA_PAIRS_SYMMETRIC", "PA_FRAGANI_HITS", "PA_FRAGANI_SORT_MAX"} <= names
+    product, tools = _capi.LIB_PATH.read_bytes(), _capi.TOOLS_LIB_PATH.read_bytes()
+    for name in names:
+        assert name.encode() not in product, name
+        assert name.encode() in tools, name
+    tools_lib = _capi.load_library(tools=True)
+    assert tools_lib is not _capi.load_library() and tools_lib.pa_abi_version() == _capi.load_library().pa_abi_version()
+    # a host-side call with every switch set: the product library's answer does not move (the device-side form of this
+    # check is tests/test_gpu_fragani.py::test_product_library_ignores_the_tool_switches)
+    before = _capi.load_library().pa_fragani_window(16, 3000)
+    saved = {n: os.environ.get(n) for n in names}
+    try:
+        for n in names:
+            os.environ[n] = "1"
+        assert _capi.load_library().pa_fragani_window(16, 3000) == before == 24
+    finally:
+        for n, v in saved.items():
+            if v is None:
+                os.environ.pop(n, None)
+            else:
+                os.environ[n] = v
 
 
 def test_no_cpu_fallback_without_gpu():

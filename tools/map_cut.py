@@ -15,7 +15,7 @@ from pyani_plus_amd.synth import synth_arena_torch  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 length, k, frag = 5_000_000, 16, 3000
-eng = HipEngine(0)
+eng = HipEngine(0, tools=True)  # PA_MAP_CUT exists in the -DPA_TOOLS build of the library only
 arena = synth_arena_torch(eng, n, length)
 starts = arena.genome_start[:-1].copy()
 lens = np.full(n, length, dtype=np.uint32)
