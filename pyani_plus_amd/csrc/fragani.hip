@@ -916,7 +916,7 @@ __global__ __launch_bounds__(kThreads) void fill_hits_kernel(
   uint32_t base = hit_off[f];
   for (uint32_t i0 = 0; i0 < s; i0 += 64) {
     const uint32_t i = i0 + lane;
-    uint32_t lo = 0, n = 0, qp = 0;
+    uint32_t lo = 0, n = 0;
     if (i < s) {
       lo = q_id[(uint64_t)f * kQMax + i];  // (first posting, length) as query_sketch_kernel left them
       n = q_pos[(uint64_t)f * kQMax + i];
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(kThreads) void fill_hits_kernel(
     for (uint32_t t = 0; t < n; ++t) {
       const uint32_t g = sorted_idx[lo + t];
       keys[base + ex + t] = ((uint64_t)f << 44) | ((uint64_t)mini_contig[g] << 24) | mini_wpos[g];
-      vals[base + ex + t] = qp;
+      vals[base + ex + t] = i;  // the rank of the hit's hash among the fragment's (the sketch is in hash order)
     }
     base += wave_sum(n);
   }
@@ -962,13 +962,14 @@ __global__ __launch_bounds__(kThreads) void segment_starts_kernel(const uint32_t
 // segment in LDS, longer segments (repeats) are listed for segment_sort.  Eight lanes walk one posting
 // list, so a wave reads 8 lists at a time in 64-byte pieces.
 constexpr int kBucketWaves = 4;
+constexpr uint32_t kHitRankShift = 55;  // a bucketed hit: rank of its hash in the fragment's sketch (9 bits) << 55 | contig << 24 | window id
 __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
     uint32_t n_frags, const uint32_t *__restrict__ q_pos, const uint32_t *__restrict__ q_id,
     const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ hit_off, const uint16_t *__restrict__ post_genome,
     const uint64_t *__restrict__ post_cw, uint32_t n_genomes, const uint32_t *__restrict__ tab_min_hits,
     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-    uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t seg_cap, uint32_t *__restrict__ counters,
-    unsigned long long *__restrict__ cursor64, uint32_t ref0, uint32_t ref1, bool write_all) {
+    uint32_t *__restrict__ seg_a0, uint32_t *__restrict__ seg_nh, uint32_t *__restrict__ seg_f, uint32_t seg_cap,
+    uint32_t *__restrict__ counters, unsigned long long *__restrict__ cursor64, uint32_t ref0, uint32_t ref1, bool write_all) {
   extern __shared__ uint32_t bk_lds[];
   __shared__ uint32_t s_part[kBucketWaves][2], s_draw[2];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -1088,19 +1089,29 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
       if (keep) {
         const uint64_t below = (1ULL << lane) - 1ULL;
         const uint32_t slot = small ? s0 + (uint32_t)__popcll(sm & below) : seg_cap - 1u - (l0 + (uint32_t)__popcll(lm & below));
-        if (slot < seg_cap) { seg_a0[slot] = base + off; seg_nh[slot] = cnt; }
+        if (slot < seg_cap) { seg_a0[slot] = base + off; seg_nh[slot] = cnt; seg_f[slot] = f; }
       }
       s0 += (uint32_t)__popcll(sm);
       l0 += (uint32_t)__popcll(lm);
     }
   }
   __builtin_amdgcn_wave_barrier();
-  // (the query window id of a hit is no longer carried along: the mapping kernel slides over reference positions)
-  for_each_posting(post_cw, [&](uint32_t, uint64_t cw) {
+  // A hit carries the RANK of its hash among the fragment's hashes -- the sketch is in hash order, so that is the number i
+  // of the posting list it comes from -- on top of its (contig, window id): the mapping kernel's bound on what a window
+  // can share asks which of a window's hits lie below a pivot rank (kHitRankShift; the fragment itself is named by the
+  // segment lists).
+  // write_all: the batch is about to be ordered as a whole (a repeat family too long for an LDS sort), and that keeps
+  // the (fragment, genome) slices in place only when every slot holds its own key with the fragment on top; the rank
+  // then rides in the sort's payload.
+  for_each_posting(post_cw, [&](uint32_t i, uint64_t cw) {
     const uint32_t at = atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
-    // write_all: the batch is about to be ordered as a whole (a repeat family too long for an LDS sort), and that keeps
-    // the (fragment, genome) slices in place only when every slot holds its own key
-    if (!(at & 0x80000000u) || write_all) keys[base + (at & 0x7fffffffu)] = ((uint64_t)f << 44) | (cw & ((1ULL << 44) - 1ULL));
+    const uint64_t cw44 = cw & ((1ULL << 44) - 1ULL);
+    if (write_all) {
+      keys[base + (at & 0x7fffffffu)] = ((uint64_t)f << 44) | cw44;
+      vals[base + (at & 0x7fffffffu)] = i;
+    } else if (!(at & 0x80000000u)) {
+      keys[base + at] = ((uint64_t)i << kHitRankShift) | cw44;
+    }
   });
 }
 
@@ -1111,21 +1122,23 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
 constexpr uint32_t kTinySegment = 8;
 __global__ __launch_bounds__(kThreads) void prefilter_segments_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh,
-    uint32_t n_segs, const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ tab_min_hits, uint32_t frag_len,
-    uint32_t *__restrict__ out_a0, uint32_t *__restrict__ out_nh, uint32_t *__restrict__ counter) {
+    const uint32_t *__restrict__ seg_f, uint32_t n_segs, const uint32_t *__restrict__ q_s,
+    const uint32_t *__restrict__ tab_min_hits, uint32_t frag_len, uint32_t *__restrict__ out_a0,
+    uint32_t *__restrict__ out_nh, uint32_t *__restrict__ out_f, uint32_t *__restrict__ counter) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t a0 = 0, nh = 0;
+  uint32_t a0 = 0, nh = 0, f = 0;
   bool keep = false;
   if (i < n_segs) {
     a0 = seg_a0[i];
     nh = seg_nh[i];
+    f = seg_f[i];
     if (nh > kTinySegment) {
       keep = true;
     } else {
       uint64_t k[kTinySegment];
 #pragma unroll
-      for (uint32_t j = 0; j < kTinySegment; ++j) k[j] = j < nh ? keys[a0 + j] : ~0ULL;
+      for (uint32_t j = 0; j < kTinySegment; ++j) k[j] = j < nh ? (keys[a0 + j] & ((1ULL << 44) - 1ULL)) : ~0ULL;  // (contig, window id)
 #pragma unroll
       for (uint32_t pass = 0; pass < kTinySegment; ++pass)  // odd-even transposition sort: 8 passes sort 8 keys
 #pragma unroll
@@ -1134,7 +1147,7 @@ __global__ __launch_bounds__(kThreads) void prefilter_segments_kernel(
           k[j] = lo;
           k[j + 1] = hi;
         }
-      const uint32_t s = q_s[(uint32_t)(k[0] >> 44)];
+      const uint32_t s = q_s[f];
       const uint32_t mh = s ? tab_min_hits[s] : 0xffffffffu;
 #pragma unroll
       for (uint32_t a = 0; a < kTinySegment; ++a) {
@@ -1167,6 +1180,7 @@ __global__ __launch_bounds__(kThreads) void prefilter_segments_kernel(
       if ((uint32_t)q < wave) slot += s_kept[q];
     out_a0[slot] = a0;
     out_nh[slot] = nh;
+    out_f[slot] = f;
   }
 }
 
@@ -1195,7 +1209,10 @@ __global__ __launch_bounds__(kFragSortThreads) void frag_sort_kernel(uint64_t *_
                                                                      uint32_t *__restrict__ vals,
                                                                      const uint32_t *__restrict__ hit_off,
                                                                      const uint32_t *__restrict__ hit_count,
-                                                                     uint32_t np2_max) {
+                                                                     uint32_t np2_max, uint32_t rot) {
+  // rot: bits the keys are turned left by while they are sorted -- 0 for keys with the fragment on top (one fragment's
+  // hits: by contig and window id), 20 for the bucketed hits of one long segment, whose top bits hold the rank of the
+  // hit's hash: ordered by (contig, window id) all the same
   extern __shared__ uint64_t fs_key[];
   uint32_t *fs_val = reinterpret_cast<uint32_t *>(fs_key + np2_max);
   const uint32_t f = blockIdx.x, tid = threadIdx.x;
@@ -1205,7 +1222,8 @@ __global__ __launch_bounds__(kFragSortThreads) void frag_sort_kernel(uint64_t *_
   uint32_t np2 = 2;
   while (np2 < n) np2 <<= 1;
   for (uint32_t i = tid; i < np2; i += kFragSortThreads) {
-    fs_key[i] = i < n ? keys[a0 + i] : ~0ULL;
+    const uint64_t key = i < n ? keys[a0 + i] : 0ULL;
+    fs_key[i] = i < n ? (rot ? (key << rot) | (key >> (64u - rot)) : key) : ~0ULL;
     fs_val[i] = i < n ? vals[a0 + i] : 0u;
   }
   __syncthreads();
@@ -1228,7 +1246,8 @@ __global__ __launch_bounds__(kFragSortThreads) void frag_sort_kernel(uint64_t *_
     }
   }
   for (uint32_t i = tid; i < n; i += kFragSortThreads) {
-    keys[a0 + i] = fs_key[i];
+    const uint64_t key = fs_key[i];
+    keys[a0 + i] = rot ? (key >> rot) | (key << (64u - rot)) : key;
     vals[a0 + i] = fs_val[i];
   }
 }
@@ -1283,13 +1302,16 @@ struct EvalShared {
   uint32_t *matched;   // [kQMax / 32] bitset over query ranks (cooperative evaluation of one over-long window)
   uint32_t *cand;      // [4 * 8] candidates of the L1 scan waiting for their evaluation: contig, first and last start, first hit
   uint32_t *scan;      // [24] the L1 scan's state while the candidates it has listed are evaluated [0..10], the best mapping so far [16..23]
-  uint32_t *hw;        // [kHitCap] window id of each staged hit
+  uint32_t *lmask;     // [kLmaskWords] one bit per staged hit: the rank of its hash lies below the pivot of the tight bound;
+  uint32_t *lpre;      // [kLmaskWords] set bits in the words before (so "hits below the pivot among the first i" is two reads)
+  uint32_t *hw;        // [kHitCap] window id of each staged hit << 8 | rank of its hash in the fragment's sketch >> 1
   uint16_t *hc;        // [kHitCap] contig of each staged hit, relative to the segment's first
   uint16_t *ref_w;     // [kRefCap] window id relative to the first minimizer's of the stretch
   uint16_t *prev;      // [kRefCap] 1 + stretch position of the same hash earlier in the stretch, 0: none
   uint16_t *qt;        // [kQtBuckets] the fragment's sketch bucketed by the top bits of the hash: first rank (10 bits) | hashes in the bucket (6 bits)
 };
 constexpr uint32_t kQtBits = 9, kQtBuckets = 1u << kQtBits, kQtShift = 32u - kQtBits;
+constexpr uint32_t kLmaskWords = (uint32_t)kHitCap / 32u + 2u;  // a word per 32 staged hits, one more for "all of them", even
 // Bit tables of the windowed evaluation: one row per query rank r = the stretch positions (one bit each, kRefCap / 32
 // words) whose minimizer has rank <= r among the fragment's hashes.  Coarse rows stand at every kCoarse-th rank; the
 // fine rows cover kFineGroups coarse groups at a time, every rank of them.
@@ -1300,7 +1322,8 @@ __host__ __device__ inline uint32_t eval_tab_words(uint32_t s_cap, uint32_t ref_
   return ((t > c ? t : c) + 3u) & ~3u;
 }
 __host__ __device__ inline uint32_t eval_lds_bytes(uint32_t s_cap, uint32_t hit_cap, uint32_t ref_cap) {
-  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + 96u + hit_cap * 6u + ref_cap * 4u + 2u * kQtBuckets;
+  return 4u * s_cap + 4u * eval_tab_words(s_cap, ref_cap) + 4u * (kQMax / 32) + 128u + 96u + 8u * kLmaskWords + hit_cap * 6u + ref_cap * 4u +
+         2u * kQtBuckets;
 }
 // The arrays whose length is known at compile time come first, so that their addresses are constants of the kernel
 // (immediate offsets of the LDS instructions, no registers); the fragment's sketch and the tables follow.
@@ -1309,7 +1332,9 @@ __device__ __forceinline__ EvalShared eval_carve(uint32_t *base, uint32_t s_cap,
   sh.matched = base;
   sh.cand = sh.matched + kQMax / 32;
   sh.scan = sh.cand + 32;
-  sh.qt = reinterpret_cast<uint16_t *>(sh.scan + 24);
+  sh.lmask = sh.scan + 24;
+  sh.lpre = sh.lmask + kLmaskWords;
+  sh.qt = reinterpret_cast<uint16_t *>(sh.lpre + kLmaskWords);  // (2 kLmaskWords is a multiple of 4: still on a 16-byte boundary)
   sh.hw = reinterpret_cast<uint32_t *>(sh.qt + kQtBuckets);
   sh.hc = reinterpret_cast<uint16_t *>(sh.hw + hit_cap);
   sh.ref_w = sh.hc + hit_cap;  // hit_cap and kRefCap are multiples of 64: everything stays on 16-byte boundaries
@@ -1334,14 +1359,15 @@ __device__ __forceinline__ uint32_t atomicAdd_u16(uint16_t *counters, uint32_t i
 // Two uint4: {first hit, hits, fragment, sketch size} {hits a run needs, first contig, hashes of the sketch that lost seed hits to the
 // frequency cut, 0}; sketch size 0 = nothing to do.
 __global__ __launch_bounds__(kThreads) void segment_records_kernel(
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh, uint32_t n_segs,
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh,
+    const uint32_t *__restrict__ seg_f /* null: the fragment is the top of the key */, uint32_t n_segs,
     const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ q_cut, const uint32_t *__restrict__ tab_min_hits,
     const uint32_t *__restrict__ contig_genome, const uint32_t *__restrict__ genome_first_contig, uint4 *__restrict__ rec) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= n_segs) return;
   const uint32_t a0 = seg_a0[i], nh = seg_nh[i];
   const uint64_t key = keys[a0];
-  const uint32_t f = (uint32_t)(key >> 44);
+  const uint32_t f = seg_f ? seg_f[i] : (uint32_t)(key >> 44);
   uint32_t s = q_s[f];
   const uint32_t mh = s ? tab_min_hits[s] : 0u;
   if (nh < mh) s = 0;  // chance matches with unrelated genomes: fewer seed hits than any L1 run needs
@@ -1350,32 +1376,48 @@ __global__ __launch_bounds__(kThreads) void segment_records_kernel(
   rec[2 * (uint64_t)i + 1] = make_uint4(mh, hc_base, q_cut[f], 0u);
 }
 
-// the segment's hits from the hit array into LDS, in order: window id and contig (relative to the genome's first)
+// the segment's hits from the hit array into LDS, in order: window id and rank (see EvalShared::hw), contig relative to
+// the genome's first.  The hits come as the bucketing pass left them: rank << kHitRankShift | contig << 24 | window id.
 template <int E>
 __device__ __forceinline__ void stage_hits_sorted(const uint64_t *__restrict__ seg_keys, uint32_t nh, uint32_t hc_base,
                                                   uint32_t lane, uint32_t *hw, uint16_t *hc) {
   uint64_t k[E];
-  uint32_t widest = 0;  // largest relative contig of the segment
+  uint32_t widest = 0, furthest = 0;  // largest relative contig and largest window id of the segment
 #pragma unroll
   for (int q = 0; q < E; ++q) {
     const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
-    k[q] = e < nh ? (seg_keys[e] & 0xfffffffffffULL) : ~0ULL;  // (contig, window id): the low 44 bits of a hit
-    if (e < nh) widest = max(widest, ((uint32_t)(k[q] >> 24) & 0xfffffu) - hc_base);
+    const uint64_t raw = e < nh ? seg_keys[e] : 0ULL;
+    // sort key: (contig, window id) on top of the rank -- a (contig, window id) occurs once, the rank decides nothing
+    k[q] = e < nh ? ((raw & 0xfffffffffffULL) << 9) | (raw >> kHitRankShift) : ~0ULL;
+    if (e < nh) {
+      widest = max(widest, ((uint32_t)(raw >> 24) & 0xfffffu) - hc_base);
+      furthest = max(furthest, (uint32_t)raw & 0xffffffu);
+    }
   }
-  if (pa_dev::wave_max_dpp(widest) < 255u) {  // uniform
+  widest = pa_dev::wave_max_dpp(widest);
+  furthest = pa_dev::wave_max_dpp(furthest);
+  // 32-bit keys where contig, window id and rank fit (uniform): one shuffle, a minimum, a maximum and a select per key and
+  // stage.  A genome of one contig of up to 8 Mb always does.
+  const uint32_t w_bits = 32u - (uint32_t)__builtin_clz(furthest | 1u);
+  if (((uint64_t)(widest + 1u) << w_bits) <= (1ull << 23)) {
     uint32_t k32[E];
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
-      k32[q] = e < nh ? ((((uint32_t)(k[q] >> 24) & 0xfffffu) - hc_base) << 24) | ((uint32_t)k[q] & 0xffffffu) : 0xffffffffu;
+      k32[q] = 0xffffffffu;
+      if (e < nh) {
+        const uint32_t c_rel = ((uint32_t)(k[q] >> 33) & 0xfffffu) - hc_base, wpos = (uint32_t)(k[q] >> 9) & 0xffffffu;
+        k32[q] = ((((c_rel << w_bits) | wpos)) << 9) | ((uint32_t)k[q] & 0x1ffu);
+      }
     }
     bitonic_sort_lanes<E, uint32_t>(k32, lane);
 #pragma unroll
     for (int q = 0; q < E; ++q) {
       const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
       if (e < nh) {
-        hw[e] = k32[q] & 0xffffffu;
-        hc[e] = (uint16_t)(k32[q] >> 24);
+        const uint32_t cw = k32[q] >> 9;
+        hw[e] = ((cw & ((1u << w_bits) - 1u)) << 8) | ((k32[q] & 0x1ffu) >> 1);
+        hc[e] = (uint16_t)(cw >> w_bits);
       }
     }
     return;
@@ -1385,8 +1427,8 @@ __device__ __forceinline__ void stage_hits_sorted(const uint64_t *__restrict__ s
   for (int q = 0; q < E; ++q) {
     const uint32_t e = lane * (uint32_t)E + (uint32_t)q;
     if (e < nh) {
-      hw[e] = (uint32_t)k[q] & 0xffffffu;
-      hc[e] = (uint16_t)(((uint32_t)(k[q] >> 24) & 0xfffffu) - hc_base);
+      hw[e] = (((uint32_t)(k[q] >> 9) & 0xffffffu) << 8) | (((uint32_t)k[q] & 0x1ffu) >> 1);
+      hc[e] = (uint16_t)(((uint32_t)(k[q] >> 33) & 0xfffffu) - hc_base);
     }
   }
 }
@@ -1425,7 +1467,6 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   constexpr uint32_t kStageCap = kAllStaged ? (uint32_t)kHitCapSmall : (uint32_t)kHitCap;
   const EvalShared sh = eval_carve(eval_lds, s_cap, kStageCap, kRefCap);
   const uint32_t lane = threadIdx.x;
-  (void)vals;
   if (blockIdx.x >= n_segs) return;
 #ifdef PA_MAP_STATS  // event counts of the mapping kernel in run_g[0 .. 15] (tools: -DPA_MAP_STATS, PA_FRAGANI_TRACE=1)
 #define PA_STAT(slot, v) do { const uint32_t pa_stat_v = (uint32_t)(v); if (lane == 0) atomicAdd(&run_g[slot], pa_stat_v); } while (0)  // (v may hold a ballot: every lane evaluates it)
@@ -1446,7 +1487,12 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   const uint32_t hc_base = rec1.y;
   const bool staged = kAllStaged || nh <= kStageCap;
   (void)hit_cap;
-  auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] : (uint32_t)(keys[a0 + i] & 0xffffffu); };
+  auto HW = [&](uint32_t i) -> uint32_t { return staged ? sh.hw[i] >> 8 : (uint32_t)(keys[a0 + i] & 0xffffffu); };
+  // "the window id of hit i is below w" without the shift (the searches of the bounds ask nothing else)
+  // (window ids stay below 2^24 - 1: contigs are shorter than 2^24)
+  auto HW_below = [&](uint32_t i, uint32_t w) -> bool {
+    return staged ? sh.hw[i] < ((w < 0xffffffu ? w : 0xffffffu) << 8) : (uint32_t)(keys[a0 + i] & 0xffffffu) < w;
+  };
   auto HC = [&](uint32_t i) -> uint32_t {
     return staged ? hc_base + sh.hc[i] : (uint32_t)(keys[a0 + i] >> 24) & 0xfffffu;
   };
@@ -1458,9 +1504,9 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   PA_CUT(10);  // segment header and sketch
   if (staged) {
     if (presorted) {
-      for (uint32_t i = lane; i < nh; i += 64) {
+      for (uint32_t i = lane; i < nh; i += 64) {  // hits ordered as a whole: the fragment on top of the key, the rank in the payload
         const uint64_t key = keys[a0 + i];
-        sh.hw[i] = (uint32_t)(key & 0xffffffu);
+        sh.hw[i] = ((uint32_t)(key & 0xffffffu) << 8) | ((vals[a0 + i] & 0x1ffu) >> 1);
         sh.hc[i] = (uint16_t)(((uint32_t)(key >> 24) & 0xfffffu) - hc_base);
       }
     } else {
@@ -1520,7 +1566,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     uint32_t pos = lo;  // hits [lo, pos) are below w
     for (uint32_t step = steps ? 1u << (steps - 1u) : 0u; step > 0u; step >>= 1) {
       const uint32_t idx = pos + step;
-      const bool ok = (idx <= hi) & (HW(min(idx, nh) - 1u) < w);
+      const bool ok = (idx <= hi) & HW_below(min(idx, nh) - 1u, w);
       pos = ok ? idx : pos;
     }
     return pos;
@@ -1578,10 +1624,16 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // The best mapping so far lives in LDS (sh.scan[16..19]: it is looked at once per candidate, and values kept in
   // registers across the whole kernel were spills): shared minimizers; contig; window ids of the first minimizers of its
   // first and of its last optimal state.
-  enum { kBestShared = 16, kBestC, kBestFirst, kBestLast };
+  // kBestT: how many of the fragment's smallest hashes lie in the bottom-s of the union with the best window so far (T
+  // below) -- the pivot rank of the tight bound; 0xffffffff: not known.
+  // kLmaskPivot: the pivot sh.lmask stands for (the hits are the segment's: the bits outlive a candidate).
+  enum { kBestShared = 16, kBestC, kBestFirst, kBestLast, kBestT, kLmaskPivot };
+  constexpr uint32_t kNoT = 0xffffffffu;
   if (lane == 0) {
     sh.scan[kBestShared] = 0xffffffffu;  // -1
     sh.scan[kBestC] = 0xffffffffu;
+    sh.scan[kBestT] = kNoT;
+    sh.scan[kLmaskPivot] = kNoT;
   }
   uint32_t half0 = 1;
   while (2u * half0 <= s) half0 *= 2u;
@@ -1673,6 +1725,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     PA_STAT(2, 1);  // candidates with begins
     int32_t c_best = -1;
     uint32_t c_first = 0, c_last = 0;
+    // T of this candidate's best state so far, until there is one that of the fragment's best mapping so far: the pivot of the tight bound
+    uint32_t pivot_T = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.scan[kBestT]);
     const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
     // A begin matters only if one of its windows can hold min_shared minimizers of the fragment (less is never reported)
     // and reach the best so far.  The group holding the candidate's first seed hit goes first -- for a true mapping the
@@ -1712,7 +1766,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       const uint32_t i0 = hit_lower_bound_w(h_lo, h_hi, wp, h_steps);
       auto holds_hits = [&](int32_t b) -> bool {
         const uint32_t idx = i0 + (uint32_t)max(b, 1) - 1u;
-        return has & (idx < h_hi) & (HW(min(idx, nh - 1u)) < w_end);
+        return has & (idx < h_hi) & HW_below(min(idx, nh - 1u), w_end);
       };
       bool pending = bar > 0 ? holds_hits(bar) : has;
       if (PA_CUT_IS(4)) pending = false;  // seed-hit bounds of every group
@@ -1777,7 +1831,84 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             hi_known = xe_hi < n || at_end;
           }
         }
+        // ---- The tight bound.  With T = the number of the fragment's smallest hashes that lie in the bottom-s of the union
+        // with a window (rank r is one of them iff r + c(r) < s, c(r) = the window's reference-only hashes below the
+        // fragment's hash of rank r), the window shares its matches of rank < T.  For ANY pivot rank r0: c(r) >= c(r0) from
+        // r0 on, hence T <= max(r0, s - c(r0)), and
+        //     shared <= matches of rank < r0  +  min(matches of rank >= r0, max(0, s - r0 - c(r0))).
+        // The matches of a begin's windows are seed hits, and a hit knows the rank of its hash: those below r0 among the
+        // hits inside the begin's WIDEST window come from a bit per hit and two prefix counts (sh.lmask).  c(r0) is bounded
+        // from below over the begin's NARROWEST window: stretch entries there whose hash is below the fragment's hash of
+        // rank r0 -- entries that repeat a hash of the stretch left out, so that no hash counts twice -- less the hits below
+        // r0 (they are such entries; taking those of the widest window only lowers the count).  With r0 = T of the best
+        // window so far the bound is what the window would share if its reference-only hashes were as dense as that
+        // window's: begins a few matches away from the optimum fail it, where the count of seed hits alone lets windows a
+        // third of a fragment away pass (a window shares ~0.7 of its hits).  Asked before the stretch is ranked and the bit
+        // tables are built -- the expensive part of a round --, for every pending begin at once.  Not asked when the
+        // frequency cut took hashes of the sketch out of the seeds (their matches are not among the hits) and for segments
+        // whose hits are not staged.
+        {
+          if (staged && unseeded == 0 && pivot_T != kNoT) {
+            const uint32_t r0 = min(pivot_T, s - 1u) & ~1u;  // even: a staged hit keeps its rank without the lowest bit
+            if ((uint32_t)__builtin_amdgcn_readfirstlane((int)sh.scan[kLmaskPivot]) != r0) {  // the bits stand for another pivot
+              for (uint32_t chunk = 0; chunk <= nh; chunk += 64) {
+                const uint32_t i = chunk + lane;
+                const uint64_t lm = __ballot(i < nh && (sh.hw[min(i, nh - 1u)] & 0xffu) < (r0 >> 1));
+                if (lane == 0) { sh.lmask[chunk / 32u] = (uint32_t)lm; sh.lmask[chunk / 32u + 1u] = (uint32_t)(lm >> 32); }
+              }
+              __builtin_amdgcn_wave_barrier();
+              const uint32_t n_words = 2u * (nh / 64u) + 2u;
+              const uint32_t pc = lane < n_words ? (uint32_t)__popc(sh.lmask[min(lane, kLmaskWords - 1u)]) : 0u;
+              const uint32_t ex = pa_dev::wave_incl_scan_dpp(pc) - pc;
+              if (lane < n_words) sh.lpre[lane] = ex;
+              if (lane == 0) sh.scan[kLmaskPivot] = r0;
+              __builtin_amdgcn_wave_barrier();
+            }
+            const uint32_t ph = sh.qh[r0];
+            uint32_t *bw = sh.matched;   // 2 kPer words: stretch entries below the pivot hash; their prefix counts in sh.tab
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+              const uint32_t x = (uint32_t)q * 64u + lane;
+              const uint64_t mb = __ballot((x < n) & (hh[q] < ph) & (((dup_q >> q) & 1u) == 0u));
+              if (lane == 0) { bw[2 * q] = (uint32_t)mb; bw[2 * q + 1] = (uint32_t)(mb >> 32); }
+            }
+            __builtin_amdgcn_wave_barrier();
+            {
+              const uint32_t pc = lane < 2u * (uint32_t)kPer ? (uint32_t)__popc(bw[min(lane, 2u * (uint32_t)kPer - 1u)]) : 0u;
+              const uint32_t ex = pa_dev::wave_incl_scan_dpp(pc) - pc;
+              if (lane < 2u * (uint32_t)kPer) sh.tab[lane] = ex;
+            }
+            __builtin_amdgcn_wave_barrier();
+            auto below_upto = [&](uint32_t x) -> uint32_t {  // entries [0, x) below the pivot hash, x <= n
+              const uint32_t w = min(x >> 5, 2u * (uint32_t)kPer - 1u), bits = x - (w << 5);
+              const uint32_t m = bits >= 32u ? 0xffffffffu : (1u << bits) - 1u;
+              return sh.tab[w] + (uint32_t)__popc(bw[w] & m);
+            };
+            auto hits_below = [&](uint32_t i) -> uint32_t {  // hits [0, i) whose rank lies below the pivot
+              const uint32_t w = i >> 5;
+              return sh.lpre[w] + (uint32_t)__popc(sh.lmask[w] & ((1u << (i & 31u)) - 1u));
+            };
+            int32_t bar_full = c_best > best_shared ? c_best : best_shared;
+            if (bar_full < floor_bar) bar_full = floor_bar;
+            bool fails = false;
+            if (lane_on) {
+              const uint32_t cb = below_upto(min(xe_lo, n)) - below_upto(min(b - base, n));
+              const uint32_t i1 = hit_lower_bound_w(i0, h_hi, w_end, h_steps);
+              const uint32_t mlow = hits_below(i1) - hits_below(i0), mhigh = (i1 - i0) - mlow;
+              const uint32_t c2 = cb > mlow ? cb - mlow : 0u;
+              const uint32_t room = s - r0 > c2 ? s - r0 - c2 : 0u;
+              fails = (int32_t)(mlow + min(mhigh, room)) < bar_full;
+            }
+            PA_STAT(16, __popcll(__ballot(fails)));  // begins the tight bound drops
+            pending = pending && !fails;
+            if (!((__ballot(pending) >> first_lane) & 1ULL)) {  // the stretch was loaded for a begin that is gone: the next one, if any
+              PA_STAT(17, 1);  // rounds that end here
+              continue;
+            }
+          }
+        }
         uint32_t f_shared = 0, p_state = 0;  // p_state: the position of the lane's state = the window id of its begin
+        uint32_t t_state = kNoT;             // its T, where the fine search found it
         bool counted = false;  // the lane holds the exact value of a state (a window found out of reach of the bar is done, but not counted)
         uint32_t taken = 0;
         bool complete = false;  // the begin's last state is behind it
@@ -1794,6 +1925,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             c_last = group_best > c_best ? w_last : max(c_last, w_last);
             c_first = group_best > c_best ? w_first : min(c_first, w_first);
             c_best = group_best;
+            const uint32_t tt = (uint32_t)__builtin_amdgcn_readlane((int)t_state, __builtin_ctzll(top_items));
+            if (tt != kNoT) pivot_T = tt;
           }
         };
         if (__builtin_amdgcn_readlane((int)cnt, (int)first_lane) == 0) {
@@ -2090,7 +2223,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
                   r_lo = (open & !ge) ? mid + 1u : r_lo;
                 }
                 const uint32_t c = count_in(bf + (r_lo - band0) * kRow + kW);  // matches of rank < T = r_lo
-                if (now) { f_shared = c; unresolved = false; }
+                if (now) { f_shared = c; t_state = r_lo; unresolved = false; }
               }
               __syncthreads();
               PA_STAT(14, __popcll(__ballot(counted)));  // windows whose exact value was found
@@ -2118,6 +2251,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     __syncthreads();
     if (c_best >= best_shared && lane == 0) {
       sh.scan[kBestShared] = (uint32_t)c_best; sh.scan[kBestC] = c; sh.scan[kBestFirst] = c_first; sh.scan[kBestLast] = c_last;
+      sh.scan[kBestT] = pivot_T;
     }
     __syncthreads();
   };
@@ -2282,7 +2416,7 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at;
+      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at, seg_f, seg2_f;
   // the reference index (stages 1 and 2) of the last pa_fragani(_ex) call, for PA_FRAGANI_REUSE_INDEX
   bool index_valid = false;
   const void *index_packed = nullptr;
@@ -2297,7 +2431,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at, &seg_f, &seg2_f};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -2832,7 +2966,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         hv[1] = W.hvals[1].as<uint32_t>();
         return PA_OK;
       };
-      PA_TRY(W.run_g.reserve(64));  // the mapping kernel's event counters (-DPA_MAP_STATS)
+      PA_TRY(W.run_g.reserve(128));  // the mapping kernel's event counters (-DPA_MAP_STATS)
       int bits = 44;
       for (uint32_t x = nf; x > 1; x >>= 1) ++bits;
       bits = (bits + 1 + 7) & ~7;
@@ -2846,6 +2980,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         const uint32_t seg_cap = (uint32_t)std::min<uint64_t>(seg_cap64, 0xfffffff0ull);
         PA_TRY(W.seg_a0.reserve((uint64_t)seg_cap * 4 + 16));
         PA_TRY(W.seg_nh.reserve((uint64_t)seg_cap * 4 + 16));
+        PA_TRY(W.seg_f.reserve((uint64_t)seg_cap * 4 + 16));
         unsigned long long *d_cursor64 = reinterpret_cast<unsigned long long *>(W.scalars.as<uint32_t>() + 14);  // [lo] short, [hi] long segments
         const uint32_t lds_bytes = (uint32_t)kBucketWaves * n_genomes * 4u;
         PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_hits_kernel),
@@ -2858,8 +2993,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                              c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
                              W.hit_off.as<uint32_t>(), W.post_g.as<uint16_t>(), W.post_cw.as<uint64_t>(), n_genomes,
                              W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
-                             W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), seg_cap, d_seg_counters, d_cursor64, ref0, ref1,
-                             write_all);
+                             W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), W.seg_f.as<uint32_t>(), seg_cap, d_seg_counters,
+                             d_cursor64, ref0, ref1, write_all);
           PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters, 16, hipMemcpyDeviceToHost, c->stream));
           PA_HIP(hipMemcpyAsync(c->h_pinned + 2, d_cursor64, 8, hipMemcpyDeviceToHost, c->stream));
           PA_HIP(hipStreamSynchronize(c->stream));
@@ -2899,7 +3034,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
           PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(frag_sort_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds));
           hipLaunchKernelGGL(frag_sort_kernel, dim3(n_big), dim3(kFragSortThreads), sort_lds, c->stream, hk[0], hv[0],
-                             big_a0, big_nh, np2_max);
+                             big_a0, big_nh, np2_max, 64u - kHitRankShift + 11u);  // (contig, window id) to the top, the rank below
         }
       } else {
         // general path: all hits sorted by key, segments from head flags
@@ -2914,7 +3049,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
           PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(frag_sort_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
           hipLaunchKernelGGL(frag_sort_kernel, dim3(nf), dim3(kFragSortThreads), lds_bytes, c->stream, hk[0], hv[0],
-                             W.hit_off.as<uint32_t>(), W.hit_count.as<uint32_t>(), np2_max);
+                             W.hit_off.as<uint32_t>(), W.hit_count.as<uint32_t>(), np2_max, 0u);
         } else {
           PA_TRY(second_buffers());
           PA_TRY(pa_radix_sort_pairs(c, hk, hv, n_hits, 0, bits, false, &hw));
@@ -2957,18 +3092,19 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
       const uint32_t per_window = (uint32_t)(2.0 * count_windows / (w + 1.0));
       const uint32_t ref_cap = std::min<uint32_t>(kRefCapMax, std::max<uint32_t>(256u, (per_window * 4u / 3u + 63u) / 64u * 64u));
 #ifdef PA_MAP_STATS
-      PA_HIP(hipMemsetAsync(W.run_g.p, 0, 64, c->stream));
+      PA_HIP(hipMemsetAsync(W.run_g.p, 0, 128, c->stream));
 #endif
 #ifdef PA_TOOLS
       const char *cut_env = PA_TOOL_ENV("PA_MAP_CUT");  // tools: the mapping kernel cut short after a phase (timing by difference)
       const uint32_t map_cut = cut_env ? (uint32_t)atoi(cut_env) : 0xffffffffu;
 #endif
-      auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, uint32_t count, uint32_t hit_cap, auto all_staged) -> int {
+      auto launch_map = [&](const uint32_t *list_a0, const uint32_t *list_nh, const uint32_t *list_f, uint32_t count, uint32_t hit_cap,
+                            auto all_staged) -> int {
         if (count == 0) return PA_OK;
         constexpr bool kAll = decltype(all_staged)::value;
         PA_TRY(W.seg_rec.reserve((uint64_t)count * 32));
         hipLaunchKernelGGL(segment_records_kernel, dim3(ceil_div_u64(count, kThreads)), dim3(kThreads), 0, c->stream, hk[hw],
-                           list_a0, list_nh, count, W.q_s.as<uint32_t>(), W.q_cut.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(),
+                           list_a0, list_nh, list_f, count, W.q_s.as<uint32_t>(), W.q_cut.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(),
                            W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(), W.seg_rec.as<uint4>());
 #define PA_MAP_CASE(CAP)                                                                                                  \
   case CAP:                                                                                                               \
@@ -2991,31 +3127,35 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         if (n_keep) {
           PA_TRY(W.seg2_a0.reserve((uint64_t)n_keep * 4 + 16));
           PA_TRY(W.seg2_nh.reserve((uint64_t)n_keep * 4 + 16));
+          PA_TRY(W.seg2_f.reserve((uint64_t)n_keep * 4 + 16));
           PA_HIP(hipMemsetAsync(d_seg_counters + 6, 0, 4, c->stream));
           hipLaunchKernelGGL(prefilter_segments_kernel, dim3(ceil_div_u64(n_keep, kThreads)), dim3(kThreads), 0, c->stream,
-                             hk[hw], W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, W.q_s.as<uint32_t>(),
-                             W.tab_min_hits.as<uint32_t>(), frag_len, W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(),
-                             d_seg_counters + 6);
+                             hk[hw], W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), W.seg_f.as<uint32_t>(), n_keep,
+                             W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(), frag_len, W.seg2_a0.as<uint32_t>(),
+                             W.seg2_nh.as<uint32_t>(), W.seg2_f.as<uint32_t>(), d_seg_counters + 6);
           PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters + 6, 4, hipMemcpyDeviceToHost, c->stream));
           PA_HIP(hipStreamSynchronize(c->stream));
           const uint32_t n_small = *reinterpret_cast<const uint32_t *>(c->h_pinned);
           if (trace)
             fprintf(stderr, "pa_fragani: genomes %u..%u: %u fragments, %llu seed hits, %u + %u listed segments, %u left "
                             "after the tiny-segment filter\n", g0, g1, nf, (unsigned long long)n_hits, n_keep, n_large, n_small);
-          PA_TRY(launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall, std::true_type{}));
+          PA_TRY(launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), W.seg2_f.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall,
+                            std::true_type{}));
         }
-        PA_TRY(launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, n_large, (uint32_t)kHitCap, std::false_type{}));
+        PA_TRY(launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, W.seg_f.as<uint32_t>() + large_at, n_large,
+                          (uint32_t)kHitCap, std::false_type{}));
       } else {
-        PA_TRY(launch_map(W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), n_keep, (uint32_t)kHitCap, std::false_type{}));
+        PA_TRY(launch_map(W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), nullptr, n_keep, (uint32_t)kHitCap, std::false_type{}));
       }
 #ifdef PA_MAP_STATS
       if (trace) {
-        uint32_t st[16];
-        PA_HIP(hipMemcpy(st, W.run_g.p, 64, hipMemcpyDeviceToHost));
+        uint32_t st[32];
+        PA_HIP(hipMemcpy(st, W.run_g.p, 128, hipMemcpyDeviceToHost));
         fprintf(stderr, "pa_fragani: map stats: %u segments at L1 with %u hits, %u candidates, %u groups, %u begins past the bound, "
                         "%u rounds, %u stretch entries, %u windows evaluated, %u fine passes, %u cooperative, %u begins in rounds, "
-                        "%u begins finished, %u rounds without items, %u second passes, %u windows with an exact value, %u of them at or above the bar\n",
-                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15]);
+                        "%u begins finished, %u rounds without items, %u second passes, %u windows with an exact value, %u of them at or above the bar, "
+                        "%u begins dropped by the tight bound, %u rounds ended by it\n",
+                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15], st[16], st[17]);
       }
 #endif
     }
