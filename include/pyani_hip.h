@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 3
+#define PA_ABI_VERSION 4
 
 /* every entry point below is exported with default visibility */
 #define PA_API __attribute__((visibility("default")))
@@ -287,6 +287,21 @@ PA_API int pa_fragani_ex(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *
                   uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t qry0, uint32_t qry1,
                   uint32_t ref0, uint32_t ref1, uint32_t flags, uint32_t *h_total_frags, uint32_t *h_matched,
                   double *h_ident_sum);
+/* Residues that are neither ACGT nor N.  The arena keeps two bits per residue and one "not ACGT" bit, which the
+ * fragment-ANI kernels read as N; fastANI, which the reference hands the FASTA text itself
+ * (pyani_plus/private_cli.py:1044-1063), hashes every upper-cased character as it is, so a k-mer over an IUPAC code
+ * (R, Y, K, M, S, W, ...) hashes differently from the same k-mer over N.  The packers list such residues --
+ * pa_text_ambiguous for a text packed by pa_pack_fasta / pa_pack_seq (positions relative to the genome's first),
+ * pa_fasta_batch_ambiguous for a loaded batch (arena positions) --, and pa_fragani_set_ambiguous hands the list of the
+ * arena at d_packed to the context (ascending arena positions, upper-cased bytes; copied; n = 0 forgets it): every later
+ * pa_fragani / pa_fragani_ex / pa_fragani_sketch call on that arena hashes those residues as the characters they are.
+ * Without a list every residue that is not ACGT is an N.  The sourmash path is not concerned: a window over any such
+ * residue is skipped there, whatever the letter. */
+PA_API int64_t pa_text_ambiguous(const uint8_t *h_text, uint64_t n_text, int fasta, uint64_t *h_pos, uint8_t *h_byte,
+                                 uint64_t cap);
+PA_API int64_t pa_fasta_batch_ambiguous(const pa_fasta_batch *batch, uint64_t *h_pos, uint8_t *h_byte, uint64_t cap);
+PA_API int pa_fragani_set_ambiguous(pa_ctx *ctx, const uint32_t *d_packed, const uint64_t *h_pos, const uint8_t *h_byte,
+                                    uint64_t n);
 /* stage 1 alone (testing): the winnowed minimizers of every contig, in arena order */
 PA_API int pa_fragani_sketch(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                       const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,

@@ -215,7 +215,8 @@ static int mv_push(MiniVec *a, Mini m) {
  * sequence, hashes the k characters AS THEY ARE and their reverse complement (A<->T, C<->G, anything else left in place),
  * takes the smaller hash and passes over k-mers whose two strands hash alike -- reverse palindromes, runs of N.  No residue
  * is special: a k-mer holding an N is a k-mer.  (RESTATEMENT: the 2^-32 case of a hash equal to the SKIP marker is passed
- * over too.  The HIP path keeps two bits per residue and one "not ACGT" bit: there every such residue is an N.) */
+ * over too.  The HIP path keeps two bits per residue, one "not ACGT" bit and a list of the residues that are neither ACGT
+ * nor N with their letters: the same characters reach the hash there.) */
 ORC_API uint32_t orc_fragani_kmer_hash(const uint8_t *s, int k) {
   uint8_t f[32], r[32];
   for (int j = 0; j < k; ++j) {

@@ -19,7 +19,7 @@ LIB_PATH = _PKG / "_lib" / "libpyani_hip.so"
 # the tests of those paths load it (``HipEngine(tools=True)``); nothing else does.
 TOOLS_LIB_PATH = _PKG / "_lib" / "libpyani_hip_tools.so"
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PA_OK = 0
 PA_E_CAPACITY = -4
 PA_E_IO = -6
@@ -108,6 +108,9 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [_vp, _vp, _vp, C.c_uint64, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, C.c_uint64, _u64p],
     ),
+    "pa_text_ambiguous": (C.c_int64, [_vp, C.c_uint64, C.c_int, _vp, _vp, C.c_uint64]),
+    "pa_fasta_batch_ambiguous": (C.c_int64, [_vp, _vp, _vp, C.c_uint64]),
+    "pa_fragani_set_ambiguous": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64]),
     "pa_fragani_window": (C.c_int, [C.c_uint32, C.c_uint32]),
     "pa_fragani_tables": (C.c_int, [C.c_uint32, C.c_uint32, _vp, _vp]),
     "pa_fragani_identity": (C.c_double, [C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -34,7 +34,8 @@
 void pa_set_error(const char *fmt, ...);
 int pa_pack_fasta_records(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask, uint64_t cap_bases,
                           uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records, uint64_t *n_invalid,
-                          std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len);
+                          std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len, std::vector<uint64_t> *amb_pos,
+                          std::vector<uint8_t> *amb_byte);
 
 namespace {
 
@@ -49,6 +50,9 @@ struct FileResult {
   const uint32_t *packed = nullptr, *mask = nullptr;
   std::vector<uint32_t> own_packed, own_mask;
   std::vector<uint64_t> rec_start, rec_len;  // FASTA records, positions relative to the genome start
+  // residues that are neither ACGT nor N: position relative to the genome start, upper-cased byte (pa_fasta_batch_ambiguous)
+  std::vector<uint64_t> amb_pos;
+  std::vector<uint8_t> amb_byte;
 };
 
 // Anonymous mapping, huge pages asked for: one per batch for the packed genomes, one for their masks, one for the bytes
@@ -285,7 +289,7 @@ void finish(const std::string &path, FileResult &r, const uint8_t *data, size_t 
     mask = r.own_mask.data();
   }
   const int st = pa_pack_fasta_records(data, n_data, packed, mask, cap, &r.n_bases, &r.n_residues, &r.n_records, &r.n_invalid,
-                                       &r.rec_start, &r.rec_len);
+                                       &r.rec_start, &r.rec_len, &r.amb_pos, &r.amb_byte);
   if (st != PA_OK) { r.status = st; r.message = name + ": packing failed"; return; }
   r.packed = packed;
   r.mask = mask;
@@ -455,6 +459,20 @@ int pa_fasta_batch_copy_arena(const pa_fasta_batch *b, uint32_t *h_packed, uint3
     });
     return (int)PA_OK;
   });
+}
+
+// The residues of the batch's genomes that are neither ACGT nor N, in arena coordinates (the genome starts of
+// pa_fasta_batch_copy_arena), ascending.  Returns their number (only the first `cap` are written), negative on failure.
+int64_t pa_fasta_batch_ambiguous(const pa_fasta_batch *b, uint64_t *h_pos, uint8_t *h_byte, uint64_t cap) {
+  if (!b || (cap && (!h_pos || !h_byte))) { pa_set_error("pa_fasta_batch_ambiguous: null argument"); return -1; }
+  uint64_t start = 0, n = 0;
+  for (const FileResult &r : b->files) {
+    if (r.status != PA_OK) continue;  // failed files occupy no space
+    for (size_t i = 0; i < r.amb_pos.size(); ++i, ++n)
+      if (n < cap) { h_pos[n] = start + r.amb_pos[i]; h_byte[n] = r.amb_byte[i]; }
+    start += r.n_bases;
+  }
+  return (int64_t)n;
 }
 
 void pa_fasta_batch_free(pa_fasta_batch *b) { delete b; }

@@ -25,6 +25,7 @@
 //      fragments and the float sum of their float identities in bin order (fastANI's arithmetic).
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #include <vector>
 
@@ -167,12 +168,43 @@ constexpr uint32_t kLookSpinLimit = 1u << 24;
 // A k-mer that holds residues other than A, C, G, T: fastANI hashes the characters as they are (upper-cased; the reverse
 // complement leaves what it does not know in place), so such a k-mer is a k-mer like any other -- only a k-mer equal to its
 // own reverse complement (a run of N, for one) is passed over, as every k-mer whose two strands hash alike is.  The packed
-// arena keeps two bits per residue and one "not ACGT" bit: every such residue is taken to be 'N' (by far the commonest).
+// arena keeps two bits per residue and one "not ACGT" bit: such a residue is 'N' (by far the commonest) unless the arena's
+// list of other letters (IUPAC codes, ...) holds its position -- one search per such residue, only here.
 // Rare, and off the hot path: the bytes are put together one by one, the two multiplies of MurmurHash3 done in full.
-// `codes`: residue j in bits 2j, 2j+1; `bad`: bit j set = residue j is not ACGT.  Returns kSkip when the strands hash alike.
+// `codes`: residue j in bits 2j, 2j+1; `bad`: bit j set = residue j is not ACGT; `pos`: arena position of residue 0.
+// Returns kSkip when the strands hash alike.
+// The residues that are neither ACGT nor N, as the packers list them (pa_fragani_set_ambiguous): ascending arena
+// positions and upper-cased bytes.  The letter at arena position `pos`, of a residue whose "not ACGT" bit is set.
+struct AmbiguousList {
+  const uint64_t *pos;
+  const uint8_t *byte;
+  uint32_t n;
+};
+__device__ __forceinline__ uint32_t ambiguous_letter(const AmbiguousList &amb, uint64_t pos) {
+  uint32_t lo = 0, hi = amb.n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (amb.pos[mid] < pos) lo = mid + 1; else hi = mid;
+  }
+  return (lo < amb.n && amb.pos[lo] == pos) ? (uint32_t)amb.byte[lo] : (uint32_t)'N';
+}
+
 template <int K>
-__device__ __forceinline__ uint32_t hash_kmer_with_unknowns(uint32_t codes, uint32_t bad) {
+__device__ __forceinline__ uint32_t hash_kmer_with_unknowns(uint32_t codes, uint32_t bad, uint64_t pos, const AmbiguousList &amb) {
   constexpr int kWords = (K + 7) / 8;
+  // the letters of the residues that are not ACGT, four to a word (only when the arena has a list: else every one is N)
+  uint32_t letters[(K + 3) / 4];
+#pragma unroll
+  for (int q = 0; q < (K + 3) / 4; ++q) letters[q] = 0x4e4e4e4eu;  // "NNNN"
+  if (amb.n) {
+    for (uint32_t rest = bad; rest; rest &= rest - 1u) {
+      const int j = __builtin_ctz(rest);
+      const uint32_t ch = ambiguous_letter(amb, pos + (uint64_t)j);
+#pragma unroll
+      for (int q = 0; q < (K + 3) / 4; ++q)
+        if ((j >> 2) == q) letters[q] = (letters[q] & ~(0xffu << (8 * (j & 3)))) | (ch << (8 * (j & 3)));
+    }
+  }
   uint32_t hs[2];
 #pragma unroll
   for (int strand = 0; strand < 2; ++strand) {
@@ -186,7 +218,7 @@ __device__ __forceinline__ uint32_t hash_kmer_with_unknowns(uint32_t codes, uint
         if (j >= K) break;
         const int src = strand ? K - 1 - j : j;
         const uint32_t code = ((codes >> (2 * src)) & 3u) ^ (strand ? 3u : 0u);
-        const uint32_t ch = ((bad >> src) & 1u) ? (uint32_t)'N' : (0x54474341u >> (8 * code)) & 0xffu;  // "ACGT"
+        const uint32_t ch = ((bad >> src) & 1u) ? (letters[src >> 2] >> (8 * (src & 3))) & 0xffu : (0x54474341u >> (8 * code)) & 0xffu;  // "ACGT"
         word |= (uint64_t)ch << (8 * t);
       }
       P[q] = word * ((q & 1) ? kC2 : kC1);
@@ -201,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
     const uint64_t *__restrict__ contig_start, const uint32_t *__restrict__ contig_len, uint32_t n_contigs, int w,
     unsigned long long *__restrict__ look, uint32_t *__restrict__ scalars, uint32_t cap, uint32_t *__restrict__ out_hash,
-    uint32_t *__restrict__ out_wpos, uint32_t *__restrict__ out_contig, uint32_t n_tiles) {
+    uint32_t *__restrict__ out_wpos, uint32_t *__restrict__ out_contig, uint32_t n_tiles, AmbiguousList amb) {
   static_assert(K >= 8 && K <= 16, "both k-mer registers are 32-bit");
   constexpr int kWords = (K + 7) / 8;
   // the first-multiply tables; once the hashes are there, the same memory holds the winnowing's suffix-minimum positions
@@ -323,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void minimizer_kernel(
           next = cc + 1 < n_contigs ? contig_start[cc + 1] : ~0ULL;
         }
         if (pos - beg + K > len) continue;
-        s_h[tid * kPPT + j] = hash_kmer_with_unknowns<K>((uint32_t)(bases >> (2 * j)) & kMask, (uint32_t)((bad >> j) & kBadMask));
+        s_h[tid * kPPT + j] = hash_kmer_with_unknowns<K>((uint32_t)(bases >> (2 * j)) & kMask, (uint32_t)((bad >> j) & kBadMask), pos, amb);
       }
 #pragma unroll
       for (int j = 0; j < kPPT; ++j) own[j] = s_h[tid * kPPT + j];
@@ -748,7 +780,7 @@ __global__ __launch_bounds__(kThreads) void windows_without_selection_kernel(
     const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask, uint64_t arena_bases,
     const uint64_t *__restrict__ contig_start, uint32_t k, uint32_t w, const uint32_t *__restrict__ frag_contig,
     const uint32_t *__restrict__ frag_no, uint32_t n_frags, uint32_t frag_len, uint32_t count_windows,
-    uint32_t *__restrict__ frag_d) {
+    uint32_t *__restrict__ frag_d, AmbiguousList amb) {
   const uint32_t f = blockIdx.x * kThreads + threadIdx.x;
   if (f >= n_frags) return;
   const uint64_t x0 = contig_start[frag_contig[f]] + (uint64_t)frag_no[f] * frag_len + w - 1u;
@@ -774,6 +806,16 @@ __global__ __launch_bounds__(kThreads) void windows_without_selection_kernel(
     known = (known | (known << 1)) & 0x55555555u;
     known |= known << 1;
     if (!(bad == rbad && ((fwd ^ rc) & known & k_mask) == 0u)) break;  // a used k-mer
+    // residues that are not ACGT stay where they are in the reverse complement: the strands are the same text only if the
+    // letters at mirrored positions are the same letter (all N without a list)
+    if (bad && amb.n) {
+      bool same = true;
+      for (uint32_t rest = bad; rest && same; rest &= rest - 1u) {
+        const uint32_t j = (uint32_t)__builtin_ctz(rest);
+        if (j < k - 1u - j) same = ambiguous_letter(amb, x + j) == ambiguous_letter(amb, x + (k - 1u - j));
+      }
+      if (!same) break;  // a used k-mer
+    }
   }
   frag_d[f] = d;
 }
@@ -1479,6 +1521,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   const int32_t unseeded = (int32_t)rec1.z;  // hashes of the sketch whose reference occurrences are not all seed hits (frequency cut)
   if (s == 0) return;  // no sketch, or fewer seed hits than any L1 run needs
   PA_STAT(0, 1);   // segments that reach L1
+  PA_STAT(25 + min(6u, (uint32_t)(32 - __builtin_clz(nh | 1u)) > 3u ? (uint32_t)(32 - __builtin_clz(nh | 1u)) - 3u : 0u), 1);  // ... by their seed hits
   PA_STAT(1, nh);  // their seed hits
   // segments of up to kHitCap hits are staged in LDS; larger ones (repeats: rRNA operons, IS elements)
   // are read in place from the sorted hit arrays
@@ -1679,6 +1722,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     // and eight registers are free)
     constexpr int kStartBatch = 8;
     uint32_t b_hi = 0xffffffffu, at = 0xffffffffu, i_max;
+    uint32_t h_lo, h_hi;  // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, i_max + count_windows)
+    uint32_t est = first_hit_w;  // where the optimum is expected
     {
       uint32_t wpv[kStartBatch];
 #pragma unroll
@@ -1707,44 +1752,55 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       }
       if (z < wp_lo + count_windows) return;  // the first window's end is already at the limit: nothing is evaluated
       i_max = z - count_windows;
-      // the first begin past the slide's last position and the first one at the first seed hit: every lane the first of
+      hit_range(c, cs, i_max + count_windows, h_lo, h_hi);
+      // Where the optimum is expected: a fragment that maps at P leaves its hits in [P, P + count_windows), so P is about the
+      // middle of the candidate's first and last hit less half a window -- for a diverged pair, whose first matching minimizer
+      // sits anywhere in the fragment, a better guess than the first hit itself (never past it: the optimum holds hits).
+      if (h_hi > h_lo) {
+        const uint32_t mid = (HW(h_lo) + HW(h_hi - 1u)) / 2u, half = count_windows / 2u;
+        est = min(first_hit_w, max(cs, mid > half ? mid - half : 0u));
+      }
+      // the first begin past the slide's last position and the first one at the expected optimum: every lane the first of
       // its own eight, then the minimum over the wave (the window ids ascend with the begin index)
       uint32_t my_over = 0xffffffffu, my_reach = 0xffffffffu;
 #pragma unroll
       for (int q = kStartBatch - 1; q >= 0; --q) {
         my_over = wpv[q] > i_max ? (uint32_t)q * 64u + lane : my_over;
-        my_reach = wpv[q] >= first_hit_w ? (uint32_t)q * 64u + lane : my_reach;
+        my_reach = wpv[q] >= est ? (uint32_t)q * 64u + lane : my_reach;
       }
       const uint32_t w_over = pa_dev::wave_min_dpp(my_over), w_reach = pa_dev::wave_min_dpp(my_reach);
       if (w_over != 0xffffffffu) b_hi = b_lo + w_over;
       if (w_reach != 0xffffffffu) at = b_lo + w_reach;
     }
     if (b_hi == 0xffffffffu) b_hi = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, i_max + 1u);  // a range of more than 512 begins
-    if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, first_hit_w);
+    if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, est);
     if (b_lo >= b_hi) return;
     PA_STAT(2, 1);  // candidates with begins
     int32_t c_best = -1;
     uint32_t c_first = 0, c_last = 0;
     // T of this candidate's best state so far, until there is one that of the fragment's best mapping so far: the pivot of the tight bound
     uint32_t pivot_T = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.scan[kBestT]);
-    const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
+    // The begins are taken up in groups of 64 (one lane each), tiled so that the begin at the expected optimum sits in the
+    // MIDDLE of its group (the tiles start `pad` begins before the first begin): that group goes first and sets the bar, and
+    // with the tight bound below a begin more than a few matches away from the optimum is dropped -- the optimum in the
+    // middle of the first group, the other groups are passed over or end with the bound.  (With the count of seed hits as
+    // the only bound the tiling did not matter: the begins that passed spanned two groups by their number.)
     // A begin matters only if one of its windows can hold min_shared minimizers of the fragment (less is never reported)
-    // and reach the best so far.  The group holding the candidate's first seed hit goes first -- for a true mapping the
-    // window that starts there is at or next to the optimum -- and sets the bar the other groups are pruned against:
-    // first per group (seed hits between its first begin and the end of its last window), then per begin.
+    // and reach the best so far: first asked per group (seed hits between its first begin and the end of its last
+    // window), then per begin.
+    const uint32_t pad = (32u - ((at - b_lo) & 63u)) & 63u;
+    const uint32_t tile0 = b_lo - pad;  // (may wrap below zero: begins before b_lo take no part)
+    const uint32_t n_groups = (b_hi - tile0 + 63u) / 64u;
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
-    // the seed hits any window of this candidate can hold: hits on contig c with window id in [cs, i_max + count_windows)
-    uint32_t h_lo, h_hi;
-    hit_range(c, cs, i_max + count_windows, h_lo, h_hi);
     const uint32_t h_steps = 32u - (uint32_t)__builtin_clz(h_hi - h_lo + 1u);  // 2^steps > the number of hits: enough halvings
     PA_CUT(3);  // candidate set-up
-    const uint32_t g_first = (n_groups > 1 && at > b_lo) ? min((at - b_lo) / 64u, n_groups - 1u) : 0u;
+    const uint32_t g_first = min((at - tile0) / 64u, n_groups - 1u);
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
       const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
       if (gi > 0 && PA_CUT_IS(23)) break;  // (timing experiment: the group of the first seed hit only; results wrong)
-      const uint32_t sb = b_lo + g * 64u;
+      const uint32_t sb = tile0 + g * 64u;
       const uint32_t b = sb + lane;
-      const bool has = b < b_hi;
+      const bool has = b >= b_lo && b < b_hi;
       const uint32_t wp = has ? mini_wpos[b] : 0u;
       const uint32_t wp_next = (has && b + 1u < m1) ? mini_wpos[b + 1u] : 0xffffffffu;
       const uint32_t w_end = min(wp_next - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
@@ -1775,6 +1831,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       uint32_t e_next = 0;  // end (minimizer index) of the begin's next state; 0: none of its states has been evaluated yet
       while (__any(pending)) {
         PA_STAT(5, 1);  // rounds
+        PA_STAT(18 + min(6u, (uint32_t)(32 - __builtin_clz(nh | 1u)) > 3u ? (uint32_t)(32 - __builtin_clz(nh | 1u)) - 3u : 0u), 1);  // ... by the segment's seed hits: <= 7, 8-15, 16-31, ..., 256 and more
         const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
         const uint32_t base = sb + first_lane;  // stretch = minimizers [base, base + n)
         const uint32_t n = min(m1 - base, kRefCap);
@@ -2416,7 +2473,16 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at, seg_f, seg2_f;
+      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at, seg_f, seg2_f, amb_pos, amb_byte;
+  // the arena's residues that are neither ACGT nor N (pa_fragani_set_ambiguous), and the arena they belong to
+  const void *amb_for = nullptr;
+  uint32_t amb_n = 0;
+  std::vector<uint64_t> amb_host_pos;  // what the device arrays hold: a call that hands over the same list again changes nothing
+  std::vector<uint8_t> amb_host_byte;
+  AmbiguousList ambiguous(const void *d_packed) const {
+    const bool mine = amb_n && amb_for == d_packed;
+    return AmbiguousList{mine ? amb_pos.as<uint64_t>() : nullptr, mine ? amb_byte.as<uint8_t>() : nullptr, mine ? amb_n : 0u};
+  }
   // the reference index (stages 1 and 2) of the last pa_fragani(_ex) call, for PA_FRAGANI_REUSE_INDEX
   bool index_valid = false;
   const void *index_packed = nullptr;
@@ -2431,7 +2497,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at, &seg_f, &seg2_f};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at, &seg_f, &seg2_f, &amb_pos, &amb_byte};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -2548,7 +2614,7 @@ int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint3
     hipLaunchKernelGGL((minimizer_kernel<K>), dim3(blocks), dim3(kThreads), 0, c->stream,
                        d_packed, d_mask, arena_bases, W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
                        W.block_counts.as<unsigned long long>(), W.scalars.as<uint32_t>(), (uint32_t)cap,
-                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>(), blocks);
+                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>(), blocks, W.ambiguous(d_packed));
     PA_HIP(hipGetLastError());
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 16, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipStreamSynchronize(c->stream));
@@ -2611,6 +2677,35 @@ void pa_fragani_release(pa_ctx *c) {
 extern "C" {
 
 int pa_fragani_window(uint32_t k, uint32_t frag_len) { return window_size_for((int)k, (int)frag_len); }
+
+int pa_fragani_set_ambiguous(pa_ctx *c, const uint32_t *d_packed, const uint64_t *h_pos, const uint8_t *h_byte, uint64_t n) {
+  PA_REQUIRE(c && (n == 0 || (d_packed && h_pos && h_byte)), "pa_fragani_set_ambiguous: null argument");
+  PA_REQUIRE(n < (1ULL << 31), "pa_fragani_set_ambiguous: %llu residues (limit 2^31)", (unsigned long long)n);
+  for (uint64_t i = 1; i < n; ++i)
+    PA_REQUIRE(h_pos[i] > h_pos[i - 1], "pa_fragani_set_ambiguous: positions must ascend (entry %llu)", (unsigned long long)i);
+  PA_HIP(hipSetDevice(c->device));
+  FragWork &W = frag_work(c);
+  if (n == 0 && W.amb_n == 0) return PA_OK;
+  if (n && W.amb_n == n && W.amb_for == (const void *)d_packed && memcmp(W.amb_host_pos.data(), h_pos, n * 8) == 0 &&
+      memcmp(W.amb_host_byte.data(), h_byte, n) == 0)
+    return PA_OK;  // the list the context holds already (a reusable index stays reusable)
+  W.index_valid = false;  // an index built with another list (or none) hashed those residues differently
+  W.amb_for = nullptr;
+  W.amb_n = 0;
+  W.amb_host_pos.clear();
+  W.amb_host_byte.clear();
+  if (n == 0) return PA_OK;
+  W.amb_host_pos.assign(h_pos, h_pos + n);
+  W.amb_host_byte.assign(h_byte, h_byte + n);
+  PA_TRY(W.amb_pos.reserve(n * 8));
+  PA_TRY(W.amb_byte.reserve(n + 16));
+  PA_HIP(hipMemcpyAsync(W.amb_pos.p, h_pos, n * 8, hipMemcpyHostToDevice, c->stream));
+  PA_HIP(hipMemcpyAsync(W.amb_byte.p, h_byte, n, hipMemcpyHostToDevice, c->stream));
+  PA_HIP(hipStreamSynchronize(c->stream));
+  W.amb_for = d_packed;
+  W.amb_n = (uint32_t)n;
+  return PA_OK;
+}
 
 int pa_fragani_tables(uint32_t k, uint32_t s_max, uint32_t *h_min_hits, uint32_t *h_min_shared) {
   if (!h_min_hits || !h_min_shared) { pa_set_error("pa_fragani_tables: null argument"); return PA_E_INVALID; }
@@ -2930,7 +3025,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_TRY(W.frag_d.reserve((uint64_t)nf * 4));
     hipLaunchKernelGGL(windows_without_selection_kernel, dim3(ceil_div_u64(nf, kThreads)), dim3(kThreads), 0, c->stream, d_packed, d_mask,
                        arena_bases, W.contig_start.as<uint64_t>(), k, (uint32_t)w, W.frag_contig.as<uint32_t>(), W.frag_no.as<uint32_t>(),
-                       nf, frag_len, count_windows, W.frag_d.as<uint32_t>());
+                       nf, frag_len, count_windows, W.frag_d.as<uint32_t>(), W.ambiguous(d_packed));
     hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, W.frag_d.as<uint32_t>(), W.frag_contig.as<uint32_t>(),
                        W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
@@ -3154,8 +3249,10 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         fprintf(stderr, "pa_fragani: map stats: %u segments at L1 with %u hits, %u candidates, %u groups, %u begins past the bound, "
                         "%u rounds, %u stretch entries, %u windows evaluated, %u fine passes, %u cooperative, %u begins in rounds, "
                         "%u begins finished, %u rounds without items, %u second passes, %u windows with an exact value, %u of them at or above the bar, "
-                        "%u begins dropped by the tight bound, %u rounds ended by it\n",
-                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15], st[16], st[17]);
+                        "%u begins dropped by the tight bound, %u rounds ended by it; rounds by seed hits of the segment (<= 7, 8-15, 16-31, 32-63, "
+                        "64-127, 128-255, more): %u %u %u %u %u %u %u, segments: %u %u %u %u %u %u %u\n",
+                st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15], st[16], st[17],
+                st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27], st[28], st[29], st[30], st[31]);
       }
 #endif
     }

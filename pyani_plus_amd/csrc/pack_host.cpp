@@ -34,6 +34,18 @@ struct ArenaWriter {
   uint64_t cap, pos = 0;
   uint32_t pw = 0, mw = 0;
   bool overflow = false;
+  // Residues that are neither ACGT nor N (IUPAC codes and anything else a file holds), as (position, upper-cased byte):
+  // the arena keeps one "not ACGT" bit per residue, which stands for N; fastANI hashes the characters as they are
+  // (pyani_plus/private_cli.py:1044-1063 hands it the FASTA text), so the fragment-ANI kernels take these from the list.
+  std::vector<uint64_t> *amb_pos = nullptr;
+  std::vector<uint8_t> *amb_byte = nullptr;
+  inline void put_other(uint8_t ch) {
+    if (amb_pos) {
+      const uint8_t up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 'a' + 'A') : ch;
+      if (up != 'N') { amb_pos->push_back(pos); amb_byte->push_back(up); }
+    }
+    put(0, 1);
+  }
   inline void put(uint32_t code, uint32_t invalid) {
     if (pos >= cap) { overflow = true; ++pos; return; }
     pw |= code << (2 * (pos & 15));
@@ -233,7 +245,7 @@ inline void pack_line(ArenaWriter &w, const uint8_t *p, const uint8_t *e, uint64
     for (; p < e; ++p) {
       const uint8_t code = kLut.v[*p];
       if (code < 4) { w.put(code, 0); ++residues; continue; }
-      if (code == 4) { w.put(0, 1); ++residues; ++invalid; }
+      if (code == 4) { w.put_other(*p); ++residues; ++invalid; }
       if (kVector && e - p > 32 && kLut.v[p[1]] < 4) { ++p; break; }
     }
   }
@@ -242,8 +254,10 @@ inline void pack_line(ArenaWriter &w, const uint8_t *p, const uint8_t *e, uint64
 template <bool kVector>
 int pack_fasta_impl(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask, uint64_t cap_bases,
                     uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records, uint64_t *n_invalid,
-                    std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len) {
+                    std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len, std::vector<uint64_t> *amb_pos,
+                    std::vector<uint8_t> *amb_byte) {
   ArenaWriter w{h_packed, h_mask, cap_bases};
+  if (amb_pos && amb_byte) { w.amb_pos = amb_pos; w.amb_byte = amb_byte; }
   uint64_t residues = 0, records = 0, invalid = 0, record_first_residue = 0;
   const uint8_t *p = h_text, *const end = h_text + n_text;
   bool in_record = false;
@@ -281,24 +295,56 @@ int pack_fasta_impl(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, 
 
 }  // namespace
 
-// pa_pack_fasta plus the record table of pa_fasta_records from the same pass (the FASTA loader's form)
+// pa_pack_fasta plus the record table of pa_fasta_records from the same pass (the FASTA loader's form), and the list of
+// residues that are neither ACGT nor N (positions relative to the genome's first)
 int pa_pack_fasta_records(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask, uint64_t cap_bases,
                           uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records, uint64_t *n_invalid,
-                          std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len) {
+                          std::vector<uint64_t> *rec_start, std::vector<uint64_t> *rec_len, std::vector<uint64_t> *amb_pos,
+                          std::vector<uint8_t> *amb_byte) {
   if ((!h_text && n_text) || !h_packed || !h_mask || (cap_bases & 63)) {
     pa_set_error("pa_pack_fasta: null buffer or capacity %llu not a multiple of 64", (unsigned long long)cap_bases);
     return PA_E_INVALID;
   }
   static const bool avx2 = __builtin_cpu_supports("avx2") && getenv("PA_PACK_SCALAR") == nullptr;
-  return avx2 ? pack_fasta_impl<true>(h_text, n_text, h_packed, h_mask, cap_bases, n_bases, n_residues, n_records, n_invalid, rec_start, rec_len)
-              : pack_fasta_impl<false>(h_text, n_text, h_packed, h_mask, cap_bases, n_bases, n_residues, n_records, n_invalid, rec_start, rec_len);
+  return avx2 ? pack_fasta_impl<true>(h_text, n_text, h_packed, h_mask, cap_bases, n_bases, n_residues, n_records, n_invalid, rec_start, rec_len, amb_pos, amb_byte)
+              : pack_fasta_impl<false>(h_text, n_text, h_packed, h_mask, cap_bases, n_bases, n_residues, n_records, n_invalid, rec_start, rec_len, amb_pos, amb_byte);
 }
 
 extern "C" int pa_pack_fasta(const uint8_t *h_text, uint64_t n_text, uint32_t *h_packed, uint32_t *h_mask,
                              uint64_t cap_bases, uint64_t *n_bases, uint64_t *n_residues, uint64_t *n_records,
                              uint64_t *n_invalid) {
   return pa_pack_fasta_records(h_text, n_text, h_packed, h_mask, cap_bases, n_bases, n_residues, n_records, n_invalid,
-                               nullptr, nullptr);
+                               nullptr, nullptr, nullptr, nullptr);
+}
+
+// The residues of a text that are neither ACGT nor N, as the packers above place them: (arena position relative to the
+// genome's first, upper-cased byte), ascending.  `fasta`: the text is FASTA (pa_pack_fasta's rules) or a bare sequence
+// (pa_pack_seq's).  Returns how many there are (more than `cap`: only the first `cap` were written), negative on failure.
+extern "C" int64_t pa_text_ambiguous(const uint8_t *h_text, uint64_t n_text, int fasta, uint64_t *h_pos, uint8_t *h_byte,
+                                     uint64_t cap) {
+  if ((!h_text && n_text) || (cap && (!h_pos || !h_byte))) { pa_set_error("pa_text_ambiguous: null argument"); return -1; }
+  int64_t found = -1;
+  const int st = pa_host_guard("pa_text_ambiguous", pa_set_error, [&] {
+    std::vector<uint64_t> pos;
+    std::vector<uint8_t> bytes;
+    if (fasta) {
+      const uint64_t room = pa_pack_bound(n_text);
+      std::vector<uint32_t> packed(room / 16 + 2), mask(room / 32 + 2);
+      uint64_t nb = 0, nr = 0, nrec = 0, ninv = 0;
+      const int rc = pa_pack_fasta_records(h_text, n_text, packed.data(), mask.data(), room, &nb, &nr, &nrec, &ninv, nullptr, nullptr, &pos, &bytes);
+      if (rc != PA_OK) return rc;
+    } else {
+      for (uint64_t i = 0; i < n_text; ++i) {
+        if (kLut.v[h_text[i]] < 4) continue;  // (a bare sequence: every byte is a residue, blanks included -- pa_pack_seq)
+        const uint8_t ch = h_text[i], up = (ch >= 'a' && ch <= 'z') ? (uint8_t)(ch - 'a' + 'A') : ch;
+        if (up != 'N') { pos.push_back(i); bytes.push_back(up); }
+      }
+    }
+    for (size_t i = 0; i < pos.size() && i < cap; ++i) { h_pos[i] = pos[i]; h_byte[i] = bytes[i]; }
+    found = (int64_t)pos.size();
+    return (int)PA_OK;
+  });
+  return st == PA_OK ? found : -1;
 }
 
 extern "C" int64_t pa_fasta_records(const uint8_t *h_text, uint64_t n_text, uint64_t *h_rec_start,

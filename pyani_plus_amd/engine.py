@@ -41,6 +41,10 @@ class HostArena:
     contig_len: np.ndarray | None = None
     contig_genome: np.ndarray | None = None
     pinned_packed: "object" = None  # torch tensor owning ``packed`` when the loader wrote it into page-locked memory
+    # residues that are neither ACGT nor N (IUPAC codes, ...): ascending arena positions and upper-cased bytes.  The mask
+    # bit stands for N; the fragment-ANI path hashes these as the characters they are, as fastANI does
+    ambig_pos: np.ndarray | None = None  # uint64
+    ambig_byte: np.ndarray | None = None  # uint8
 
     @property
     def n_genomes(self) -> int:
@@ -49,6 +53,19 @@ class HostArena:
     @property
     def arena_bases(self) -> int:
         return int(self.genome_start[-1])
+
+
+def _text_ambiguous(lib, text: bytes, fasta: bool) -> tuple[np.ndarray, np.ndarray]:
+    """(positions relative to the genome's first, upper-cased bytes) of the residues that are neither ACGT nor N."""
+    if not len(text):
+        return np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+    n = int(lib.pa_text_ambiguous(text, len(text), int(fasta), None, None, 0))
+    if n < 0:
+        raise HipBackendError(f"pa_text_ambiguous failed: {_capi.last_error()}")
+    pos, byte = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint8)
+    if n:
+        lib.pa_text_ambiguous(text, len(text), int(fasta), pos.ctypes.data, byte.ctypes.data, n)
+    return pos, byte
 
 
 def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
@@ -61,6 +78,7 @@ def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
     starts = np.zeros(len(texts) + 1, dtype=np.uint64)
     residues, records, invalid = [], [], []
     c_start, c_len, c_genome = [], [], []
+    a_pos, a_byte = [], []
     pos = 0
     for g, text in enumerate(texts):
         nb, nr, nrec, ninv = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
@@ -84,6 +102,10 @@ def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
             c_start.append(pos)
             c_len.append(len(text))
             c_genome.append(g)
+        if ninv.value:
+            ap, ab = _text_ambiguous(lib, bytes(text), fasta)
+            a_pos.append(ap + np.uint64(pos))
+            a_byte.append(ab)
         starts[g] = pos
         pos += int(nb.value)
         residues.append(int(nr.value))
@@ -93,6 +115,7 @@ def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
     return HostArena(
         packed[: pos // 16].copy(), mask[: pos // 32].copy(), starts, residues, records, invalid,
         np.array(c_start, dtype=np.uint64), np.array(c_len, dtype=np.uint32), np.array(c_genome, dtype=np.uint32),
+        ambig_pos=np.concatenate(a_pos) if a_pos else np.zeros(0, np.uint64), ambig_byte=np.concatenate(a_byte) if a_byte else np.zeros(0, np.uint8),
     )
 
 
@@ -167,9 +190,14 @@ def load_fasta_files(paths, threads: int = 0, *, pinned: bool = False) -> tuple[
         c_start = np.concatenate([rs + starts[g] for g, (rs, _rl) in enumerate(rec_tables)]) if rec_tables else np.zeros(0, np.uint64)
         c_len = np.concatenate([rl for _rs, rl in rec_tables]).astype(np.uint32) if rec_tables else np.zeros(0, np.uint32)
         c_genome = np.concatenate([np.full(len(rs), g, dtype=np.uint32) for g, (rs, _rl) in enumerate(rec_tables)]) if rec_tables else np.zeros(0, np.uint32)
+        n_amb = int(lib.pa_fasta_batch_ambiguous(batch, None, None, 0))
+        a_pos, a_byte = np.zeros(max(n_amb, 0), dtype=np.uint64), np.zeros(max(n_amb, 0), dtype=np.uint8)
+        if n_amb > 0:
+            lib.pa_fasta_batch_ambiguous(batch, a_pos.ctypes.data, a_byte.ctypes.data, n_amb)
         return infos, HostArena(
             packed[: total // 16], mask[: total // 32], starts, ok_residues, ok_records, ok_invalid,
             c_start.astype(np.uint64), c_len, c_genome, pinned_packed[: max(total // 16, 1)] if pinned_packed is not None else None,
+            ambig_pos=a_pos, ambig_byte=a_byte,
         )
     finally:
         lib.pa_fasta_batch_free(batch)
@@ -182,6 +210,10 @@ class DeviceArena:
     mask: "object"
     genome_start: np.ndarray  # host uint64 [n+1]
     dirty: "object" = None  # torch.int64 tensor: one bit per 64-position block that needs its mask words (built on first use)
+    # the host arena's list of residues that are neither ACGT nor N (``HostArena.ambig_pos`` / ``ambig_byte``), handed to the
+    # library before a fragment-ANI call on this arena
+    ambig_pos: np.ndarray | None = None
+    ambig_byte: np.ndarray | None = None
 
     @property
     def n_genomes(self) -> int:
@@ -303,7 +335,19 @@ class HipEngine:
         t = self.torch
         packed = t.from_numpy(arena.packed.view(np.int32)).to(self.device)
         mask = t.from_numpy(arena.mask.view(np.int32)).to(self.device)
-        return DeviceArena(packed, mask, arena.genome_start.copy())
+        return DeviceArena(packed, mask, arena.genome_start.copy(), ambig_pos=arena.ambig_pos, ambig_byte=arena.ambig_byte)
+
+    def _set_ambiguous(self, arena: DeviceArena) -> None:
+        """Hand the arena's residues that are neither ACGT nor N to the fragment-ANI kernels (``pa_fragani_set_ambiguous``:
+        a list the context holds already changes nothing there, a reusable index included)."""
+        pos = getattr(arena, "ambig_pos", None)
+        n = 0 if pos is None else len(pos)
+        if n:
+            p = np.ascontiguousarray(pos, dtype=np.uint64)
+            b = np.ascontiguousarray(arena.ambig_byte, dtype=np.uint8)
+            self._check(self.lib.pa_fragani_set_ambiguous(self.ctx, arena.packed.data_ptr(), p.ctypes.data, b.ctypes.data, n), "pa_fragani_set_ambiguous")
+        else:
+            self._check(self.lib.pa_fragani_set_ambiguous(self.ctx, None, None, None, 0), "pa_fragani_set_ambiguous")
 
     def sketches_from_host(self, sketches: list[np.ndarray]) -> DeviceSketches:
         t = self.torch
@@ -495,6 +539,7 @@ class HipEngine:
             assert total.dtype == np.uint32 and matched.dtype == np.uint32 and ident_sum.dtype == np.float64
             assert matched.flags.c_contiguous and ident_sum.flags.c_contiguous
         flags = (_capi.PA_FRAGANI_REUSE_INDEX if reuse_index else 0) | (_capi.PA_FRAGANI_COLUMNS_ONLY if columns_only else 0)
+        self._set_ambiguous(arena)
         self._check(
             self.lib.pa_fragani_ex(
                 self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,
@@ -515,6 +560,7 @@ class HipEngine:
         wp = np.zeros(cap, dtype=np.uint32)
         ct = np.zeros(cap, dtype=np.uint32)
         n = C.c_uint64(0)
+        self._set_ambiguous(arena)
         self._check(
             self.lib.pa_fragani_sketch(
                 self.ctx, arena.packed.data_ptr(), arena.mask.data_ptr(), arena.arena_bases, cs.ctypes.data, cl.ctypes.data,

@@ -64,6 +64,9 @@ def arena_to_ascii(arena: HostArena, g: int) -> bytes:
     inv = ((mwords[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool).reshape(-1)
     out = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
     out[inv] = ord("N")
+    if getattr(arena, "ambig_pos", None) is not None and len(arena.ambig_pos):  # the letters the mask bit does not tell
+        sel = (arena.ambig_pos >= s) & (arena.ambig_pos < e)
+        out[(arena.ambig_pos[sel] - np.uint64(s)).astype(np.int64)] = arena.ambig_byte[sel]
     length = e - s
     if arena.residues:  # residues + one separator between consecutive records
         length = arena.residues[g] + (max(arena.records[g] - 1, 0) if arena.records else 0)

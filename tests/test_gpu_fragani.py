@@ -748,3 +748,70 @@ def test_product_library_ignores_the_tool_switches(engine, tools_engine, monkeyp
     dev_t = tools_engine.upload(arena)
     cut_short = tools_engine.fragani(dev_t, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
     assert not np.array_equal(cut_short[1], want_b[1])  # PA_MAP_CUT=2 ends the mapping kernel after L1: nothing is mapped
+
+
+def test_iupac_letters_are_hashed_as_fastani_hashes_them(engine):
+    """fastANI hashes every upper-cased character as it is and leaves what it does not know in place in the reverse
+    complement (the reference hands it the FASTA text: /root/reference/pyani_plus/private_cli.py:1044-1063): a k-mer over R,
+    Y, K, M, S, W, B, D, H, V -- or any other byte -- is a k-mer with its own hash, not the k-mer over N.  The arena keeps one
+    "not ACGT" bit per residue; the packers list the other letters and the kernels look them up.  Letters at fragment
+    starts and ends, at contig ends, inside minimizer windows, in runs, mirrored (a k-mer equal to its own reverse
+    complement over non-ACGT letters), in lower case, next to N: the minimizers and every integer equal the oracle's."""
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(2024)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    letters = np.frombuffer(b"RYKMSWBDHVryksX*-", dtype=np.uint8)
+    root = rng.choice(acgt, size=36_000)
+    genomes = []
+    for g, rate in enumerate([0.0, 0.01, 0.04, 0.0]):
+        seq = root.copy()
+        hit = rng.random(seq.size) < rate
+        seq[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+        # scattered single letters (about 1 in 150 residues), different ones in different genomes
+        where = rng.choice(seq.size, size=240, replace=False)
+        seq[where] = letters[rng.integers(0, len(letters), size=where.size)]
+        for f in range(0, 12):  # first and last residue of fragments, and the residues around the first window's end
+            seq[3000 * f] = letters[(g + f) % 10]
+            seq[3000 * f + 2999] = letters[(g + 2 * f) % 10]
+            seq[3000 * f + 23 + (f % 5)] = letters[(g + 3 * f) % 10]
+        seq[5_000:5_030] = ord("R") if g % 2 else ord("N")  # a run: of R in one genome, of N in its relative
+        seq[7_000:7_016] = np.frombuffer(b"ACGTRRYYYYRRACGT", dtype=np.uint8)  # its own reverse complement but for R/Y: a USED k-mer
+        seq[9_000:9_016] = np.frombuffer(b"ACGTRYKMMKYRACGT", dtype=np.uint8)  # mirrored letters over a reverse-palindromic frame: passed over
+        seq[12_000] = ord("n")
+        seq[12_001] = ord("R")
+        genomes.append(seq.tobytes())
+    cuts = [[36_000], [9_000, 27_000], [36_000], [2_999, 3_001, 30_000]]
+    contig_lists, texts = [], []
+    for g, seq in enumerate(genomes):
+        contigs, pos = [], 0
+        for n in cuts[g]:
+            contigs.append(seq[pos : pos + n])
+            pos += n
+        contig_lists.append(contigs)
+        texts.append(b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs)))
+    arena = pack_genomes(texts)
+    assert len(arena.ambig_pos) > 900 and ord("N") not in set(arena.ambig_byte.tolist())
+    dev = engine.upload(arena)
+    for k, w in ((16, 24), (15, 19), (12, 9)):
+        h, wp, ct = engine.fragani_sketch(dev, arena.contig_start, arena.contig_len, arena.contig_genome, k, w)
+        ci = 0
+        differs_from_n = False
+        for contigs in contig_lists:
+            for contig in contigs:
+                want_h, want_p = oracle.fragani_minimizers(contig, k, w)
+                sel = ct == ci
+                assert np.array_equal(h[sel], want_h), f"k={k} contig {ci}: minimizers differ from the oracle's"
+                assert np.array_equal(wp[sel].astype(np.int32), want_p)
+                as_n = bytes(c if c in b"ACGTacgt" else ord("N") for c in contig)
+                differs_from_n = differs_from_n or not np.array_equal(oracle.fragani_minimizers(as_n, k, w)[0], want_h)
+                ci += 1
+        assert differs_from_n  # the letters matter: read as N the same contigs give other minimizers
+    _check_against_oracle(engine, texts, contig_lists)
+    _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
+    # the same arena without its list: every such residue is an N again (and the library forgets a list it was given)
+    plain = pack_genomes(texts)
+    plain.ambig_pos, plain.ambig_byte = None, None
+    h_n, _wp, _ct = engine.fragani_sketch(engine.upload(plain), plain.contig_start, plain.contig_len, plain.contig_genome, 16, 24)
+    all_n = [bytes(c if c in b"ACGTacgt" else ord("N") for c in contig) for contigs in contig_lists for contig in contigs]
+    assert np.array_equal(h_n, np.concatenate([oracle.fragani_minimizers(c, 16, 24)[0] for c in all_n]))

@@ -34,7 +34,7 @@ def test_library_exports_every_header_symbol():
     lib = _capi.load_library()  # raises if the .so is missing or lacks a symbol
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.pa_abi_version() == 3
+    assert lib.pa_abi_version() == 4
     assert lib.pa_max_hash(300) == 61489146912365176 and lib.pa_max_hash(1000) == 18446744073709552
     assert max_hash_for_scaled(1) == 2**64 - 1
 
@@ -111,6 +111,35 @@ def test_pack_fasta_semantics():
     exact = pack_genomes([b"ACGT" * 16, b"ACGT" * 16], fasta=False)
     assert exact.genome_start.tolist() == [0, 128, 256]
     assert arena_to_ascii(exact, 0) == b"ACGT" * 16 and (int(exact.mask[2]) & 1) == 1
+
+
+def test_packers_list_the_residues_that_are_neither_acgt_nor_n(tmp_path):
+    """The arena's mask bit stands for N; IUPAC codes and every other byte are listed beside it -- (arena position, upper-cased
+    byte), ascending -- by pa_text_ambiguous (texts packed one by one) and pa_fasta_batch_ambiguous (the threaded loader),
+    so that the fragment-ANI kernels hash them as fastANI does: as the characters they are."""
+    import gzip
+
+    from pyani_plus_amd.engine import load_fasta_files
+
+    text_a = b"junk\n>r1 t\nACGTRYKMnnACGT\n>r2\nSWacgtBDHVxACGT*\n"
+    text_b = b">y\nRRRRACGT\nACGTK\n"
+    arena = pack_genomes([text_a, b">x\nACGTNNNN\n", text_b])
+    # r1 holds 14 residues at 0..13, one separator, r2 starts at 15; genome 2 starts at 128
+    assert arena.ambig_pos.tolist() == [4, 5, 6, 7, 15, 16, 21, 22, 23, 24, 25, 30, 128, 129, 130, 131, 140]
+    assert bytes(arena.ambig_byte) == b"RYKMSWBDHVX*RRRRK"  # lower case folded, N and n left to the mask bit
+    assert arena_to_ascii(arena, 0) == b"ACGTRYKMNNACGTNSWACGTBDHVXACGT*" and arena_to_ascii(arena, 1) == b"ACGTNNNN"
+    assert arena.invalid == [14, 4, 5]
+    bare = pack_genomes([b"ACGTRYn* "], fasta=False)  # a bare sequence: every byte is a residue
+    assert bare.ambig_pos.tolist() == [4, 5, 7, 8] and bytes(bare.ambig_byte) == b"RY* "
+    (tmp_path / "a.fasta").write_bytes(text_a)
+    with gzip.open(tmp_path / "b.fna.gz", "wb") as fh:
+        fh.write(text_b)
+    infos, loaded = load_fasta_files([tmp_path / "a.fasta", tmp_path / "b.fna.gz"])
+    assert [i.status for i in infos] == [0, 0]
+    assert loaded.ambig_pos.tolist() == [4, 5, 6, 7, 15, 16, 21, 22, 23, 24, 25, 30, 64, 65, 66, 67, 76]
+    assert bytes(loaded.ambig_byte) == b"RYKMSWBDHVX*RRRRK"
+    clean = pack_genomes([b">c\nACGTNNACGT\n"])
+    assert len(clean.ambig_pos) == 0
 
 
 @pytest.mark.parametrize("name", ["viral_example", "bad_alignments"])

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential test of the fragment-ANI path: device against oracle on small genome sets with everything that has
-broken it before -- repeats (tandem and dispersed), runs of N and single N, contigs shorter than a fragment, contigs that end
-with their last fragment, lower case, several k and fragment lengths.
+broken it before -- repeats (tandem and dispersed), runs of N and single N, IUPAC codes and other bytes (hashed as the
+characters they are), contigs shorter than a fragment, contigs that end with their last fragment, lower case, several k
+and fragment lengths.
 
     python tests/tools/fragani_stress.py [cases=200] [seed=1] [big]
 
@@ -22,6 +23,7 @@ from pyani_plus_amd.engine import HipEngine, pack_genomes  # noqa: E402
 from pyani_plus_amd.methods.fastani_hip import fastani_mean  # noqa: E402
 
 ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+IUPAC = np.frombuffer(b"RYKMSWBDHVrykmX*", dtype=np.uint8)
 
 
 def make_case(rng):
@@ -48,6 +50,11 @@ def make_case(rng):
             n = int(rng.choice([1, 1, 2, 17, 40, 300, frag + 7, 2 * frag + 100]))
             at = int(rng.integers(0, max(1, len(g) - n)))
             g[at : at + n] = b"N" * n
+        if rng.random() < 0.5:  # IUPAC codes and other bytes, hashed as the characters they are: single ones and short runs
+            for _ in range(int(rng.integers(1, 40))):
+                n = int(rng.choice([1, 1, 1, 2, 5, 20]))
+                at = int(rng.integers(0, max(1, len(g) - n)))
+                g[at : at + n] = bytes(rng.choice(IUPAC, size=n).tolist())
         if rng.random() < 0.3:
             at = int(rng.integers(0, len(g) - 100))
             g[at : at + 100] = bytes(g[at : at + 100]).lower()
