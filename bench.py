@@ -62,10 +62,67 @@ def parse_args(argv=None):
     ap.add_argument("--also", default="bottom,k51,mixed,n10000,fragani", help="comma list of the extra runs at N=1")
     ap.add_argument("--also-fragani-genomes", type=int, default=1000)
     ap.add_argument("--also-n", type=int, default=10000)
+    ap.add_argument("--no-fresh-child", action="store_true", help="skip the fresh-process fragment-ANI call (a child started before this process touches the GPU)")
+    ap.add_argument("--fresh-fragani-child", action="store_true", help=argparse.SUPPRESS)  # the child's own mode
     ap.add_argument("--dry-run-plan", action="store_true",
                     help="print, without touching a GPU (or importing torch), what every rank of `--gpus N` would hold and exchange: "
                     "shards, all-gather sizes, tile buffers, the strong_basis memory need")
     return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------- fragment ANI in a fresh process
+def fresh_fragani_child(args) -> None:
+    """The child's side: one all-columns fragment-ANI call as the first device work of a new process (after the arena
+    is there): what a `fastANI-hip` worker pays, the first use of its workspace's device memory included.  Prints one JSON line."""
+    t_proc = time.perf_counter()
+    import torch
+
+    from pyani_plus_amd.engine import HipEngine
+    from pyani_plus_amd.synth import synth_arena_torch
+
+    n, k, frag = args.also_fragani_genomes, 16, 3000
+    engine = HipEngine(0)
+    arena = synth_arena_torch(engine, n, args.length, n_species=args.species)
+    starts = np.ascontiguousarray(arena.genome_start[:-1])
+    lens = np.full(n, args.length, dtype=np.uint32)
+    genome = np.arange(n, dtype=np.uint32)
+    torch.cuda.synchronize()
+    free0, total_mem = torch.cuda.mem_get_info()
+    t_ready = time.perf_counter()
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        total, matched, _sums = engine.fragani(arena, starts, lens, genome, k, frag)
+        times.append(time.perf_counter() - t0)
+    free1, _ = torch.cuda.mem_get_info()
+    print(json.dumps({
+        "genomes": n, "first_call_seconds": times[0], "second_call_seconds": times[1],
+        "workspace_device_bytes": int(free0 - free1), "arena_device_bytes": int(arena.packed.numel() * 4 + arena.mask.numel() * 4),
+        "device_bytes_in_use_after": int(total_mem - free1), "seconds_from_process_start_to_arena": t_ready - t_proc,
+        "kept_fragments_checksum": int(matched.astype(np.uint64).sum()), "fragments": int(total.astype(np.uint64).sum()),
+    }), flush=True)
+    engine.close()
+
+
+def run_fresh_fragani_child(args) -> dict:
+    """Start the child above from THIS process, which has not touched the GPU (no torch import yet): a fresh child, not a
+    re-exec of a process that holds the device.  Its one JSON line, or the reason there is none."""
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"skipped": "under a profiler the parent holds the device before it starts"}
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--fresh-fragani-child", "--also-fragani-genomes", str(args.also_fragani_genomes),
+           "--length", str(args.length), "--species", str(args.species)]
+    try:
+        proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    except subprocess.TimeoutExpired:
+        return {"error": "the child did not finish in 600 s"}
+    for line in reversed(proc.stdout.splitlines()):
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return {"error": f"child exited with {proc.returncode}: {proc.stderr[-400:]}"}
 
 
 # --------------------------------------------------------------------------- the plan of a multi-GPU run, on paper
@@ -691,7 +748,7 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
 
 
 # --------------------------------------------------------------------------- one rank
-def run_rank(args) -> None:
+def run_rank(args, fresh_fragani: dict | None = None) -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1124,6 +1181,11 @@ def run_rank(args) -> None:
                 extra("long_kmer_k51", also_long_kmer, engine, arena, args, n_total, lengths)
             if "fragani" in wanted:
                 extra("fragment_ani", also_fragani, engine, arena, args, n_total, lengths)
+                if fresh_fragani is not None and isinstance(also.get("fragment_ani"), dict):
+                    fresh_fragani["what"] = ("a child process started before this one touched the GPU: torch import, the synthetic arena, then ONE "
+                                             "all-columns pa_fragani call as the first use of its workspace (first_call_seconds: what a fresh "
+                                             "fastANI-hip worker pays, first-touch page mapping of the workspace included) and the same call again")
+                    also["fragment_ani"]["fresh_process"] = fresh_fragani
             engine.prof_enable(False)
             del out, sk_local, sk, counts, ident, cov
             arena = None
@@ -1180,9 +1242,17 @@ def main():
     if args.dry_run_plan:
         print(json.dumps(dry_run_plan(args), indent=1))
         return
+    if args.fresh_fragani_child:
+        fresh_fragani_child(args)
+        return
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(launch_ranks(args))
-    run_rank(args)
+    # before this process imports torch or touches the GPU: the fragment-ANI call of a fresh process (also.fragment_ani.fresh_process)
+    fresh = None
+    if (args.gpus == 1 and "RANK" not in os.environ and os.environ.get("PA_BENCH_FORCE_DIST") != "1" and not args.no_also and not args.no_fresh_child
+            and "fragani" in args.also.split(",") and args.sketch_mode == "scaled" and not args.mixed_lengths):
+        fresh = run_fresh_fragani_child(args)
+    run_rank(args, fresh)
 
 
 if __name__ == "__main__":

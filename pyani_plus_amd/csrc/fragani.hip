@@ -2490,6 +2490,7 @@ struct FragWork {
   uint32_t index_contigs = 0, index_genomes = 0, index_k = 0, index_frag_len = 0, index_m = 0, index_ids = 0;
   uint32_t index_ref0 = 0, index_ref1 = 0;  // the reference genomes whose minimizers the dictionary holds
   uint32_t index_lookup_bits = 10;          // log2 of the slots of the look-up table by hash value (such a dictionary only)
+  uint64_t index_key_room = 0;              // keys of one half of the sort's key buffer (W.keys[0] holds both halves)
   int index_which = 0;
   ~FragWork() {
     DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
@@ -2880,14 +2881,18 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   const uint32_t md = m_hi - m_lo;  // minimizers in the dictionary
   if (!reuse) {  // (an index that is taken over stays where it is: asking for room again could move -- and lose -- it)
     const uint64_t md_room = std::max<uint32_t>(md, 1u);
-    for (int b = 0; b < 2; ++b) { PA_TRY(W.keys[b].reserve(md_room * 8)); PA_TRY(W.vals[b].reserve(md_room * 4)); }
+    // (the two key buffers of the sort are the halves of ONE allocation: once the index stands they are free, and the seed
+    // hits of the batches, 8 bytes each, go there -- memory this process has touched already instead of fresh pages)
+    PA_TRY(W.keys[0].reserve(2 * md_room * 8));
+    for (int b = 0; b < 2; ++b) PA_TRY(W.vals[b].reserve(md_room * 4));
     PA_TRY(W.flags.reserve(md_room * 8 + 64));
+    W.index_key_room = md_room;
     PA_TRY(W.mini_id.reserve((uint64_t)m * 4));
     PA_TRY(W.prev_same.reserve((uint64_t)m * 4));
     PA_TRY(W.post_cw.reserve(md_room * 8));
     PA_TRY(W.post_g.reserve(md_room * 2 + 16));
   }
-  uint64_t *keys[2] = {W.keys[0].as<uint64_t>(), W.keys[1].as<uint64_t>()};
+  uint64_t *keys[2] = {W.keys[0].as<uint64_t>(), W.keys[0].as<uint64_t>() + W.index_key_room};
   uint32_t *vals[2] = {W.vals[0].as<uint32_t>(), W.vals[1].as<uint32_t>()};
   int which = reuse ? W.index_which : 0;
   if (!reuse) {
@@ -3012,9 +3017,24 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_TRY(upload(c, W.frag_no, fn));
     PA_TRY(upload(c, W.frag_genome_local, fg));
     PA_HIP(hipStreamSynchronize(c->stream));
-    PA_TRY(W.q_hash.reserve((uint64_t)nf * kQMax * 4));
-    PA_TRY(W.q_pos.reserve((uint64_t)nf * kQMax * 4));
-    PA_TRY(W.q_id.reserve((uint64_t)nf * kQMax * 4));
+    // The batch's working arrays go into memory the index build has left behind wherever they fit (a fresh process pays
+    // ~65 ms per GB for the FIRST use of device memory -- more than the kernels of a whole 1 000-genome run for the 6 GB
+    // these are): the fragments' sketches into the sort's spare value buffer, the seed hits into its key buffers, the
+    // table of best fragments into the flag / scan scratch.  (All three are dead once the index stands, also for a call
+    // that takes the index over.)
+    uint32_t *q_hash_p, *q_pos_p, *q_id_p;
+    {
+      const uint64_t per = (uint64_t)nf * kQMax;
+      DevBuf &spare = W.vals[1 - which];
+      if (spare.bytes >= 3 * per * 4) {
+        q_hash_p = spare.as<uint32_t>(); q_pos_p = q_hash_p + per; q_id_p = q_pos_p + per;
+      } else {
+        PA_TRY(W.q_hash.reserve(per * 4));
+        PA_TRY(W.q_pos.reserve(per * 4));
+        PA_TRY(W.q_id.reserve(per * 4));
+        q_hash_p = W.q_hash.as<uint32_t>(); q_pos_p = W.q_pos.as<uint32_t>(); q_id_p = W.q_id.as<uint32_t>();
+      }
+    }
     PA_TRY(W.q_s.reserve((uint64_t)nf * 4));
     PA_TRY(W.q_cut.reserve((uint64_t)nf * 4));
     PA_TRY(W.hit_count.reserve((uint64_t)nf * 4));
@@ -3029,8 +3049,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     hipLaunchKernelGGL(query_sketch_kernel, dim3(gw), dim3(kThreads), 0, c->stream, W.frag_d.as<uint32_t>(), W.frag_contig.as<uint32_t>(),
                        W.frag_no.as<uint32_t>(), nf, frag_len, count_windows, W.contig_mini_off.as<uint32_t>(),
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
-                       W.post_start.as<uint32_t>(), W.q_hash.as<uint32_t>(), W.q_pos.as<uint32_t>(),
-                       W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits,
+                       W.post_start.as<uint32_t>(), q_hash_p, q_pos_p,
+                       q_id_p, W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits,
                        W.q_cut.as<uint32_t>(), restricted ? W.lookup_at.as<uint4>() : nullptr, W.index_lookup_bits);
     PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -3047,12 +3067,19 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     if (trace) fprintf(stderr, "pa_fragani: batch of genomes %u..%u: %u fragments, %llu seed hits\n", g0, g1, nf, (unsigned long long)n_hits);
     PA_REQUIRE(n_hits < (1ULL << 31), "pa_fragani: %llu seed hits for the fragments of genome %u alone (limit 2^31); highly "
                "repetitive input", (unsigned long long)n_hits, g0);
-    PA_TRY(W.table.reserve((uint64_t)nq * range_bins * 8));
-    PA_HIP(hipMemsetAsync(W.table.p, 0, (uint64_t)nq * range_bins * 8, c->stream));
+    unsigned long long *table_p;
+    if (use_buckets && W.flags.bytes >= (uint64_t)nq * range_bins * 8) {
+      table_p = W.flags.as<unsigned long long>();  // (the sorted path keeps its head flags there)
+    } else {
+      PA_TRY(W.table.reserve((uint64_t)nq * range_bins * 8));
+      table_p = W.table.as<unsigned long long>();
+    }
+    PA_HIP(hipMemsetAsync(table_p, 0, (uint64_t)nq * range_bins * 8, c->stream));
     if (n_hits) {
-      PA_TRY(W.hkeys[0].reserve(n_hits * 8));
-      PA_TRY(W.hvals[0].reserve(n_hits * 4));
-      uint64_t *hk[2] = {W.hkeys[0].as<uint64_t>(), nullptr};
+      const bool hits_in_sort_keys = W.keys[0].bytes >= n_hits * 8;
+      if (!hits_in_sort_keys) PA_TRY(W.hkeys[0].reserve(n_hits * 8));
+      PA_TRY(W.hvals[0].reserve(n_hits * 4));  // (written by the paths that order the hits as a whole only)
+      uint64_t *hk[2] = {hits_in_sort_keys ? W.keys[0].as<uint64_t>() : W.hkeys[0].as<uint64_t>(), nullptr};
       uint32_t *hv[2] = {W.hvals[0].as<uint32_t>(), nullptr};
       auto second_buffers = [&]() -> int {  // only the radix sort needs the ping-pong copies
         PA_TRY(W.hkeys[1].reserve(n_hits * 8));
@@ -3085,7 +3112,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
           PA_HIP(hipMemsetAsync(d_seg_counters, 0, 16, c->stream));
           PA_HIP(hipMemsetAsync(d_cursor64, 0, 8, c->stream));
           hipLaunchKernelGGL(bucket_hits_kernel, dim3(ceil_div_u64(nf, kBucketWaves)), dim3(kBucketWaves * 64), lds_bytes,
-                             c->stream, nf, W.q_pos.as<uint32_t>(), W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(),
+                             c->stream, nf, q_pos_p, q_id_p, W.q_s.as<uint32_t>(),
                              W.hit_off.as<uint32_t>(), W.post_g.as<uint16_t>(), W.post_cw.as<uint64_t>(), n_genomes,
                              W.tab_min_hits.as<uint32_t>(), hk[0], hv[0],
                              W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), W.seg_f.as<uint32_t>(), seg_cap, d_seg_counters,
@@ -3133,8 +3160,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         }
       } else {
         // general path: all hits sorted by key, segments from head flags
-        hipLaunchKernelGGL(fill_hits_kernel, dim3(gw), dim3(kThreads), 0, c->stream, nf, W.q_pos.as<uint32_t>(),
-                           W.q_id.as<uint32_t>(), W.q_s.as<uint32_t>(), W.hit_off.as<uint32_t>(),
+        hipLaunchKernelGGL(fill_hits_kernel, dim3(gw), dim3(kThreads), 0, c->stream, nf, q_pos_p,
+                           q_id_p, W.q_s.as<uint32_t>(), W.hit_off.as<uint32_t>(),
                            W.post_start.as<uint32_t>(), d_sorted_idx, W.mini_wpos.as<uint32_t>(),
                            W.mini_contig.as<uint32_t>(), hk[0], hv[0]);
         if (max_hits <= kFragSortMax) {  // every fragment's hits fit one LDS sort
@@ -3204,12 +3231,12 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
 #define PA_MAP_CASE(CAP)                                                                                                  \
   case CAP:                                                                                                               \
     hipLaunchKernelGGL((map_segments_kernel<CAP, kAll>), dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap, CAP), c->stream,  \
-                       hk[hw], hv[hw], W.seg_rec.as<uint4>(), count, presorted, W.q_hash.as<uint32_t>(),                   \
+                       hk[hw], hv[hw], W.seg_rec.as<uint4>(), count, presorted, q_hash_p,                                  \
                        W.frag_genome_local.as<uint32_t>(), frag_len, count_windows,                                        \
                        W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),                                  \
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),      \
                        W.mini_wpos.as<uint32_t>(), W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), range_bins, \
-                       W.table.as<unsigned long long>(), W.run_g.as<uint32_t>(), s_cap, hit_cap PA_MAP_CUT_ARG);          \
+                       table_p, W.run_g.as<uint32_t>(), s_cap, hit_cap PA_MAP_CUT_ARG);                                   \
     break;
         switch (ref_cap) {
           PA_MAP_CASE(256) PA_MAP_CASE(320) PA_MAP_CASE(384) PA_MAP_CASE(448)
@@ -3259,7 +3286,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
     PA_TRY(W.matched.reserve((uint64_t)nq * n_genomes * 4));
     PA_TRY(W.ident_sum.reserve((uint64_t)nq * n_genomes * 8));
     hipLaunchKernelGGL(reduce_pairs_kernel, dim3(nq * n_genomes), dim3(64), 0, c->stream,
-                       W.table.as<unsigned long long>(), range_bins, W.genome_bin_off.as<uint32_t>(), n_genomes,
+                       table_p, range_bins, W.genome_bin_off.as<uint32_t>(), n_genomes,
                        W.ident_tab.as<float>(), W.matched.as<uint32_t>(), W.ident_sum.as<double>());
     PA_HIP(hipGetLastError());
     prof.reset();
