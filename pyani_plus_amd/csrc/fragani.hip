@@ -1157,6 +1157,175 @@ __global__ __launch_bounds__(kBucketWaves * 64) void bucket_hits_kernel(
   });
 }
 
+// ---- the same for one fragment per WORKGROUP, the hits of the listed pairs staged in LDS ----------------------------
+// bucket_hits_kernel above writes every hit of a listed pair with a lone 8-byte store into its genome's slice of the
+// fragment's hit range: the eight hits of a 64-byte sector arrive at eight different times from eight posting lists, the
+// L2 cannot hold the lines of all fragments in flight until they are full, and the counters show 19.6 written bytes per
+// hit against 8 (profiles/r04_pmc_bucket_hits_summary.txt).  Here the eight waves of a workgroup share one fragment:
+// they split its posting lists (a step of sixteen lists per wave and turn), count into ONE histogram in LDS, place the
+// hits of the LISTED genomes in a compact LDS copy of their slices (21 KB on average at 1 000 genomes: the pairs that
+// are not listed -- fewer hits than a run needs -- are not written at all), and then every listed slice leaves as a run
+// of consecutive 8-byte stores -- whole sectors but for a slice's two ends.  A fragment whose listed hits do not fit the
+// staging area (repeat families) writes them directly, as above.
+constexpr int kStageWaves = 8;
+__global__ __launch_bounds__(kStageWaves * 64) void bucket_hits_staged_kernel(
+    uint32_t n_frags, const uint32_t *__restrict__ q_pos, const uint32_t *__restrict__ q_id,
+    const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ hit_off,
+    const uint16_t *__restrict__ post_genome, const uint64_t *__restrict__ post_cw, uint32_t n_genomes,
+    const uint32_t *__restrict__ tab_min_hits, uint64_t *__restrict__ keys, uint32_t *__restrict__ seg_a0,
+    uint32_t *__restrict__ seg_nh, uint32_t *__restrict__ seg_f, uint32_t seg_cap, uint32_t *__restrict__ counters,
+    unsigned long long *__restrict__ cursor64, uint32_t ref0, uint32_t ref1, uint32_t stage_cap) {
+  extern __shared__ uint64_t st_lds[];
+  uint64_t *stage = st_lds;                                           // [stage_cap] the listed slices, one after the other
+  uint32_t *hist = reinterpret_cast<uint32_t *>(st_lds + stage_cap);  // [n_genomes] counts, then offsets in the fragment's hit range
+  uint32_t *coff = hist + n_genomes;                                  // [n_genomes] cursors into `stage` (listed genomes)
+  __shared__ uint32_t s_tot[kStageWaves][2], s_part[kStageWaves][2], s_draw[2];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t f = blockIdx.x;
+  if (f >= n_frags) return;
+  const uint32_t s = q_s[f], base = hit_off[f];
+  for (uint32_t g = tid; g < n_genomes; g += kStageWaves * 64) hist[g] = 0;
+  __syncthreads();
+  // sixteen lists per step and wave, 32 lanes' worth of slots each, eight independent posting loads per lane in flight
+  constexpr int kLoads = 8;
+  auto for_each_posting = [&](const auto *__restrict__ postings, auto &&visit) {
+    using Elem = std::remove_cv_t<std::remove_reference_t<decltype(postings[0])>>;
+    for (uint32_t i0 = 2u * kLoads * wave; i0 < s; i0 += 2u * kLoads * kStageWaves) {
+      uint32_t lo_u[kLoads], n_u[kLoads], longest = 0;
+#pragma unroll
+      for (int u = 0; u < kLoads; ++u) {
+        const uint32_t i = i0 + 2u * (uint32_t)u + (lane >> 5);
+        lo_u[u] = i < s ? q_id[(uint64_t)f * kQMax + i] : 0u;  // (first posting, length) from query_sketch_kernel
+        n_u[u] = i < s ? q_pos[(uint64_t)f * kQMax + i] : 0u;
+        longest = max(longest, n_u[u]);
+      }
+      longest = pa_dev::wave_max_dpp(longest);
+      for (uint32_t r = 0; r < longest; r += 32) {
+        const uint32_t slot = r + (lane & 31u);
+        Elem cw[kLoads];
+#pragma unroll
+        for (int u = 0; u < kLoads; ++u) cw[u] = slot < n_u[u] ? postings[lo_u[u] + slot] : Elem(0);
+#pragma unroll
+        for (int u = 0; u < kLoads; ++u)
+          if (slot < n_u[u]) visit(i0 + 2u * (uint32_t)u + (lane >> 5), cw[u]);
+      }
+    }
+  };
+  for_each_posting(post_genome, [&](uint32_t, uint16_t g) { atomicAdd(&hist[g], 1u); });
+  __syncthreads();
+  // exclusive scans over the genomes, 512 at a time (a wave per 64 genomes, the waves chained through their totals): of all
+  // counts -- the offsets in the fragment's hit range -- and of the listed genomes' counts -- the offsets in `stage`
+  const uint32_t mh = s ? tab_min_hits[s] : 0xffffffffu;
+  uint32_t carry = 0, ccarry = 0, n_small = 0, n_large = 0, n_big = 0, max_big = 0;
+  for (uint32_t g0 = 0; g0 < n_genomes; g0 += kStageWaves * 64) {
+    const uint32_t g = g0 + tid;
+    const uint32_t cnt = g < n_genomes ? hist[g] : 0u;
+    const bool keep = cnt >= mh && g >= ref0 && g < ref1;
+    const uint32_t kcnt = keep ? cnt : 0u;
+    const uint32_t ex = wave_excl_scan(cnt, lane), wsum = wave_sum(cnt);
+    const uint32_t kex = wave_excl_scan(kcnt, lane), kwsum = wave_sum(kcnt);
+    if (lane == 0) { s_tot[wave][0] = wsum; s_tot[wave][1] = kwsum; }
+    __syncthreads();
+    uint32_t before = 0, chunk = 0, kbefore = 0, kchunk = 0;
+#pragma unroll
+    for (int q = 0; q < kStageWaves; ++q) {
+      const uint32_t t = s_tot[q][0], kt = s_tot[q][1];
+      before += (uint32_t)q < wave ? t : 0u; chunk += t;
+      kbefore += (uint32_t)q < wave ? kt : 0u; kchunk += kt;
+    }
+    if (g < n_genomes) {
+      hist[g] = (carry + before + ex) | (keep ? 0u : 0x80000000u);  // top bit: nobody will read this genome's hits
+      coff[g] = ccarry + kbefore + kex;
+    }
+    const bool small = keep && cnt <= (uint32_t)kHitCapSmall;
+    n_small += (uint32_t)__popcll(__ballot(small));
+    n_large += (uint32_t)__popcll(__ballot(keep && !small));
+    n_big += (uint32_t)__popcll(__ballot(keep && cnt > (uint32_t)kHitCap));
+    if (keep && cnt > (uint32_t)kHitCap) max_big = max(max_big, cnt);
+    carry += chunk;
+    ccarry += kchunk;
+    __syncthreads();  // s_tot is written again in the next turn
+  }
+  const uint32_t total_hits = carry;
+  const bool staged = ccarry <= stage_cap;  // the listed hits fit the staging area (uniform over the workgroup)
+  if (n_big) max_big = pa_dev::wave_max_dpp(max_big);
+  if (lane == 0) {
+    s_part[wave][0] = n_small;
+    s_part[wave][1] = n_large;
+    if (n_big) { atomicAdd(&counters[1], n_big); atomicMax(&counters[2], max_big); }
+  }
+  __syncthreads();
+  if (tid == 0) {  // both list cursors in one 64-bit word: one draw per workgroup
+    uint32_t ws = 0, wl = 0;
+#pragma unroll
+    for (int q = 0; q < kStageWaves; ++q) { ws += s_part[q][0]; wl += s_part[q][1]; }
+    unsigned long long got = 0;
+    if (ws | wl) got = atomicAdd(cursor64, ((unsigned long long)wl << 32) | ws);
+    s_draw[0] = (uint32_t)got;
+    s_draw[1] = (uint32_t)(got >> 32);
+  }
+  __syncthreads();
+  uint32_t s0 = s_draw[0], l0 = s_draw[1];
+#pragma unroll
+  for (int q = 0; q < kStageWaves; ++q)
+    if ((uint32_t)q < wave) { s0 += s_part[q][0]; l0 += s_part[q][1]; }
+  if (n_small | n_large) {  // (uniform over the wave)
+    for (uint32_t g0 = 0; g0 < n_genomes; g0 += kStageWaves * 64) {
+      const uint32_t g = g0 + tid;
+      uint32_t off = 0, cnt = 0;
+      if (g < n_genomes) {
+        off = hist[g] & 0x7fffffffu;
+        cnt = (g + 1 < n_genomes ? (hist[g + 1] & 0x7fffffffu) : total_hits) - off;
+      }
+      const bool keep = cnt >= mh && g >= ref0 && g < ref1;
+      const bool small = keep && cnt <= (uint32_t)kHitCapSmall, large = keep && !small;
+      const uint64_t sm = __ballot(small), lm = __ballot(large);
+      if (keep) {
+        const uint64_t below = (1ULL << lane) - 1ULL;
+        const uint32_t slot = small ? s0 + (uint32_t)__popcll(sm & below) : seg_cap - 1u - (l0 + (uint32_t)__popcll(lm & below));
+        if (slot < seg_cap) { seg_a0[slot] = base + off; seg_nh[slot] = cnt; seg_f[slot] = f; }
+      }
+      s0 += (uint32_t)__popcll(sm);
+      l0 += (uint32_t)__popcll(lm);
+    }
+  }
+  // scatter pass.  Staged: a hit of a listed genome draws its place from the genome's cursor into `stage` (the offsets
+  // in the hit range stay as they are: the copy below reads them); else from the genome's offset, which moves.
+  if (staged) {
+    for_each_posting(post_cw, [&](uint32_t i, uint64_t cw) {
+      const uint32_t g = (uint32_t)(cw >> 44);
+      if (!(hist[g] & 0x80000000u)) stage[atomicAdd(&coff[g], 1u)] = ((uint64_t)i << kHitRankShift) | (cw & ((1ULL << 44) - 1ULL));
+    });
+    __syncthreads();
+    // the listed slices, from LDS to the hit array: a wave per genome, consecutive lanes consecutive hits.  A genome's
+    // cursor stands at the END of its slice in `stage` now; its length is the distance to the next genome's offset.
+    for (uint32_t g0 = 0; g0 < n_genomes; g0 += kStageWaves * 64) {
+      const uint32_t g = g0 + tid;
+      uint32_t off = 0, cnt = 0, cend = 0;
+      bool keep = false;
+      if (g < n_genomes) {
+        const uint32_t v = hist[g];
+        keep = !(v & 0x80000000u);
+        off = v & 0x7fffffffu;
+        cnt = (g + 1 < n_genomes ? (hist[g + 1] & 0x7fffffffu) : total_hits) - off;
+        cend = coff[g];
+      }
+      for (uint64_t todo = __ballot(keep && cnt > 0u); todo; todo &= todo - 1) {
+        const int src = __builtin_ctzll(todo);
+        const uint32_t o0 = (uint32_t)__builtin_amdgcn_readlane((int)off, src), n0 = (uint32_t)__builtin_amdgcn_readlane((int)cnt, src);
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cend, src) - n0;
+        for (uint32_t i = lane; i < n0; i += 64) keys[base + o0 + i] = stage[c0 + i];
+      }
+    }
+  } else {
+    __syncthreads();  // every offset has been read before the scatter pass moves it
+    for_each_posting(post_cw, [&](uint32_t i, uint64_t cw) {
+      const uint32_t at = atomicAdd(&hist[(uint32_t)(cw >> 44)], 1u);
+      if (!(at & 0x80000000u)) keys[base + at] = ((uint64_t)i << kHitRankShift) | (cw & ((1ULL << 44) - 1ULL));
+    });
+  }
+}
+
 // Chance matches with unrelated genomes still leave millions of listed segments with a handful of hits and
 // no valid L1 run.  One THREAD settles each segment of <= 8 hits here (sort its keys in registers, test the
 // run condition of map_segments_kernel exactly) so that the mapping kernel does not spend a workgroup
@@ -3108,9 +3277,26 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_hits_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         uint32_t n_big = 0, max_big = 0;
+        // one fragment per workgroup with the listed pairs' hits staged in LDS (whole-sector writes) when the two per-genome
+        // arrays leave room for a staging area; the batch that is about to be ordered as a whole (write_all) keeps the
+        // wave-per-fragment form, which writes every slot
+        // (four workgroups of eight waves per CU: 40 KB of LDS each)
+        const uint32_t lds_room = 40u * 1024u;
+        const uint32_t stage_cap = n_genomes * 8u + 8192u <= lds_room ? ((lds_room - n_genomes * 8u) / 8u) & ~63u : 0u;
+        const uint32_t stage_lds = stage_cap * 8u + n_genomes * 8u;
+        const bool stage_hits = stage_cap >= 1024u;
+        if (stage_hits)
+          PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bucket_hits_staged_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_lds));
         auto bucket_pass = [&](bool write_all) -> int {
           PA_HIP(hipMemsetAsync(d_seg_counters, 0, 16, c->stream));
           PA_HIP(hipMemsetAsync(d_cursor64, 0, 8, c->stream));
+          if (stage_hits && !write_all)
+            hipLaunchKernelGGL(bucket_hits_staged_kernel, dim3(nf), dim3(kStageWaves * 64), stage_lds, c->stream, nf, q_pos_p, q_id_p,
+                               W.q_s.as<uint32_t>(), W.hit_off.as<uint32_t>(), W.post_g.as<uint16_t>(),
+                               W.post_cw.as<uint64_t>(), n_genomes, W.tab_min_hits.as<uint32_t>(), hk[0], W.seg_a0.as<uint32_t>(),
+                               W.seg_nh.as<uint32_t>(), W.seg_f.as<uint32_t>(), seg_cap, d_seg_counters, d_cursor64, ref0, ref1, stage_cap);
+          else
           hipLaunchKernelGGL(bucket_hits_kernel, dim3(ceil_div_u64(nf, kBucketWaves)), dim3(kBucketWaves * 64), lds_bytes,
                              c->stream, nf, q_pos_p, q_id_p, W.q_s.as<uint32_t>(),
                              W.hit_off.as<uint32_t>(), W.post_g.as<uint16_t>(), W.post_cw.as<uint64_t>(), n_genomes,
