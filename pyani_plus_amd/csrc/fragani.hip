@@ -628,25 +628,38 @@ __global__ __launch_bounds__(kThreads) void postings_kernel(const uint64_t *__re
 // threshold are taken out of the posting lists -- everything after the index sees lists that never held them.  The
 // minimizers themselves stay where they are: the L2 windows hold every minimizer, as fastANI's do.
 constexpr uint32_t kFreqBins = 256;
-__device__ __forceinline__ uint32_t posting_run_length(const uint32_t *__restrict__ heads, const uint16_t *__restrict__ post_genome,
-                                                       uint32_t i, uint32_t m) {
-  const uint16_t g = post_genome[i];
-  uint32_t j = i + 1;
-  while (j < m && !heads[j] && post_genome[j] == g) ++j;
-  return j - i;
+// The runs are numbered first -- a flag at every run's first posting, their prefix sums, the runs' first postings
+// gathered by number -- so that a run's length is a difference of two entries, whoever asks: one thread per POSTING
+// everywhere below.  (A thread walking its run cost the run's length in dependent loads, twice per index build: a
+// homopolymer or an array of a short unit in a reference is one minimizer per position with one hash, runs of 10^5-10^6
+// postings on one lane while the grid idled.)
+__global__ __launch_bounds__(kThreads) void posting_run_flags_kernel(const uint32_t *__restrict__ heads,
+                                                                     const uint16_t *__restrict__ post_genome, uint32_t m,
+                                                                     uint32_t *__restrict__ run_flag) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i < m) run_flag[i] = (i == 0 || heads[i] || post_genome[i - 1] != post_genome[i]) ? 1u : 0u;
 }
-__global__ __launch_bounds__(kThreads) void posting_run_hist_kernel(const uint32_t *__restrict__ heads,
+__global__ __launch_bounds__(kThreads) void posting_run_starts_kernel(const uint32_t *__restrict__ run_flag,
+                                                                      const uint32_t *__restrict__ runs_before, uint32_t m,
+                                                                      uint32_t *__restrict__ run_start) {
+  const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+  if (i >= m) return;
+  if (run_flag[i]) run_start[runs_before[i]] = i;
+  if (i == m - 1) run_start[runs_before[i] + run_flag[i]] = m;  // the closing entry
+}
+__global__ __launch_bounds__(kThreads) void posting_run_hist_kernel(const uint32_t *__restrict__ run_flag,
+                                                                    const uint32_t *__restrict__ runs_before,
+                                                                    const uint32_t *__restrict__ run_start,
                                                                     const uint16_t *__restrict__ post_genome, uint32_t m,
                                                                     uint32_t *__restrict__ hist /* [genomes][kFreqBins] */,
                                                                     uint32_t *__restrict__ dups /* [genomes] */,
                                                                     uint2 *__restrict__ over, uint32_t over_cap,
                                                                     uint32_t *__restrict__ over_n) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-  if (i >= m) return;
+  if (i >= m || !run_flag[i]) return;  // a run's first posting speaks for the run
+  const uint32_t c = run_start[runs_before[i] + 1u] - i;
+  if (c < 2u) return;  // a run of one: the common case, counted by difference
   const uint16_t g = post_genome[i];
-  if (!heads[i] && post_genome[i - 1] == g) return;  // inside a run
-  if (i + 1 >= m || heads[i + 1] || post_genome[i + 1] != g) return;  // a run of one: the common case, counted by difference
-  const uint32_t c = posting_run_length(heads, post_genome, i, m);
   atomicAdd(&dups[g], c - 1u);
   if (c < kFreqBins - 1u) {
     atomicAdd(&hist[(uint64_t)g * kFreqBins + c], 1u);
@@ -656,22 +669,25 @@ __global__ __launch_bounds__(kThreads) void posting_run_hist_kernel(const uint32
     if (at < over_cap) over[at] = make_uint2(g, c);
   }
 }
-// keep[] (all ones on entry) = 0 for the postings of runs at or above their genome's threshold: the thread of a run's first
-// posting measures the run and, where it is cut, clears its flags (one thread per run: a run costs its length once)
+// keep[i] = 0 for the postings of runs at or above their genome's threshold, 1 for the others.  `keep` is the memory of
+// the run flags: a thread reads its own flag before it writes its own entry.
 __global__ __launch_bounds__(kThreads) void posting_cut_flags_kernel(const uint32_t *__restrict__ heads,
                                                                      const uint32_t *__restrict__ ids_before,
+                                                                     const uint32_t *__restrict__ runs_before,
+                                                                     const uint32_t *__restrict__ run_start,
                                                                      const uint16_t *__restrict__ post_genome, uint32_t m,
                                                                      const uint32_t *__restrict__ threshold,
-                                                                     uint32_t *__restrict__ keep, uint32_t *__restrict__ hash_cut) {
+                                                                     uint32_t *__restrict__ keep /* in: run flags */,
+                                                                     uint32_t *__restrict__ hash_cut) {
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   if (i >= m) return;
-  const uint16_t g = post_genome[i];
-  if (!heads[i] && post_genome[i - 1] == g) return;  // inside a run
-  const uint32_t thr = threshold[g];
-  if (thr == 0xffffffffu) return;
-  const uint32_t c = posting_run_length(heads, post_genome, i, m);
-  if (c >= thr) {
-    for (uint32_t j = i; j < i + c; ++j) keep[j] = 0u;
+  const uint32_t first = keep[i];  // the run flag
+  const uint32_t run = runs_before[i] + first - 1u;
+  const uint32_t c = run_start[run + 1u] - run_start[run];
+  const uint32_t thr = threshold[post_genome[i]];
+  const bool cut = thr != 0xffffffffu && c >= thr;
+  keep[i] = cut ? 0u : 1u;
+  if (cut && first) {
     // the hash has lost seed hits somewhere: its matches in an L2 window are no longer all among the seed hits (the mapping
     // kernel's bounds allow for them).  A bit per hash (dense id: the hashes before this posting's own, plus one where it
     // is its hash's first) says so; mark_cut_minimizers_kernel hands it on to the minimizers.
@@ -2699,7 +2715,13 @@ int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const
     PA_TRY(W.long_runs.reserve((uint64_t)kOverCap * 8));
     uint32_t *d_hist = W.run_hist.as<uint32_t>(), *d_dups = d_hist + (uint64_t)n_genomes * kFreqBins, *d_over_n = d_dups + n_genomes;
     PA_HIP(hipMemsetAsync(d_hist, 0, hist_words * 4, c->stream));
-    hipLaunchKernelGGL(posting_run_hist_kernel, dim3(ceil_div_u64(m, kThreads)), dim3(kThreads), 0, c->stream, d_heads,
+    // the runs numbered: flags in scratch_a, runs before each posting in scratch_b, the runs' first postings in idx_spare
+    // (m + 1 words: every buffer here was reserved with room to spare)
+    const uint32_t gm0 = ceil_div_u64(m, kThreads);
+    hipLaunchKernelGGL(posting_run_flags_kernel, dim3(gm0), dim3(kThreads), 0, c->stream, d_heads, W.post_g.as<uint16_t>(), m, scratch_a);
+    PA_TRY(pa_exclusive_scan_u32(c, scratch_a, scratch_b, m, nullptr));
+    hipLaunchKernelGGL(posting_run_starts_kernel, dim3(gm0), dim3(kThreads), 0, c->stream, scratch_a, scratch_b, m, d_idx_spare);
+    hipLaunchKernelGGL(posting_run_hist_kernel, dim3(gm0), dim3(kThreads), 0, c->stream, scratch_a, scratch_b, d_idx_spare,
                        W.post_g.as<uint16_t>(), m, d_hist, d_dups, W.long_runs.as<uint2>(), kOverCap, d_over_n);
     std::vector<uint32_t> h((size_t)hist_words);
     PA_HIP(hipMemcpyAsync(h.data(), d_hist, hist_words * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2742,8 +2764,7 @@ int cut_frequent_postings(pa_ctx *c, FragWork &W, const uint32_t *d_heads, const
   PA_TRY(W.post_cw2.reserve((uint64_t)m * 8));
   PA_TRY(W.post_g2.reserve((uint64_t)m * 2 + 16));
   const uint32_t gm = ceil_div_u64(m, kThreads);
-  PA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scratch_a), 1, m, c->stream));
-  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before,
+  hipLaunchKernelGGL(posting_cut_flags_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before, scratch_b, d_idx_spare,
                      W.post_g.as<uint16_t>(), m, W.run_hist.as<uint32_t>(), scratch_a, W.hash_cut.as<uint32_t>());
   hipLaunchKernelGGL(mark_cut_minimizers_kernel, dim3(gm), dim3(kThreads), 0, c->stream, d_heads, d_ids_before, d_sorted_idx, m,
                      W.hash_cut.as<uint32_t>(), W.mini_id.as<uint32_t>());

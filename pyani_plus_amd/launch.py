@@ -64,15 +64,23 @@ def signals_as_interrupt():
             signal.signal(sig, handler)
 
 
-def _die_with_parent() -> None:  # runs in the child between fork and exec
-    """The worker gets SIGTERM when the process that started it goes away, however that happens (``kill -9`` included):
-    no rank is left computing on a GPU for a parent that no longer exists."""
+PARENT_PID_ENV = "PYANI_HIP_PARENT_PID"
+
+
+def die_with_parent() -> None:
+    """Called by the worker itself, first thing in ``worker.main`` (no Python runs between fork and exec in the parent, which
+    may have threads): the worker gets SIGTERM when the process that started it goes away, however that happens
+    (``kill -9`` included) -- no rank is left computing on a GPU for a parent that no longer exists.  The parent's pid
+    comes in the environment: a parent that died before this call is noticed right here."""
     import ctypes
 
     try:
         ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)  # PR_SET_PDEATHSIG
     except (OSError, AttributeError):
         pass
+    want = os.environ.get(PARENT_PID_ENV)
+    if want and want.isdigit() and os.getppid() != int(want):
+        raise SystemExit("the process that started this worker is gone")
 
 
 def choose_backend(world: int) -> str:
@@ -107,23 +115,25 @@ def launch_workers(world: int, spec: dict, work_dir: Path, *, timeout: float | N
     spec.setdefault("backend", choose_backend(world))
     spec_file = work_dir / "spec.json"
     spec_file.write_text(json.dumps(spec))
-    for stale in work_dir.glob("result_rank*.json"):  # a resumed run reuses the directory
-        stale.unlink()
+    for pattern in ("result_rank*.json", "*.tile_*.npz", "*.tile.npz", "*.columns_*.json", "*.part", ".*.part.npz"):  # a resumed run reuses the directory:
+        for stale in work_dir.glob(pattern):  # nothing an earlier attempt left may be taken for this one's
+            stale.unlink()
     port = free_port()
     procs: list[tuple[subprocess.Popen, object]] = []
     exchanging = spec.get("task") == "sourmash"  # ranks that take part in a collective
     interrupted_here = False
+    ended_here: set[int] = set()  # ranks THIS function ended (kill by handle): only those are "ended by the parent"
     try:
         for rank in range(world):
             env = dict(os.environ)
             env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))  # fmt: skip
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **{PARENT_PID_ENV: str(os.getpid())})  # fmt: skip
             env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
             root = str(Path(__file__).resolve().parent.parent)
             env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
             log = (work_dir / f"worker_rank{rank}.log").open("w")
             procs.append((subprocess.Popen([sys.executable, "-m", "pyani_plus_amd.worker", str(spec_file)], env=env, stdout=log,
-                                           stderr=subprocess.STDOUT, start_new_session=True, preexec_fn=_die_with_parent), log))  # fmt: skip
+                                           stderr=subprocess.STDOUT, start_new_session=True), log))  # fmt: skip
         (work_dir / "pids.json").write_text(json.dumps([p.pid for p, _ in procs]))
         t0 = time.monotonic()
         deadline = None  # when the ranks still running are ended
@@ -147,8 +157,9 @@ def launch_workers(world: int, spec: dict, work_dir: Path, *, timeout: float | N
                     elif exchanging and any(c == 0 and rank_interrupted(r) for r, c in enumerate(codes)):
                         deadline = now + 5.0  # its peers wait for it in a collective
                 if (deadline is not None and now > deadline) or (timeout is not None and now - t0 > timeout):
-                    for p, _ in procs:
+                    for rank, (p, _) in enumerate(procs):
                         if p.poll() is None:
+                            ended_here.add(rank)
                             p.kill()
                 time.sleep(poll)
             except KeyboardInterrupt:
@@ -160,8 +171,9 @@ def launch_workers(world: int, spec: dict, work_dir: Path, *, timeout: float | N
                         p.send_signal(signal.SIGINT)
                 deadline = time.monotonic() + grace
     finally:
-        for p, log in procs:
+        for rank, (p, log) in enumerate(procs):
             if p.poll() is None:
+                ended_here.add(rank)
                 p.kill()
             try:
                 p.wait(timeout=30)
@@ -179,10 +191,15 @@ def launch_workers(world: int, spec: dict, work_dir: Path, *, timeout: float | N
         results.append(res)
     any_interrupt = interrupted_here or any(r.get("interrupted") for r in results)
     if any_interrupt:
-        for r in results:  # a rank ended while it waited for an interrupted peer (or for too long after the interrupt)
-            if not r.get("ok") and not r.get("error"):
+        # A rank this function ended while it waited for an interrupted peer (or for too long after the interrupt) and that
+        # left no report is part of the interrupt.  A rank that went down by itself at the same moment (a crash, the OOM
+        # killer: no report, not ended here) is NOT: it stays a failure below.
+        for rank, r in enumerate(results):
+            if rank in ended_here and not r.get("ok") and not r.get("error"):
                 r.update(ok=True, interrupted=True, ended_by_parent=True)
-    errors = [r for r in results if not r.get("ok") or (r["returncode"] != 0 and not r.get("ended_by_parent"))]
+    # a rank whose report says "interrupted" has done its part whatever its exit code (it may have been ended after the
+    # grace period, report written); any other non-zero exit is a failure
+    errors = [r for r in results if not r.get("ok") or (r["returncode"] != 0 and not r.get("ended_by_parent") and not r.get("interrupted"))]
     if errors:
         # a rank's own message first; a rank that was killed while waiting for a failed peer has none
         told = [r["error"] for r in errors if r.get("error")]

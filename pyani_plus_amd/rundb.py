@@ -23,6 +23,7 @@ import datetime
 import logging
 import os
 import sqlite3
+import zipfile
 import sys
 import tempfile
 from dataclasses import dataclass
@@ -1039,7 +1040,11 @@ def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, eng
                 run.status = "Worker interrupted"
             if direct:
                 for tile in r.get("tiles") or sorted(str(t) for t in work_dir.glob(f"{fastani_hip.METHOD}.rank_{rank}.tile_*.npz")):
-                    _cfg, queries, subjects, ident, cov, null, aln, sim = wire.load_tile(Path(tile), with_proxies=True)
+                    try:
+                        _cfg, queries, subjects, ident, cov, null, aln, sim = wire.load_tile(Path(tile), with_proxies=True)
+                    except (ValueError, OSError, KeyError, zipfile.BadZipFile) as err:  # a rank ended while it wrote: the other ranks' batches still go in
+                        logger.warning("Skipping unreadable tile file %s of rank %d: %s", tile, rank, err)
+                        continue
                     blocks.append((queries, subjects, ident, aln, sim, cov, null))
             else:
                 # the rank's column file: a complete JSON document after every finished query batch, also when the rank
@@ -1047,7 +1052,12 @@ def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, eng
                 c0, c1 = column_ranges[rank]
                 json_file = Path(r["json"]) if r.get("json") else work_dir / f"{fastani_hip.METHOD}.run_{run.run_id}.columns_{c0 + 1}_{c1}.json"
                 if c0 != c1 and json_file.is_file():
-                    import_json_comparisons(logger, conn, json_file)
+                    try:
+                        import_json_comparisons(logger, conn, json_file)
+                    except (ValueError, OSError) as err:  # a column file cut short by the end of its rank (it is rewritten whole after every batch)
+                        if not r.get("interrupted"):
+                            raise
+                        logger.warning("Skipping unreadable column file %s of rank %d: %s", json_file, rank, err)
         if run.status == "Worker interrupted":
             session.commit()
     else:

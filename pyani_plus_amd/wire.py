@@ -84,8 +84,11 @@ def save_tile(path: Path, configuration, queries: list[str], subjects: list[str]
     extra = {}
     if aln_length is not None:
         extra = {"aln_length": np.asarray(aln_length, dtype=np.int64), "sim_errors": np.asarray(sim_errors, dtype=np.int64)}
+    # written under another name and renamed: a reader (the parent, after an interrupt) never sees half a file
+    path = Path(path)
+    tmp = path.with_name("." + path.name + ".part.npz")  # (a name no reader's pattern matches)
     np.savez(
-        path,
+        tmp,
         configuration=np.array(json.dumps(configuration_dict(configuration))),
         queries=np.array(queries),
         subjects=np.array(subjects),
@@ -94,6 +97,7 @@ def save_tile(path: Path, configuration, queries: list[str], subjects: list[str]
         is_null=np.asarray(is_null, dtype=bool),
         **extra,
     )
+    tmp.replace(path)
 
 
 def load_tile(path: Path, *, with_proxies: bool = False):

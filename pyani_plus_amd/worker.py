@@ -161,6 +161,9 @@ TASKS = {"sourmash": sourmash_rank, "fastani": fastani_rank}
 def main(argv: list[str]) -> int:
     import signal
 
+    from .launch import die_with_parent
+
+    die_with_parent()  # before any GPU call: this rank ends with the process that started it
     # Ctrl-C and a scheduler's SIGTERM alike end the work through KeyboardInterrupt (pyani_plus/private_cli.py:816-823)
     signal.signal(signal.SIGINT, signal.default_int_handler)
     signal.signal(signal.SIGTERM, signal.default_int_handler)

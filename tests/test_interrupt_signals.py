@@ -177,3 +177,21 @@ def test_workers_are_ended_when_the_launch_fails_midway(tmp_path, monkeypatch):
     pids = json.loads((tmp_path / "w" / "pids.json").read_text())
     real_sleep(0.2)
     assert not any(_alive(pid) for pid in pids)
+
+
+def test_worker_notices_a_parent_that_is_already_gone():
+    """The worker arms PR_SET_PDEATHSIG itself, first thing (no Python between fork and exec in the parent), and compares its
+    parent with the pid the launcher put in the environment: a parent that died in between is noticed at once."""
+    import os
+    import subprocess
+    import sys
+
+    from pyani_plus_amd import launch
+
+    root = str(Path(__file__).resolve().parent.parent)
+    code = "from pyani_plus_amd.launch import die_with_parent; die_with_parent(); print('armed')"
+    env = {**os.environ, "PYTHONPATH": root}
+    ok = subprocess.run([sys.executable, "-c", code], env={**env, launch.PARENT_PID_ENV: str(os.getpid())}, capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0 and "armed" in ok.stdout
+    gone = subprocess.run([sys.executable, "-c", code], env={**env, launch.PARENT_PID_ENV: "1"}, capture_output=True, text=True, timeout=60)
+    assert gone.returncode != 0 and "armed" not in gone.stdout and "gone" in gone.stderr
