@@ -1660,8 +1660,25 @@ __device__ __forceinline__ void stage_hits_sorted(const uint64_t *__restrict__ s
   }
 }
 
-// The kernel cut short after a phase (tools/map_cut.py: phase times by difference, results wrong): an argument of the
-// tools build only.
+// The phases of map_segments_kernel in the order they run.  In the tools build the kernel takes one of these as an argument
+// and ends after that phase (or leaves a part out): tools/map_cut.py times the phases by difference -- results wrong --
+// and READS THIS LIST (name = number, // description), so the kernel and the tool cannot disagree about what a cut means.
+enum MapCut : uint32_t {
+  kCutHeader = 10,         // segment record and sketch loaded
+  kCutStaged = 11,         // hits loaded, ordered, staged
+  kCutSketchTable = 1,     // bucket table of the sketch
+  kCutL1 = 2,              // L1 scan: candidates listed, none evaluated
+  kCutCandidate = 3,       // candidate set-up: begins, end of the slide, hit range
+  kCutGroupBounds = 4,     // seed-hit bounds of every group of begins, no rounds (nothing raises the bar: an upper estimate)
+  kCutStretch = 5,         // first round only: stretch loaded, window ends found
+  kCutRanks = 6,           // first round only: stretch ranked against the sketch
+  kCutCoarseTable = 7,     // first round only: coarse bit table built
+  kCutCoarseSearch = 8,    // first round only: window masks and coarse search
+  kCutNone = 9,            // the whole kernel
+  kCutNoSecondPass = 21,   // the whole kernel without the second pass of rounds with more than 64 items
+  kCutNoFinePass = 22,     // the whole kernel without the fine passes
+  kCutFirstGroupOnly = 23, // the whole kernel, the group of the expected optimum only (one group per candidate)
+};
 #ifdef PA_TOOLS
 #define PA_MAP_CUT_PARAM , uint32_t cut
 #define PA_MAP_CUT_ARG , map_cut
@@ -1729,7 +1746,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     uint4 *dst4 = reinterpret_cast<uint4 *>(sh.qh);
     for (uint32_t i = lane; i < s_cap / 4u; i += 64) dst4[i] = src4[i];
   }
-  PA_CUT(10);  // segment header and sketch
+  PA_CUT(kCutHeader);  // segment header and sketch
   if (staged) {
     if (presorted) {
       for (uint32_t i = lane; i < nh; i += 64) {  // hits ordered as a whole: the fragment on top of the key, the rank in the payload
@@ -1745,7 +1762,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
       else if constexpr (!kAllStaged) stage_hits_sorted<8>(keys + a0, nh, hc_base, lane, sh.hw, sh.hc);
     }
   }
-  PA_CUT(11);  // hits staged in order
+  PA_CUT(kCutStaged);  // hits staged in order
   // (sh.cnt is zeroed where the cooperative evaluation uses it: the bit tables of the rounds live in the same memory)
   if (lane < (uint32_t)kQMax / 32) sh.matched[lane] = 0;
   // The fragment's hashes bucketed by their top kQtBits bits: a reference minimizer's rank among them is then the
@@ -1848,7 +1865,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     return shared;
   };
 
-  PA_CUT(1);  // staging, sort, bucket table
+  PA_CUT(kCutSketchTable);  // staging, sort, bucket table
   // The best mapping so far lives in LDS (sh.scan[16..19]: it is looked at once per candidate, and values kept in
   // registers across the whole kernel were spills): shared minimizers; contig; window ids of the first minimizers of its
   // first and of its last optimal state.
@@ -1882,7 +1899,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   // of the fragment's smallest hashes lie in the bottom-s of the union with its own window and how many of them the window
   // holds.  Begins none of whose windows can hold as many seed hits as the best so far shares are never evaluated.
   auto process_candidate = [&](uint32_t c, uint32_t cs, uint32_t ce, uint32_t first_hit_w) __attribute__((always_inline)) {
-    PA_CUT(2);  // L1 only
+    PA_CUT(kCutL1);  // L1 only
     const int32_t best_shared = (int32_t)__builtin_amdgcn_readfirstlane((int)sh.scan[kBestShared]);  // (fixed while this candidate is evaluated)
     const uint32_t m1 = contig_mini_off[c + 1];
     const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
@@ -1961,6 +1978,14 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     if (at == 0xffffffffu) at = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, est);
     if (b_lo >= b_hi) return;
     PA_STAT(2, 1);  // candidates with begins
+#ifdef PA_MAP_STATS
+    // the work model's units (profiles/README.md): the minimizers of the candidate's range, each of which a perfect bound
+    // still has to look at once (from the first begin to the end of the last window), and -- below -- the states that tie the
+    // candidate's optimum, which no bound can spare
+    PA_STAT(32, wpos_lower_bound(mini_wpos, bucket_first, bb, nb, i_max + count_windows) - b_lo);
+    uint32_t stat_ties = 0;
+    int32_t stat_best_of_candidate = -1;
+#endif
     int32_t c_best = -1;
     uint32_t c_first = 0, c_last = 0;
     // T of this candidate's best state so far, until there is one that of the fragment's best mapping so far: the pivot of the tight bound
@@ -1978,11 +2003,11 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
     const uint32_t n_groups = (b_hi - tile0 + 63u) / 64u;
     const int32_t floor_bar = (int32_t)tab_min_shared[s];
     const uint32_t h_steps = 32u - (uint32_t)__builtin_clz(h_hi - h_lo + 1u);  // 2^steps > the number of hits: enough halvings
-    PA_CUT(3);  // candidate set-up
+    PA_CUT(kCutCandidate);  // candidate set-up
     const uint32_t g_first = min((at - tile0) / 64u, n_groups - 1u);
     for (uint32_t gi = 0; gi < n_groups; ++gi) {
       const uint32_t g = gi == 0 ? g_first : (gi <= g_first ? gi - 1u : gi);
-      if (gi > 0 && PA_CUT_IS(23)) break;  // (timing experiment: the group of the first seed hit only; results wrong)
+      if (gi > 0 && PA_CUT_IS(kCutFirstGroupOnly)) break;  // (timing experiment: the group of the first seed hit only; results wrong)
       const uint32_t sb = tile0 + g * 64u;
       const uint32_t b = sb + lane;
       const bool has = b >= b_lo && b < b_hi;
@@ -2010,7 +2035,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         return has & (idx < h_hi) & HW_below(min(idx, nh - 1u), w_end);
       };
       bool pending = bar > 0 ? holds_hits(bar) : has;
-      if (PA_CUT_IS(4)) pending = false;  // seed-hit bounds of every group
+      if (PA_CUT_IS(kCutGroupBounds)) pending = false;  // seed-hit bounds of every group
       PA_STAT(3, 1);                              // groups of 64 begins
       PA_STAT(4, __popcll(__ballot(pending)));    // begins that pass the seed-hit bound
       uint32_t e_next = 0;  // end (minimizer index) of the begin's next state; 0: none of its states has been evaluated yet
@@ -2158,6 +2183,9 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         // state that has it (the lanes hold the states in slide order; the groups of a candidate do not come in that order).
         // The states that are not evaluated -- reached by taking in a minimizer the fragment does not hold -- share as many
         // as the state before them or fewer and have that state's begin, hence its position: they change neither.
+#ifdef PA_MAP_STATS
+        int32_t &stat_best = stat_best_of_candidate;
+#endif
         auto fold_items = [&]() {
           const uint64_t dm = __ballot(counted);
           const int32_t group_best = (int32_t)pa_dev::wave_max_dpp(counted ? f_shared + 1u : 0u) - 1;
@@ -2169,6 +2197,10 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             c_best = group_best;
             const uint32_t tt = (uint32_t)__builtin_amdgcn_readlane((int)t_state, __builtin_ctzll(top_items));
             if (tt != kNoT) pivot_T = tt;
+#ifdef PA_MAP_STATS
+            stat_ties = (group_best > stat_best ? 0u : stat_ties) + (uint32_t)__popcll(top_items);
+            stat_best = group_best;
+#endif
           }
         };
         if (__builtin_amdgcn_readlane((int)cnt, (int)first_lane) == 0) {
@@ -2277,13 +2309,13 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             }
             complete = lane_on && hi_known && x_next > xe_hi;
           }
-          PA_CUT(5);  // stretch loads and window ends
+          PA_CUT(kCutStretch);  // stretch loads and window ends
           PA_STAT(6, n_rank);                           // stretch entries ranked
           PA_STAT(7, n_items);                          // windows evaluated in the round
           PA_STAT(12, n_items == 0u ? 1u : 0u);
           PA_STAT(13, n_items > 64u ? 1u : 0u);
           if (n_items) {
-            PA_CUT(6);  // ranks
+            PA_CUT(kCutRanks);  // ranks
             // Every window of the round, one lane each, without ordering the stretch.  A window holds the stretch
             // positions [xs, xw) minus later occurrences of a hash it already holds: a bit mask W over the positions.  With
             // R_r / M_r = the positions of reference-only / matching minimizers of rank <= r among the fragment's hashes, the
@@ -2371,8 +2403,8 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
             }
           };
           prefix_or_rows(bc, n_coarse);
-          PA_CUT(7);  // coarse table
-            for (uint32_t pass = 0; pass * 64u < n_items && !(pass && PA_CUT_IS(21)); ++pass) {
+          PA_CUT(kCutCoarseTable);  // coarse table
+            for (uint32_t pass = 0; pass * 64u < n_items && !(pass && PA_CUT_IS(kCutNoSecondPass)); ++pass) {
               if (pass) item_setup(pass);
               // the lane's window as a mask over the stretch positions
               uint32_t wm[kW];
@@ -2421,7 +2453,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
                 g_hi = (open & ge) ? mid : g_hi;
                 g_lo = (open & !ge) ? mid + 1u : g_lo;
               }
-              PA_CUT(8);  // window masks, coarse search
+              PA_CUT(kCutCoarseSearch);  // window masks, coarse search
               // fine: the groups of the lanes lie next to each other as a rule; kFineGroups of them per pass
               // A window shares |M_(T-1) & W| minimizers and T - 1 lies in the coarse group just found, so the matches up to the
               // group's last rank bound it from above (by the matches of at most 15 more ranks): windows that cannot reach
@@ -2431,7 +2463,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
               if (bar_now < floor_bar) bar_now = floor_bar;
               const bool in_reach = (int32_t)count_in(bc + g_lo * kRow + kW) >= bar_now;
               counted = it_on && in_reach;
-              bool unresolved = counted && !PA_CUT_IS(22);
+              bool unresolved = counted && !PA_CUT_IS(kCutNoFinePass);
               while (__any(unresolved)) {
                 PA_STAT(8, 1);  // fine passes
                 const uint32_t g_cur = pa_dev::wave_min_dpp(unresolved ? g_lo : 0xffffffffu);
@@ -2486,6 +2518,9 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         }
       }
     }
+#ifdef PA_MAP_STATS
+    PA_STAT(33, stat_ties ? stat_ties : 1u);  // states tying the candidate's optimum (one probe where nothing was evaluated)
+#endif
     if (c_best < 0) return;
     // fastANI keeps every candidate as a mapping, orders a fragment's mappings by identity and lets each overwrite the one
     // before: of several candidates that share equally many minimizers the LAST one -- the candidates come in (contig,
@@ -3278,7 +3313,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
         hv[1] = W.hvals[1].as<uint32_t>();
         return PA_OK;
       };
-      PA_TRY(W.run_g.reserve(128));  // the mapping kernel's event counters (-DPA_MAP_STATS)
+      PA_TRY(W.run_g.reserve(256));  // the mapping kernel's event counters (-DPA_MAP_STATS)
       int bits = 44;
       for (uint32_t x = nf; x > 1; x >>= 1) ++bits;
       bits = (bits + 1 + 7) & ~7;
@@ -3421,7 +3456,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
       const uint32_t per_window = (uint32_t)(2.0 * count_windows / (w + 1.0));
       const uint32_t ref_cap = std::min<uint32_t>(kRefCapMax, std::max<uint32_t>(256u, (per_window * 4u / 3u + 63u) / 64u * 64u));
 #ifdef PA_MAP_STATS
-      PA_HIP(hipMemsetAsync(W.run_g.p, 0, 128, c->stream));
+      PA_HIP(hipMemsetAsync(W.run_g.p, 0, 256, c->stream));
 #endif
 #ifdef PA_TOOLS
       const char *cut_env = PA_TOOL_ENV("PA_MAP_CUT");  // tools: the mapping kernel cut short after a phase (timing by difference)
@@ -3478,15 +3513,16 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
       }
 #ifdef PA_MAP_STATS
       if (trace) {
-        uint32_t st[32];
-        PA_HIP(hipMemcpy(st, W.run_g.p, 128, hipMemcpyDeviceToHost));
+        uint32_t st[64];
+        PA_HIP(hipMemcpy(st, W.run_g.p, 256, hipMemcpyDeviceToHost));
         fprintf(stderr, "pa_fragani: map stats: %u segments at L1 with %u hits, %u candidates, %u groups, %u begins past the bound, "
                         "%u rounds, %u stretch entries, %u windows evaluated, %u fine passes, %u cooperative, %u begins in rounds, "
                         "%u begins finished, %u rounds without items, %u second passes, %u windows with an exact value, %u of them at or above the bar, "
                         "%u begins dropped by the tight bound, %u rounds ended by it; rounds by seed hits of the segment (<= 7, 8-15, 16-31, 32-63, "
-                        "64-127, 128-255, more): %u %u %u %u %u %u %u, segments: %u %u %u %u %u %u %u\n",
+                        "64-127, 128-255, more): %u %u %u %u %u %u %u, segments: %u %u %u %u %u %u %u; work model: %u minimizers in the candidates' ranges, "
+                        "%u states tying their candidate's optimum\n",
                 st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15], st[16], st[17],
-                st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27], st[28], st[29], st[30], st[31]);
+                st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27], st[28], st[29], st[30], st[31], st[32], st[33]);
       }
 #endif
     }

@@ -21,9 +21,14 @@ starts = arena.genome_start[:-1].copy()
 lens = np.full(n, length, dtype=np.uint32)
 genome = np.arange(n, dtype=np.uint32)
 eng.prof_enable(True)
-names = {10: "segment header + sketch load", 11: "hits loaded, ordered, staged", 1: "staging + sort + bucket table", 2: "L1", 3: "candidate set-up", 4: "seed-hit bounds per group", 5: "stretch loads + window ends",
-         6: "ranks", 7: "coarse table", 8: "window masks + coarse search", 9: "fine passes (whole kernel)",
-         21: "whole kernel without second passes", 22: "whole kernel without fine passes", 23: "whole kernel, the group of the first seed hit only"}
+# the phases and their numbers come from the kernel's own list (enum MapCut in csrc/fragani.hip)
+import re  # noqa: E402
+
+_src = (Path(__file__).resolve().parent.parent / "pyani_plus_amd" / "csrc" / "fragani.hip").read_text()
+_enum = _src[_src.index("enum MapCut"):]
+_enum = _enum[: _enum.index("};")]
+names = {int(m.group(2)): f"{m.group(1)}: {m.group(3).strip()}" for m in re.finditer(r"(kCut\w+) = (\d+),\s*// (.*)", _enum)}
+assert {9, 10, 11, 1, 2, 3, 4}.issubset(names), names
 prev = 0.0
 cuts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [9, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7, 8, 9]
 for cut in cuts:
