@@ -1350,8 +1350,10 @@ constexpr uint32_t kTinySegment = 8;
 __global__ __launch_bounds__(kThreads) void prefilter_segments_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh,
     const uint32_t *__restrict__ seg_f, uint32_t n_segs, const uint32_t *__restrict__ q_s,
-    const uint32_t *__restrict__ tab_min_hits, uint32_t frag_len, uint32_t *__restrict__ out_a0,
-    uint32_t *__restrict__ out_nh, uint32_t *__restrict__ out_f, uint32_t *__restrict__ counter) {
+    const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ q_cut, uint32_t frag_len, uint32_t *__restrict__ out_a0,
+    uint32_t *__restrict__ out_nh, uint32_t *__restrict__ out_f, unsigned long long *__restrict__ counter, uint32_t sparse_max) {
+  // Kept segments of at most `sparse_max` hits (0: none) whose fragment lost no hash to the frequency cut are listed from
+  // the BACK of the out arrays: map_sparse_kernel takes them, map_segments_kernel the ones listed from the front.
   const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t a0 = 0, nh = 0, f = 0;
@@ -1387,24 +1389,28 @@ __global__ __launch_bounds__(kThreads) void prefilter_segments_kernel(
       }
     }
   }
-  // one draw from the list cursor per workgroup (same-address atomics queue up in the L2, ~11 ns each)
-  __shared__ uint32_t s_kept[kThreads / 64], s_base;
-  const uint64_t km = __ballot(keep);
+  const bool sparse = keep && nh <= sparse_max && q_cut[f] == 0u;
+  // one draw from the two list cursors (one 64-bit word) per workgroup (same-address atomics queue up in the L2, ~11 ns each)
+  __shared__ uint32_t s_kept[kThreads / 64][2], s_base[2];
+  const uint64_t km = __ballot(keep && !sparse), sm = __ballot(sparse);
   const uint32_t wave = threadIdx.x >> 6;
-  if (lane == 0) s_kept[wave] = (uint32_t)__popcll(km);
+  if (lane == 0) { s_kept[wave][0] = (uint32_t)__popcll(km); s_kept[wave][1] = (uint32_t)__popcll(sm); }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t sum = 0;
+    uint32_t sum = 0, ssum = 0;
 #pragma unroll
-    for (int q = 0; q < kThreads / 64; ++q) sum += s_kept[q];
-    s_base = sum ? atomicAdd(counter, sum) : 0u;
+    for (int q = 0; q < kThreads / 64; ++q) { sum += s_kept[q][0]; ssum += s_kept[q][1]; }
+    const unsigned long long got = (sum | ssum) ? atomicAdd(counter, ((unsigned long long)ssum << 32) | sum) : 0ull;
+    s_base[0] = (uint32_t)got;
+    s_base[1] = (uint32_t)(got >> 32);
   }
   __syncthreads();
   if (keep) {
-    uint32_t slot = s_base + (uint32_t)__popcll(km & ((1ULL << lane) - 1ULL));
+    uint32_t slot = s_base[sparse ? 1 : 0] + (uint32_t)__popcll((sparse ? sm : km) & ((1ULL << lane) - 1ULL));
 #pragma unroll
     for (int q = 0; q < kThreads / 64; ++q)
-      if ((uint32_t)q < wave) slot += s_kept[q];
+      if ((uint32_t)q < wave) slot += s_kept[q][sparse ? 1 : 0];
+    if (sparse) slot = n_segs - 1u - slot;  // from the back (n_segs slots in all: the two lists cannot meet)
     out_a0[slot] = a0;
     out_nh[slot] = nh;
     out_f[slot] = f;
@@ -2644,6 +2650,262 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
   }
 }
 
+// ============================================================== 4b. segments of a handful of seed hits
+// A pair of the same species that has diverged far leaves a fragment two to eight seed hits in a reference genome.  Such a
+// segment is the mapping kernel's worst customer: every window that holds its few hits shares the same few minimizers or
+// nearly, so the states that tie the optimum span hundreds of begins -- four or five rounds of ranking a stretch and
+// building bit tables where a window holds eight matches at most (13 % of the segments, a quarter of the rounds at 1 000
+// genomes).  With so few matches the windowed MinHash has a direct form: hit j, of rank r_j among the fragment's hashes,
+// is shared by a window iff it lies in it and r_j + c_j < s, c_j = the window's reference-only minimizers below the hit's
+// hash -- a count over a range of the stretch, two prefix sums per hit and state.  One wave per segment: no sketch, no
+// rank, no table; per group of 64 begins the stretch's hashes are compared with the (at most eight) hit hashes, one bit
+// mask and its prefix counts per hit go to LDS, and every begin evaluates all its states.  Same candidates, same slide,
+// same positions and ties as map_segments_kernel (of which this is the small-segment form); whatever does not fit the
+// simple form -- a hash met twice in a stretch, windows longer than the stretch -- sends the segment to
+// map_segments_kernel through the overflow list.
+constexpr uint32_t kSparseHits = kTinySegment;
+constexpr uint32_t kSparseCap = 384;  // stretch entries of a group of 64 begins (a window holds ~237: 5 sigma to spare)
+__global__ __launch_bounds__(64) void map_sparse_kernel(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh,
+    const uint32_t *__restrict__ seg_f, uint32_t n_segs, const uint32_t *__restrict__ q_s, const uint32_t *__restrict__ q_hash,
+    const uint32_t *__restrict__ frag_genome_local, uint32_t frag_len, uint32_t count_windows,
+    const uint32_t *__restrict__ tab_min_hits, const uint32_t *__restrict__ tab_min_shared,
+    const uint32_t *__restrict__ contig_mini_off, const uint32_t *__restrict__ contig_bucket_off,
+    const uint32_t *__restrict__ bucket_first, const uint32_t *__restrict__ mini_hash, const uint32_t *__restrict__ mini_wpos,
+    const int32_t *__restrict__ prev_same, const uint32_t *__restrict__ contig_bin_off, uint64_t table_stride,
+    unsigned long long *__restrict__ table, uint32_t *__restrict__ over_a0, uint32_t *__restrict__ over_nh,
+    uint32_t *__restrict__ over_f, uint32_t *__restrict__ over_n) {
+  constexpr int kPer = (int)(kSparseCap / 64u);
+  constexpr uint32_t kWords = kSparseCap / 32u;  // 12
+  __shared__ uint32_t s_hc[kSparseHits], s_hw[kSparseHits], s_hr[kSparseHits], s_ph[kSparseHits], s_pos[kSparseHits];
+  __shared__ uint32_t s_cand[kSparseHits][4];
+  __shared__ uint16_t s_refw[kSparseCap];
+  __shared__ uint32_t s_B[kSparseHits][kWords + 1], s_P[kSparseHits][kWords + 1];
+  const uint32_t lane = threadIdx.x;
+  if (blockIdx.x >= n_segs) return;
+  const uint32_t a0 = seg_a0[blockIdx.x], nh = seg_nh[blockIdx.x], f = seg_f[blockIdx.x];
+  const uint32_t s = q_s[f];
+  if (s == 0 || nh > kSparseHits) return;
+  const uint32_t mh = tab_min_hits[s];
+  if (nh < mh) return;
+  const int32_t floor_bar = (int32_t)tab_min_shared[s];
+  {  // the hits in (contig, window id) order, with the rank and the hash of each
+    uint64_t k1[1];
+    const uint64_t raw = lane < nh ? keys[a0 + lane] : 0ULL;
+    k1[0] = lane < nh ? ((raw & 0xfffffffffffULL) << 9) | (raw >> kHitRankShift) : ~0ULL;
+    bitonic_sort_lanes<1, uint64_t>(k1, lane);
+    if (lane < nh) {
+      const uint32_t r = (uint32_t)k1[0] & 0x1ffu;
+      s_hw[lane] = (uint32_t)(k1[0] >> 9) & 0xffffffu;
+      s_hc[lane] = (uint32_t)(k1[0] >> 33) & 0xfffffu;
+      s_hr[lane] = r;
+      s_ph[lane] = q_hash[(uint64_t)f * kQMax + r];
+    }
+  }
+  __syncthreads();
+  // ---- L1 (map_segments_kernel's rule, one after the other: at most eight hits)
+  uint32_t n_cand = 0;
+  {
+    bool have = false, have_prev = false;
+    uint32_t cur_c = 0, cur_cs = 0, cur_ce = 0, cur_fw = 0, prev_c = 0, prev_ce = 0;
+    for (uint32_t i = 0; i + mh <= nh; ++i) {
+      const uint32_t c_i = s_hc[i], ce_i = s_hw[i], yw = s_hw[i + mh - 1u];
+      if (!(s_hc[i + mh - 1u] == c_i && yw - ce_i < frag_len)) continue;
+      const uint32_t cs_i = yw + 1u > frag_len ? yw + 1u - frag_len : 0u;
+      if (!have_prev || prev_c != c_i || cs_i > prev_ce) {
+        if (have) { if (lane == 0) { s_cand[n_cand][0] = cur_c; s_cand[n_cand][1] = cur_cs; s_cand[n_cand][2] = cur_ce; s_cand[n_cand][3] = cur_fw; } ++n_cand; }
+        cur_c = c_i; cur_cs = cs_i; cur_ce = ce_i; cur_fw = ce_i; have = true;
+      } else {
+        cur_ce = max(cur_ce, ce_i);
+      }
+      prev_c = c_i; prev_ce = ce_i; have_prev = true;
+    }
+    if (have) { if (lane == 0) { s_cand[n_cand][0] = cur_c; s_cand[n_cand][1] = cur_cs; s_cand[n_cand][2] = cur_ce; s_cand[n_cand][3] = cur_fw; } ++n_cand; }
+  }
+  __syncthreads();
+  bool overflow = false;
+  int32_t best_shared = -1;
+  uint32_t best_c = 0, best_first = 0, best_last = 0;
+  for (uint32_t ci = 0; ci < n_cand && !overflow; ++ci) {
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cand[ci][0]);
+    const uint32_t cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cand[ci][1]);
+    const uint32_t ce = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_cand[ci][2]);
+    const uint32_t m1 = contig_mini_off[c + 1];
+    const uint32_t bb = contig_bucket_off[c], nb = contig_bucket_off[c + 1] - bb - 1;
+    uint32_t b_lo;
+    {
+      uint32_t bk = cs >> kBucketShift;
+      if (bk >= nb) bk = nb;
+      const uint32_t lo = bucket_first[bb + bk];
+      const uint32_t hi = bk < nb ? bucket_first[bb + bk + 1] : lo;
+      b_lo = hi;
+      for (uint32_t base = lo; base < hi; base += 64) {
+        const uint32_t t = base + lane;
+        const uint64_t ge = __ballot(t < hi && mini_wpos[t] >= cs);
+        if (ge) { b_lo = base + (uint32_t)__builtin_ctzll(ge); break; }
+      }
+    }
+    if (b_lo >= m1) continue;
+    uint32_t b_hi, i_max;
+    {
+      constexpr int kStartBatch = 8;
+      uint32_t wpv[kStartBatch];
+#pragma unroll
+      for (int q = 0; q < kStartBatch; ++q) {
+        const uint32_t t = b_lo + (uint32_t)q * 64u + lane;
+        wpv[q] = t < m1 ? mini_wpos[t] : 0xffffffffu;
+      }
+      const uint32_t limit = ce + frag_len;
+      uint32_t z = 0;
+      bool reached = false;
+#pragma unroll
+      for (int q = 0; q < kStartBatch; ++q) {
+        z = wpv[q] < limit ? max(z, wpv[q]) : z;
+        reached = reached || wpv[q] >= limit;
+      }
+      const uint32_t wp_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)wpv[0]);
+      if (wp_lo >= limit) continue;
+      if (__any(reached)) {
+        z = pa_dev::wave_max_dpp(z);
+      } else {  // a range of more than 512 minimizers (two far-apart runs merged): through the bucket index, as the general kernel does
+        const uint32_t last_end = wpos_lower_bound(mini_wpos, bucket_first, bb, nb, limit);
+        z = mini_wpos[last_end - 1];
+      }
+      if (z < wp_lo + count_windows) continue;
+      i_max = z - count_windows;
+      uint32_t my_over = 0xffffffffu;
+#pragma unroll
+      for (int q = kStartBatch - 1; q >= 0; --q) my_over = wpv[q] > i_max ? (uint32_t)q * 64u + lane : my_over;
+      const uint32_t w_over = pa_dev::wave_min_dpp(my_over);
+      b_hi = w_over != 0xffffffffu ? b_lo + w_over : wpos_lower_bound(mini_wpos, bucket_first, bb, nb, i_max + 1u);
+    }
+    if (b_lo >= b_hi) continue;
+    int32_t c_best = -1;
+    uint32_t c_first = 0, c_last = 0;
+    const uint32_t n_groups = (b_hi - b_lo + 63u) / 64u;
+    for (uint32_t g = 0; g < n_groups && !overflow; ++g) {
+      const uint32_t sb = b_lo + g * 64u, b = sb + lane;
+      const bool has = b < b_hi;
+      const uint32_t wp = has ? mini_wpos[b] : 0u;
+      const uint32_t wp_next = (has && b + 1u < m1) ? mini_wpos[b + 1u] : 0xffffffffu;
+      const uint32_t w_end = min(wp_next - 1u, i_max) + count_windows;  // window ids below this: the begin's widest window
+      int32_t bar = c_best > best_shared ? c_best : best_shared;
+      if (bar < floor_bar) bar = floor_bar;
+      uint32_t held = 0;  // seed hits inside the begin's widest window: no window of the begin shares more
+      for (uint32_t i = 0; i < nh; ++i) held += (s_hc[i] == c && s_hw[i] >= wp && s_hw[i] < w_end) ? 1u : 0u;
+      const bool pending = has && (int32_t)held >= bar;
+      if (!__any(pending)) continue;
+      const uint32_t first_lane = (uint32_t)__builtin_ctzll(__ballot(pending));
+      const uint32_t base = sb + first_lane, n = min(m1 - base, kSparseCap);
+      const uint32_t wbase = mini_wpos[base];
+      __syncthreads();
+      uint32_t hh[kPer];
+      bool any_dup = false;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const uint32_t x = (uint32_t)q * 64u + lane;
+        const bool in = x < n;
+        const uint32_t t = base + min(x, n - 1u);
+        const uint32_t h = mini_hash[t], dw = mini_wpos[t] - wbase;
+        const int32_t pv = prev_same[t];
+        hh[q] = in ? h : 0xffffffffu;
+        any_dup = any_dup || (in && pv >= (int32_t)base);
+        s_refw[x] = (uint16_t)((dw > 0xfffeu || !in) ? 0xffffu : dw);
+      }
+      if (__any(any_dup)) { overflow = true; break; }  // a hash twice in the stretch: the windows' distinct hashes are the general kernel's to count
+      __syncthreads();
+      const bool at_end = base + n == m1;
+      auto first_at_or_after = [&](uint32_t lo, uint32_t target) -> uint32_t {
+        uint32_t hi = n;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)s_refw[mid] < target) lo = mid + 1; else hi = mid; }
+        return lo;
+      };
+      const bool lane_on = pending && lane >= first_lane;
+      uint32_t xs = 0, xe_lo = 0, xe_hi = 0;
+      if (lane_on) {
+        xs = b - base;
+        xe_lo = first_at_or_after(min(xs, n), wp + count_windows - wbase);  // (a target past 0xfffe finds nothing: the window runs past the stretch)
+        xe_hi = first_at_or_after(xe_lo, w_end - wbase);
+      }
+      if (__any(lane_on && !(xe_hi < n || at_end))) { overflow = true; break; }  // a window runs past the stretch
+      // where the hits sit in the stretch
+      if (lane < nh) {
+        uint32_t p = 0xffffffffu;
+        if (s_hc[lane] == c && s_hw[lane] >= wbase && s_hw[lane] - wbase < 0xffffu) {
+          const uint32_t x = first_at_or_after(0u, s_hw[lane] - wbase);
+          if (x < n && (uint32_t)s_refw[x] == s_hw[lane] - wbase) p = x;
+        }
+        s_pos[lane] = p;
+      }
+      // per hit: the stretch entries that are reference-only (no hit's hash) and below the hit's hash, as bits, with the
+      // counts of the bits before each word
+      uint32_t is_match = 0;
+      for (uint32_t i = 0; i < nh; ++i) {
+        const uint32_t ph = s_ph[i];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) is_match |= (hh[q] == ph ? 1u : 0u) << q;
+      }
+      for (uint32_t i = 0; i < nh; ++i) {
+        const uint32_t ph = s_ph[i];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const uint64_t mb = __ballot(((uint32_t)q * 64u + lane < n) & (hh[q] < ph) & (((is_match >> q) & 1u) == 0u));
+          if (lane == 0) { s_B[i][2 * q] = (uint32_t)mb; s_B[i][2 * q + 1] = (uint32_t)(mb >> 32); }
+        }
+      }
+      __syncthreads();
+      for (uint32_t i = 0; i < nh; ++i) {
+        const uint32_t pc = lane < kWords ? (uint32_t)__popc(s_B[i][lane]) : 0u;
+        const uint32_t inc = pa_dev::wave_incl_scan_dpp(pc);
+        if (lane < kWords) s_P[i][lane] = inc - pc;
+        if (lane == kWords - 1u) { s_P[i][kWords] = inc; s_B[i][kWords] = 0u; }
+      }
+      __syncthreads();
+      // every state of every pending begin: the window holds the stretch entries [xs, e), e from the begin's first end to its last
+      int32_t lane_best = -1;
+      const uint32_t most = pa_dev::wave_max_dpp(lane_on ? xe_hi - xe_lo + 1u : 0u);
+      for (uint32_t t = 0; t < most; ++t) {
+        const uint32_t e = xe_lo + t;
+        if (!(lane_on && e <= xe_hi)) continue;
+        int32_t shared = 0;
+        for (uint32_t i = 0; i < nh; ++i) {
+          const uint32_t p = s_pos[i];
+          if (!(p != 0xffffffffu && p >= xs && p < e)) continue;
+          const uint32_t we = e >> 5, ws = xs >> 5;
+          const uint32_t ce_ = s_P[i][we] + (uint32_t)__popc(s_B[i][we] & ((1u << (e & 31u)) - 1u));
+          const uint32_t cs_ = s_P[i][ws] + (uint32_t)__popc(s_B[i][ws] & ((1u << (xs & 31u)) - 1u));
+          shared += (s_hr[i] + (ce_ - cs_) < s) ? 1 : 0;
+        }
+        lane_best = max(lane_best, shared);
+      }
+      // fold: most shared; window ids of the first and of the last begin that has it (a state's position is its begin's)
+      const int32_t group_best = (int32_t)pa_dev::wave_max_dpp(lane_on ? (uint32_t)(lane_best + 1) : 0u) - 1;
+      if (__any(lane_on) && group_best >= c_best) {
+        const uint64_t top = __ballot(lane_on && lane_best == group_best);
+        const uint32_t w_first = __shfl(wp, __builtin_ctzll(top), 64), w_last = __shfl(wp, 63 - __builtin_clzll(top), 64);
+        c_last = group_best > c_best ? w_last : max(c_last, w_last);
+        c_first = group_best > c_best ? w_first : min(c_first, w_first);
+        c_best = group_best;
+      }
+    }
+    if (overflow) break;
+    if (c_best >= 0 && c_best >= best_shared) { best_shared = c_best; best_c = c; best_first = c_first; best_last = c_last; }  // of equals, the last
+  }
+  if (overflow) {  // (rare: one draw per such segment)
+    if (lane == 0) {
+      const uint32_t slot = atomicAdd(over_n, 1u);
+      over_a0[slot] = a0; over_nh[slot] = nh; over_f[slot] = f;
+    }
+    return;
+  }
+  if (lane == 0 && best_shared >= 0 && (uint32_t)best_shared >= tab_min_shared[s]) {
+    const uint64_t jq = ((uint64_t)best_shared << 30) / s;
+    const unsigned long long packed = ((unsigned long long)jq << 32) | ((unsigned long long)best_shared << 16) | s;
+    const uint64_t bin = contig_bin_off[best_c] + (best_first + best_last) / 2u / (frag_len - 20u);
+    atomicMax(&table[(uint64_t)frag_genome_local[f] * table_stride + bin], packed);
+  }
+}
+
 // ============================================================== 5. per-pair reduction
 // One wave per (query of the batch, reference genome): kept fragments and the sum of their identities.  fastANI holds the
 // identities as floats and adds them up in a float, in (contig, bin) order; a float sum depends on its order, so the wave
@@ -2693,7 +2955,7 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at, seg_f, seg2_f, amb_pos, amb_byte;
+      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at, seg_f, seg2_f, amb_pos, amb_byte, seg_over;
   // the arena's residues that are neither ACGT nor N (pa_fragani_set_ambiguous), and the arena they belong to
   const void *amb_for = nullptr;
   uint32_t amb_n = 0;
@@ -2718,7 +2980,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at, &seg_f, &seg2_f, &amb_pos, &amb_byte};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at, &seg_f, &seg2_f, &amb_pos, &amb_byte, &seg_over};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -3492,19 +3754,44 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
           PA_TRY(W.seg2_a0.reserve((uint64_t)n_keep * 4 + 16));
           PA_TRY(W.seg2_nh.reserve((uint64_t)n_keep * 4 + 16));
           PA_TRY(W.seg2_f.reserve((uint64_t)n_keep * 4 + 16));
-          PA_HIP(hipMemsetAsync(d_seg_counters + 6, 0, 4, c->stream));
+          // segments of at most kSparseHits hits go to map_sparse_kernel (listed from the back of the same arrays), unless
+          // the hits carry their ranks in the sort's payload (a batch ordered as a whole)
+          uint32_t sparse_max = presorted ? 0u : kSparseHits;
+          if (const char *v = PA_TOOL_ENV("PA_FRAGANI_SPARSE")) sparse_max = atoi(v) ? kSparseHits : 0u;  // tests: 0 = every segment through the general kernel
+          unsigned long long *d_pre_cursor = reinterpret_cast<unsigned long long *>(d_seg_counters + 6);  // [6] general, [7] sparse (8-byte aligned)
+          PA_HIP(hipMemsetAsync(d_pre_cursor, 0, 8, c->stream));
           hipLaunchKernelGGL(prefilter_segments_kernel, dim3(ceil_div_u64(n_keep, kThreads)), dim3(kThreads), 0, c->stream,
                              hk[hw], W.seg_a0.as<uint32_t>(), W.seg_nh.as<uint32_t>(), W.seg_f.as<uint32_t>(), n_keep,
-                             W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(), frag_len, W.seg2_a0.as<uint32_t>(),
-                             W.seg2_nh.as<uint32_t>(), W.seg2_f.as<uint32_t>(), d_seg_counters + 6);
-          PA_HIP(hipMemcpyAsync(c->h_pinned, d_seg_counters + 6, 4, hipMemcpyDeviceToHost, c->stream));
+                             W.q_s.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(), W.q_cut.as<uint32_t>(), frag_len, W.seg2_a0.as<uint32_t>(),
+                             W.seg2_nh.as<uint32_t>(), W.seg2_f.as<uint32_t>(), d_pre_cursor, sparse_max);
+          PA_HIP(hipMemcpyAsync(c->h_pinned, d_pre_cursor, 8, hipMemcpyDeviceToHost, c->stream));
           PA_HIP(hipStreamSynchronize(c->stream));
-          const uint32_t n_small = *reinterpret_cast<const uint32_t *>(c->h_pinned);
+          const uint32_t n_small = (uint32_t)c->h_pinned[0], n_sparse = (uint32_t)(c->h_pinned[0] >> 32);
           if (trace)
             fprintf(stderr, "pa_fragani: genomes %u..%u: %u fragments, %llu seed hits, %u + %u listed segments, %u left "
                             "after the tiny-segment filter\n", g0, g1, nf, (unsigned long long)n_hits, n_keep, n_large, n_small);
           PA_TRY(launch_map(W.seg2_a0.as<uint32_t>(), W.seg2_nh.as<uint32_t>(), W.seg2_f.as<uint32_t>(), n_small, (uint32_t)kHitCapSmall,
                             std::true_type{}));
+          if (n_sparse) {
+            const uint32_t at = n_keep - n_sparse;  // the sparse list sits at the back of the same arrays
+            PA_TRY(W.seg_over.reserve((uint64_t)n_sparse * 12 + 16));
+            uint32_t *over_a0 = W.seg_over.as<uint32_t>(), *over_nh = over_a0 + n_sparse, *over_f = over_nh + n_sparse;
+            uint32_t *d_over_n = W.scalars.as<uint32_t>() + 3;
+            PA_HIP(hipMemsetAsync(d_over_n, 0, 4, c->stream));
+            hipLaunchKernelGGL(map_sparse_kernel, dim3(n_sparse), dim3(64), 0, c->stream, hk[hw], W.seg2_a0.as<uint32_t>() + at,
+                               W.seg2_nh.as<uint32_t>() + at, W.seg2_f.as<uint32_t>() + at, n_sparse, W.q_s.as<uint32_t>(), q_hash_p,
+                               W.frag_genome_local.as<uint32_t>(), frag_len, count_windows, W.tab_min_hits.as<uint32_t>(),
+                               W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(), W.contig_bucket_off.as<uint32_t>(),
+                               W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(),
+                               W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), range_bins, table_p, over_a0, over_nh, over_f,
+                               d_over_n);
+            PA_HIP(hipMemcpyAsync(c->h_pinned, d_over_n, 4, hipMemcpyDeviceToHost, c->stream));
+            PA_HIP(hipStreamSynchronize(c->stream));
+            const uint32_t n_over = *reinterpret_cast<const uint32_t *>(c->h_pinned);
+            if (trace) fprintf(stderr, "pa_fragani: %u segments of at most %u hits in the sparse kernel, %u of them handed on\n", n_sparse, kSparseHits, n_over);
+            // what does not fit the simple form (a hash twice in a stretch, over-long windows or ranges) goes through the general kernel
+            PA_TRY(launch_map(over_a0, over_nh, over_f, n_over, (uint32_t)kHitCapSmall, std::true_type{}));
+          }
         }
         PA_TRY(launch_map(W.seg_a0.as<uint32_t>() + large_at, W.seg_nh.as<uint32_t>() + large_at, W.seg_f.as<uint32_t>() + large_at, n_large,
                           (uint32_t)kHitCap, std::false_type{}));

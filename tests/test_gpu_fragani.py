@@ -815,3 +815,46 @@ def test_iupac_letters_are_hashed_as_fastani_hashes_them(engine):
     h_n, _wp, _ct = engine.fragani_sketch(engine.upload(plain), plain.contig_start, plain.contig_len, plain.contig_genome, 16, 24)
     all_n = [bytes(c if c in b"ACGTacgt" else ord("N") for c in contig) for contigs in contig_lists for contig in contigs]
     assert np.array_equal(h_n, np.concatenate([oracle.fragani_minimizers(c, 16, 24)[0] for c in all_n]))
+
+
+def test_sparse_segments_equal_the_general_kernel(tools_engine, monkeypatch):
+    """Segments of at most eight seed hits -- diverged pairs -- take ``map_sparse_kernel`` (the hit-by-hit form of the windowed
+    MinHash); with ``PA_FRAGANI_SPARSE=0`` (tools build) they go through ``map_segments_kernel`` like the rest.  Same
+    integers and float sums either way, and the oracle's: pairs at 15 to 25 % divergence (a handful of hits per fragment),
+    with repeats (a hash twice in a stretch: handed on), runs of N, short contigs and contig ends."""
+    engine = tools_engine  # the -DPA_TOOLS build: the switch below exists there only
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(515)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    root = rng.choice(acgt, size=60_000)
+    root[20_000:23_000] = root[5_000:8_000]  # a dispersed repeat
+    genomes = []
+    for rate in (0.0, 0.08, 0.12, 0.16, 0.2):
+        seq = root.copy()
+        hit = rng.random(seq.size) < rate
+        seq[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+        genomes.append(seq)
+    genomes[2][30_000:30_200] = ord("N")
+    cuts = [[60_000], [25_000, 35_000], [60_000], [3_100, 56_900], [60_000]]
+    texts, contig_lists = [], []
+    for g, seq in enumerate(genomes):
+        contigs, pos = [], 0
+        for n in cuts[g]:
+            contigs.append(seq[pos : pos + n].tobytes())
+            pos += n
+        contig_lists.append(contigs)
+        texts.append(b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs)))
+    arena = pack_genomes(texts)
+    dev = engine.upload(arena)
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PA_FRAGANI_SPARSE", mode)
+        monkeypatch.setenv("PA_FRAGANI_TRACE", "1")
+        results[mode] = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    for a, b in zip(results["1"], results["0"]):
+        assert np.array_equal(a, b)
+    monkeypatch.setenv("PA_FRAGANI_SPARSE", "1")
+    total, matched, _ = _check_against_oracle(engine, texts, contig_lists)
+    assert matched[0, 4] > 0 and matched[4, 0] > 0  # the most diverged pair still maps fragments: through the sparse kernel
+    _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
