@@ -2663,7 +2663,7 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
 // same positions and ties as map_segments_kernel (of which this is the small-segment form); whatever does not fit the
 // simple form -- a hash met twice in a stretch, windows longer than the stretch -- sends the segment to
 // map_segments_kernel through the overflow list.
-constexpr uint32_t kSparseHits = kTinySegment;
+constexpr uint32_t kSparseHits = kTinySegment;  // (16: 426 ms of mapping per 1 000-genome run against 419)
 constexpr uint32_t kSparseCap = 384;  // stretch entries of a group of 64 begins (a window holds ~237: 5 sigma to spare)
 __global__ __launch_bounds__(64) void map_sparse_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ seg_a0, const uint32_t *__restrict__ seg_nh,
