@@ -2615,6 +2615,11 @@ __global__ __launch_bounds__(64, PA_MAP_WAVES) void map_segments_kernel(
         chunk += 64;
       }
     }
+    // A turn that lists nothing (most do: a segment of 139 hits is three chunks and ends with ONE candidate) goes straight on.
+    if (n_list == 0u) {
+      if (tail) break;
+      continue;
+    }
     // The scan's state sits in LDS while the listed candidates are evaluated: kept in registers across the evaluation --
     // the register-hungriest part of the kernel -- it was spilled to scratch memory (HBM traffic, and a wait) at every turn.
     if (lane == 0) {

@@ -16,6 +16,12 @@ from pathlib import Path
 import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os  # noqa: E402
+
+from pyani_plus_amd import _capi  # noqa: E402
+
+if os.environ.get("PA_AB_LIB"):  # tools/ab_fragani.sh: time another build of the library (A/B on one box)
+    _capi.LIB_PATH = Path(os.environ["PA_AB_LIB"]).resolve()
 from pyani_plus_amd.engine import HipEngine  # noqa: E402
 from pyani_plus_amd.synth import synth_arena_torch  # noqa: E402
 

@@ -16,8 +16,13 @@ bash tools/pmc_passes.sh ${TAG}_hash kmer_hash tools/pmc_hash.py 1000
 # the fragment-ANI kernels at the benchmark's 1 000 genomes, one batch of 2^17 query fragments (78 query genomes) per repetition
 bash tools/pmc_passes.sh ${TAG}_fragmap "map_segments_kernel<320u, true>" tools/bench_fragani.py 1000 0 interleaved 78
 bash tools/pmc_passes.sh ${TAG}_bucket bucket_hits tools/bench_fragani.py 1000 0 interleaved 78
-# seed hits per bucket_hits dispatch of that run (the denominator of its bytes per hit)
-PA_FRAGANI_TRACE=1 python3 tools/bench_fragani.py 1000 0 interleaved 78 2>&1 | grep "seed hits" | head -1 > gpurun_out/${TAG}_fragani1000_onebatch_trace.txt
+# seed hits per bucket_hits dispatch of that run (the denominator of its bytes per hit) and the mapping kernels' event counts
+# (the switches live in the tools build: tools/map_stats.py loads libpyani_hip_stats.so, `make -C pyani_plus_amd/csrc stats`)
+python3 tools/map_stats.py 1000 78 2>&1 | grep "pa_fragani:" > gpurun_out/${TAG}_fragani1000_onebatch_trace.txt
+# where the mapping kernel's time goes: the kernel cut short after each phase (tools build)
+python3 tools/map_cut.py 1000 9,9,10,11,1,2,3,4,9,23,9 > gpurun_out/${TAG}_map_cut.txt 2>&1
+# the bench line itself, un-profiled
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 for d in gpurun_out/${TAG}_stats_bench gpurun_out/${TAG}_stats_fragani; do
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then
