@@ -724,11 +724,18 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
     seed_ms = prof.get("frag_seed", (0.0, 0))[0] / 2
     if map_ms > 0:
         mc = (counters or {}).get("map_segments_kernel", {})
+        work = mc.get("work") or {}
         out["roofline"] = {
-            "kernel": "map_segments_kernel", "bound": "issue",
-            "what": "vector and scalar instruction issue of one wave per (fragment, reference genome) segment; no HBM or MFMA roof applies "
-            "(integer/index work on LDS-resident data)",
-            "frac": mc.get("valu_busy"), "valu_busy": mc.get("valu_busy"), "salu_busy": mc.get("salu_busy"),
+            "kernel": "map_segments_kernel", "bound": "valu-issue",
+            "what": "vector instruction issue of one wave per (fragment, reference genome) segment; no HBM or MFMA roof applies "
+            "(integer/index work on LDS-resident data).  frac = the vector instructions the dispatch NEEDS (work model) / the vector "
+            "instructions it ISSUED (SQ_INSTS_VALU); the pipe itself is valu_busy full while the kernel runs",
+            "frac": work.get("frac"), "work_model": work.get("work_model"),
+            "algorithmic_units_per_dispatch": work.get("algorithmic_units_per_dispatch"),
+            "valu_instructions_per_unit": work.get("valu_instructions_per_unit"),
+            "algorithmic_valu_instructions_per_dispatch": work.get("algorithmic_valu_instructions_per_dispatch"),
+            "counted_valu_instructions_per_dispatch": work.get("counted_valu_instructions_per_dispatch"),
+            "valu_busy": mc.get("valu_busy"), "salu_busy": mc.get("salu_busy"),
             "wait_share_of_wave_time": mc.get("wait_share"), "waves_per_simd": mc.get("waves_per_simd"),
             "definition": "valu_busy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / (GRBM_GUI_ACTIVE / 8); salu_busy = SQ_INSTS_SALU / CUs / (GRBM_GUI_ACTIVE / 8) "
             "(one scalar unit per CU); the two pipes issue side by side, so the busier one is the fraction of the issue roof",

@@ -4,8 +4,8 @@
 copied to profiles/: the benchmark's 1 000 genomes, one batch of 2^17 query fragments per repetition).  bench.py copies
 these figures into `also.fragment_ani.roofline*`, labelled as coming from these passes.
 
-    python tools/pmc_fragani_to_json.py profiles/r04_pmc_map_segments_summary.txt profiles/r04_pmc_bucket_hits_summary.txt \
-        <seed hits per bucket_hits dispatch> [workload label]
+    python tools/pmc_fragani_to_json.py profiles/r05_pmc_map_segments_summary.txt profiles/r05_pmc_bucket_hits_summary.txt \
+        <seed hits per bucket_hits dispatch> [workload label] [profiles/r05_fragani_n1000_one_batch_trace.txt: event counts for the work model]
 """
 import json
 import re
@@ -27,10 +27,57 @@ def parse(path: Path) -> dict:
     return out
 
 
+# ---- the work model of map_segments_kernel (profiles/README.md, "Work-based roofline of the mapping kernel")
+# Units, from the event counters of the stats build (tools/map_stats.py, one dispatch = one batch of 2^17 fragments):
+#   S segments that reach L1, H their seed hits, C candidates, W states that tie their candidate's optimum (no bound can
+#   spare them; one probe where nothing was evaluated).
+# Algorithmic work of a dispatch: every segment set up once (sketch loaded and bucketed, candidate set up), every hit
+# ordered and scanned once, per candidate the minimizers of ONE window (2 count_windows / (w + 1) = 237 expected for
+# k = 16, fragLen = 3000) plus one per further tying state ranked and entered in the bit tables once, one exact window
+# evaluation per tying state.  Costs in vector instructions of a wave per unit: the kernel's own, from the static listing
+# (tools/isa_lines.py on the build the counters come from) with the loop trip counts of the benchmark.
+WORK_COSTS = {
+    "per_segment": 400.0,   # record + sketch load 75, bucket table of the sketch 80, candidate set-up 160, result 20, L1 tail 65
+    "per_hit": 11.6,        # ordered in registers (36 stages x 4 keys x ~5.5 = 800 per <= 256 hits), L1 scan 348 per 64 hits, staged: / 139 hits
+    "per_entry": 2.4,       # stretch load + window ends 200, ranks 190, match bitmap 50, coarse table 320: 760 per round of 320 entries
+    "per_window": 13.0,     # window mask + coarse search 410, fine pass 285 x 1.2, fold 80: 830 per pass of 64 windows
+}
+WINDOW_ENTRIES = 237.0
+
+
+def work_model(trace_file: Path, valu_instructions: float) -> dict:
+    text = trace_file.read_text()
+    m = re.search(r"map stats: (\d+) segments at L1 with (\d+) hits, (\d+) candidates", text)
+    w = re.search(r"work model: (\d+) minimizers in the candidates' ranges, (\d+) states tying", text)
+    if not m or not w:
+        return {"error": f"no event counts in {trace_file.name}"}
+    seg, hits, cand = (float(x) for x in m.groups())
+    range_entries, ties = (float(x) for x in w.groups())
+    entries = cand * WINDOW_ENTRIES + ties
+    parts = {
+        "segments": seg * WORK_COSTS["per_segment"], "hits": hits * WORK_COSTS["per_hit"],
+        "entries": entries * WORK_COSTS["per_entry"], "windows": ties * WORK_COSTS["per_window"],
+    }
+    total = sum(parts.values())
+    return {
+        "work_model": "vector instructions a dispatch needs with a perfect bound: each segment set up once, each seed hit ordered and scanned "
+        "once, per candidate the minimizers of one window (237) plus one per further state tying the optimum ranked once, one exact window "
+        "evaluation per tying state; per-unit costs are the kernel's own (static listing x loop trips), profiles/README.md",
+        "algorithmic_units_per_dispatch": {"segments": seg, "seed_hits": hits, "candidates": cand, "tying_states": ties,
+                                           "entries_of_one_window_per_candidate_plus_ties": entries, "minimizers_in_candidate_ranges": range_entries},
+        "valu_instructions_per_unit": WORK_COSTS,
+        "algorithmic_valu_instructions_per_dispatch": total, "algorithmic_valu_instructions_by_unit": parts,
+        "counted_valu_instructions_per_dispatch": valu_instructions,
+        "frac": total / valu_instructions if valu_instructions else None,
+        "events_source": trace_file.name,
+    }
+
+
 def main() -> None:
     map_file, bucket_file = Path(sys.argv[1]), Path(sys.argv[2])
     hits_per_dispatch = float(sys.argv[3]) if len(sys.argv) > 3 else None
     what = sys.argv[4] if len(sys.argv) > 4 else "tools/bench_fragani.py 1000 0 interleaved 78 (the benchmark's 1 000 genomes, one batch of 2^17 query fragments)"
+    trace_file = Path(sys.argv[5]) if len(sys.argv) > 5 else None
     m, b = parse(map_file), parse(bucket_file)
     cycles = m["GRBM_GUI_ACTIVE"] / XCDS
     out = {
@@ -47,6 +94,8 @@ def main() -> None:
             "fetch_bytes_per_dispatch_as_counted": m.get("FETCH_SIZE", 0.0) * 1024, "write_bytes_per_dispatch": m.get("WRITE_SIZE", 0.0) * 1024,
         },
     }
+    if trace_file is not None:
+        out["map_segments_kernel"]["work"] = work_model(trace_file, m["SQ_INSTS_VALU"])
     cyc_b = b["GRBM_GUI_ACTIVE"] / XCDS
     # FETCH_SIZE / WRITE_SIZE are KiB per dispatch.  The guide's gfx950 rule (FETCH_SIZE reports half the bytes) is
     # calibrated for wide coalesced streaming reads; this kernel reads 2- and 8-byte items scattered over short lists,
