@@ -1040,3 +1040,49 @@ def test_native_sig_writer_equals_python_writer_and_fixture(tmp_path):
         max_hash=sketch["max_hash"], sketches=[np.array(sketch["mins"], dtype=np.uint64)],
     )  # fmt: skip
     assert (tmp_path / "fixture.sig").read_bytes() == fixture.read_bytes()
+
+
+# ------------------------------------------------------------------ measurement plumbing that needs no GPU
+def test_bench_dry_run_plan_of_the_eight_gpu_configs():
+    """``bench.py --gpus 8 --dry-run-plan``: the 8-rank run on paper (no GPU, no torch).  The per-rank shards, the padded
+    all-gather sizes and the strong_basis memory need follow from the same shard arithmetic the ranks use."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--dry-run-plan"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    plan = json.loads(out.stdout)
+    assert plan["world"] == 8 and plan["genomes"] == 10_000 and len(plan["ranks"]) == 8
+    assert [r["genomes"] for r in plan["ranks"]] == [[1250 * i, 1250 * (i + 1)] for i in range(8)]
+    pay = plan["collectives_per_step"][1]
+    assert pay["bytes_per_rank"] == plan["padded_payload_hashes"] * 8 >= 1250 * 5000 * 8
+    for r in plan["ranks"]:
+        assert r["allgather_payload_bytes_received"] == 8 * pay["bytes_per_rank"]
+        assert r["torch_cat_after_gather"] and r["payload_staging_copy"]  # FracMinHash totals differ between ranks: both are taken
+        assert r["device_bytes_estimate"] < 0.05 * plan["hbm_bytes"]
+    basis = plan["strong_basis"]
+    assert basis["fits_hbm"] and basis["within_watchdog"] and basis["full_arena_bytes"] > 18e9
+    assert json.loads((ROOT / "profiles" / "r05_plan_config2_8gpu.json").read_text())["ranks"] == plan["ranks"]  # the committed plan is this one
+    mixed = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8", "--genomes", "2000", "--mixed-lengths", "--dry-run-plan"],
+                           capture_output=True, text=True, timeout=120)
+    plan4 = json.loads(mixed.stdout)
+    assert sum(r["n_genomes"] for r in plan4["ranks"]) == 2000 and plan4["shard_balance_bases_max_over_mean"] < 1.02
+
+
+def test_work_based_roofline_is_reproducible_from_the_committed_profiles():
+    """``also.fragment_ani.roofline.frac`` = events x cost / counted instructions, from files under profiles/: the event counts
+    of the stats build, the per-unit costs, SQ_INSTS_VALU of the counter pass."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("pmc_fragani_to_json", ROOT / "tools" / "pmc_fragani_to_json.py")
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    counters = json.loads((ROOT / "profiles" / "fragani_counters.json").read_text())["map_segments_kernel"]
+    summary = tool.parse(ROOT / "profiles" / "r05_pmc_map_segments_summary.txt")
+    work = tool.work_model(ROOT / "profiles" / "r05_fragani_n1000_one_batch_trace.txt", summary["SQ_INSTS_VALU"])
+    assert work["frac"] == counters["work"]["frac"] and 0.3 < work["frac"] < 1.0
+    u, c = work["algorithmic_units_per_dispatch"], tool.WORK_COSTS
+    by_hand = (u["segments"] * c["per_segment"] + u["seed_hits"] * c["per_hit"]
+               + (u["candidates"] * tool.WINDOW_ENTRIES + u["tying_states"]) * c["per_entry"] + u["tying_states"] * c["per_window"])
+    assert abs(by_hand / summary["SQ_INSTS_VALU"] - work["frac"]) < 1e-12
+    assert counters["valu_instructions"] == summary["SQ_INSTS_VALU"]
