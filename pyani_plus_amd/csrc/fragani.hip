@@ -15,12 +15,16 @@
 //                         inside the fragment + the one still active at the first window at which the
 //                         fragment, sketched alone as fastANI does it, selects any): sort, de-duplicate
 //                         in LDS, no re-hashing
-//   4. seed hits           every posting of every sketch hash -> (fragment, ref contig, window id),
-//                         bucketed by reference genome; one wave per (fragment, reference genome)
-//                         segment then orders its hits in registers, applies the L1 run test and
+//   4. seed hits           every posting of every sketch hash -> (rank of the hash in the sketch, ref contig, window id),
+//                         bucketed by reference genome (one fragment per workgroup, the listed pairs' hits
+//                         staged in LDS and written as whole slices); one wave per (fragment, reference
+//                         genome) segment then orders its hits in registers, applies the L1 run test and
 //                         slides the fragment over every candidate range: the winnowed-MinHash Jaccard
 //                         of every window that could be the optimum (bit tables over query rank x
-//                         reference position in LDS, no per-window sort); of equally good candidates the last
+//                         reference position in LDS, no per-window sort; a tight bound from the hits' ranks
+//                         and one hash comparison per stretch entry decides which windows that is); segments
+//                         of at most eight hits take the hit-by-hit form (map_sparse_kernel); of equally
+//                         good candidates the last
 //   5. one best fragment per reference bin by atomicMax on (J, shared, s); per pair the kept
 //      fragments and the float sum of their float identities in bin order (fastANI's arithmetic).
 #include <cmath>
