@@ -44,7 +44,8 @@ def test_tool_switches_are_not_in_the_product_library():
     ``PA_TOOL_ENV`` and exist in ``libpyani_hip_tools.so`` (-DPA_TOOLS) only: the product library does not hold their names,
     so no variable in a worker's environment can change what it computes.  Both libraries export the whole header."""
     names = set()
-    for src in (ROOT / "pyani_plus_amd" / "csrc").glob("*.hip"):
+    csrc = ROOT / "pyani_plus_amd" / "csrc"
+    for src in [*csrc.glob("*.hip"), *csrc.glob("*.inc")]:
         text = src.read_text()
         names |= set(re.findall(r'PA_TOOL_ENV\("([A-Z_]+)"\)', text))
         # nothing in the kernels' sources reads the environment any other way

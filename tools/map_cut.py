@@ -21,10 +21,10 @@ starts = arena.genome_start[:-1].copy()
 lens = np.full(n, length, dtype=np.uint32)
 genome = np.arange(n, dtype=np.uint32)
 eng.prof_enable(True)
-# the phases and their numbers come from the kernel's own list (enum MapCut in csrc/fragani.hip)
+# the phases and their numbers come from the kernel's own list (enum MapCut in csrc/fragani_map.inc)
 import re  # noqa: E402
 
-_src = (Path(__file__).resolve().parent.parent / "pyani_plus_amd" / "csrc" / "fragani.hip").read_text()
+_src = (Path(__file__).resolve().parent.parent / "pyani_plus_amd" / "csrc" / "fragani_map.inc").read_text()
 _enum = _src[_src.index("enum MapCut"):]
 _enum = _enum[: _enum.index("};")]
 names = {int(m.group(2)): f"{m.group(1)}: {m.group(3).strip()}" for m in re.finditer(r"(kCut\w+) = (\d+),\s*// (.*)", _enum)}
