@@ -43,6 +43,11 @@
  * as fastANI wrote them.  tests/test_fragani_oracle.py asserts exactly that.  Not pinned by any of those values --
  * it changes none of the 25 rows -- and applied because fastANI does: the frequency cut of the seeds (OPT_FREQ; the
  * bacterial fixtures lose the seeds of 2 to 4 minimizers each: thresholds 26, 56, 26 and 21 occurrences).
+ *
+ * Two forms of the L2 evaluation: the CHECKING form (default; every state's window gathered, ordered and merged: slow and
+ * plain, what every parity test compares the device with) and a TUNED form (orc_fragani_set_fast: the window kept as the
+ * slide moves, ~12 x faster on related genomes) that bench.py times as the CPU baseline of the fragment-ANI leg;
+ * tests/test_fragani_oracle.py holds the tuned form to all 25 rows and pins too, and to the checking form mapping by mapping.
  */
 #include <math.h>
 #ifdef _OPENMP
@@ -319,6 +324,98 @@ static int shared_in_bottom_s(const uint32_t *q, int s, const uint32_t *win, int
   return shared;
 }
 
+/* ------------------------------------------------------------------ the tuned form of the L2 evaluation (CPU baseline)
+ * The checking form above gathers, orders and merges the hashes of EVERY state of the slide: ~5 s per related pair of 5 Mb
+ * genomes.  The tuned form keeps the window as the slide moves -- what Mashmap's own L2 does with its ordered map --:
+ * every minimizer of the candidate's range is ranked against the fragment's hashes once (its number of smaller fragment
+ * hashes, and whether it IS one), a count per hash says whether it is in the window (a hash counts once however often it
+ * occurs), two Fenwick trees over the ranks hold the distinct reference-only hashes and the matching ones, and a state's
+ * value is a search over the first and a prefix sum of the second: the fragment's hash of rank r lies in the bottom-s of
+ * the union iff r + (reference-only hashes of rank <= r) < s.  Same states, same positions, same ties: only the
+ * arithmetic per state differs, and tests/test_fragani_oracle.py holds the two forms to each other.  Switched on by
+ * orc_fragani_set_fast (bench.py's cpu_baseline leg, kind "port"); every parity check uses the checking form. */
+static int g_fast = 0;
+ORC_API void orc_fragani_set_fast(int on) { g_fast = on; }
+
+typedef struct {
+  int s, room_s;         /* sketch size of the fragment at hand: ranks 0 .. s; what the trees have room for */
+  int *ref_tree;         /* Fenwick over ranks 0 .. s: distinct reference-only hashes in the window by rank */
+  int *match_tree;       /* Fenwick over ranks 0 .. s-1: fragment hashes present in the window */
+  uint32_t *keys;        /* open table of the candidate at hand: hash -> occurrences in the window, and its rank */
+  int *counts;
+  int *ranks;            /* rank << 1 | is a fragment hash */
+  uint32_t *stamp;       /* a slot belongs to the candidate whose number it carries: no clearing between candidates */
+  uint32_t mask, generation;
+} SlideWin;
+
+static void fen_add(int *t, int n, int i, int d) { for (++i; i <= n; i += i & -i) t[i] += d; }
+static int fen_prefix(const int *t, int i) { int r = 0; for (; i > 0; i -= i & -i) r += t[i]; return r; } /* sum of [0, i) */
+
+static void slide_free(SlideWin *w) {
+  free(w->ref_tree); free(w->match_tree); free(w->keys); free(w->counts); free(w->ranks); free(w->stamp);
+  memset(w, 0, sizeof(*w));
+}
+
+/* ready for one candidate of a fragment with s hashes whose range holds `entries` minimizers */
+static int slide_begin(SlideWin *w, int s, size_t entries) {
+  if (s > w->room_s || !w->ref_tree) {
+    free(w->ref_tree); free(w->match_tree);
+    w->room_s = s + 64;
+    w->ref_tree = (int *)malloc(sizeof(int) * ((size_t)w->room_s + 3));
+    w->match_tree = (int *)malloc(sizeof(int) * ((size_t)w->room_s + 3));
+    if (!w->ref_tree || !w->match_tree) return -1;
+  }
+  w->s = s;
+  memset(w->ref_tree, 0, sizeof(int) * ((size_t)s + 3));
+  memset(w->match_tree, 0, sizeof(int) * ((size_t)s + 3));
+  if (!w->keys || 2 * entries + 16 > (size_t)w->mask + 1) {
+    uint32_t cap = 1024;
+    while ((size_t)cap < 4 * entries + 16) cap <<= 1;
+    free(w->keys); free(w->counts); free(w->ranks); free(w->stamp);
+    w->keys = (uint32_t *)malloc(sizeof(uint32_t) * cap);
+    w->counts = (int *)malloc(sizeof(int) * cap);
+    w->ranks = (int *)malloc(sizeof(int) * cap);
+    w->stamp = (uint32_t *)calloc(cap, sizeof(uint32_t));
+    if (!w->keys || !w->counts || !w->ranks || !w->stamp) return -1;
+    w->mask = cap - 1;
+    w->generation = 0;
+  }
+  if (++w->generation == 0) { memset(w->stamp, 0, sizeof(uint32_t) * ((size_t)w->mask + 1)); w->generation = 1; }
+  return 0;
+}
+
+/* the slot of hash h in the candidate's table; a new one gets its rank among the fragment's hashes */
+static uint32_t slide_slot(SlideWin *w, uint32_t h, const uint32_t *qh) {
+  uint32_t at = (h * 0x9e3779b1u) & w->mask;
+  while (w->stamp[at] == w->generation && w->keys[at] != h) at = (at + 1) & w->mask;
+  if (w->stamp[at] != w->generation) {
+    int lo = 0, hi = w->s; /* the number of fragment hashes below h */
+    while (lo < hi) { const int mid = (lo + hi) / 2; if (qh[mid] < h) lo = mid + 1; else hi = mid; }
+    w->stamp[at] = w->generation; w->keys[at] = h; w->counts[at] = 0;
+    w->ranks[at] = lo << 1 | (lo < w->s && qh[lo] == h);
+  }
+  return at;
+}
+static void slide_enter(SlideWin *w, uint32_t h, const uint32_t *qh) {
+  const uint32_t at = slide_slot(w, h, qh);
+  if (w->counts[at]++ != 0) return; /* the hash is in the window already */
+  fen_add((w->ranks[at] & 1) ? w->match_tree : w->ref_tree, w->s + 1, w->ranks[at] >> 1, +1);
+}
+static void slide_leave(SlideWin *w, uint32_t h, const uint32_t *qh) {
+  const uint32_t at = slide_slot(w, h, qh);
+  if (--w->counts[at] != 0) return; /* other occurrences stay */
+  fen_add((w->ranks[at] & 1) ? w->match_tree : w->ref_tree, w->s + 1, w->ranks[at] >> 1, -1);
+}
+/* shared minimizers of the window: T = the first rank r with r + (reference-only hashes of rank <= r) >= s; the matches below T */
+static int slide_shared(const SlideWin *w) {
+  int lo = 0, hi = w->s; /* T in [0, s] */
+  while (lo < hi) {
+    const int mid = (lo + hi) / 2;
+    if (mid + fen_prefix(w->ref_tree, mid + 1) >= w->s) hi = mid; else lo = mid + 1;
+  }
+  return fen_prefix(w->match_tree, lo);
+}
+
 /* One record per query fragment that maps: fragment index (running over contigs), reference contig,
  * reference window id of the mapping, shared minimizers and sketch size. */
 typedef struct { int32_t frag, ref_seq, ref_pos, shared, s; } FragMap;
@@ -453,6 +550,7 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
   MiniVec qm = {0, 0, 0};
   Mini *hits = NULL; size_t hits_cap = 0;
   uint32_t *winh = NULL; size_t win_cap = 0;
+  SlideWin slide; memset(&slide, 0, sizeof(slide));
   const int64_t count_windows = (int64_t)frag_len - (w - 1) - (k - 1);
 
   /* A fragment is sketched on its own, as fastANI does it (winnowing restarts at the fragment's first residue).  The HIP
@@ -525,14 +623,23 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
           int64_t i = rpos.v[b].wpos;
           size_t e = lower_bound_pos(rpos.v, c1, cseq, i + count_windows);
           int c_best = -1; int64_t c_first = 0, c_last = 0;
+          size_t in_b = b, in_e = b; /* the tuned form: the window it holds, [in_b, in_e) */
+          if (g_fast && slide_begin(&slide, s, (last_end < c1 ? last_end : c1) - b + 1)) return -1;
           while (e != last_end && !(stop >= 1 && i > cands[ci].end)) {
+            int sh;
+            if (g_fast) {
+              for (; in_e < e; ++in_e) slide_enter(&slide, rpos.v[in_e].hash, qh);
+              for (; in_b < b; ++in_b) slide_leave(&slide, rpos.v[in_b].hash, qh);
+              sh = slide_shared(&slide);
+            } else {
             const size_t nw = e - b;
             if (nw > win_cap) { win_cap = nw * 2 + 64; winh = (uint32_t *)realloc(winh, win_cap * sizeof(uint32_t)); }
             for (size_t t = 0; t < nw; ++t) winh[t] = rpos.v[b + t].hash;
             qsort(winh, nw, sizeof(uint32_t), cmp_u32);
             size_t u = 0;
             for (size_t t = 0; t < nw; ++t) if (t == 0 || winh[t] != winh[t - 1]) winh[u++] = winh[t];
-            const int sh = shared_in_bottom_s(qh, s, winh, (int)u);
+            sh = shared_in_bottom_s(qh, s, winh, (int)u);
+            }
             /* the next event: minimizer b + 1 becomes the active one, or minimizer e enters at the end */
             const int64_t next_b = b + 1 < c1 ? (int64_t)rpos.v[b + 1].wpos : INT64_MAX;
             const int64_t next_e = e < c1 ? (int64_t)rpos.v[e].wpos - count_windows + 1 : INT64_MAX;
@@ -623,7 +730,7 @@ static int map_fragments_ix(const uint8_t *q_seq, const uint64_t *q_off, uint32_
       if (i + 1 == n_emit || emit[i + 1].frag != emit[i].frag) maps[n_maps++] = emit[i];
   }
   free(emit);
-  free(qm.v); free(hits); free(winh);
+  free(qm.v); free(hits); free(winh); slide_free(&slide);
   *maps_out = maps; *n_maps_out = n_maps; *total_out = total;
   return 0;
 }

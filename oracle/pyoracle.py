@@ -197,6 +197,15 @@ def fragani_set_option(name: str, value: float) -> None:
     _load_frag().orc_fragani_set_option(FRAGANI_OPTIONS[name], float(value))
 
 
+def fragani_set_fast(on: bool) -> None:
+    """The tuned form of the L2 evaluation (the window kept as the slide moves) instead of the checking form; process-wide.
+    bench.py's CPU-baseline leg times it; parity checks use the checking form (tests/test_fragani_oracle.py holds the two equal)."""
+    lib = _load_frag()
+    lib.orc_fragani_set_fast.restype = None
+    lib.orc_fragani_set_fast.argtypes = [C.c_int]
+    lib.orc_fragani_set_fast(1 if on else 0)
+
+
 def fragani_get_option(name: str) -> float:
     return float(_load_frag().orc_fragani_get_option(FRAGANI_OPTIONS[name]))
 

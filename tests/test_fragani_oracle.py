@@ -207,3 +207,89 @@ def test_fastani_mean_is_a_float_quotient():
     assert float(fastani_mean(float(total), m)) == ani and fastani_print_round(ani) == 99.9953
     got = fastani_mean(np.array([[float(total), 0.0]]), np.array([[m, 0]], dtype=np.uint32))
     assert got.shape == (1, 2) and got[0, 0] == ani and np.isnan(got[0, 1])
+
+
+# ---------------------------------------------------------------- the tuned form of the L2 evaluation (bench.py's CPU baseline)
+def _pair_tuned(pair):
+    from oracle import pyoracle
+
+    q, r = pair
+    pyoracle.fragani_set_fast(True)
+    try:
+        return oracle.fragani_pair(contigs_of(GOLDEN / "bacterial_example" / q), contigs_of(GOLDEN / "bacterial_example" / r), K, FRAG, 0.2)
+    finally:
+        pyoracle.fragani_set_fast(False)
+
+
+def test_tuned_form_reproduces_every_fastani_row():
+    """The oracle's tuned L2 (the window kept as the slide moves: what bench.py times as the CPU baseline) against everything
+    the checking form is pinned to: all 16 bacterial and all 9 viral rows, the self hits of the two small contigs."""
+    from concurrent.futures import ProcessPoolExecutor
+
+    from oracle import pyoracle
+
+    rows = {(a, b): (ani, m, t) for a, b, ani, m, t in fixture_rows("bacterial_example")}
+    assert len(rows) == 16
+    with ProcessPoolExecutor(max_workers=8) as pool:
+        for (q, r), got in zip(rows, pool.map(_pair_tuned, list(rows))):
+            bacterial_row_bounds(q, r, *rows[(q, r)], *got)
+    pyoracle.fragani_set_fast(True)
+    try:
+        genomes = {p.name: contigs_of(p) for p in (GOLDEN / "viral_example").glob("*.f*")}
+        for q, r, ani, matched, total in fixture_rows("viral_example"):
+            got_ani, got_m, got_t = oracle.fragani_pair(genomes[q], genomes[r], K, FRAG, 0.2)
+            assert (got_m, got_t) == (matched, total) and printed(got_ani) == ani, (q, r)
+        small, large = contigs_of(GOLDEN / "MIBY01000005.fasta"), contigs_of(GOLDEN / "MIBY01000011.fasta")
+        assert oracle.fragani_pair(small, small, K, FRAG, 0.2) == (100.0, 2, 2)
+        ani, m, t = oracle.fragani_pair(large, large, K, FRAG, 0.2)
+        assert (m, t) == (6, 6) and printed(ani) == 99.9953
+    finally:
+        pyoracle.fragani_set_fast(False)
+
+
+def test_tuned_form_equals_the_checking_form_fragment_by_fragment():
+    """Every mapping (fragment, contig, position, shared, sketch size) of the two forms on sequences made to stress the window
+    bookkeeping: repeats inside and across contigs (a hash several times in one window), low-complexity stretches (few
+    distinct hashes: the union shorter than the sketch), runs of N, mutated copies at several rates, short contigs, k = 15 /
+    fragLen 2000 as the coverage fixtures use."""
+    from oracle import pyoracle
+
+    rng = np.random.default_rng(11)
+    letters = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def mutate(seq: np.ndarray, rate: float) -> np.ndarray:
+        out = seq.copy()
+        at = rng.random(len(out)) < rate
+        out[at] = rng.choice(letters, size=int(at.sum()))
+        return out
+
+    base = rng.choice(letters, size=60_000)
+    unit = rng.choice(letters, size=700)
+    ref = base.copy()
+    ref[5_000:12_000] = np.tile(unit, 10)                    # a tandem repeat: every hash ten times over
+    ref[20_000:23_000] = ref[30_000:33_000]                  # an exact repeat a fragment long
+    ref[40_000:40_400] = np.frombuffer(b"ACAC" * 100, dtype=np.uint8)  # low complexity
+    ref[50_000:50_120] = ord("N")
+    refs = [ref[:41_000].tobytes(), ref[41_000:].tobytes(), rng.choice(letters, size=3_500).tobytes()]
+    queries = [
+        [mutate(ref, 0.0).tobytes()],
+        [mutate(ref, 0.02)[1_234:].tobytes()],
+        [mutate(ref, 0.08).tobytes(), mutate(ref[:9_000], 0.15).tobytes()],
+        [np.tile(unit, 30).tobytes()],
+        [rng.choice(letters, size=20_000).tobytes()],
+    ]
+    compared = 0
+    for k, frag in ((16, 3000), (15, 2000), (16, 1000)):
+        for q in queries:
+            pyoracle.fragani_set_fast(False)
+            slow, total = oracle.fragani_map(q, refs, k, frag)
+            pyoracle.fragani_set_fast(True)
+            try:
+                fast, total_f = oracle.fragani_map(q, refs, k, frag)
+            finally:
+                pyoracle.fragani_set_fast(False)
+            assert total == total_f
+            for name in slow:
+                assert np.array_equal(slow[name], fast[name]), (k, frag, name)
+            compared += len(slow["frag"])
+    assert compared > 150
