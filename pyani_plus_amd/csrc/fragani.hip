@@ -349,7 +349,7 @@ int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint3
     PA_TRY(W.mini_contig.reserve(cap * 4 + 16));
     PA_HIP(hipMemsetAsync(W.block_counts.p, 0, (uint64_t)blocks * 8, c->stream));
     PA_HIP(hipMemsetAsync(W.scalars.p, 0, 16, c->stream));
-    hipLaunchKernelGGL((minimizer_kernel<K>), dim3(blocks), dim3(kThreads), 0, c->stream,
+    hipLaunchKernelGGL((minimizer_kernel<K>), dim3(blocks), dim3(kMiniThreads), 0, c->stream,
                        d_packed, d_mask, arena_bases, W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
                        W.block_counts.as<unsigned long long>(), W.scalars.as<uint32_t>(), (uint32_t)cap,
                        W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>(), blocks, W.ambiguous(d_packed));
@@ -704,7 +704,10 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   // ---- batches of query genomes
   // Query genomes go through in batches of up to 2^17 fragments (13 batches for 1 000 genomes of 5 Mb: 1.46 s against
   // 1.48 s with 2^16).  A batch whose seed hits do not fit 31-bit indices is halved and started again.
-  uint32_t batch_frags = 1u << 17;
+#ifndef PA_FRAGANI_BATCH_FRAGS
+#define PA_FRAGANI_BATCH_FRAGS (1u << 17)
+#endif
+  uint32_t batch_frags = PA_FRAGANI_BATCH_FRAGS;
   uint64_t hit_limit = 1ULL << 31;
   if (const char *v = PA_TOOL_ENV("PA_FRAGANI_BATCH_HITS")) hit_limit = std::max<uint64_t>(1, strtoull(v, nullptr, 10));  // tests: force the halving
   const uint64_t kMaxTableBytes = 1ULL << 31;
