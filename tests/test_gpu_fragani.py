@@ -192,6 +192,26 @@ def test_reference_of_hundreds_of_contigs(engine):
     assert total[1] == 320  # one fragment per contig of the draft
 
 
+def test_draft_assemblies_of_ten_kilobase_contigs(engine):
+    """Genomes handed over as contigs of 10 000 residues at fastANI's defaults (three fragments and a remainder per contig,
+    every contig's last window short of its end): what `tools/bench_fragani.py 1000 0 interleaved 1000 1000 500` times.  A
+    genome keeps fewer of its own fragments than a one-contig genome does -- and exactly as many as the oracle says."""
+    rng = np.random.default_rng(21)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    root = rng.choice(acgt, size=24 * 10_000)
+    contig_lists = []
+    for rate in (0.0, 0.01, 0.06):
+        seq = root.copy()
+        hit = rng.random(seq.size) < rate
+        seq[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+        contig_lists.append([seq[i * 10_000 : (i + 1) * 10_000].tobytes() for i in range(24)])
+    contig_lists.append([root.tobytes()])  # the same sequence in one piece
+    texts = [b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs)) for contigs in contig_lists]
+    total, matched, _ = _check_against_oracle(engine, texts, contig_lists)
+    assert total[0] == 24 * 3 and total[3] == 80
+    assert matched[0, 0] <= total[0] and matched[3, 3] >= 79
+
+
 def test_batches_are_halved_when_the_seed_hits_outgrow_their_indices(tools_engine, monkeypatch):
     """A batch of query genomes whose seed hits pass 2^31 is halved and started again; forced here with a limit of a few
     thousand hits, down to one query genome per batch.  Same integers as the one-batch run and as the oracle."""
