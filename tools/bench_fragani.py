@@ -61,5 +61,10 @@ related = ~np.isnan(ani)
 print("fragments per genome", int(total[0]), "pairs with mappings", int(related.sum()), "ANI range", float(np.nanmin(ani)), float(np.nanmax(ani)))
 # (a draft of 10 kb contigs keeps 69 of its own 72 fragments per 24 contigs -- the slide's end rule at every contig's end, as the oracle: tests/test_gpu_fragani.py)
 assert np.all(np.diag(matched)[: min(n_query, n_ref)] >= (0.99 if n_contigs == 1 else 0.9) * total[: min(n_query, n_ref)])
-out = {"n": n, "query_genomes": n_query, "reference_genomes": n_ref, "seconds": dt, "pairs_per_s": n_query * n_ref / dt}
+import hashlib  # noqa: E402
+
+# every integer and every float sum of the run in one line: two builds of the library agree on it or they differ somewhere
+digest = hashlib.sha256(total.tobytes() + matched.tobytes() + ident_sum.tobytes()).hexdigest()[:16]
+print("results sha256/16", digest, "kept fragments", int(matched.sum()))
+out = {"n": n, "query_genomes": n_query, "reference_genomes": n_ref, "seconds": dt, "pairs_per_s": n_query * n_ref / dt, "results_sha16": digest}
 print(json.dumps(out))
