@@ -205,7 +205,7 @@ struct FragWork {
       contig_mini_off, keys[2], vals[2], flags, mini_id, post_start, prev_same, sorted_idx, frag_contig, frag_no,
       frag_genome_local, q_hash, q_pos, q_id, q_s, hit_count, hit_off, hkeys[2], hvals[2], seg_start, tab_min_hits,
       tab_min_shared, ident_tab, contig_bin_off, genome_bin_off, table, matched, ident_sum, scalars, run_g, seg_list, seg2_a0, seg2_nh, post_cw, seg_a0, seg_nh, genome_first_contig,
-      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at, seg_f, seg2_f, amb_pos, amb_byte, seg_over;
+      contig_bucket_off, bucket_first, post_g, seg_rec, hash_cut, q_cut, post_cw2, post_g2, run_hist, long_runs, frag_d, uniq_hash, lookup_at, seg_f, seg2_f, amb_pos, amb_byte, seg_over, q_tab;
   // the arena's residues that are neither ACGT nor N (pa_fragani_set_ambiguous), and the arena they belong to
   const void *amb_for = nullptr;
   uint32_t amb_n = 0;
@@ -230,7 +230,7 @@ struct FragWork {
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
-                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at, &seg_f, &seg2_f, &amb_pos, &amb_byte, &seg_over};
+                     &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at, &seg_f, &seg2_f, &amb_pos, &amb_byte, &seg_over, &q_tab};
     for (DevBuf *b : all) b->release();
   }
 };
@@ -776,6 +776,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
       }
     }
     PA_TRY(W.q_s.reserve((uint64_t)nf * 4));
+    PA_TRY(W.q_tab.reserve((uint64_t)nf * kQtBuckets * 2));  // the sketches' bucket tables
     PA_TRY(W.q_cut.reserve((uint64_t)nf * 4));
     PA_TRY(W.hit_count.reserve((uint64_t)nf * 4));
     PA_TRY(W.hit_off.reserve((uint64_t)nf * 4));
@@ -791,7 +792,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_id.as<uint32_t>(),
                        W.post_start.as<uint32_t>(), q_hash_p, q_pos_p,
                        q_id_p, W.q_s.as<uint32_t>(), W.hit_count.as<uint32_t>(), d_overflow, d_max_hits,
-                       W.q_cut.as<uint32_t>(), restricted ? W.lookup_at.as<uint4>() : nullptr, W.index_lookup_bits);
+                       W.q_cut.as<uint32_t>(), restricted ? W.lookup_at.as<uint4>() : nullptr, W.index_lookup_bits, W.q_tab.as<uint32_t>());
     PA_TRY(pa_exclusive_scan_u32(c, W.hit_count.as<uint32_t>(), W.hit_off.as<uint32_t>(), nf, W.scalars.as<uint64_t>()));
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 8, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipMemcpyAsync(c->h_pinned + 1, d_max_hits, 8, hipMemcpyDeviceToHost, c->stream));
@@ -991,7 +992,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
 #define PA_MAP_CASE(CAP)                                                                                                  \
   case CAP:                                                                                                               \
     hipLaunchKernelGGL((map_segments_kernel<CAP, kAll>), dim3(count), dim3(64), eval_lds_bytes(s_cap, hit_cap, CAP) + PA_MAP_LDS_PAD, c->stream,  \
-                       hk[hw], hv[hw], W.seg_rec.as<uint4>(), count, presorted, q_hash_p,                                  \
+                       hk[hw], hv[hw], W.seg_rec.as<uint4>(), count, presorted, q_hash_p, W.q_tab.as<uint32_t>(),          \
                        W.frag_genome_local.as<uint32_t>(), frag_len, count_windows,                                        \
                        W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(),                                  \
                        W.contig_bucket_off.as<uint32_t>(), W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(),      \
