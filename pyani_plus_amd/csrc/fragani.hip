@@ -982,10 +982,11 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
                             auto all_staged) -> int {
         if (count == 0) return PA_OK;
         constexpr bool kAll = decltype(all_staged)::value;
-        PA_TRY(W.seg_rec.reserve((uint64_t)count * 32));
+        PA_TRY(W.seg_rec.reserve((uint64_t)count * 48));
         hipLaunchKernelGGL(segment_records_kernel, dim3(ceil_div_u64(count, kThreads)), dim3(kThreads), 0, c->stream, hk[hw],
                            list_a0, list_nh, list_f, count, W.q_s.as<uint32_t>(), W.q_cut.as<uint32_t>(), W.tab_min_hits.as<uint32_t>(),
-                           W.tab_min_shared.as<uint32_t>(), W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(), W.seg_rec.as<uint4>());
+                           W.tab_min_shared.as<uint32_t>(), W.contig_genome.as<uint32_t>(), W.genome_first_contig.as<uint32_t>(),
+                           W.contig_mini_off.as<uint32_t>(), W.contig_bucket_off.as<uint32_t>(), W.frag_genome_local.as<uint32_t>(), W.seg_rec.as<uint4>());
 #ifndef PA_MAP_LDS_PAD
 #define PA_MAP_LDS_PAD 0u  // (an experiment's switch: LDS asked for and not used, to see what a wave less per SIMD costs)
 #endif
