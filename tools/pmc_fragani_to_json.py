@@ -37,7 +37,7 @@ def parse(path: Path) -> dict:
 # evaluation per tying state.  Costs in vector instructions of a wave per unit: the kernel's own, from the static listing
 # (tools/isa_lines.py on the build the counters come from) with the loop trip counts of the benchmark.
 WORK_COSTS = {
-    "per_segment": 400.0,   # record + sketch load 75, bucket table of the sketch 80, candidate set-up 160, result 20, L1 tail 65
+    "per_segment": 320.0,   # record + sketch load 75, candidate set-up 160, result 20, L1 tail 65 (the sketch's bucket table, 80, is made once per fragment by query_sketch_kernel since the end of round 5)
     "per_hit": 11.6,        # ordered in registers (36 stages x 4 keys x ~5.5 = 800 per <= 256 hits), L1 scan 348 per 64 hits, staged: / 139 hits
     "per_entry": 2.4,       # stretch load + window ends 200, ranks 190, match bitmap 50, coarse table 320: 760 per round of 320 entries
     "per_window": 13.0,     # window mask + coarse search 410, fine pass 285 x 1.2, fold 80: 830 per pass of 64 windows
