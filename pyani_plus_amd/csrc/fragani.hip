@@ -1015,7 +1015,7 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
           // segments of at most kSparseHits hits go to map_sparse_kernel (listed from the back of the same arrays), unless
           // the hits carry their ranks in the sort's payload (a batch ordered as a whole)
           uint32_t sparse_max = presorted ? 0u : kSparseHits;
-          if (const char *v = PA_TOOL_ENV("PA_FRAGANI_SPARSE")) sparse_max = atoi(v) ? kSparseHits : 0u;  // tests: 0 = every segment through the general kernel
+          if (const char *v = PA_TOOL_ENV("PA_FRAGANI_SPARSE")) sparse_max = (atoi(v) && !presorted) ? kSparseHits : 0u;  // tests: 0 = every segment through the general kernel (the switch can only take the sparse kernel away: its key layout is the bucketed one)
           unsigned long long *d_pre_cursor = reinterpret_cast<unsigned long long *>(d_seg_counters + 6);  // [6] general, [7] sparse (8-byte aligned)
           PA_HIP(hipMemsetAsync(d_pre_cursor, 0, 8, c->stream));
           hipLaunchKernelGGL(prefilter_segments_kernel, dim3(ceil_div_u64(n_keep, kThreads)), dim3(kThreads), 0, c->stream,

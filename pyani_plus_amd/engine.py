@@ -55,17 +55,24 @@ class HostArena:
         return int(self.genome_start[-1])
 
 
-def _text_ambiguous(lib, text: bytes, fasta: bool) -> tuple[np.ndarray, np.ndarray]:
-    """(positions relative to the genome's first, upper-cased bytes) of the residues that are neither ACGT nor N."""
-    if not len(text):
+def _text_ambiguous(lib, text: bytes, fasta: bool, at_most: int | None = None) -> tuple[np.ndarray, np.ndarray]:
+    """(positions relative to the genome's first, upper-cased bytes) of the residues that are neither ACGT nor N.
+
+    ``at_most``: a bound on their number the caller already has (the packer's count of invalid residues, N included):
+    the list then comes out of ONE pass over the text instead of a counting pass and a filling pass."""
+    if not len(text) or at_most == 0:
         return np.zeros(0, np.uint64), np.zeros(0, np.uint8)
-    n = int(lib.pa_text_ambiguous(text, len(text), int(fasta), None, None, 0))
-    if n < 0:
-        raise HipBackendError(f"pa_text_ambiguous failed: {_capi.last_error()}")
-    pos, byte = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint8)
-    if n:
-        lib.pa_text_ambiguous(text, len(text), int(fasta), pos.ctypes.data, byte.ctypes.data, n)
-    return pos, byte
+    if at_most is None:
+        at_most = int(lib.pa_text_ambiguous(text, len(text), int(fasta), None, None, 0))
+        if at_most < 0:
+            raise HipBackendError(f"pa_text_ambiguous failed: {_capi.last_error()}")
+        if at_most == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.uint8)
+    pos, byte = np.zeros(at_most, dtype=np.uint64), np.zeros(at_most, dtype=np.uint8)
+    n = int(lib.pa_text_ambiguous(text, len(text), int(fasta), pos.ctypes.data, byte.ctypes.data, at_most))
+    if n < 0 or n > at_most:
+        raise HipBackendError(f"pa_text_ambiguous failed: {_capi.last_error() if n < 0 else f'{n} residues against a bound of {at_most}'}")
+    return pos[:n].copy(), byte[:n].copy()
 
 
 def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
@@ -103,7 +110,7 @@ def pack_genomes(texts: list[bytes], *, fasta: bool = True) -> HostArena:
             c_len.append(len(text))
             c_genome.append(g)
         if ninv.value:
-            ap, ab = _text_ambiguous(lib, bytes(text), fasta)
+            ap, ab = _text_ambiguous(lib, buf, fasta, at_most=int(ninv.value))  # (ninv counts the N too: a bound, one pass)
             a_pos.append(ap + np.uint64(pos))
             a_byte.append(ab)
         starts[g] = pos

@@ -1042,7 +1042,12 @@ def _compute_missing_fastani(logger, conn, session, run: Run, tmp_dir: Path, eng
                 for tile in r.get("tiles") or sorted(str(t) for t in work_dir.glob(f"{fastani_hip.METHOD}.rank_{rank}.tile_*.npz")):
                     try:
                         _cfg, queries, subjects, ident, cov, null, aln, sim = wire.load_tile(Path(tile), with_proxies=True)
-                    except (ValueError, OSError, KeyError, zipfile.BadZipFile) as err:  # a rank ended while it wrote: the other ranks' batches still go in
+                    except (ValueError, OSError, KeyError, zipfile.BadZipFile) as err:
+                        # tiles are written under another name and renamed: a rank that ended while it wrote (interrupted, or
+                        # ended by this process) may leave an unreadable one, and the other ranks' batches still go in; from
+                        # a rank that reported success it is damage, and the run must not end quietly incomplete
+                        if not r.get("interrupted"):
+                            raise
                         logger.warning("Skipping unreadable tile file %s of rank %d: %s", tile, rank, err)
                         continue
                     blocks.append((queries, subjects, ident, aln, sim, cov, null))

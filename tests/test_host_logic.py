@@ -511,6 +511,38 @@ def test_native_row_insert_equals_the_python_one(tmp_path):
     assert status == _capi.PA_E_IO and "no such table" in _capi.last_error()
 
 
+def test_environment_selectors_pick_equivalent_implementations(tmp_path):
+    """The product library reads four environment variables, each choosing between implementations that must be
+    indistinguishable by their results: PA_GUNZIP=z (zlib instead of the library's own inflate, csrc/fasta_batch.cpp),
+    PA_PACK_SCALAR (the per-character packer instead of the AVX2 one, csrc/pack_host.cpp), PA_HOST_SLAB_CACHE=0 (no
+    reuse of host mappings between batches) and PA_SQLITE_SYNCHRONOUS=OFF (csrc/sqlite_ingest.cpp).  A child process per
+    setting -- three of the four are read once per process -- loads the reference's gzipped bacteria and two plain files
+    twice, packs a text that takes every packer path, and inserts a matrix natively: checksums (the reference's genome
+    identity, utils.py:178-196), lengths, arenas, ambiguity lists and database rows are the same under every setting."""
+    import os
+    import subprocess
+    import sys
+
+    paths = [GOLDEN / "bacterial_example" / f for f in ("NC_002696.fasta.gz", "NC_010338.fna.gz")] + [GOLDEN / "viral_example" / "OP073605.fasta", GOLDEN / "MIBY01000005.fasta"]
+    settings = {"default": {}, "zlib": {"PA_GUNZIP": "z"}, "scalar": {"PA_PACK_SCALAR": "1"}, "no_slab_cache": {"PA_HOST_SLAB_CACHE": "0"},
+                "sync_off": {"PA_SQLITE_SYNCHRONOUS": "OFF"}, "all": {"PA_GUNZIP": "z", "PA_PACK_SCALAR": "1", "PA_HOST_SLAB_CACHE": "0", "PA_SQLITE_SYNCHRONOUS": "OFF"}}
+    results = {}
+    for name, extra in settings.items():
+        work = tmp_path / name
+        work.mkdir()
+        env = {k: v for k, v in os.environ.items() if not k.startswith("PA_")}
+        env.update(extra)
+        done = subprocess.run([sys.executable, str(Path(__file__).parent / "tools" / "env_selectors_child.py"), str(work), *map(str, paths)],
+                              env=env, capture_output=True, text=True, timeout=600, check=False)
+        assert done.returncode == 0, f"{name}: {done.stderr[-2000:]}"
+        results[name] = json.loads(done.stdout.strip().splitlines()[-1])
+    base = results["default"]
+    assert base["load_0"] == base["load_1"] and base["n_rows"] == 23 * 23
+    assert base["load_0"]["md5"][0] == "f19cb07198a41a4406a22b2f57a6b5e7"  # NC_002696 as the reference names it (tests/fixtures/bacterial_example)
+    for name, got in results.items():
+        assert got == base, f"PA_* setting {name!r} changed a result"
+
+
 def test_driver_rejects_duplicates_and_bad_gzip(tmp_path):
     d = tmp_path / "in"
     d.mkdir()
