@@ -59,7 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive passes (keeps a rocprof kernel trace to the timed steps' launches)")
     ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other BASELINE configs")
-    ap.add_argument("--also", default="bottom,k51,mixed,n10000,fragani", help="comma list of the extra runs at N=1")
+    ap.add_argument("--also", default="bottom,k51,mixed,n10000,fragani,config1", help="comma list of the extra runs at N=1 (config1: BASELINE configs[0] from files, the last key of the line)")
     ap.add_argument("--also-fragani-genomes", type=int, default=1000)
     ap.add_argument("--also-n", type=int, default=10000)
     ap.add_argument("--no-fresh-child", action="store_true", help="skip the fresh-process fragment-ANI call (a child started before this process touches the GPU)")
@@ -625,6 +625,60 @@ def also_n10000(engine, args) -> dict:
     }
 
 
+def config1_files() -> dict:
+    """BASELINE configs[0] on SURVEY.md 8(d)'s third clock, T_file: the four gzipped bacteria of the reference's own
+    fixture set (tests/golden/bacterial_example = /root/reference/tests/fixtures/bacterial_example, copied as data) go from
+    FASTA files on disk through this build's run driver -- the counterpart of `pyani-plus sourmash <dir> -d <db> --create-db`
+    (pyani_plus/public_cli.py:598-639): file discovery, checksums, sketches, `.sig` cache, the worker's JSON column file,
+    import, matrix cache -- to a SQLite database on disk.  IN THE RUN the identity and query-coverage matrices exported from
+    that database are compared with the reference's own tests/fixtures/bacterial_example/matrices/sourmash_{identity,
+    coverage}.tsv at the reference's tolerance (atol 2e-8, tests/snakemake/__init__.py:125-144), NULL pattern included."""
+    import tempfile
+
+    from pyani_plus_amd import rundb
+
+    golden = ROOT / "tests" / "golden" / "bacterial_example"
+
+    def read_matrix(path: Path):
+        rows = [line.rstrip("\n").split("\t") for line in path.read_text().splitlines()]
+        labels = rows[0][1:]
+        assert [r[0] for r in rows[1:]] == labels, f"{path.name}: row and column labels differ"
+        return labels, np.array([[float(v) if v not in ("", "nan", "NaN") else np.nan for v in r[1:]] for r in rows[1:]])
+
+    seconds, phases = [], None
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = Path(tmp)
+        for rep in range(3):  # the first run of the process also pays for the context and the first touch of its buffers
+            timings: dict = {}
+            t0 = time.perf_counter()
+            run = rundb.run_sourmash_hip(golden, tmp / f"run{rep}.sqlite", cache=tmp / f"cache{rep}", temp=tmp / f"work{rep}", timings=timings)
+            seconds.append(time.perf_counter() - t0)
+            phases = {k: round(float(v), 4) for k, v in timings.items()}
+        n = len(run.fasta_hashes)
+        written = rundb.export_run(tmp / "run2.sqlite", tmp / "export")
+        by_name = {w.name: w for w in written}
+        worst = 0.0
+        for ours, theirs in ((f"{run.configuration.method}_identity.tsv", "sourmash_identity.tsv"), (f"{run.configuration.method}_query_cov.tsv", "sourmash_coverage.tsv")):
+            got_labels, got = read_matrix(by_name[ours])
+            want_labels, want = read_matrix(golden / "matrices" / theirs)
+            if got_labels != want_labels or not np.array_equal(np.isnan(got), np.isnan(want)):
+                raise SystemExit(f"PARITY FAILURE: config1_files: labels or NULL pattern of {ours} differ from the reference's {theirs}")
+            diff = float(np.nanmax(np.abs(got - want)))
+            worst = max(worst, diff)
+            if not diff <= 2e-8:
+                raise SystemExit(f"PARITY FAILURE: config1_files: {ours} differs from the reference's {theirs} by {diff}")
+        rows = int(rundb.count_run_comparisons(rundb.connect_to_db(tmp / "run2.sqlite"), run))
+    return {
+        "workload": "BASELINE configs[0]: the 4 gzipped bacterial genomes of the reference's fixture set (5.4 MB of .gz, 17 Mb), k=31 scaled=1000, "
+                    "FASTA files on disk -> .sig cache -> JSON column file -> SQLite database with all N^2 comparisons and the cached matrices (T_file, SURVEY.md 8d)",
+        "genomes": n, "comparisons": rows, "seconds": min(seconds[1:]), "seconds_first_run_of_the_process": seconds[0], "seconds_all_runs": [round(x, 4) for x in seconds],
+        "phases_s_last_run": phases, "matrices": "equal",
+        "matrices_note": f"identity and query-coverage matrices exported from the database equal the reference's matrices/sourmash_{{identity,coverage}}.tsv "
+                         f"(labels, NULL pattern, values within atol 2e-8: largest difference {worst:.3g}), asserted in this run",
+        "pairs_per_s": rows / min(seconds[1:]),
+    }
+
+
 def also_fragani(engine, arena, args, n_total, lengths) -> dict:
     """BASELINE configs[3]: fastANI-style fragment ANI, k=16, fragLen=3000 (the restatement reproduces every fastANI value the reference holds)."""
     import oracle
@@ -661,6 +715,24 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
         col_times.append(time.perf_counter() - t0)
     if not (np.array_equal(c_total, total) and np.array_equal(c_matched[:, 0], matched[:, 0]) and np.array_equal(c_sum[:, 0], ident_sum[:, 0])):
         raise SystemExit("PARITY FAILURE (fragment ANI): the subject column computed alone differs from the column of the all-against-all run")
+    # The workspace: device bytes the context holds after the all-against-all call (it only grows: the peak), and what fresh
+    # contexts hold after ONE subject column and after an eighth of the columns (the share of one rank of run_fastani_hip on
+    # eight GPUs) -- the reference bounds a worker's memory by 500-query batches (pyani_plus/private_cli.py:1029-1033), here
+    # the reference range does: the dictionary, the postings and the best-fragment table hold that range only.
+    workspace = {"all_columns": engine.fragani_workspace()}
+    from pyani_plus_amd.engine import HipEngine
+
+    for label, r1 in (("one_column", 1), ("one_eighth_of_the_columns", max(1, n // 8))):
+        other = HipEngine(0)
+        try:
+            other.fragani(sub, starts, lens, genome, k, frag, ref_range=(0, r1), columns_only=True)
+            workspace[label] = {**other.fragani_workspace(), "reference_genomes": r1}
+        finally:
+            other.close()
+        torch.cuda.empty_cache()
+    workspace["what"] = ("device bytes of the fragment-ANI workspace as allocated (pa_fragani_workspace; buffers grow by a quarter when they grow): "
+                         "9.6 bytes per arena residue for all genomes' minimizers + 28 bytes per minimizer of the reference range (one per 12.5 residues) + "
+                         "8 bytes per seed hit of the largest query batch (DESIGN.md 4.5, Memory); pa_fragani_set_workspace_cap bounds it")
     from pyani_plus_amd.methods.fastani_hip import fastani_mean
 
     ani = fastani_mean(ident_sum, matched)  # fastANI's own mean: a float sum by a float count
@@ -721,6 +793,7 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
                                "what": f"the {n} genomes against genome 0 alone (pa_fragani reference range [0, 1), columns only): what one per-column "
                                "worker of the reference's layout asks for; equals column 0 of the all-against-all run"},
         "phases_ms_per_run": {name: v[0] / 2 for name, v in prof.items() if name.startswith("frag")},
+        "workspace_device_bytes": workspace,
         "cpu_baseline": {"value": n_q / cpu_sec, "unit": "pairs/s", "cores": cores, "kind": "port", "seconds": cpu_sec,
                          "sample": f"{n_q} query genomes (ten cycles of the {args.species} species: 1 related query in {args.species}, as in the N x N matrix) against "
                          f"ONE reference genome whose index is built once (oracle.fragani_many: the shape of `fastANI --ql queries -r subject`), {cores} OpenMP threads over the queries; "
@@ -1186,6 +1259,14 @@ def run_rank(args, fresh_fragani: dict | None = None) -> None:
                 if cb is not None:
                     result["value_e2e_strict_vs_cpu_baseline"] = result["value_e2e_strict"] / cb["value"]
                     result["value_vs_cpu_baseline"] = result["value"] / cb["value"]
+                    # the same figures inside `cpu_baseline`, which the driver's record of this line keeps whole: the ratio to
+                    # quote is the one on SURVEY.md 8(d)'s headline clock, T_e2e with the reference's own doubles
+                    cb["gpu_over_cpu"] = {
+                        "t_e2e_strict_pairs_per_s": result["value_e2e_strict"], "t_e2e_strict_ms_per_step": t_e2e["strict"]["ms_per_step"],
+                        "t_e2e_strict_over_cpu": result["value_e2e_strict"] / cb["value"], "value_over_cpu": result["value"] / cb["value"],
+                        "quote": "t_e2e_strict_over_cpu: packed genomes in pinned host memory -> the reference's doubles in host memory (PCIe-inclusive); "
+                                 "value_over_cpu has the genomes resident in HBM when the clock starts, as the bench contract defines `value`",
+                    }
             del h_packed, h_mask, e_ident, e_cov
         if world == 1 and not dist_path and not args.no_also and not bottom and not args.mixed_lengths:
             also = {}
@@ -1221,6 +1302,11 @@ def run_rank(args, fresh_fragani: dict | None = None) -> None:
             if "n10000" in wanted:
                 extra("n10000_one_gpu", also_n10000, engine, args)
             result["also"] = also
+            if "config1" in wanted:  # last key of the line: the driver's record keeps the line's tail
+                try:
+                    result["config1_files"] = config1_files()
+                except (Exception, SystemExit) as err:  # noqa: BLE001 - never costs the headline line
+                    result["config1_files"] = {"error": f"{type(err).__name__}: {err}", "matrices": "not compared"}
     if rank == 0 and world > 1 and os.environ.get("PA_BENCH_NO_BASIS") != "1":
         # The same workload -- all n_total genomes -- on ONE GPU, measured here and now by rank 0 while the other ranks
         # wait at the barrier below: value / strong_basis.one_gpu_pairs_per_s is the speed-up of the N-GPU run over one

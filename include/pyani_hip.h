@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PA_ABI_VERSION 4
+#define PA_ABI_VERSION 5
 
 /* every entry point below is exported with default visibility */
 #define PA_API __attribute__((visibility("default")))
@@ -264,7 +264,8 @@ PA_API int pa_ani_mash(pa_ctx *ctx, const uint32_t *d_common, const uint32_t *d_
  * dictionary, the seed-hit arrays and the table of best fragments hold the reference range only.
  * Algorithm and its parity (every fastANI value the reference holds, exactly): oracle/fragani_oracle.c.  k from 8 to 16 (fastANI itself stops at 16); fragLen in
  * [100, 65535]; at most 65535 genomes; contigs listed genome by genome, at most 65535 per genome and 2^20-1 in all;
- * at most 2^20-1 fragments per genome.  The workspace (about 12 GB for 1000 x 5 Mb genomes) stays in the context. */
+ * at most 2^20-1 fragments per genome.  The workspace (44 GB as allocated for 1000 x 5 Mb genomes all against all; pa_fragani_workspace
+ * reports it, pa_fragani_set_workspace_cap bounds it) stays in the context. */
 PA_API int pa_fragani(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
                uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t ref0, uint32_t ref1,
@@ -287,6 +288,18 @@ PA_API int pa_fragani_ex(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *
                   uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t qry0, uint32_t qry1,
                   uint32_t ref0, uint32_t ref1, uint32_t flags, uint32_t *h_total_frags, uint32_t *h_matched,
                   double *h_ident_sum);
+/* The fragment-ANI workspace of a context (the reference bounds a worker's memory by handing fastANI at most 500
+ * queries per process, pyani_plus/private_cli.py:1029-1033; here the workspace is device memory that stays in the context
+ * and only grows).  pa_fragani_workspace: bytes held now, the most ever held (the same, until pa_ctx_destroy), the cap
+ * (0: none); any pointer may be null.  pa_fragani_set_workspace_cap: later pa_fragani / pa_fragani_ex / pa_fragani_sketch
+ * calls that would take the workspace past cap_bytes end with PA_E_NOMEM and a pa_last_error() message that names the
+ * call (genomes, arena residues, query and reference range, fragLen) and the sizes (bytes held, the buffer that wanted to
+ * grow, the cap); a call that ends that way (or with the device's own out-of-memory) gives the whole workspace back, so a
+ * smaller call in the same context starts from nothing and goes on working.  What a call needs, DESIGN.md 4.5:
+ * about 9.6 bytes per arena residue for the minimizers and their links, 28 bytes per minimizer of the REFERENCE RANGE
+ * for the dictionary (a minimizer per 12.5 residues), 8 bytes per seed hit of the largest query batch. */
+PA_API int pa_fragani_workspace(pa_ctx *ctx, uint64_t *held_bytes, uint64_t *peak_bytes, uint64_t *cap_bytes);
+PA_API int pa_fragani_set_workspace_cap(pa_ctx *ctx, uint64_t cap_bytes);
 /* Residues that are neither ACGT nor N.  The arena keeps two bits per residue and one "not ACGT" bit, which the
  * fragment-ANI kernels read as N; fastANI, which the reference hands the FASTA text itself
  * (pyani_plus/private_cli.py:1044-1063), hashes every upper-cased character as it is, so a k-mer over an IUPAC code

@@ -19,8 +19,9 @@ LIB_PATH = _PKG / "_lib" / "libpyani_hip.so"
 # the tests of those paths load it (``HipEngine(tools=True)``); nothing else does.
 TOOLS_LIB_PATH = _PKG / "_lib" / "libpyani_hip_tools.so"
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PA_OK = 0
+PA_E_NOMEM = -3
 PA_E_CAPACITY = -4
 PA_E_IO = -6
 PA_SIG_UNHANDLED = 1
@@ -112,6 +113,8 @@ SIGNATURES: dict[str, tuple] = {
     "pa_fasta_batch_ambiguous": (C.c_int64, [_vp, _vp, _vp, C.c_uint64]),
     "pa_fragani_set_ambiguous": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64]),
     "pa_fragani_window": (C.c_int, [C.c_uint32, C.c_uint32]),
+    "pa_fragani_workspace": (C.c_int, [_vp, _u64p, _u64p, _u64p]),
+    "pa_fragani_set_workspace_cap": (C.c_int, [_vp, C.c_uint64]),
     "pa_fragani_tables": (C.c_int, [C.c_uint32, C.c_uint32, _vp, _vp]),
     "pa_fragani_identity": (C.c_double, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "pa_fasta_records": (C.c_int64, [_vp, C.c_uint64, _vp, _vp, C.c_uint64]),
@@ -204,4 +207,6 @@ def last_error(lib: C.CDLL | None = None) -> str:
 
 def check(status: int, what: str, lib: C.CDLL | None = None) -> None:
     if status != PA_OK:
-        raise HipBackendError(f"{what} failed with status {status}: {last_error(lib)}")
+        err = HipBackendError(f"{what} failed with status {status}: {last_error(lib)}")
+        err.status = status  # the library's code (PA_E_*), for callers that tell failures apart
+        raise err

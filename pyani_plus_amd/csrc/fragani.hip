@@ -224,15 +224,22 @@ struct FragWork {
   uint32_t index_lookup_bits = 10;          // log2 of the slots of the look-up table by hash value (such a dictionary only)
   uint64_t index_key_room = 0;              // keys of one half of the sort's key buffer (W.keys[0] holds both halves)
   int index_which = 0;
-  ~FragWork() {
+  // every buffer of the workspace shares one budget: what pa_fragani_workspace reports and pa_fragani_set_workspace_cap bounds
+  DevBudget budget;
+  template <class Fn>
+  void each_buffer(Fn &&fn) {
     DevBuf *all[] = {&contig_start, &contig_len, &contig_genome, &block_counts, &block_offsets, &mini_hash, &mini_wpos,
                      &mini_contig, &contig_mini_off, &keys[0], &keys[1], &vals[0], &vals[1], &flags, &mini_id,
                      &post_start, &prev_same, &sorted_idx, &frag_contig, &frag_no, &frag_genome_local, &q_hash, &q_pos,
                      &q_id, &q_s, &hit_count, &hit_off, &hkeys[0], &hkeys[1], &hvals[0], &hvals[1], &seg_start,
                      &tab_min_hits, &tab_min_shared, &ident_tab, &contig_bin_off, &genome_bin_off, &table, &matched,
                      &ident_sum, &scalars, &run_g, &seg_list, &seg2_a0, &seg2_nh, &post_cw, &seg_a0, &seg_nh, &genome_first_contig, &contig_bucket_off, &bucket_first, &post_g, &seg_rec, &hash_cut, &q_cut, &post_cw2, &post_g2, &run_hist, &long_runs, &frag_d, &uniq_hash, &lookup_at, &seg_f, &seg2_f, &amb_pos, &amb_byte, &seg_over, &q_tab};
-    for (DevBuf *b : all) b->release();
+    for (DevBuf *b : all) fn(*b);
   }
+  FragWork() { each_buffer([this](DevBuf &b) { b.budget = &budget; }); }
+  FragWork(const FragWork &) = delete;
+  FragWork &operator=(const FragWork &) = delete;
+  ~FragWork() { each_buffer([](DevBuf &b) { b.release(); }); }
 };
 
 // The workspace lives in the context like the sketch and pair workspaces do: buffers only grow, and a
@@ -337,26 +344,39 @@ int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint3
                    uint32_t n_contigs, int w, uint32_t *m_out) {
   const uint32_t blocks = ceil_div_u64(arena_bases, kOwn);
   PA_TRY(W.block_counts.reserve((uint64_t)blocks * 8));  // the look-back words of minimizer_kernel
-  PA_TRY(W.scalars.reserve(64));
+  PA_TRY(W.scalars.reserve(kMiniScalarBytes));
+  PA_TRY(W.block_offsets.reserve((uint64_t)blocks * 4 + 16));  // the contig of every tile's first position
+  hipLaunchKernelGGL(tile_contig_kernel, dim3(ceil_div_u64(blocks, kThreads)), dim3(kThreads), 0, c->stream, W.contig_start.as<uint64_t>(), n_contigs,
+                     blocks, W.block_offsets.as<uint32_t>());
   // expected density of winnowed minimizers is 2 / (w + 1); the arrays are sized a quarter above that and the run is
   // repeated with the exact size should a low-complexity data set need more
   uint64_t cap = (uint64_t)((double)arena_bases * 2.5 / (double)(w + 1)) + (1u << 20);
   if (const char *v = PA_TOOL_ENV("PA_FRAGANI_MINIMIZER_ROOM")) cap = std::max<uint64_t>(1, strtoull(v, nullptr, 10));  // tests: force the repeat
+  // tiles are drawn from one counter per XCD; from a single counter when a wait of the chained scan ran out under that
+  // scheme (see the kernel) -- or when a tool asks for it
+  uint32_t ticket_mode = 1;
+  if (const char *v = PA_TOOL_ENV("PA_FRAGANI_ONE_TICKET")) { if (atoi(v)) ticket_mode = 0; }
   for (int attempt = 0; attempt < 2; ++attempt) {
     PA_REQUIRE(cap < (1ULL << 31), "fragment ANI: room for %llu minimizers exceeds the 31-bit index space", (unsigned long long)cap);
     PA_TRY(W.mini_hash.reserve(cap * 4 + 16));
     PA_TRY(W.mini_wpos.reserve(cap * 4 + 16));
     PA_TRY(W.mini_contig.reserve(cap * 4 + 16));
     PA_HIP(hipMemsetAsync(W.block_counts.p, 0, (uint64_t)blocks * 8, c->stream));
-    PA_HIP(hipMemsetAsync(W.scalars.p, 0, 16, c->stream));
+    PA_HIP(hipMemsetAsync(W.scalars.p, 0, kMiniScalarBytes, c->stream));
     hipLaunchKernelGGL((minimizer_kernel<K>), dim3(blocks), dim3(kMiniThreads), 0, c->stream,
                        d_packed, d_mask, arena_bases, W.contig_start.as<uint64_t>(), W.contig_len.as<uint32_t>(), n_contigs, w,
                        W.block_counts.as<unsigned long long>(), W.scalars.as<uint32_t>(), (uint32_t)cap,
-                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>(), blocks, W.ambiguous(d_packed));
+                       W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(), W.mini_contig.as<uint32_t>(), blocks, W.ambiguous(d_packed), ticket_mode,
+                       W.block_offsets.as<uint32_t>());
     PA_HIP(hipGetLastError());
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 16, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipStreamSynchronize(c->stream));
     const uint32_t *h = reinterpret_cast<const uint32_t *>(c->h_pinned);
+    if (h[2] != 0 && ticket_mode != 0) {  // a wait ran out with the tiles drawn per XCD: once more, from one counter
+      ticket_mode = 0;
+      --attempt;
+      continue;
+    }
     PA_REQUIRE(h[2] == 0, "fragment ANI: the minimizer scan gave up waiting for a tile (%u tiles)", blocks);
     const uint64_t m = h[1];
     if (m <= cap) {
@@ -415,6 +435,23 @@ void pa_fragani_release(pa_ctx *c) {
 extern "C" {
 
 int pa_fragani_window(uint32_t k, uint32_t frag_len) { return window_size_for((int)k, (int)frag_len); }
+
+// The fragment-ANI workspace of a context: bytes held now, the most it ever held (buffers only grow: the same until
+// pa_fragani_release), and the cap (0: none).  A cap bounds what later calls may ask the device for: a call that would
+// pass it ends with PA_E_NOMEM and a message naming the call and the sizes, the workspace as it was.
+int pa_fragani_workspace(pa_ctx *c, uint64_t *held_bytes, uint64_t *peak_bytes, uint64_t *cap_bytes) {
+  PA_REQUIRE(c, "pa_fragani_workspace: null context");
+  const FragWork *W = static_cast<const FragWork *>(c->frag_work);
+  if (held_bytes) *held_bytes = W ? W->budget.held : 0;
+  if (peak_bytes) *peak_bytes = W ? W->budget.peak : 0;
+  if (cap_bytes) *cap_bytes = W ? W->budget.cap : 0;
+  return PA_OK;
+}
+int pa_fragani_set_workspace_cap(pa_ctx *c, uint64_t cap_bytes) {
+  PA_REQUIRE(c, "pa_fragani_set_workspace_cap: null context");
+  frag_work(c).budget.cap = cap_bytes;
+  return PA_OK;
+}
 
 int pa_fragani_set_ambiguous(pa_ctx *c, const uint32_t *d_packed, const uint64_t *h_pos, const uint8_t *h_byte, uint64_t n) {
   PA_REQUIRE(c && (n == 0 || (d_packed && h_pos && h_byte)), "pa_fragani_set_ambiguous: null argument");
@@ -499,11 +536,35 @@ int pa_fragani(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint
                        n_genomes, k, frag_len, 0, n_genomes, ref0, ref1, 0, h_total_frags, h_matched, h_ident_sum);
 }
 
+static int fragani_ex_impl(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                           const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
+                           uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t qry0, uint32_t qry1,
+                           uint32_t ref0, uint32_t ref1, uint32_t flags, uint32_t *h_total_frags, uint32_t *h_matched,
+                           double *h_ident_sum);
 int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
                   const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
                   uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t qry0, uint32_t qry1,
                   uint32_t ref0, uint32_t ref1, uint32_t flags, uint32_t *h_total_frags, uint32_t *h_matched,
                   double *h_ident_sum) {
+  const int status = fragani_ex_impl(c, d_packed, d_mask, arena_bases, h_contig_start, h_contig_len, h_contig_genome, n_contigs, n_genomes, k,
+                                     frag_len, qry0, qry1, ref0, ref1, flags, h_total_frags, h_matched, h_ident_sum);
+  if (status == PA_E_NOMEM && c && c->frag_work) {
+    // A call that ends for want of memory -- the cap, or the device -- gives back what the workspace held (the buffers that
+    // had grown for it included), so that a smaller call starts from nothing instead of from a half-grown workspace; the
+    // index of an earlier call goes with it.  The list of residues that are neither ACGT nor N stays (a few bytes).
+    FragWork &W = frag_work(c);
+    (void)hipStreamSynchronize(c->stream);
+    W.each_buffer([&](DevBuf &b) { if (&b != &W.amb_pos && &b != &W.amb_byte) b.release(); });
+    W.index_valid = false;
+  }
+  return status;
+}
+
+static int fragani_ex_impl(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t arena_bases,
+                           const uint64_t *h_contig_start, const uint32_t *h_contig_len, const uint32_t *h_contig_genome,
+                           uint32_t n_contigs, uint32_t n_genomes, uint32_t k, uint32_t frag_len, uint32_t qry0, uint32_t qry1,
+                           uint32_t ref0, uint32_t ref1, uint32_t flags, uint32_t *h_total_frags, uint32_t *h_matched,
+                           double *h_ident_sum) {
   PA_REQUIRE(c && d_packed && d_mask && h_total_frags && h_matched && h_ident_sum, "pa_fragani: null argument");
   PA_REQUIRE(ref0 <= ref1 && ref1 <= n_genomes, "pa_fragani: reference range [%u,%u) outside [0,%u)", ref0, ref1, n_genomes);
   PA_REQUIRE(qry0 <= qry1 && qry1 <= n_genomes, "pa_fragani: query range [%u,%u) outside [0,%u)", qry0, qry1, n_genomes);
@@ -519,6 +580,8 @@ int pa_fragani_ex(pa_ctx *c, const uint32_t *d_packed, const uint32_t *d_mask, u
   PA_REQUIRE((int)frag_len > w + (int)k, "pa_fragani: fragLen %u too short for window %d", frag_len, w);
   const uint32_t count_windows = frag_len - (uint32_t)(w - 1) - (k - 1);
   FragWork &W = frag_work(c);
+  snprintf(W.budget.what, sizeof(W.budget.what), "pa_fragani: %u genomes (%llu residues of arena), queries [%u,%u), reference range [%u,%u), fragLen %u",
+           n_genomes, (unsigned long long)arena_bases, qry0, qry1, ref0, ref1, frag_len);
   PA_TRY(stage_contigs(c, W, h_contig_start, h_contig_len, h_contig_genome, n_contigs, n_genomes, arena_bases));
 
   // ---- 1. minimizers of every contig

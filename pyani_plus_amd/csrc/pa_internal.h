@@ -50,27 +50,50 @@ void pa_set_error(const char *fmt, ...);
 #endif
 
 // ---- growable device buffer owned by the context ---------------------------
+// A group of buffers may share a budget: bytes held, the most ever held, and an optional cap (0: none) past which a
+// buffer refuses to grow -- with a message that names the sizes -- instead of asking the driver (fragani.hip).
+struct DevBudget {
+  uint64_t held = 0, peak = 0, cap = 0;
+  char what[192] = {0};  // the call the buffers are growing for, for the message
+};
 struct DevBuf {
   void *p = nullptr;
   uint64_t bytes = 0;
+  DevBudget *budget = nullptr;
   int reserve(uint64_t want) {
     if (want <= bytes) return PA_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
     // grow geometrically so steady-state calls never allocate
     uint64_t sz = want + want / 4 + 256;
+    if (budget && budget->cap && budget->held - bytes + sz > budget->cap) {
+      pa_set_error("%s: the workspace would grow to %llu bytes (%llu held; this buffer from %llu to %llu), above the cap of %llu bytes",
+                   budget->what[0] ? budget->what : "device workspace", (unsigned long long)(budget->held - bytes + sz),
+                   (unsigned long long)budget->held, (unsigned long long)bytes, (unsigned long long)sz, (unsigned long long)budget->cap);
+      return PA_E_NOMEM;
+    }
+    if (p) (void)hipFree(p);
+    if (budget) budget->held -= bytes;
+    p = nullptr;
+    bytes = 0;
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
-      pa_set_error("hipMalloc(%llu) failed: %s", (unsigned long long)sz, hipGetErrorString(e));
+      if (budget)
+        pa_set_error("%s: hipMalloc(%llu) failed with %llu bytes of workspace held: %s", budget->what[0] ? budget->what : "device workspace",
+                     (unsigned long long)sz, (unsigned long long)budget->held, hipGetErrorString(e));
+      else
+        pa_set_error("hipMalloc(%llu) failed: %s", (unsigned long long)sz, hipGetErrorString(e));
       p = nullptr;
       return PA_E_NOMEM;
     }
     bytes = sz;
+    if (budget) {
+      budget->held += sz;
+      if (budget->held > budget->peak) budget->peak = budget->held;
+    }
     return PA_OK;
   }
   void release() {
     if (p) (void)hipFree(p);
+    if (budget) budget->held -= bytes;
     p = nullptr;
     bytes = 0;
   }

@@ -578,6 +578,17 @@ class HipEngine:
         m = int(n.value)
         return h[:m], wp[:m], ct[:m]
 
+    def fragani_workspace(self) -> dict:
+        """Device bytes of the context's fragment-ANI workspace: held now, the most ever held, the cap (0: none)."""
+        held, peak, cap = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.pa_fragani_workspace(self.ctx, C.byref(held), C.byref(peak), C.byref(cap)), "pa_fragani_workspace")
+        return {"held_bytes": int(held.value), "peak_bytes": int(peak.value), "cap_bytes": int(cap.value)}
+
+    def fragani_set_workspace_cap(self, cap_bytes: int) -> None:
+        """Later fragment-ANI calls that would take the workspace past ``cap_bytes`` (0: no cap) fail with a message naming
+        the call and the sizes (``HipBackendError``), the workspace as it was."""
+        self._check(self.lib.pa_fragani_set_workspace_cap(self.ctx, int(cap_bytes)), "pa_fragani_set_workspace_cap")
+
     # -- profiling
     def prof_enable(self, on: bool = True) -> None:
         self._check(self.lib.pa_prof_enable(self.ctx, int(on)), "pa_prof_enable")

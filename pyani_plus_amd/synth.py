@@ -124,6 +124,198 @@ def synth_arena_torch(engine, n_genomes: int, length, n_species: int = 40, seed:
     return DeviceArena(packed, mask, starts)
 
 
+# ---- a second generator mode: genomes that differ from their species' root by more than substitutions -----------------
+# (fragment ANI, BASELINE configs[3]).  The substitution-only sets above are the friendliest input a fragment mapper can
+# get: every fragment of a genome has ONE locus in every genome of its species, on one contig, at the same offset.  Real
+# assemblies of one species differ by indels, by a handful of inversions and translocations, carry repeat families
+# (IS elements, rRNA operons: seed hits at several loci) and come as tens to hundreds of contigs -- the regime of the
+# reference's own bacterial fixtures (/root/reference/tests/fixtures/bacterial_example/intermediates/fastANI/*.fastani).
+# A genome here is a list of PIECES of its species' root (which already holds the species' repeat copies): forward or
+# reverse-complemented stretches, random insertions, contig separators -- drawn on the host from (seed, genome), expanded
+# on the device by one gather.  Plumbing, not part of any measured path.
+REARRANGED_CONTIGS = (30, 200)      # contigs per genome
+REARRANGED_EVENTS = (3, 5)          # inversions / translocations per genome
+REARRANGED_FAMILIES = 3             # repeat families per species,
+REARRANGED_COPIES = (5, 20)         # copies of each in the root,
+REARRANGED_ELEMENT = (1000, 2000)   # residues per copy
+_P_ROOT, _P_REVCOMP, _P_RANDOM, _P_SEPARATOR = 0, 1, 2, 3
+
+
+def _species_root_pieces(rng, length: int) -> list[tuple[int, int, int]]:
+    """The species' root as pieces over a plain random string of ``length`` residues: copies of the species' repeat
+    elements (pieces of the string's tail, where the elements live) spliced in at random places.  (kind, start, n)."""
+    families = [(int(rng.integers(*REARRANGED_ELEMENT)), int(rng.integers(REARRANGED_COPIES[0], REARRANGED_COPIES[1] + 1))) for _ in range(REARRANGED_FAMILIES)]
+    elements, tail = [], length
+    for n_el, _copies in families:  # the elements themselves sit past the root's own residues
+        elements.append((tail, n_el))
+        tail += n_el
+    cuts = sorted((int(rng.integers(0, length)), f) for f, (_n, copies) in enumerate(families) for _ in range(copies))
+    pieces, at = [], 0
+    for pos, f in cuts:
+        if pos > at:
+            pieces.append((_P_ROOT, at, pos - at))
+        pieces.append((_P_ROOT if rng.random() < 0.5 else _P_REVCOMP, elements[f][0], elements[f][1]))
+        at = pos
+    if at < length:
+        pieces.append((_P_ROOT, at, length - at))
+    return pieces, tail
+
+
+def _slice_pieces(pieces, a: int, b: int):
+    """Pieces covering positions [a, b) of the sequence the pieces spell."""
+    out, at = [], 0
+    for kind, start, n in pieces:
+        lo, hi = max(a, at), min(b, at + n)
+        if lo < hi:
+            off, m = lo - at, hi - lo
+            if kind == _P_REVCOMP:  # a reverse-complemented stretch: the slice counts from its far end
+                out.append((kind, start + n - off - m, m))
+            elif kind == _P_ROOT:
+                out.append((kind, start + off, m))
+            else:
+                out.append((kind, start, m))
+        at += n
+        if at >= b:
+            break
+    return out
+
+
+def _revcomp_pieces(pieces):
+    flip = {_P_ROOT: _P_REVCOMP, _P_REVCOMP: _P_ROOT}
+    return [(flip.get(kind, kind), start, n) for kind, start, n in reversed(pieces)]
+
+
+def rearranged_genome_pieces(g: int, length: int, n_species: int, seed: int = SEED, contigs: tuple[int, int] = REARRANGED_CONTIGS):
+    """Pieces of genome ``g`` -- (kind, start in the species' substituted root, residues) -- and its contig lengths."""
+    sp, rate = species_and_rate(g, n_species)
+    root_pieces, root_len = _species_root_pieces(np.random.Generator(np.random.Philox(key=seed * 31 + 7 * sp + 3)), length)
+    total = sum(n for _k, _s, n in root_pieces)
+    rng = np.random.Generator(np.random.Philox(key=seed * 131 + 977 * (g + 1)))
+    pieces = root_pieces
+    # inversions and translocations of 20 - 300 kb (as far as the genome allows)
+    for _ in range(int(rng.integers(REARRANGED_EVENTS[0], REARRANGED_EVENTS[1] + 1))):
+        seg = int(min(total // 4, rng.integers(20_000, 300_000))) if total >= 8 else 0
+        if seg < 2:
+            break
+        a = int(rng.integers(0, total - seg))
+        left, mid, right = _slice_pieces(pieces, 0, a), _slice_pieces(pieces, a, a + seg), _slice_pieces(pieces, a + seg, total)
+        if rng.random() < 0.5:
+            pieces = left + _revcomp_pieces(mid) + right  # inversion in place
+        else:  # translocation: cut out, put back somewhere else (in either orientation)
+            rest = left + right
+            to = int(rng.integers(0, total - seg + 1))
+            moved = mid if rng.random() < 0.5 else _revcomp_pieces(mid)
+            pieces = _slice_pieces(rest, 0, to) + moved + _slice_pieces(rest, to, total - seg)
+    # indels with geometric lengths: one per ~8 substitutions, at most one per 200 residues
+    n_indel = int(min(total / 200, rate * total / 8))
+    if n_indel:
+        at_list = np.sort(rng.integers(0, total, size=n_indel))
+        lens = np.minimum(rng.geometric(0.4, size=n_indel), 50)
+        insert = rng.random(n_indel) < 0.5
+        out, done, src = [], 0, pieces
+        # walk the pieces once, cutting at the indel positions
+        flat, at = [], 0
+        idx = 0
+        for kind, start, n in src:
+            piece_end = at + n
+            cur_off = 0
+            while idx < n_indel and at_list[idx] < piece_end:
+                cut = int(at_list[idx]) - at
+                cut = max(cut, cur_off)
+                if cut > cur_off:
+                    flat.extend(_slice_pieces([(kind, start, n)], cur_off, cut))
+                if insert[idx]:
+                    flat.append((_P_RANDOM, 0, int(lens[idx])))
+                    cur_off = cut
+                else:
+                    cur_off = min(n, cut + int(lens[idx]))  # deleted (a deletion ends with its piece at the latest)
+                idx += 1
+            if cur_off < n:
+                flat.extend(_slice_pieces([(kind, start, n)], cur_off, n))
+            at = piece_end
+        pieces = flat
+        del out, done
+    total = sum(n for _k, _s, n in pieces)
+    # contigs: cut points anywhere (some contigs come out shorter than a fragment, as in real drafts)
+    n_contigs = int(rng.integers(contigs[0], contigs[1] + 1))
+    n_contigs = max(1, min(n_contigs, total // 64))
+    cuts = np.unique(rng.integers(1, max(total, 2), size=n_contigs - 1)) if n_contigs > 1 else np.zeros(0, dtype=np.int64)
+    bounds = [0, *[int(x) for x in cuts if 0 < x < total], total]
+    contig_lens = [b - a for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    with_seps, at = [], 0
+    for ci, n in enumerate(contig_lens):
+        with_seps.extend(_slice_pieces(pieces, at, at + n))
+        at += n
+        if ci + 1 < len(contig_lens):
+            with_seps.append((_P_SEPARATOR, 0, 1))
+    return with_seps, contig_lens, root_len, sp, rate
+
+
+def synth_rearranged_arena_torch(engine, n_genomes: int, length: int, n_species: int = 40, seed: int = SEED, *, genome_ids=None, device=None,
+                                 contigs: tuple[int, int] = REARRANGED_CONTIGS):
+    """The rearranged set on the device: (DeviceArena, contig_start, contig_len, contig_genome).  Contigs of a genome are
+    separated by one invalid position, as the FASTA packers leave them (include/pyani_hip.h); ``device``: for host-side tests
+    (torch CPU tensors) -- by default the engine's."""
+    t = engine.torch
+    dev = engine.device if device is None else device
+    plans = [rearranged_genome_pieces(i if genome_ids is None else int(genome_ids[i]), int(length), n_species, seed, contigs) for i in range(n_genomes)]
+    lengths = [sum(n for _k, _s, n in pl[0]) for pl in plans]  # residues + separators
+    pads = [_padded(x) for x in lengths]
+    starts = np.zeros(n_genomes + 1, dtype=np.uint64)
+    np.cumsum(pads, out=starts[1:])
+    total = int(starts[-1])
+    packed = t.empty(max(total // 16, 1), dtype=t.int32, device=dev)
+    mask = t.empty(max(total // 32, 1), dtype=t.int32, device=dev)
+    shifts = (t.arange(16, device=dev, dtype=t.int64) * 2)[None, :]
+    mshifts = t.arange(32, device=dev, dtype=t.int64)[None, :]
+    gen = t.Generator(device=dev)
+    roots: dict[int, object] = {}
+    c_start, c_len, c_genome = [], [], []
+    for i, (pieces, contig_lens, root_len, sp, rate) in enumerate(plans):
+        g = i if genome_ids is None else int(genome_ids[i])
+        if sp not in roots:
+            gen.manual_seed(seed * 1000003 + sp)
+            roots[sp] = t.randint(0, 4, (root_len,), generator=gen, device=dev, dtype=t.int64)
+        gen.manual_seed(seed * 7919 + 104729 * (g + 1))
+        hit = t.rand(root_len, generator=gen, device=dev) < rate
+        delta = t.randint(1, 4, (root_len,), generator=gen, device=dev, dtype=t.int64) * hit
+        subbed = (roots[sp] + delta) & 3
+        kinds = t.tensor([p[0] for p in pieces], dtype=t.int64, device=dev)
+        p_start = t.tensor([p[1] for p in pieces], dtype=t.int64, device=dev)
+        p_len = t.tensor([p[2] for p in pieces], dtype=t.int64, device=dev)
+        out_off = t.cumsum(p_len, 0) - p_len
+        pid = t.repeat_interleave(t.arange(len(pieces), device=dev), p_len)
+        j = t.arange(lengths[i], device=dev) - out_off[pid]
+        kind = kinds[pid]
+        src = t.where(kind == _P_REVCOMP, p_start[pid] + p_len[pid] - 1 - j, p_start[pid] + j)
+        src = t.where(kind >= _P_RANDOM, t.zeros_like(src), src)
+        codes = subbed[src]
+        codes = t.where(kind == _P_REVCOMP, 3 - codes, codes)
+        codes = t.where(kind == _P_RANDOM, t.randint(0, 4, (lengths[i],), generator=gen, device=dev, dtype=t.int64), codes)
+        valid = kind != _P_SEPARATOR
+        padded = pads[i]
+        full = t.zeros(padded, dtype=t.int64, device=dev)
+        full[: lengths[i]] = codes * valid
+        inv = t.ones(padded, dtype=t.int64, device=dev)
+        inv[: lengths[i]] = (~valid).to(t.int64)
+        words = (full.view(-1, 16) << shifts).sum(1)
+        words = t.where(words >= 2**31, words - 2**32, words).to(t.int32)
+        s0 = int(starts[i])
+        packed[s0 // 16 : s0 // 16 + padded // 16] = words
+        iw = (inv.view(-1, 32) << mshifts).sum(1)
+        mask[s0 // 32 : s0 // 32 + padded // 32] = t.where(iw >= 2**31, iw - 2**32, iw).to(t.int32)
+        at = s0
+        for n in contig_lens:
+            c_start.append(at)
+            c_len.append(n)
+            c_genome.append(i)
+            at += n + 1
+    if dev != "cpu" and str(dev) != "cpu":
+        t.cuda.synchronize(dev)
+    return (DeviceArena(packed, mask, starts), np.array(c_start, dtype=np.uint64), np.array(c_len, dtype=np.uint32),
+            np.array(c_genome, dtype=np.uint32))
+
+
 def device_arena_to_host(arena: DeviceArena, genomes: list[int], length) -> HostArena:
     """Copy a few genomes of a device arena back to the host (oracle sample)."""
     starts = np.zeros(len(genomes) + 1, dtype=np.uint64)

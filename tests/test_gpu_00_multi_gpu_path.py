@@ -61,6 +61,20 @@ def test_bench_launches_its_own_ranks_two_ranks_on_one_gpu():
     assert res["speedup_vs_one_gpu_same_workload"] == pytest.approx(res["value"] / res["strong_basis"]["one_gpu_pairs_per_s"])
 
 
+def test_bench_eight_ranks_on_one_gpu_with_the_one_gpu_basis():
+    """The form the driver's SCALE run takes at N = 8 (`bench.py --gpus 8`: eight ranks, genome shards, the all-gather of
+    unequal sketch payloads, column tiles, rank 0's one-GPU basis while seven ranks wait in the barrier), with the eight
+    ranks sharing this box's one device and the collectives on host copies (gloo).  No scaling figure comes out of this --
+    eight ranks on one GPU -- only that the eight-rank path runs to its end and its line is consistent."""
+    res = _run_bench({"PA_BENCH_BACKEND": "gloo"}, "--gpus", "8", "--genomes", "72", "--length", "120000", "--steps", "2", "--warmup", "1")
+    assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8 and res["collective_backend"] == "gloo"
+    assert res["config"]["genomes"] == 72 and res["config"]["genomes_per_gpu"] == 9
+    assert res["value"] > 0 and res["scaling"] == "weak" and res["value"] == pytest.approx(72 * 72 / (res["ms_per_step"] * 1e-3))
+    assert len(res["shard_balance"]["busy_ms_per_step_by_rank"]) == 8 and all(b > 0 for b in res["shard_balance"]["busy_ms_per_step_by_rank"])
+    assert res["strong_basis"]["genomes"] == 72 and res["strong_basis"]["one_gpu_pairs_per_s"] > 0
+    assert res["speedup_vs_one_gpu_same_workload"] == pytest.approx(res["value"] / res["strong_basis"]["one_gpu_pairs_per_s"])
+
+
 def test_bench_rccl_path_on_one_rank():
     res = _run_bench({"PA_BENCH_FORCE_DIST": "1", "MASTER_PORT": str(_free_port())}, "--gpus", "1", "--genomes", "48", "--length", "300000",
                      "--steps", "2", "--warmup", "1", "--no-also")
@@ -81,7 +95,7 @@ def _dump(db):
     return out
 
 
-def test_product_drivers_with_two_ranks_sharing_the_gpu(tmp_path, monkeypatch):
+def test_product_drivers_with_two_and_eight_ranks_sharing_the_gpu(tmp_path, monkeypatch):
     """The multi-GPU PRODUCT path on the device: ``rundb.run_sourmash_hip(gpus=2)`` and ``rundb.run_fastani_hip(gpus=2)``
     start two worker processes (before this process has initialised HIP), which share the box's one GPU -- collectives
     on host copies (gloo), kernels on the device -- and must give the databases the single-process drivers give."""
@@ -105,6 +119,14 @@ def test_product_drivers_with_two_ranks_sharing_the_gpu(tmp_path, monkeypatch):
             (indir / f"g{g}.fasta").write_bytes(text)
     many = rundb.run_sourmash_hip(indir, tmp_path / "s2.sqlite", cache=tmp_path / "c2", scaled=100, temp=tmp_path / "t2", gpus=2)
     fmany = rundb.run_fastani_hip(indir, tmp_path / "f2.sqlite", temp=tmp_path / "tf2", gpus=2)
+    # eight ranks (the node the reference's column fan-out would cover, pyani_plus/public_cli.py:232-261), all on this one device:
+    # nine genomes over eight shards, eight column ranges, the tile placement and the watchdogs at world size 8
+    many8 = rundb.run_sourmash_hip(indir, tmp_path / "s8.sqlite", cache=tmp_path / "c8", scaled=100, temp=tmp_path / "t8", gpus=8)
+    fmany8 = rundb.run_fastani_hip(indir, tmp_path / "f8.sqlite", temp=tmp_path / "tf8", gpus=8)
+    results8 = [json.loads(q.read_text()) for q in sorted((tmp_path / "t8" / "sourmash-hip.workers").glob("result_rank*.json"))]
+    assert len(results8) == 8 and all(r["ok"] and r["device"].startswith("cuda") for r in results8)
+    fresults8 = [json.loads(q.read_text()) for q in sorted((tmp_path / "tf8").glob("*.workers/result_rank*.json"))]
+    assert len(fresults8) == 8 and all(r["ok"] and r["device"].startswith("cuda") for r in fresults8)
     # the same worker code over RCCL (backend nccl, collectives on device tensors) with the one rank this box has a GPU for
     monkeypatch.delenv("PYANI_HIP_DIST_BACKEND")
     monkeypatch.setenv("PYANI_HIP_FORCE_WORKERS", "1")
@@ -123,6 +145,8 @@ def test_product_drivers_with_two_ranks_sharing_the_gpu(tmp_path, monkeypatch):
     assert many.status == one.status == fmany.status == fone.status == "Done"
     assert _dump(tmp_path / "s1.sqlite") == _dump(tmp_path / "s2.sqlite") == _dump(tmp_path / "s_rccl.sqlite")
     assert _dump(tmp_path / "f1.sqlite") == _dump(tmp_path / "f2.sqlite")
+    assert many8.status == fmany8.status == "Done"
+    assert _dump(tmp_path / "s1.sqlite") == _dump(tmp_path / "s8.sqlite") and _dump(tmp_path / "f1.sqlite") == _dump(tmp_path / "f8.sqlite")
     rows = _dump(tmp_path / "f2.sqlite")[1]
     assert len(rows) == len(lengths) ** 2 and sum(r[2] is not None for r in rows) > len(lengths)  # related genomes do map
     # against the oracle: every sourmash pair

@@ -125,6 +125,39 @@ def test_minimizer_run_is_repeated_when_the_estimate_is_too_small(tools_engine, 
         assert len(h) > 5_000  # the homopolymer alone gives one minimizer per window
 
 
+def test_minimizers_with_the_tiles_drawn_per_xcd_and_from_one_counter(tools_engine, monkeypatch):
+    """minimizer_kernel hands its tiles out through one ticket counter per XCD and falls back to a single counter should
+    a wait of its chained scan ever run out; which counter a tile came from decides nothing: both forms (the second forced
+    through the tools build) give the oracle's minimizers, in arena order, over a few hundred tiles of many short contigs,
+    runs of N and a window size that takes the plain path (w = 5) as well as fastANI's 24."""
+    engine = tools_engine
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    contigs = []
+    for i in range(40):
+        seq = rng.choice(acgt, size=int(rng.integers(30, 40_000))).copy()
+        if i % 3 == 0 and seq.size > 400:
+            a = int(rng.integers(0, seq.size - 300))
+            seq[a : a + int(rng.integers(1, 300))] = ord("N")
+        contigs.append(seq.tobytes())
+    arena = pack_genomes([b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(contigs[:25])), b"".join(b">d%d\n" % i + c + b"\n" for i, c in enumerate(contigs[25:]))])
+    dev = engine.upload(arena)
+    for k, w in ((16, 24), (12, 5), (16, 64)):
+        got = {}
+        for one in ("0", "1"):
+            monkeypatch.setenv("PA_FRAGANI_ONE_TICKET", one)
+            got[one] = engine.fragani_sketch(dev, arena.contig_start, arena.contig_len, arena.contig_genome, k, w)
+        monkeypatch.delenv("PA_FRAGANI_ONE_TICKET")
+        for a, b in zip(got["0"], got["1"]):
+            assert np.array_equal(a, b)
+        h, wp, ct = got["0"]
+        for ci, contig in enumerate(contigs):
+            want_h, want_p = oracle.fragani_minimizers(contig, k, w)
+            assert np.array_equal(h[ct == ci], want_h) and np.array_equal(wp[ct == ci].astype(np.int32), want_p), (k, w, ci)
+
+
 def _check_against_oracle(engine, texts, contig_lists, frag=FRAG, k=K):
     from pyani_plus_amd.engine import pack_genomes
 
@@ -739,6 +772,54 @@ def test_query_batches_of_one_subject_column_in_a_fresh_context(engine):
         assert np.array_equal(out[0], total) and np.array_equal(out[1], matched[:, 1:2]) and np.array_equal(out[2], ident_sum[:, 1:2])
     finally:
         fresh.close()
+
+
+def test_workspace_is_reported_and_a_cap_ends_a_call_with_the_sizes_named(engine):
+    """The reference bounds a fastANI worker's memory by batches of 500 queries (pyani_plus/private_cli.py:1029-1033); this
+    build's workspace is device memory that stays in the context and only grows.  pa_fragani_workspace reports it; with
+    pa_fragani_set_workspace_cap a call that would pass the cap ends with PA_E_NOMEM and a message that names the call and
+    the sizes -- not a HIP abort --, the workspace given back, and a call that fits (one subject column of the same genomes)
+    goes on working in the same context and gives the column of the uncapped run."""
+    from pyani_plus_amd import _capi
+    from pyani_plus_amd.engine import HipEngine, load_fasta_files
+
+    files = sorted((GOLDEN / "bacterial_example").glob("*.gz"))
+    infos, arena = load_fasta_files(files)
+    args = (arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    total, matched, ident_sum = engine.fragani(engine.upload(arena), *args)
+    needs = {}
+    for name, kwargs in (("all", {}), ("one", {"ref_range": (1, 2), "columns_only": True})):
+        fresh = HipEngine(0)
+        try:
+            assert fresh.fragani_workspace() == {"held_bytes": 0, "peak_bytes": 0, "cap_bytes": 0}
+            fresh.fragani(fresh.upload(arena), *args, **kwargs)
+            ws = fresh.fragani_workspace()
+            assert ws["held_bytes"] == ws["peak_bytes"] > 0 and ws["cap_bytes"] == 0
+            needs[name] = ws["held_bytes"]
+        finally:
+            fresh.close()
+    # 17 Mb of arena: the minimizers and their links alone are ~9.6 bytes per residue; the dictionary of ONE genome is a quarter of all four's
+    assert 9 * arena.genome_start[-1] < needs["one"] < needs["all"]
+    capped = HipEngine(0)
+    try:
+        cap = (needs["one"] + needs["all"]) // 2
+        capped.fragani_set_workspace_cap(cap)
+        dev = capped.upload(arena)
+        with pytest.raises(_capi.HipBackendError) as err:
+            capped.fragani(dev, *args)
+        text = str(err.value)
+        assert err.value.status == _capi.PA_E_NOMEM
+        assert "pa_fragani: 4 genomes" in text and "reference range [0,4)" in text and f"above the cap of {cap} bytes" in text and "held" in text
+        ws = capped.fragani_workspace()  # the call that ended for want of memory gave the workspace back
+        assert ws["held_bytes"] <= (1 << 20) and 0 < ws["peak_bytes"] <= cap == ws["cap_bytes"]
+        t, m, s = capped.fragani(dev, *args, ref_range=(1, 2), columns_only=True)  # the same context still serves what fits
+        assert np.array_equal(t, total) and np.array_equal(m, matched[:, 1:2]) and np.array_equal(s, ident_sum[:, 1:2])
+        assert capped.fragani_workspace()["held_bytes"] <= cap
+        capped.fragani_set_workspace_cap(0)  # no cap: the whole set
+        t, m, s = capped.fragani(dev, *args)
+        assert np.array_equal(m, matched) and np.array_equal(s, ident_sum)
+    finally:
+        capped.close()
 
 
 def test_product_library_ignores_the_tool_switches(engine, tools_engine, monkeypatch):

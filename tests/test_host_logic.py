@@ -34,7 +34,7 @@ def test_library_exports_every_header_symbol():
     lib = _capi.load_library()  # raises if the .so is missing or lacks a symbol
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.pa_abi_version() == 4
+    assert lib.pa_abi_version() == 5
     assert lib.pa_max_hash(300) == 61489146912365176 and lib.pa_max_hash(1000) == 18446744073709552
     assert max_hash_for_scaled(1) == 2**64 - 1
 
