@@ -59,7 +59,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive passes (keeps a rocprof kernel trace to the timed steps' launches)")
     ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other BASELINE configs")
-    ap.add_argument("--also", default="bottom,k51,mixed,n10000,fragani,config1", help="comma list of the extra runs at N=1 (config1: BASELINE configs[0] from files, the last key of the line)")
+    ap.add_argument("--also", default="bottom,k51,mixed,n10000,fragani,rearranged,config1", help="comma list of the extra runs at N=1 (rearranged: fragment ANI on the set with indels, rearrangements, repeats and contigs; config1: BASELINE configs[0] from files, the last key of the line)")
     ap.add_argument("--also-fragani-genomes", type=int, default=1000)
     ap.add_argument("--also-n", type=int, default=10000)
     ap.add_argument("--no-fresh-child", action="store_true", help="skip the fresh-process fragment-ANI call (a child started before this process touches the GPU)")
@@ -623,6 +623,83 @@ def also_n10000(engine, args) -> dict:
         "parity": "sketches of 3 genomes equal the oracle; counts across the 2 048-column tile boundary (a block below the tile diagonal, i.e. mirrored) "
         "equal the merge kernel; the last 24x24 block equals the oracle",
     }
+
+
+def also_fragani_rearranged(engine, args) -> dict:
+    """BASELINE configs[3] on genomes that are NOT substitution-only: 1 000 x ~5 Mb with indels (geometric lengths), 3-5
+    inversions / translocations, repeat families (5-20 copies of 1-2 kb elements) and 30-200 contigs per genome
+    (synth.synth_rearranged_arena_torch) -- the regime of the reference's bacterial fastANI fixtures
+    (tests/fixtures/bacterial_example/intermediates/fastANI/*.fastani).  Timed like also.fragment_ani; every genome of one
+    species plus a few strangers against one reference is checked against the oracle (integers and float mean exact)."""
+    import oracle
+    from oracle import pyoracle
+    from pyani_plus_amd import _capi
+    from pyani_plus_amd.methods.fastani_hip import fastani_mean
+    from pyani_plus_amd.synth import species_and_rate, synth_rearranged_arena_torch
+
+    torch = engine.torch
+    n = min(args.genomes, args.also_fragani_genomes)
+    k, frag = 16, 3000
+    arena, c_start, c_len, c_genome = synth_rearranged_arena_torch(engine, n, args.length, n_species=args.species)
+    engine.prof_reset()
+    times = []
+    for _rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        total, matched, ident_sum = engine.fragani(arena, c_start, c_len, c_genome, k, frag)
+        times.append(time.perf_counter() - t0)
+        if _rep == 0:
+            engine.prof_reset()
+    sec = min(times[1:])
+    prof = engine.prof_get()
+    ani = fastani_mean(ident_sum, matched)
+    if not np.array_equal(total, np.bincount(c_genome, weights=(c_len // frag), minlength=n).astype(np.uint32)):
+        raise SystemExit("PARITY FAILURE (fragment ANI, rearranged set): fragment totals differ from floor(contig length / fragLen) summed over the contigs")
+
+    def contigs_of(g: int) -> list[bytes]:
+        s0, e0 = int(arena.genome_start[g]), int(arena.genome_start[g + 1])
+        words = arena.packed[s0 // 16 : e0 // 16].cpu().numpy().view(np.uint32)
+        codes = ((words[:, None] >> (np.arange(16, dtype=np.uint32) * 2)[None, :]) & 3).astype(np.uint8).reshape(-1)
+        text = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+        sel = c_genome == g
+        return [text[int(a) - s0 : int(a) - s0 + int(m)].tobytes() for a, m in zip(c_start[sel], c_len[sel])]
+
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(_capi.load_library().pa_host_cpu_budget())))
+    ref_g = 0
+    sp = [species_and_rate(g, args.species)[0] for g in range(n)]
+    queries = [g for g in range(n) if sp[g] == sp[ref_g]] + [g for g in range(n) if sp[g] != sp[ref_g]][:5]
+    ref_contigs = contigs_of(ref_g)
+    q_contigs = [contigs_of(g) for g in queries]
+    pyoracle.fragani_set_fast(True)
+    try:
+        t0 = time.perf_counter()
+        o_ani, o_m, o_t = oracle.fragani_many(q_contigs, ref_contigs, k, frag, 0.0, threads=cores)
+        cpu_sec = time.perf_counter() - t0
+    finally:
+        pyoracle.fragani_set_fast(False)
+    bad = [(q, int(matched[q, ref_g]), int(o_m[i])) for i, q in enumerate(queries)
+           if matched[q, ref_g] != o_m[i] or total[q] != o_t[i] or (o_m[i] and ani[q, ref_g] != o_ani[i])]
+    if bad:
+        raise SystemExit(f"PARITY FAILURE (fragment ANI, rearranged set): {len(bad)} of {len(queries)} queries against genome {ref_g} differ from the oracle, first {bad[0]}")
+    contigs_per_genome = np.bincount(c_genome, minlength=n)
+    out = {
+        "workload": f"{n} synthetic ~{args.length / 1e6:g} Mb genomes of {args.species} species that differ from their roots by substitutions, indels (geometric lengths, one per ~8 "
+                    "substitutions), 3-5 inversions / translocations of 20-300 kb, three repeat families of 5-20 copies of 1-2 kb elements, and come as 30-200 contigs each; "
+                    f"fastANI-style fragment ANI k={k} fragLen={frag}, all ordered pairs in one pa_fragani call",
+        "seconds_per_run": sec, "seconds_per_million_pairs": sec * 1e6 / (n * n), "pairs_per_s": n * n / sec, "runs": 2,
+        "contigs_per_genome": {"min": int(contigs_per_genome.min()), "mean": float(contigs_per_genome.mean()), "max": int(contigs_per_genome.max())},
+        "fragments_per_genome": {"min": int(total.min()), "mean": float(total.mean()), "max": int(total.max())},
+        "pairs_with_mappings": int((~np.isnan(ani)).sum()),
+        "phases_ms_per_run": {name: v[0] / 2 for name, v in prof.items() if name.startswith("frag")},
+        "parity": f"kept/total fragments and ANI of {len(queries)} queries (every genome of species {sp[ref_g]} and five strangers) against genome {ref_g} equal the oracle's "
+                  f"(tuned form, {cpu_sec:.1f} s on {cores} CPUs); at 200 genomes tests/test_gpu_rearranged.py holds 56 pairs to the tuned and eight to the checking form",
+    }
+    # event counts of the mapping kernels on this set (candidates per segment, share of one-run segments): from the committed
+    # stats-build run (tools/map_stats.py with PA_SYNTH=rearranged), labelled as such -- the product build does not count
+    efile = ROOT / "profiles" / "fragani_rearranged_events.json"
+    if efile.is_file():
+        out["mapping_events"] = {**json.loads(efile.read_text()), "source": f"profiles/{efile.name} (stats build, one batch of 2^17 query fragments; not measured inside this run)"}
+    return out
 
 
 def config1_files() -> dict:
@@ -1297,6 +1374,10 @@ def run_rank(args, fresh_fragani: dict | None = None) -> None:
             del out, sk_local, sk, counts, ident, cov
             arena = None
             torch.cuda.empty_cache()
+            if "fragani" in wanted and "rearranged" in wanted:
+                engine.prof_enable(True)
+                extra("fragment_ani_rearranged", also_fragani_rearranged, engine, args)
+                engine.prof_enable(False)
             if "mixed" in wanted:
                 extra("mixed_lengths", also_mixed, engine, args)
             if "n10000" in wanted:

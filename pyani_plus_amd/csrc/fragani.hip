@@ -1128,9 +1128,9 @@ static int fragani_ex_impl(pa_ctx *c, const uint32_t *d_packed, const uint32_t *
                         "%u begins finished, %u rounds without items, %u second passes, %u windows with an exact value, %u of them at or above the bar, "
                         "%u begins dropped by the tight bound, %u rounds ended by it; rounds by seed hits of the segment (<= 7, 8-15, 16-31, 32-63, "
                         "64-127, 128-255, more): %u %u %u %u %u %u %u, segments: %u %u %u %u %u %u %u; work model: %u minimizers in the candidates' ranges, "
-                        "%u states tying their candidate's optimum; past the tight bound: %u rounds, %u begins, %u windows, %u of them at or above the bar; %u begins dropped by the bound asked at a round's end; %u segments that are one run of hits (no L1 scan)\n",
+                        "%u states tying their candidate's optimum; past the tight bound: %u rounds, %u begins, %u windows, %u of them at or above the bar; %u begins dropped by the bound asked at a round's end; %u segments that are one run of hits (no L1 scan) with %u hits; hits within 4096 window ids on one contig (ordered by counting): %u segments, all but one hit: %u, all but two: %u\n",
                 st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15], st[16], st[17],
-                st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27], st[28], st[29], st[30], st[31], st[32], st[33], st[40], st[39], st[37], st[38], st[41], st[42]);
+                st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27], st[28], st[29], st[30], st[31], st[32], st[33], st[40], st[39], st[37], st[38], st[41], st[42], st[46], st[43], st[44], st[45]);
       }
 #endif
     }

@@ -186,7 +186,7 @@ def _revcomp_pieces(pieces):
 
 
 def rearranged_genome_pieces(g: int, length: int, n_species: int, seed: int = SEED, contigs: tuple[int, int] = REARRANGED_CONTIGS):
-    """Pieces of genome ``g`` -- (kind, start in the species' substituted root, residues) -- and its contig lengths."""
+    """Pieces of genome ``g`` -- arrays (kind, start in the species' substituted root, residues) -- and its contig lengths."""
     sp, rate = species_and_rate(g, n_species)
     root_pieces, root_len = _species_root_pieces(np.random.Generator(np.random.Philox(key=seed * 31 + 7 * sp + 3)), length)
     total = sum(n for _k, _s, n in root_pieces)
@@ -206,49 +206,59 @@ def rearranged_genome_pieces(g: int, length: int, n_species: int, seed: int = SE
             to = int(rng.integers(0, total - seg + 1))
             moved = mid if rng.random() < 0.5 else _revcomp_pieces(mid)
             pieces = _slice_pieces(rest, 0, to) + moved + _slice_pieces(rest, to, total - seg)
-    # indels with geometric lengths: one per ~8 substitutions, at most one per 200 residues
+    # indels with geometric lengths (one per ~8 substitutions, at most one per 200 residues) and the contig breaks (cut points
+    # anywhere: some contigs come out shorter than a fragment, as in real drafts), in one vectorised pass over the pieces:
+    # the sequence is cut at every piece boundary, indel position, deletion end and contig break; what a deletion covers goes,
+    # random insertions and one-position separators come in where they belong
+    kinds = np.array([k for k, _s, _n in pieces], dtype=np.int64)
+    p_start = np.array([st for _k, st, _n in pieces], dtype=np.int64)
+    p_len = np.array([n for _k, _s, n in pieces], dtype=np.int64)
+    bounds = np.concatenate(([0], np.cumsum(p_len)))
     n_indel = int(min(total / 200, rate * total / 8))
-    if n_indel:
-        at_list = np.sort(rng.integers(0, total, size=n_indel))
-        lens = np.minimum(rng.geometric(0.4, size=n_indel), 50)
-        insert = rng.random(n_indel) < 0.5
-        out, done, src = [], 0, pieces
-        # walk the pieces once, cutting at the indel positions
-        flat, at = [], 0
-        idx = 0
-        for kind, start, n in src:
-            piece_end = at + n
-            cur_off = 0
-            while idx < n_indel and at_list[idx] < piece_end:
-                cut = int(at_list[idx]) - at
-                cut = max(cut, cur_off)
-                if cut > cur_off:
-                    flat.extend(_slice_pieces([(kind, start, n)], cur_off, cut))
-                if insert[idx]:
-                    flat.append((_P_RANDOM, 0, int(lens[idx])))
-                    cur_off = cut
-                else:
-                    cur_off = min(n, cut + int(lens[idx]))  # deleted (a deletion ends with its piece at the latest)
-                idx += 1
-            if cur_off < n:
-                flat.extend(_slice_pieces([(kind, start, n)], cur_off, n))
-            at = piece_end
-        pieces = flat
-        del out, done
-    total = sum(n for _k, _s, n in pieces)
-    # contigs: cut points anywhere (some contigs come out shorter than a fragment, as in real drafts)
+    at = np.sort(rng.integers(0, total, size=n_indel))
+    lens = np.minimum(rng.geometric(0.4, size=n_indel), 50).astype(np.int64)
+    insert = rng.random(n_indel) < 0.5
     n_contigs = int(rng.integers(contigs[0], contigs[1] + 1))
     n_contigs = max(1, min(n_contigs, total // 64))
-    cuts = np.unique(rng.integers(1, max(total, 2), size=n_contigs - 1)) if n_contigs > 1 else np.zeros(0, dtype=np.int64)
-    bounds = [0, *[int(x) for x in cuts if 0 < x < total], total]
-    contig_lens = [b - a for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
-    with_seps, at = [], 0
-    for ci, n in enumerate(contig_lens):
-        with_seps.extend(_slice_pieces(pieces, at, at + n))
-        at += n
-        if ci + 1 < len(contig_lens):
-            with_seps.append((_P_SEPARATOR, 0, 1))
-    return with_seps, contig_lens, root_len, sp, rate
+    breaks = np.unique(rng.integers(1, max(total, 2), size=n_contigs - 1)) if n_contigs > 1 else np.zeros(0, dtype=np.int64)
+    d_start = at[~insert]
+    d_end = np.minimum(d_start + lens[~insert], total)
+    if len(d_start):  # merge deletions that run into each other
+        d_end = np.maximum.accumulate(d_end)
+    cuts = np.unique(np.concatenate((bounds, at[insert], d_start, d_end, breaks)))
+    cuts = cuts[(cuts >= 0) & (cuts <= total)]
+    i_start, i_end = cuts[:-1], cuts[1:]
+    owner = np.searchsorted(bounds, i_start, side="right") - 1
+    if len(d_start):
+        j = np.searchsorted(d_start, i_start, side="right") - 1
+        deleted = (j >= 0) & (i_start < d_end[np.maximum(j, 0)])
+    else:
+        deleted = np.zeros(len(i_start), dtype=bool)
+    keep = ~deleted
+    off = i_start - bounds[owner]
+    n = i_end - i_start
+    k_kind = kinds[owner]
+    k_start = np.where(k_kind == _P_REVCOMP, p_start[owner] + p_len[owner] - off - n, p_start[owner] + off)
+    # everything that ends up in the genome, in order: (position, what comes first at a position: separator, insertion, then the residues)
+    ev_pos = np.concatenate((breaks, at[insert], i_start[keep]))
+    ev_rank = np.concatenate((np.zeros(len(breaks), np.int64), np.ones(int(insert.sum()), np.int64), np.full(int(keep.sum()), 2, np.int64)))
+    ev_kind = np.concatenate((np.full(len(breaks), _P_SEPARATOR, np.int64), np.full(int(insert.sum()), _P_RANDOM, np.int64), k_kind[keep]))
+    ev_start = np.concatenate((np.zeros(len(breaks) + int(insert.sum()), np.int64), k_start[keep]))
+    ev_len = np.concatenate((np.ones(len(breaks), np.int64), lens[insert], n[keep]))
+    order = np.lexsort((ev_rank, ev_pos))
+    ev_kind, ev_start, ev_len = ev_kind[order], ev_start[order], ev_len[order]
+    # a separator at the very start, two in a row or one at the very end would make an empty contig: dropped
+    is_sep = ev_kind == _P_SEPARATOR
+    prev_sep = np.concatenate(([True], is_sep[:-1]))
+    drop = is_sep & prev_sep
+    if len(is_sep) and is_sep[-1]:
+        drop[-1] = True
+    ev_kind, ev_start, ev_len = ev_kind[~drop], ev_start[~drop], ev_len[~drop]
+    sep_at = np.flatnonzero(ev_kind == _P_SEPARATOR)
+    csum = np.concatenate(([0], np.cumsum(ev_len)))
+    edges = np.concatenate(([0], csum[sep_at + 1], [csum[-1] + 1]))  # a contig runs from after a separator up to the next one
+    contig_lens = [int(x) for x in (edges[1:] - edges[:-1] - 1)]
+    return (ev_kind, ev_start, ev_len), contig_lens, root_len, sp, rate
 
 
 def synth_rearranged_arena_torch(engine, n_genomes: int, length: int, n_species: int = 40, seed: int = SEED, *, genome_ids=None, device=None,
@@ -259,7 +269,7 @@ def synth_rearranged_arena_torch(engine, n_genomes: int, length: int, n_species:
     t = engine.torch
     dev = engine.device if device is None else device
     plans = [rearranged_genome_pieces(i if genome_ids is None else int(genome_ids[i]), int(length), n_species, seed, contigs) for i in range(n_genomes)]
-    lengths = [sum(n for _k, _s, n in pl[0]) for pl in plans]  # residues + separators
+    lengths = [int(pl[0][2].sum()) for pl in plans]  # residues + separators
     pads = [_padded(x) for x in lengths]
     starts = np.zeros(n_genomes + 1, dtype=np.uint64)
     np.cumsum(pads, out=starts[1:])
@@ -280,11 +290,11 @@ def synth_rearranged_arena_torch(engine, n_genomes: int, length: int, n_species:
         hit = t.rand(root_len, generator=gen, device=dev) < rate
         delta = t.randint(1, 4, (root_len,), generator=gen, device=dev, dtype=t.int64) * hit
         subbed = (roots[sp] + delta) & 3
-        kinds = t.tensor([p[0] for p in pieces], dtype=t.int64, device=dev)
-        p_start = t.tensor([p[1] for p in pieces], dtype=t.int64, device=dev)
-        p_len = t.tensor([p[2] for p in pieces], dtype=t.int64, device=dev)
+        kinds = t.from_numpy(pieces[0]).to(dev)
+        p_start = t.from_numpy(pieces[1]).to(dev)
+        p_len = t.from_numpy(pieces[2]).to(dev)
         out_off = t.cumsum(p_len, 0) - p_len
-        pid = t.repeat_interleave(t.arange(len(pieces), device=dev), p_len)
+        pid = t.repeat_interleave(t.arange(len(pieces[0]), device=dev), p_len)
         j = t.arange(lengths[i], device=dev) - out_off[pid]
         kind = kinds[pid]
         src = t.where(kind == _P_REVCOMP, p_start[pid] + p_len[pid] - 1 - j, p_start[pid] + j)

@@ -58,7 +58,12 @@ def test_rearranged_genomes_against_the_oracle_at_full_size():
         # a genome keeps (nearly) all its fragments against itself -- repeat copies compete for reference bins, as in the
         # reference's own self rows (1820 of 1825, ...) --, species mates map, strangers do not reach minFraction
         assert np.all(np.diag(matched) >= 0.97 * total) and np.all(np.diag(ani) > 99.9)
-        assert np.all(matched[same] > 0.5 * np.minimum(total[:, None], total[None, :])[same])
+        # species mates whose substitutions alone leave them above 90 % identity (the generator's rates go up to 20 % per genome: two
+        # such genomes are 65 % identical and below fastANI's 80 % floor) map most of their fragments; strangers stay below minFraction
+        rate = np.array([species_and_rate(g, SPECIES)[1] for g in range(N)])
+        p_true = (1 - rate[:, None]) * (1 - rate[None, :]) + rate[:, None] * rate[None, :] / 3.0
+        close = same & (p_true >= 0.9)
+        assert int(close.sum()) > 1000 and np.all(matched[close] > 0.5 * np.minimum(total[:, None], total[None, :])[close])
         assert np.all(matched[~same] < 0.2 * total[:, None].repeat(N, 1)[~same])
         # ---- the oracle on sampled ordered pairs: two references, every genome of their species + four strangers each
         cores = max(1, min(len(os.sched_getaffinity(0)), int(_capi.load_library().pa_host_cpu_budget())))

@@ -24,8 +24,13 @@ n_query = int(sys.argv[2]) if len(sys.argv) > 2 else 78
 length, k, frag = 5_000_000, 16, 3000
 os.environ["PA_FRAGANI_TRACE"] = "1"
 eng = HipEngine(0, tools=True)
-arena = synth_arena_torch(eng, n, length)
-starts = arena.genome_start[:-1].copy()
-lens = np.full(n, length, dtype=np.uint32)
-genome = np.arange(n, dtype=np.uint32)
+if os.environ.get("PA_SYNTH") == "rearranged":  # the set with indels, inversions, repeat families and 30-200 contigs per genome
+    from pyani_plus_amd.synth import synth_rearranged_arena_torch  # noqa: E402
+
+    arena, starts, lens, genome = synth_rearranged_arena_torch(eng, n, length)
+else:
+    arena = synth_arena_torch(eng, n, length)
+    starts = arena.genome_start[:-1].copy()
+    lens = np.full(n, length, dtype=np.uint32)
+    genome = np.arange(n, dtype=np.uint32)
 eng.fragani(arena, starts, lens, genome, k, frag, query_range=(0, min(n_query, n)))
