@@ -625,7 +625,7 @@ def also_n10000(engine, args) -> dict:
     }
 
 
-def also_fragani_rearranged(engine, args) -> dict:
+def also_fragani_rearranged(engine, args, n_total: int) -> dict:
     """BASELINE configs[3] on genomes that are NOT substitution-only: 1 000 x ~5 Mb with indels (geometric lengths), 3-5
     inversions / translocations, repeat families (5-20 copies of 1-2 kb elements) and 30-200 contigs per genome
     (synth.synth_rearranged_arena_torch) -- the regime of the reference's bacterial fastANI fixtures
@@ -638,7 +638,7 @@ def also_fragani_rearranged(engine, args) -> dict:
     from pyani_plus_amd.synth import species_and_rate, synth_rearranged_arena_torch
 
     torch = engine.torch
-    n = min(args.genomes, args.also_fragani_genomes)
+    n = min(n_total, args.also_fragani_genomes)
     k, frag = 16, 3000
     arena, c_start, c_len, c_genome = synth_rearranged_arena_torch(engine, n, args.length, n_species=args.species)
     engine.prof_reset()
@@ -808,8 +808,9 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
             other.close()
         torch.cuda.empty_cache()
     workspace["what"] = ("device bytes of the fragment-ANI workspace as allocated (pa_fragani_workspace; buffers grow by a quarter when they grow): "
-                         "9.6 bytes per arena residue for all genomes' minimizers + 28 bytes per minimizer of the reference range (one per 12.5 residues) + "
-                         "8 bytes per seed hit of the largest query batch (DESIGN.md 4.5, Memory); pa_fragani_set_workspace_cap bounds it")
+                         "~2.3 bytes per arena residue for all genomes' minimizers, ids and links + ~5.2 bytes per residue of the reference range for its dictionary, "
+                         "postings and sort buffers + 8 bytes per seed hit of the largest query batch and ~1 GB of per-batch tables (DESIGN.md 4.5, Memory); "
+                         "pa_fragani_set_workspace_cap bounds it")
     from pyani_plus_amd.methods.fastani_hip import fastani_mean
 
     ani = fastani_mean(ident_sum, matched)  # fastANI's own mean: a float sum by a float count
@@ -1376,7 +1377,7 @@ def run_rank(args, fresh_fragani: dict | None = None) -> None:
             torch.cuda.empty_cache()
             if "fragani" in wanted and "rearranged" in wanted:
                 engine.prof_enable(True)
-                extra("fragment_ani_rearranged", also_fragani_rearranged, engine, args)
+                extra("fragment_ani_rearranged", also_fragani_rearranged, engine, args, n_total)
                 engine.prof_enable(False)
             if "mixed" in wanted:
                 extra("mixed_lengths", also_mixed, engine, args)

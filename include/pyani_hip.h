@@ -295,9 +295,12 @@ PA_API int pa_fragani_ex(pa_ctx *ctx, const uint32_t *d_packed, const uint32_t *
  * calls that would take the workspace past cap_bytes end with PA_E_NOMEM and a pa_last_error() message that names the
  * call (genomes, arena residues, query and reference range, fragLen) and the sizes (bytes held, the buffer that wanted to
  * grow, the cap); a call that ends that way (or with the device's own out-of-memory) gives the whole workspace back, so a
- * smaller call in the same context starts from nothing and goes on working.  What a call needs, DESIGN.md 4.5:
- * about 9.6 bytes per arena residue for the minimizers and their links, 28 bytes per minimizer of the REFERENCE RANGE
- * for the dictionary (a minimizer per 12.5 residues), 8 bytes per seed hit of the largest query batch. */
+ * smaller call in the same context starts from nothing and goes on working.  What a call needs (Memory;
+ * as allocated, buffers grow by a quarter when they grow): about 2.3 bytes per arena residue for the minimizers of ALL
+ * genomes, their hash ids and links; about 5.2 bytes per residue of the REFERENCE RANGE for its dictionary, postings and
+ * the sort's buffers (a range that is not the whole set adds a look-up table of 32-64 bytes per distinct hash); 8 bytes per
+ * seed hit of the largest query batch and ~1 GB of per-batch tables.  Measured at 1000 x 5 Mb (bench.py,
+ * also.fragment_ani.workspace_device_bytes): 44.1 GB all against all, 19.7 GB an eighth of the columns, 12.9 GB one column. */
 PA_API int pa_fragani_workspace(pa_ctx *ctx, uint64_t *held_bytes, uint64_t *peak_bytes, uint64_t *cap_bytes);
 PA_API int pa_fragani_set_workspace_cap(pa_ctx *ctx, uint64_t cap_bytes);
 /* Residues that are neither ACGT nor N.  The arena keeps two bits per residue and one "not ACGT" bit, which the

@@ -681,6 +681,32 @@ def test_the_path_for_more_than_8192_genomes(tools_engine, monkeypatch):
     _check_against_oracle(engine, [b">g%d\n" % i + g + b"\n" for i, g in enumerate(genomes)], [[g] for g in genomes])
 
 
+def test_long_fragments_with_the_widest_window_the_kernels_take(engine):
+    """fragLen 8000 at k = 16 is a winnowing window of 64 positions -- the widest ``minimizer_kernel`` takes (its look-back) --,
+    windows of ~7 900 window ids and candidate ranges of 24 000: the far end of what the 16-bit offsets inside a stretch and the
+    counting sort's span are sized for.  With runs of N (one nearly a fragment long, right before a contig's last kilobases)
+    and contigs that end mid-fragment: same integers as the oracle."""
+    rng = np.random.default_rng(99)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    frag = 8_000
+    root = rng.choice(acgt, size=230_000)
+    gap = np.full(7_000, ord("N"), dtype=np.uint8)
+
+    def mutated(seq, rate):
+        out = seq.copy()
+        hit = rng.random(out.size) < rate
+        out[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+        return out
+
+    ref = [np.concatenate((root[:180_000], gap, root[180_000:186_000])).tobytes(), root[186_000:230_000].tobytes()]
+    q1 = [mutated(root[:186_000], 0.01).tobytes(), mutated(root[186_000:230_000], 0.02).tobytes()]
+    q2 = [np.concatenate((mutated(root[100_000:180_000], 0.03), gap[:6_600], mutated(root[180_000:186_000], 0.03))).tobytes()]
+    contig_lists = [ref, q1, q2]
+    texts = [b"".join(b">c%d\n" % i + c + b"\n" for i, c in enumerate(cs)) for cs in contig_lists]
+    total, matched, _ = _check_against_oracle(engine, texts, contig_lists, frag=frag)
+    assert total.tolist() == [24 + 5, 23 + 5, 11] and matched[1, 0] >= 24 and matched[0, 0] >= 25 and matched[2, 0] >= 8
+
+
 def test_low_complexity_fragments(engine):
     """Inside a homopolymer run or an array of a short unit every window records its minimum anew: a fragment's slice of the
     genome's minimizers then holds one entry per position (thousands, all of one hash) where its sketch holds one hash.  The
