@@ -1105,7 +1105,11 @@ static int fragani_ex_impl(pa_ctx *c, const uint32_t *d_packed, const uint32_t *
                                W.tab_min_shared.as<uint32_t>(), W.contig_mini_off.as<uint32_t>(), W.contig_bucket_off.as<uint32_t>(),
                                W.bucket_first.as<uint32_t>(), W.mini_hash.as<uint32_t>(), W.mini_wpos.as<uint32_t>(),
                                W.prev_same.as<int32_t>(), W.contig_bin_off.as<uint32_t>(), range_bins, table_p, over_a0, over_nh, over_f,
-                               d_over_n);
+                               d_over_n
+#ifdef PA_MAP_STATS
+                               , W.run_g.as<uint32_t>()
+#endif
+            );
             PA_HIP(hipMemcpyAsync(c->h_pinned, d_over_n, 4, hipMemcpyDeviceToHost, c->stream));
             PA_HIP(hipStreamSynchronize(c->stream));
             const uint32_t n_over = *reinterpret_cast<const uint32_t *>(c->h_pinned);
@@ -1131,6 +1135,8 @@ static int fragani_ex_impl(pa_ctx *c, const uint32_t *d_packed, const uint32_t *
                         "%u states tying their candidate's optimum; past the tight bound: %u rounds, %u begins, %u windows, %u of them at or above the bar; %u begins dropped by the bound asked at a round's end; %u segments that are one run of hits (no L1 scan) with %u hits; hits within 4096 window ids on one contig (ordered by counting): %u segments, all but one hit: %u, all but two: %u\n",
                 st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15], st[16], st[17],
                 st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27], st[28], st[29], st[30], st[31], st[32], st[33], st[40], st[39], st[37], st[38], st[41], st[42], st[46], st[43], st[44], st[45]);
+        fprintf(stderr, "pa_fragani: sparse stats: %u segments with a candidate, %u candidates, %u groups of begins evaluated, %u begins, %u states, %u begins tying "
+                        "their candidate's best when folded; %u one-run segments with strays\n", st[48], st[49], st[50], st[51], st[52], st[53], st[47]);
       }
 #endif
     }

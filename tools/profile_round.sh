@@ -15,7 +15,18 @@ cd "$ROOT"
 bash tools/pmc_passes.sh ${TAG}_hash kmer_hash tools/pmc_hash.py 1000
 # the fragment-ANI kernels at the benchmark's 1 000 genomes, one batch of 2^17 query fragments (78 query genomes) per repetition
 bash tools/pmc_passes.sh ${TAG}_fragmap "map_segments_kernel<320u, true>" tools/bench_fragani.py 1000 0 interleaved 78
+bash tools/pmc_passes.sh ${TAG}_sparse "map_sparse_kernel" tools/bench_fragani.py 1000 0 interleaved 78
 bash tools/pmc_passes.sh ${TAG}_bucket bucket_hits tools/bench_fragani.py 1000 0 interleaved 78
+bash tools/pmc_passes.sh ${TAG}_minimizer "minimizer_kernel" tools/bench_fragani.py 1000 0 interleaved 78
+bash tools/pmc_passes.sh ${TAG}_postings "postings_kernel" tools/bench_fragani.py 1000 0 interleaved 78
+bash tools/pmc_passes.sh ${TAG}_rs_scatter "rs_scatter_kernel" tools/bench_fragani.py 1000 0 interleaved 78
+# vector instructions of the general mapping kernel per phase (the kernel cut short after each phase under --pmc)
+bash tools/map_cut_valu.sh ${TAG} > /dev/null
+# FETCH_SIZE calibrated for the seeding kernel's access pattern
+bash tools/fetch_calib.sh ${TAG} > /dev/null
+# the set with indels, rearrangements, repeat families and contigs: event counts of one batch, and the whole run
+PA_SYNTH=rearranged python3 tools/map_stats.py 1000 78 2>&1 | grep "pa_fragani:" > gpurun_out/${TAG}_fragani1000_rearranged_onebatch_trace.txt
+PA_SYNTH=rearranged python3 tools/bench_fragani.py 1000 > gpurun_out/${TAG}_fragani1000_rearranged.log 2>&1
 # seed hits per bucket_hits dispatch of that run (the denominator of its bytes per hit) and the mapping kernels' event counts
 # (the switches live in the tools build: tools/map_stats.py loads libpyani_hip_stats.so, `make -C pyani_plus_amd/csrc stats`)
 python3 tools/map_stats.py 1000 78 2>&1 | grep "pa_fragani:" > gpurun_out/${TAG}_fragani1000_onebatch_trace.txt
