@@ -900,10 +900,13 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
             "what": "vector instruction issue of one wave per (fragment, reference genome) segment; no HBM or MFMA roof applies "
             "(integer/index work on LDS-resident data).  frac = the vector instructions the dispatch NEEDS (work model) / the vector "
             "instructions it ISSUED (SQ_INSTS_VALU); the pipe itself is valu_busy full while the kernel runs",
-            "frac": work.get("frac"), "work_model": work.get("work_model"),
+            "frac": work.get("frac"), "frac_first_group": work.get("frac_first_group"), "frac_minimal_sort": work.get("frac_minimal_sort"),
+            "work_model": work.get("work_model"),
             "algorithmic_units_per_dispatch": work.get("algorithmic_units_per_dispatch"),
-            "valu_instructions_per_unit": work.get("valu_instructions_per_unit"),
+            "valu_instructions_per_phase_per_segment": work.get("valu_instructions_per_phase_per_segment"),
+            "share_of_a_round_needed": work.get("share_of_a_round_needed"),
             "algorithmic_valu_instructions_per_dispatch": work.get("algorithmic_valu_instructions_per_dispatch"),
+            "algorithmic_valu_instructions_by_unit": work.get("algorithmic_valu_instructions_by_unit"),
             "counted_valu_instructions_per_dispatch": work.get("counted_valu_instructions_per_dispatch"),
             "valu_busy": mc.get("valu_busy"), "salu_busy": mc.get("salu_busy"),
             "wait_share_of_wave_time": mc.get("wait_share"), "waves_per_simd": mc.get("waves_per_simd"),
@@ -913,12 +916,33 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
             "counted_fetch_bytes_per_dispatch": mc.get("fetch_bytes_per_dispatch_as_counted"), "counted_write_bytes_per_dispatch": mc.get("write_bytes_per_dispatch"),
             "counted_bytes_note": "the kernel's results are a few MB per dispatch; the counted writes are its register spills (scratch memory)",
         }
+        sc = (counters or {}).get("map_sparse_kernel", {})
+        if sc:
+            out["roofline_sparse"] = {
+                "kernel": "map_sparse_kernel", "bound": "valu-issue", "frac": sc.get("frac"), "frac_what": sc.get("frac_what"), "valu_busy": sc.get("valu_busy"),
+                "valu_instructions_per_segment": sc.get("valu_instructions_per_segment"), "valu_instructions_per_state_evaluated": sc.get("valu_instructions_per_state_evaluated"),
+                "events_per_dispatch": sc.get("events_per_dispatch"), "avg_ms_per_dispatch": sc.get("avg_ms_per_dispatch"), "waves_per_simd": sc.get("waves_per_simd"),
+                "source": sc.get("source"),
+            }
+        ic = (counters or {}).get("minimizer_kernel", {})
+        if ic:
+            out["roofline_index"] = {
+                "kernel": "minimizer_kernel<16>", "bound": "valu-issue", "frac": ic.get("frac"), "frac_what": ic.get("frac_what"), "valu_busy": ic.get("valu_busy"),
+                "valu_instructions_per_position": ic.get("valu_instructions_per_position"), "hash_valu_instructions_per_position": ic.get("hash_valu_instructions_per_position"),
+                "avg_ms_per_dispatch": ic.get("avg_ms_per_dispatch"), "waves_per_simd": ic.get("waves_per_simd"), "wait_share_of_wave_time": ic.get("wait_share"),
+                "algorithmic_gbs": ic.get("algorithmic_gbs"), "algorithmic_bytes_note": ic.get("algorithmic_bytes_note"), "source": ic.get("source"),
+                "avg_ms_per_run_of_the_index_phase": prof.get("frag_index", (0.0, 0))[0] / 2,
+            }
         bc = (counters or {}).get("bucket_hits_kernel", {})
         out["roofline_seeding"] = {
-            "kernel": "bucket_hits_kernel", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "kernel": "bucket_hits_staged_kernel", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
             "algorithmic_bytes_per_hit": bc.get("algorithmic_bytes_per_hit"), "counter_bytes_per_hit": bc.get("counter_bytes_per_hit"),
             "achieved": bc.get("algorithmic_gbs"), "frac": (bc.get("algorithmic_gbs") or 0) / HBM_PEAK_GBS if bc.get("algorithmic_gbs") else None,
-            "traffic_gbs": bc.get("counter_gbs"), "source": bc.get("source", "no counter passes committed"),
+            "traffic_gbs": bc.get("counter_gbs"), "traffic_over_algorithmic": bc.get("traffic_over_algorithmic"),
+            "fetch_calibration": bc.get("fetch_calibration"),
+            "counter_bytes_note": "FETCH_SIZE turned into 64-byte lines moved with the factor measured for this access pattern (runs of 2- and 8-byte items at unrelated "
+                                  "places: tools/fetch_calib, profiles/r06_fetch_calibration.txt) + WRITE_SIZE (exact); one calibrated number, not two alternatives",
+            "source": bc.get("source", "no counter passes committed"),
             "avg_ms_per_run_of_the_seeding_phase": seed_ms,
         }
     return out

@@ -1103,19 +1103,58 @@ def test_bench_dry_run_plan_of_the_eight_gpu_configs():
 
 
 def test_work_based_roofline_is_reproducible_from_the_committed_profiles():
-    """``also.fragment_ani.roofline.frac`` = events x cost / counted instructions, from files under profiles/: the event counts
-    of the stats build, the per-unit costs, SQ_INSTS_VALU of the counter pass."""
+    """Every ``also.fragment_ani.roofline*.frac`` of the bench line follows from files under profiles/ and from nothing else:
+    ``profiles/fragani_counters.json`` is what ``tools/pmc_fragani_to_json.py r06`` makes of the committed counter summaries,
+    the per-phase instruction counts (the mapping kernel cut short after each phase under ``--pmc``), the event counts of the
+    stats build and the FETCH_SIZE calibration -- and the fractions are re-derived here by hand from those numbers."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("pmc_fragani_to_json", ROOT / "tools" / "pmc_fragani_to_json.py")
     tool = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tool)
-    counters = json.loads((ROOT / "profiles" / "fragani_counters.json").read_text())["map_segments_kernel"]
-    summary = tool.parse(ROOT / "profiles" / "r05_pmc_map_segments_summary.txt")
-    work = tool.work_model(ROOT / "profiles" / "r05_fragani_n1000_one_batch_trace.txt", summary["SQ_INSTS_VALU"])
-    assert work["frac"] == counters["work"]["frac"] and 0.3 < work["frac"] < 1.0
-    u, c = work["algorithmic_units_per_dispatch"], tool.WORK_COSTS
-    by_hand = (u["segments"] * c["per_segment"] + u["seed_hits"] * c["per_hit"]
-               + (u["candidates"] * tool.WINDOW_ENTRIES + u["tying_states"]) * c["per_entry"] + u["tying_states"] * c["per_window"])
-    assert abs(by_hand / summary["SQ_INSTS_VALU"] - work["frac"]) < 1e-12
-    assert counters["valu_instructions"] == summary["SQ_INSTS_VALU"]
+    prof = ROOT / "profiles"
+    committed = json.loads((prof / "fragani_counters.json").read_text())
+    rebuilt = tool.build(committed["tag"], prof)
+    assert json.loads(json.dumps(rebuilt)) == committed  # the committed file is what the tool makes of the committed measurements
+    tag = committed["tag"]
+    # ---- map_segments_kernel: needed = V[3] + (V[24] - V[3]) x share, issued = V[9]
+    cuts = tool.parse_cuts(prof / f"{tag}_map_cut_valu.txt")
+    v = {c: d["SQ_INSTS_VALU"] for c, d in cuts.items()}
+    ev = tool.parse_events(prof / f"{tag}_fragani_n1000_one_batch_trace.txt")
+    share = (ev["candidates"] * 237.0 + ev["tying_states"]) / (ev["candidates"] * ev["stretch_entries_ranked"] / (ev["rounds"] - ev["rounds_ended_by_the_tight_bound"]))
+    work = committed["map_segments_kernel"]["work"]
+    assert 0.5 < share < 1.0 and abs(work["share_of_a_round_needed"] - share) < 1e-12
+    assert abs(work["frac"] - (v[3] + (v[24] - v[3]) * share) / v[9]) < 1e-12 and 0.4 < work["frac"] < 0.8
+    assert abs(work["frac_first_group"] - v[23] / v[9]) < 1e-12 and work["frac"] < work["frac_first_group"] < 1.0
+    assert v[10] < v[11] < v[1] < v[2] < v[3] < v[5] < v[7] < v[8] < v[24] < v[23] < v[9]  # every cut ends the kernel later than the one before
+    # the one-run segments' L1 scan is not charged: the L1 phase is what the kernel issues, with the scan skipped where it is
+    assert ev["one_run_segments_no_l1_scan"] > 0.9 * ev["segments"] and work["valu_instructions_per_phase_per_segment"]["l1"] < 400
+    # hits ordered by counting for (nearly) all segments: pricing every segment at the counting sort moves the fraction by < 0.01
+    assert abs(work["frac_minimal_sort"] - work["frac"]) < 0.01 and work["counting_sort_valu_per_segment"] < 0.5 * work["network_sort_valu_per_segment"]
+    # the product build's own counter pass agrees with the tools build's uncut run within the cut checks' few instructions
+    product = tool.parse(prof / f"{tag}_pmc_map_segments_summary.txt")["SQ_INSTS_VALU"]
+    assert committed["map_segments_kernel"]["valu_instructions"] == product and abs(product / v[9] - 1.0) < 0.03
+    # ---- map_sparse_kernel: states of the begins that tie / states evaluated
+    sp = committed["map_sparse_kernel"]
+    se = ev["sparse"]
+    assert abs(sp["frac"] - se["begins_tying_when_folded"] / se["begins"]) < 1e-12 and 0.3 < sp["frac"] <= 1.0 and sp["valu_busy"] > 0.9
+    # ---- minimizer_kernel: the two hashes per position / instructions issued per position
+    mi = committed["minimizer_kernel"]
+    issued = tool.parse(prof / f"{tag}_pmc_minimizer_summary.txt")["SQ_INSTS_VALU"] * 64 / (1000 * 5_000_064)
+    assert abs(mi["frac"] - 126.0 / issued) < 1e-12 and 150 < issued < 230
+    # ---- bucket_hits_staged_kernel: 18 algorithmic bytes per hit / time against 8 TB/s; traffic = calibrated FETCH_SIZE + WRITE_SIZE
+    bh = committed["bucket_hits_kernel"]
+    summary = tool.parse(prof / f"{tag}_pmc_bucket_hits_summary.txt")
+    hits = ev["seed_hits_of_the_batch"]
+    assert abs(bh["algorithmic_gbs"] - 18.0 * hits / (summary["duration_ms"] * 1e-3) / 1e9) < 1e-6
+    cal = tool.parse_calibration(prof / f"{tag}_fetch_calibration.txt")
+    assert abs(cal["calib_stream16"]["counted_over_asked"] - 0.5) < 0.01  # the guide's rule, reproduced in the same run
+    k16, k64 = cal["calib_runs<unsigned short>"], cal["calib_runs<unsigned long>"]
+    c16, c64 = 2.0 * k16["counted_over_asked"], 8.0 * k64["counted_over_asked"]
+    factor = (c16 / k16["counted_over_line_bytes"] + c64 / k64["counted_over_line_bytes"]) / (c16 + c64)
+    traffic = (summary["FETCH_SIZE"] * 1024 * factor + summary["WRITE_SIZE"] * 1024) / hits
+    assert abs(bh["counter_bytes_per_hit"] - traffic) < 1e-9 and 18.0 < traffic < 40.0
+    # what bench.py prints is this file's content (the roofline entries copy these fields)
+    bench_src = (ROOT / "bench.py").read_text()
+    for key in ("frac_first_group", "frac_minimal_sort", "roofline_sparse", "roofline_index", "traffic_over_algorithmic"):
+        assert key in bench_src

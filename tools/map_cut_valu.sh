@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/${TAG}_map_cut_valu.txt
 mkdir -p $ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 : > $OUT
-for CUT in 10 11 1 2 3 4 5 6 7 8 22 9; do
+for CUT in 10 11 1 2 3 4 5 7 8 24 23 9; do
   D=/tmp/mcv_$$_$CUT
   PA_MAP_CUT=$CUT PA_AB_LIB=$ROOT/pyani_plus_amd/_lib/libpyani_hip_tools.so rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES \
     --kernel-include-regex "map_segments_kernel<320u, true>" --kernel-trace --output-format csv -d $D -- python3 $ROOT/tools/bench_fragani.py 1000 0 interleaved 78 > $D.log 2>&1

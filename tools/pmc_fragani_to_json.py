@@ -1,11 +1,35 @@
 #!/usr/bin/env python3
-"""profiles/fragani_counters.json from the summaries of the rocprofv3 counter passes on the fragment-ANI kernels
-(tools/pmc_passes.sh <tag> <kernel> tools/bench_fragani.py 1000 0 interleaved 78 -> gpurun_out/<tag>_pmc/summary.txt,
-copied to profiles/: the benchmark's 1 000 genomes, one batch of 2^17 query fragments per repetition).  bench.py copies
-these figures into `also.fragment_ani.roofline*`, labelled as coming from these passes.
+"""profiles/fragani_counters.json from the committed measurements of the fragment-ANI kernels -- every figure of
+`also.fragment_ani.roofline*` in bench.py's line follows from files under profiles/ and from nothing else:
 
-    python tools/pmc_fragani_to_json.py profiles/r05_pmc_map_segments_summary.txt profiles/r05_pmc_bucket_hits_summary.txt \
-        <seed hits per bucket_hits dispatch> [workload label] [profiles/r05_fragani_n1000_one_batch_trace.txt: event counts for the work model]
+    <tag>_pmc_map_segments_summary.txt, _pmc_map_sparse_summary.txt, _pmc_bucket_hits_summary.txt, _pmc_minimizer_summary.txt
+        tools/pmc_passes.sh <tag> <kernel> tools/bench_fragani.py 1000 0 interleaved 78 (rocprofv3 --pmc, one set per run)
+    <tag>_map_cut_valu.txt
+        tools/map_cut_valu.sh: SQ_INSTS_VALU of map_segments_kernel cut short after each phase (enum MapCut) -- the
+        instruction counter PER PHASE of the tools build
+    <tag>_fragani_n1000_one_batch_trace.txt
+        tools/map_stats.py 1000 78: event counts of the same batch (stats build)
+    <tag>_fetch_calibration.txt
+        tools/fetch_calib.sh: what FETCH_SIZE counts for posting-list-shaped reads of 2- and 8-byte items
+
+    python tools/pmc_fragani_to_json.py r06 > profiles/fragani_counters.json
+
+The work model of map_segments_kernel (profiles/README.md, "Work-based roofline of the mapping kernel"): the vector
+instructions a dispatch NEEDS if a perfect bound spared it everything but the states that tie their candidate's optimum,
+every unit priced at what the kernel itself issues for it -- MEASURED per phase (the cut runs), not read off a listing:
+
+    fixed       everything up to and including the candidate's set-up: record, sketch, hits ordered (by counting for the
+                segments whose hits are one cluster and up to two strays, by the network for the rest), the L1 scan where a
+                segment needs one (a run of hits with or without strays skips it), candidate set-up           = V[cut 3]
+    one round   per candidate ONE complete round on the group of the expected optimum -- the group's seed-hit bound, the
+                stretch loaded, window ends, the tight bound asked once, ranks, tables, coarse search, fine passes, fold --
+                = V[24] - V[3] (cut 24: the kernel ends after its first round), of which a perfect bound needs the share that
+                the minimizers of ONE window (2 count_windows / (w + 1) = 237) plus one per further tying state are of the
+                entries such a round ranks: share = (C x 237 + W) / (C x entries ranked per full round)
+
+needed = V[3] + (V[24] - V[3]) x share; frac = needed / V[9].  `frac_first_group` = V[23] / V[9]: what the kernel issues when it only ever looks
+at the group of the expected optimum (a perfect bound on whole groups), measured directly.  `frac_minimal_sort`: the same with EVERY segment's hits ordered at the price of the counting sort
+(the network's price per segment is the start-of-round measurement, all segments through it).
 """
 import json
 import re
@@ -13,6 +37,8 @@ import sys
 from pathlib import Path
 
 SIMDS, CUS, XCDS = 1024, 256, 8
+WINDOW_ENTRIES = 237.0  # 2 count_windows / (w + 1) for k = 16, fragLen = 3000 (count_windows 2962, w 24)
+ROOT = Path(__file__).resolve().parent.parent / "profiles"
 
 
 def parse(path: Path) -> dict:
@@ -27,98 +53,212 @@ def parse(path: Path) -> dict:
     return out
 
 
-# ---- the work model of map_segments_kernel (profiles/README.md, "Work-based roofline of the mapping kernel")
-# Units, from the event counters of the stats build (tools/map_stats.py, one dispatch = one batch of 2^17 fragments):
-#   S segments that reach L1, H their seed hits, C candidates, W states that tie their candidate's optimum (no bound can
-#   spare them; one probe where nothing was evaluated).
-# Algorithmic work of a dispatch: every segment set up once (sketch loaded and bucketed, candidate set up), every hit
-# ordered and scanned once, per candidate the minimizers of ONE window (2 count_windows / (w + 1) = 237 expected for
-# k = 16, fragLen = 3000) plus one per further tying state ranked and entered in the bit tables once, one exact window
-# evaluation per tying state.  Costs in vector instructions of a wave per unit: the kernel's own, from the static listing
-# (tools/isa_lines.py on the build the counters come from) with the loop trip counts of the benchmark.
-WORK_COSTS = {
-    "per_segment": 320.0,   # record + sketch load 75, candidate set-up 160, result 20, L1 tail 65 (the sketch's bucket table, 80, is made once per fragment by query_sketch_kernel since the end of round 5)
-    "per_hit": 11.6,        # ordered in registers (36 stages x 4 keys x ~5.5 = 800 per <= 256 hits), L1 scan 348 per 64 hits, staged: / 139 hits
-    "per_entry": 2.4,       # stretch load + window ends 200, ranks 190, match bitmap 50, coarse table 320: 760 per round of 320 entries
-    "per_window": 13.0,     # window mask + coarse search 410, fine pass 285 x 1.2, fold 80: 830 per pass of 64 windows
-}
-WINDOW_ENTRIES = 237.0
+def parse_cuts(path: Path) -> dict:
+    """cut number -> {counter: mean per dispatch} from tools/map_cut_valu.sh"""
+    cuts = {}
+    for line in path.read_text().splitlines():
+        m = re.match(r"cut\s+(\d+):\s+(.*?)\s+\(", line)
+        if m:
+            vals = re.findall(r"(SQ_\w+) (\S+)", m.group(2))
+            cuts[int(m.group(1))] = {k: float(v) for k, v in vals}
+    return cuts
 
 
-def work_model(trace_file: Path, valu_instructions: float) -> dict:
-    text = trace_file.read_text()
-    m = re.search(r"map stats: (\d+) segments at L1 with (\d+) hits, (\d+) candidates", text)
-    w = re.search(r"work model: (\d+) minimizers in the candidates' ranges, (\d+) states tying", text)
-    if not m or not w:
-        return {"error": f"no event counts in {trace_file.name}"}
-    seg, hits, cand = (float(x) for x in m.groups())
-    range_entries, ties = (float(x) for x in w.groups())
-    entries = cand * WINDOW_ENTRIES + ties
-    parts = {
-        "segments": seg * WORK_COSTS["per_segment"], "hits": hits * WORK_COSTS["per_hit"],
-        "entries": entries * WORK_COSTS["per_entry"], "windows": ties * WORK_COSTS["per_window"],
+def parse_events(path: Path) -> dict:
+    text = path.read_text()
+    line = [x for x in text.splitlines() if "map stats:" in x][-1]
+
+    def grab(pattern):
+        m = re.search(pattern, line)
+        if not m:
+            raise ValueError(f"{path.name}: no {pattern!r}")
+        return [float(x) for x in m.groups()]
+
+    seg, hits, cand = grab(r"map stats: (\d+) segments at L1 with (\d+) hits, (\d+) candidates")
+    rounds, entries, windows, fine = grab(r"(\d+) rounds, (\d+) stretch entries, (\d+) windows evaluated, (\d+) fine passes")
+    (exact,) = grab(r"(\d+) windows with an exact value")
+    (ended,) = grab(r"(\d+) rounds ended by it")
+    range_entries, ties = grab(r"work model: (\d+) minimizers in the candidates' ranges, (\d+) states tying")
+    one_run, one_run_hits = grab(r"(\d+) segments that are one run of hits \(no L1 scan\) with (\d+) hits")
+    counted, but_one, but_two = grab(r"ordered by counting\): (\d+) segments, all but one hit: (\d+), all but two: (\d+)")
+    ev = {"segments": seg, "seed_hits": hits, "candidates": cand, "rounds": rounds, "rounds_ended_by_the_tight_bound": ended,
+          "full_rounds": rounds - ended, "stretch_entries_ranked": entries, "windows_evaluated": windows, "fine_passes": fine,
+          "windows_with_an_exact_value": exact, "minimizers_in_candidate_ranges": range_entries, "tying_states": ties,
+          "one_run_segments_no_l1_scan": one_run, "their_seed_hits": one_run_hits,
+          "segments_whose_hits_are_one_cluster": counted, "one_cluster_but_one_hit": but_one, "one_cluster_but_two_hits": but_two}
+    sparse = [x for x in text.splitlines() if "sparse stats:" in x]
+    if sparse:
+        m = re.search(r"sparse stats: (\d+) segments with a candidate, (\d+) candidates, (\d+) groups of begins evaluated, (\d+) begins, (\d+) states, (\d+) begins tying", sparse[-1])
+        if m:
+            ev["sparse"] = dict(zip(("segments_with_a_candidate", "candidates", "groups", "begins", "states", "begins_tying_when_folded"), (float(x) for x in m.groups())))
+    m = re.search(r"(\d+) segments of at most 8 hits in the sparse kernel, (\d+) of them handed on", text)
+    if m:
+        ev.setdefault("sparse", {})["segments"] = float(m.group(1))
+        ev["sparse"]["handed_on"] = float(m.group(2))
+    m = re.search(r"(\d+) fragments, (\d+) seed hits", text)
+    if m:
+        ev["fragments"], ev["seed_hits_of_the_batch"] = float(m.group(1)), float(m.group(2))
+    return ev
+
+
+def work_model(cuts: dict, ev: dict, network_valu_per_segment: float | None) -> dict:
+    v = {c: d["SQ_INSTS_VALU"] for c, d in cuts.items()}
+    need = {3, 9, 10, 11, 23, 24}
+    if not need.issubset(v):
+        return {"error": f"cut file lacks cuts {sorted(need - set(v))}"}
+    c, w = ev["candidates"], ev["tying_states"]
+    entries_per_round = ev["stretch_entries_ranked"] / ev["full_rounds"]
+    share = min(1.0, (c * WINDOW_ENTRIES + w) / (c * entries_per_round))
+    parts = {"fixed_up_to_the_candidates_set_up": v[3], "one_round_per_candidate_share_of_one_window_and_the_ties": (v[24] - v[3]) * share}
+    needed = sum(parts.values())
+    per_seg = lambda x: x / ev["segments"]  # noqa: E731
+    out = {
+        "work_model": "vector instructions a dispatch needs with a perfect bound, priced at what the kernel issues as MEASURED per phase (SQ_INSTS_VALU of the kernel "
+        "cut short after each phase, tools/map_cut_valu.sh): everything up to the candidate's set-up as issued (the L1 scan only where a segment takes it) + per "
+        "candidate ONE complete round on the group of the expected optimum (cut 24), scaled by the share of its ranked entries that one window (237) and the further "
+        "tying states are.  profiles/README.md shows the arithmetic",
+        "algorithmic_units_per_dispatch": {k: ev[k] for k in ("segments", "seed_hits", "candidates", "tying_states", "full_rounds", "stretch_entries_ranked",
+                                                               "windows_evaluated", "windows_with_an_exact_value", "one_run_segments_no_l1_scan",
+                                                               "segments_whose_hits_are_one_cluster", "one_cluster_but_one_hit", "one_cluster_but_two_hits")},
+        "valu_instructions_per_phase_per_segment": {
+            "record_and_sketch": per_seg(v[10]), "hits_ordered_and_staged": per_seg(v[11] - v[10]),
+            "sketch_table": per_seg(v[1] - v[11]) if 1 in v else None, "l1": per_seg(v[2] - v[1]) if 1 in v and 2 in v else None,
+            "candidate_set_up": per_seg(v[3] - v[2]) if 2 in v else None,
+            "first_round_bound_stretch_ranks_bitmap": per_seg(v[5] - v[3]) if 5 in v else None,
+            "first_round_items_and_coarse_table": per_seg(v[7] - v[5]) if 5 in v and 7 in v else None,
+            "first_round_window_masks_and_coarse_search": per_seg(v[8] - v[7]) if 7 in v and 8 in v else None,
+            "first_round_fine_passes_and_fold": per_seg(v[24] - v[8]) if 8 in v else None,
+            "rest_of_the_first_group": per_seg(v[23] - v[24]), "other_groups": per_seg(v[9] - v[23]), "whole_kernel": per_seg(v[9])},
+        "entries_ranked_per_full_round": entries_per_round, "entries_of_one_window": WINDOW_ENTRIES, "share_of_a_round_needed": share,
+        "algorithmic_valu_instructions_per_dispatch": needed, "algorithmic_valu_instructions_by_unit": parts,
+        "counted_valu_instructions_per_dispatch": v[9], "frac": needed / v[9], "frac_first_group": v[23] / v[9],
+        "frac_first_group_what": "vector instructions of the kernel when it only ever looks at the group of 64 begins around the expected optimum (cut 23) / instructions issued",
+        "source": "profiles/<tag>_map_cut_valu.txt (tools build) and profiles/<tag>_fragani_n1000_one_batch_trace.txt (stats build): one batch of 2^17 query fragments against the 1 000-genome index",
     }
-    total = sum(parts.values())
-    return {
-        "work_model": "vector instructions a dispatch needs with a perfect bound: each segment set up once, each seed hit ordered and scanned "
-        "once, per candidate the minimizers of one window (237) plus one per further state tying the optimum ranked once, one exact window "
-        "evaluation per tying state; per-unit costs are the kernel's own (static listing x loop trips), profiles/README.md",
-        "algorithmic_units_per_dispatch": {"segments": seg, "seed_hits": hits, "candidates": cand, "tying_states": ties,
-                                           "entries_of_one_window_per_candidate_plus_ties": entries, "minimizers_in_candidate_ranges": range_entries},
-        "valu_instructions_per_unit": WORK_COSTS,
-        "algorithmic_valu_instructions_per_dispatch": total, "algorithmic_valu_instructions_by_unit": parts,
-        "counted_valu_instructions_per_dispatch": valu_instructions,
-        "frac": total / valu_instructions if valu_instructions else None,
-        "events_source": trace_file.name,
-    }
+    if network_valu_per_segment:
+        # the counting sort's price from the mix: (V11 - V10) = counted x a + networked x b, b = the network's measured price
+        counted = ev["segments_whose_hits_are_one_cluster"] + ev["one_cluster_but_one_hit"] + ev["one_cluster_but_two_hits"]
+        networked = max(ev["segments"] - counted, 0.0)
+        a = max(((v[11] - v[10]) - networked * network_valu_per_segment) / counted, 0.0) if counted else None
+        if a is not None:
+            minimal_fixed = v[3] - (v[11] - v[10]) + ev["segments"] * a
+            out["counting_sort_valu_per_segment"] = a
+            out["network_sort_valu_per_segment"] = network_valu_per_segment
+            out["frac_minimal_sort"] = (needed - v[3] + minimal_fixed) / (v[9] - (v[11] - v[10]) + ev["segments"] * a)
+            out["frac_minimal_sort_note"] = ("needed and issued with EVERY segment's hits ordered at the counting sort's price (the network's price per segment: the "
+                                             "all-network build measured at the start of the round, profiles/r06_map_cut_valu_start_of_round.txt)")
+    return out
+
+
+def busy(m: dict) -> dict:
+    cycles = m["GRBM_GUI_ACTIVE"] / XCDS
+    return {"valu_busy": m["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / cycles, "salu_busy": m["SQ_INSTS_SALU"] / CUS / cycles if "SQ_INSTS_SALU" in m else None,
+            "valu_instructions": m["SQ_INSTS_VALU"], "salu_instructions": m.get("SQ_INSTS_SALU"), "lds_instructions": m.get("SQ_INSTS_LDS"),
+            "wait_share": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if "SQ_WAIT_ANY" in m else None,
+            "waves_per_simd": m["SQ_WAVE_CYCLES"] * 4 / SIMDS / cycles,  # SQ_* cycle counters are in quad-cycles
+            "avg_ms_per_dispatch": m["duration_ms"],
+            "fetch_bytes_per_dispatch_as_counted": m.get("FETCH_SIZE", 0.0) * 1024, "write_bytes_per_dispatch": m.get("WRITE_SIZE", 0.0) * 1024}
+
+
+def parse_calibration(path: Path) -> dict:
+    out = {}
+    for line in path.read_text().splitlines():
+        m = re.match(r"(calib_\S+(?: \S+)?): bytes asked (\S+), .* = (\S+), FETCH_SIZE counted (\S+) bytes -> counted / asked = (\S+), counted / line bytes = (\S+)", line)
+        if m:
+            out[m.group(1).rstrip(":")] = {"bytes_asked": float(m.group(2).rstrip(",")), "line_bytes": float(m.group(3).rstrip(",")),
+                                           "counted": float(m.group(4)), "counted_over_asked": float(m.group(5).rstrip(",")), "counted_over_line_bytes": float(m.group(6))}
+    return out
+
+
+def build(tag: str, root: Path = ROOT) -> dict:
+    what = "tools/bench_fragani.py 1000 0 interleaved 78 (the benchmark's 1 000 genomes, one batch of 2^17 query fragments)"
+    ev = parse_events(root / f"{tag}_fragani_n1000_one_batch_trace.txt")
+    cuts = parse_cuts(root / f"{tag}_map_cut_valu.txt")
+    start = root / "r06_map_cut_valu_start_of_round.txt"
+    network = None
+    if start.is_file():
+        sc = parse_cuts(start)
+        network = (sc[11]["SQ_INSTS_VALU"] - sc[10]["SQ_INSTS_VALU"]) / sc[10]["SQ_WAVES"]
+    m = parse(root / f"{tag}_pmc_map_segments_summary.txt")
+    out = {"map_segments_kernel": {"source": f"rocprofv3 --pmc passes of {what} ({tag}_pmc_map_segments_summary.txt); not measured inside this run", **busy(m)}}
+    out["map_segments_kernel"]["valu_instructions_per_segment"] = m["SQ_INSTS_VALU"] / ev["segments"]
+    out["map_segments_kernel"]["work"] = work_model(cuts, ev, network)
+    sp_file = root / f"{tag}_pmc_map_sparse_summary.txt"
+    if sp_file.is_file():
+        sp = parse(sp_file)
+        entry = {"source": f"rocprofv3 --pmc passes of {what} ({sp_file.name}); event counts of the stats build; not measured inside this run", **busy(sp)}
+        se = ev.get("sparse", {})
+        if se.get("segments"):
+            entry["segments_per_dispatch"] = se["segments"]
+            entry["valu_instructions_per_segment"] = sp["SQ_INSTS_VALU"] / se["segments"]
+        if se.get("states"):
+            # work-based: the states a perfect bound still evaluates are those of the begins that tie their candidate's best (every one of
+            # them decides the mapping's position); the kernel evaluates every state of every begin that holds enough hits
+            entry["events_per_dispatch"] = se
+            entry["valu_instructions_per_state_evaluated"] = sp["SQ_INSTS_VALU"] / se["states"]
+            entry["states_per_begin"] = se["states"] / se["begins"]
+            tying_states = se["begins_tying_when_folded"] * se["states"] / se["begins"]
+            entry["frac"] = tying_states / se["states"]
+            entry["frac_what"] = ("work-based, in states: states of the begins that tie their candidate's best when their group is folded (what no bound can spare: their positions "
+                                  "decide the mapping's) / states evaluated; the kernel's instructions are proportional to the states it evaluates (valu_busy is the pipe's share)")
+        out["map_sparse_kernel"] = entry
+    mi_file = root / f"{tag}_pmc_minimizer_summary.txt"
+    if mi_file.is_file():
+        mi = parse(mi_file)
+        entry = {"source": f"rocprofv3 --pmc passes of {what} ({mi_file.name}); not measured inside this run", **busy(mi)}
+        # 1 000 x 5 Mb: tiles of 1 920 own positions (2 048 hashed: 128 of look-back), two MurmurHash3_x64_128 of 16 bytes per position
+        positions = 1000 * 5_000_064
+        entry["arena_positions"] = positions
+        entry["valu_instructions_per_position"] = mi["SQ_INSTS_VALU"] * 64 / positions
+        # needed: the two hashes of every position, at the kernel's own 126 vector instructions per position and lane for them
+        # (static listing, lines of the hashing loop: 1 008 per eight positions), once per position (no look-back, nothing else)
+        entry["hash_valu_instructions_per_position"] = 126.0
+        entry["frac"] = 126.0 / entry["valu_instructions_per_position"]
+        entry["frac_what"] = ("work-based: vector instructions of the two MurmurHash3 per position (126 per position: the kernel's own hashing loop) / vector instructions "
+                              "issued per position (look-back positions hashed twice, winnowing, contig bookkeeping, the chained scan); valu_busy is the pipe's share")
+        entry["algorithmic_gbs"] = (positions / 4 + 12 * 4.0e8) / (mi["duration_ms"] * 1e-3) / 1e9
+        entry["algorithmic_bytes_note"] = "2 bits per position read + three 4-byte arrays written per minimizer (4*10^8 of them): nowhere near an HBM roof"
+        out["minimizer_kernel"] = entry
+    b = parse(root / f"{tag}_pmc_bucket_hits_summary.txt")
+    hits = ev.get("seed_hits_of_the_batch")
+    cal_file = root / f"{tag}_fetch_calibration.txt"
+    cal = parse_calibration(cal_file) if cal_file.is_file() else {}
+    fetch_counted = b["FETCH_SIZE"] * 1024
+    write = b["WRITE_SIZE"] * 1024
+    entry = {"source": f"rocprofv3 --pmc passes of {what} ({tag}_pmc_bucket_hits_summary.txt); FETCH_SIZE corrected by the factors measured for this access pattern "
+                       f"({cal_file.name}: tools/fetch_calib); not measured inside this run", **busy(b)}
+    if hits:
+        entry["seed_hits_per_dispatch"] = hits
+        entry["algorithmic_bytes_per_hit"] = 18.0  # the posting's 2-byte genome (counting pass) + the 8-byte posting (scatter pass) + one 8-byte hit written
+        entry["algorithmic_gbs"] = 18.0 * hits / (b["duration_ms"] * 1e-3) / 1e9
+        entry["fetch_bytes_per_hit_as_counted"] = fetch_counted / hits
+        k16, k64 = cal.get("calib_runs<unsigned short>"), cal.get("calib_runs<unsigned long>")
+        if k16 and k64:
+            # The kernel asks for 2 + 8 bytes per hit in runs like the calibration's; the counter reports f16 x 2 + f64 x 8 counted bytes
+            # per hit for them: the factor that turns counted bytes into 64-byte lines actually moved is the calibration's own
+            # (counted -> line bytes), weighted by what each pass contributes to the count.
+            c16, c64 = 2.0 * k16["counted_over_asked"], 8.0 * k64["counted_over_asked"]  # counted bytes per hit the two passes are expected to give
+            lines16, lines64 = c16 / k16["counted_over_line_bytes"], c64 / k64["counted_over_line_bytes"]  # 64-byte lines x 64 per hit behind them
+            factor = (lines16 + lines64) / (c16 + c64)
+            entry["fetch_calibration"] = {"counted_over_asked_2_byte_runs": k16["counted_over_asked"], "counted_over_asked_8_byte_runs": k64["counted_over_asked"],
+                                          "counted_over_line_bytes_2_byte_runs": k16["counted_over_line_bytes"], "counted_over_line_bytes_8_byte_runs": k64["counted_over_line_bytes"],
+                                          "expected_counted_bytes_per_hit": c16 + c64, "line_bytes_per_counted_byte": factor}
+            entry["fetch_bytes_per_hit_calibrated"] = fetch_counted / hits * factor
+            entry["counter_bytes_per_hit"] = (fetch_counted * factor + write) / hits
+            entry["counter_gbs"] = (fetch_counted * factor + write) / (b["duration_ms"] * 1e-3) / 1e9
+            entry["traffic_over_algorithmic"] = entry["counter_bytes_per_hit"] / 18.0
+        else:
+            entry["counter_bytes_per_hit"] = (fetch_counted + write) / hits
+            entry["counter_gbs"] = (fetch_counted + write) / (b["duration_ms"] * 1e-3) / 1e9
+        entry["write_bytes_per_hit"] = write / hits
+    out["bucket_hits_kernel"] = entry
+    out["tag"] = tag
+    return out
 
 
 def main() -> None:
-    map_file, bucket_file = Path(sys.argv[1]), Path(sys.argv[2])
-    hits_per_dispatch = float(sys.argv[3]) if len(sys.argv) > 3 else None
-    what = sys.argv[4] if len(sys.argv) > 4 else "tools/bench_fragani.py 1000 0 interleaved 78 (the benchmark's 1 000 genomes, one batch of 2^17 query fragments)"
-    trace_file = Path(sys.argv[5]) if len(sys.argv) > 5 else None
-    m, b = parse(map_file), parse(bucket_file)
-    cycles = m["GRBM_GUI_ACTIVE"] / XCDS
-    out = {
-        "map_segments_kernel": {
-            "source": f"rocprofv3 --pmc passes of {what} ({map_file.name}); not measured inside this run",
-            "valu_busy": m["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / cycles,
-            "salu_busy": m["SQ_INSTS_SALU"] / CUS / cycles,
-            "valu_instructions": m["SQ_INSTS_VALU"], "salu_instructions": m["SQ_INSTS_SALU"],
-            "wait_share": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
-            "waves_per_simd": m["SQ_WAVE_CYCLES"] * 4 / SIMDS / cycles,  # SQ_* cycle counters are in quad-cycles
-            "avg_ms_per_dispatch": m["duration_ms"],
-            # the kernel's own results are a few MB per dispatch: what FETCH_SIZE / WRITE_SIZE count beyond the stretches it
-            # reads is its register spill traffic (scratch memory, 72 bytes per lane in round 4)
-            "fetch_bytes_per_dispatch_as_counted": m.get("FETCH_SIZE", 0.0) * 1024, "write_bytes_per_dispatch": m.get("WRITE_SIZE", 0.0) * 1024,
-        },
-    }
-    if trace_file is not None:
-        out["map_segments_kernel"]["work"] = work_model(trace_file, m["SQ_INSTS_VALU"])
-    cyc_b = b["GRBM_GUI_ACTIVE"] / XCDS
-    # FETCH_SIZE / WRITE_SIZE are KiB per dispatch.  The guide's gfx950 rule (FETCH_SIZE reports half the bytes) is
-    # calibrated for wide coalesced streaming reads; this kernel reads 2- and 8-byte items scattered over short lists,
-    # "other access widths are uncalibrated": both readings are given, the counted one first.
-    fetch = b["FETCH_SIZE"] * 1024 * 2
-    write = b["WRITE_SIZE"] * 1024
-    entry = {
-        "source": f"rocprofv3 --pmc passes of {what} ({bucket_file.name}); FETCH_SIZE as counted and doubled (the gfx950 rule is "
-        "calibrated for wide streaming reads only); not measured inside this run",
-        "fetch_bytes_per_dispatch_as_counted": fetch / 2, "write_bytes_per_dispatch": write, "avg_ms_per_dispatch": b["duration_ms"],
-        "counter_gbs": (fetch / 2 + write) / (b["duration_ms"] * 1e-3) / 1e9,
-        "counter_gbs_fetch_doubled": (fetch + write) / (b["duration_ms"] * 1e-3) / 1e9,
-        "valu_busy": b["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / cyc_b,
-        "wait_share": b["SQ_WAIT_ANY"] / b["SQ_WAVE_CYCLES"],
-    }
-    if hits_per_dispatch:
-        entry["seed_hits_per_dispatch"] = hits_per_dispatch
-        entry["algorithmic_bytes_per_hit"] = 18.0  # the posting's 2-byte genome (counting pass) + the 8-byte posting (scatter pass) + one 8-byte hit written
-        entry["counter_bytes_per_hit"] = (fetch / 2 + write) / hits_per_dispatch  # FETCH_SIZE as counted (the x2 rule is calibrated for wide streaming reads only)
-        entry["counter_bytes_per_hit_fetch_doubled"] = (fetch + write) / hits_per_dispatch
-        entry["algorithmic_gbs"] = 18.0 * hits_per_dispatch / (b["duration_ms"] * 1e-3) / 1e9
-    out["bucket_hits_kernel"] = entry
-    json.dump(out, sys.stdout, indent=1)
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
+    json.dump(build(tag), sys.stdout, indent=1)
     print()
 
 
