@@ -372,7 +372,9 @@ int run_minimizers(pa_ctx *c, FragWork &W, const uint32_t *d_packed, const uint3
     PA_HIP(hipMemcpyAsync(c->h_pinned, W.scalars.p, 16, hipMemcpyDeviceToHost, c->stream));
     PA_HIP(hipStreamSynchronize(c->stream));
     const uint32_t *h = reinterpret_cast<const uint32_t *>(c->h_pinned);
-    if (h[2] != 0 && ticket_mode != 0) {  // a wait ran out with the tiles drawn per XCD: once more, from one counter
+    bool ran_out = h[2] != 0;
+    if (const char *v = PA_TOOL_ENV("PA_FRAGANI_TICKET_TIMEOUT")) { if (atoi(v) && ticket_mode != 0) ran_out = true; }  // tests: as if a wait had run out
+    if (ran_out && ticket_mode != 0) {  // a wait ran out with the tiles drawn per XCD: once more, from one counter
       ticket_mode = 0;
       --attempt;
       continue;
@@ -712,11 +714,16 @@ static int fragani_ex_impl(pa_ctx *c, const uint32_t *d_packed, const uint32_t *
       PA_REQUIRE(n_ids < (1u << 31), "pa_fragani: %u distinct minimizer hashes (limit 2^31)", n_ids);
       PA_TRY(W.post_start.reserve((uint64_t)(n_ids + 2) * 4));
       PA_TRY(W.uniq_hash.reserve((uint64_t)(n_ids + 2) * 4));
+      // (the contig of every block of minimizers: the look-back words of minimizer_kernel are free again)
+      const uint32_t n_blocks = (uint32_t)(((uint64_t)m + (1u << kContigBlockShift) - 1u) >> kContigBlockShift);
+      PA_TRY(W.block_counts.reserve((uint64_t)n_blocks * 4 + 16));
+      hipLaunchKernelGGL(block_contig_kernel, dim3(ceil_div_u64(n_blocks, kThreads)), dim3(kThreads), 0, c->stream, W.mini_contig.as<uint32_t>(), m,
+                         W.block_counts.as<uint32_t>());
       hipLaunchKernelGGL(postings_kernel, dim3(gm), dim3(kThreads), 0, c->stream, keys[which], vals[which], d_flags, d_pos, md,
                          n_ids, W.mini_contig.as<uint32_t>(), W.mini_id.as<uint32_t>(), W.post_start.as<uint32_t>(),
                          W.prev_same.as<int32_t>(), W.mini_wpos.as<uint32_t>(), W.contig_genome.as<uint32_t>(),
                          W.post_cw.as<uint64_t>(), W.post_g.as<uint16_t>(), W.contig_mini_off.as<uint32_t>(), n_contigs,
-                         W.uniq_hash.as<uint32_t>());
+                         W.uniq_hash.as<uint32_t>(), W.block_counts.as<uint32_t>());
       PA_TRY(cut_frequent_postings(c, W, d_flags, d_pos, vals[which], vals[1 - which], reinterpret_cast<uint32_t *>(keys[1 - which]), md, n_ids,
                                    h_contig_genome, n_contigs, n_genomes));
     } else {  // the reference genomes hold no minimizer: an empty dictionary
