@@ -108,9 +108,13 @@ Other kernels of the path (`fragani_counters.json`):
   counter's throughput; all eight k-mers of a thread hashed side by side (102 registers, 4 waves per SIMD): 46.8 ms against 39.9 for four at a time (80 registers);
 * the last L1 turn's one candidate handed to the evaluation straight from the scan's registers instead of through the list and the parked state in LDS: 126 -> 128
   registers, four spilled, mapping 364 ms against 359;
+* the groups of begins next to the optimum's asked the tight bound against the stretch the group before has left in LDS (its entries below the pivot hash kept as
+  bits), before they load a stretch of their own: the kept stretch holds 75-100 % of such a begin's narrowest window and the bound needs nearly all of it -- 31 of
+  106 million begins dropped, 0.80 of 3.51 million groups ended there (rounds 6.85 -> 5.93 million per batch), the other groups pay the test twice: mapping 373 ms against 353;
 * what the phase cuts promised and the A/Bs gave: ordering by counting, cluster alone: -5.5 ms of mapping (cut: 14 of 28); with strays -7.5 more; the L1 scan skipped for a run
   with strays: -1.4 (the cut's L1 phase is 21 ms, most of it the candidate's hand-over through LDS, which stays); in the sparse kernel the hits marked by position and one
-  comparison per entry and hit instead of three: 3.39 -> 3.28 ms per batch; `postings_kernel`'s contig from a per-block table instead of a search: 19.2 -> 18.1 ms; the host's
+  comparison per entry and hit instead of three: 3.39 -> 3.28 ms per batch, the end of a begin's last window taken from the next begin's search and the hit's
+  allowance computed once per begin instead of once per pair of states: 3.30 -> 3.16; `postings_kernel`'s contig from a per-block table instead of a search: 19.2 -> 18.1 ms; the host's
   fragment bookkeeping done while the minimizer kernel runs and its k-dependent tables made once per context: -6 ms per run.
 
 '''
