@@ -1137,7 +1137,7 @@ def test_work_based_roofline_is_reproducible_from_the_committed_profiles():
     # ---- map_sparse_kernel: states of the begins that tie / states evaluated
     sp = committed["map_sparse_kernel"]
     se = ev["sparse"]
-    assert abs(sp["frac"] - se["begins_tying_when_folded"] / se["begins"]) < 1e-12 and 0.3 < sp["frac"] <= 1.0 and sp["valu_busy"] > 0.9
+    assert abs(sp["frac"] - se["begins_tying_when_folded"] / se["begins"]) < 1e-12 and 0.3 < sp["frac"] <= 1.0 and sp["valu_busy"] > 0.8
     # ---- minimizer_kernel: the two hashes per position / instructions issued per position
     mi = committed["minimizer_kernel"]
     issued = tool.parse(prof / f"{tag}_pmc_minimizer_summary.txt")["SQ_INSTS_VALU"] * 64 / (1000 * 5_000_064)
