@@ -58,6 +58,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
   return x;
 }
 
+// inclusive prefix sums over each row of 16 lanes (four independent scans)
+__device__ __forceinline__ uint32_t row_incl_scan_dpp(uint32_t v) {
+  uint32_t x = v;
+  x += dpp_or_zero<kDppRowShr + 1>(v);
+  x += dpp_or_zero<kDppRowShr + 2>(v);
+  x += dpp_or_zero<kDppRowShr + 3>(v);
+  x += dpp_or_zero<kDppRowShr + 4, 0xf, 0xe>(x);
+  x += dpp_or_zero<kDppRowShr + 8, 0xf, 0xc>(x);
+  return x;
+}
+
 // inclusive prefix maximum over the 64 lanes (unsigned; lanes a step does not reach take 0, the identity)
 __device__ __forceinline__ uint32_t wave_incl_max_scan_dpp(uint32_t v) {
   uint32_t x = v;

@@ -111,10 +111,14 @@ Other kernels of the path (`fragani_counters.json`):
 * the groups of begins next to the optimum's asked the tight bound against the stretch the group before has left in LDS (its entries below the pivot hash kept as
   bits), before they load a stretch of their own: the kept stretch holds 75-100 % of such a begin's narrowest window and the bound needs nearly all of it -- 31 of
   106 million begins dropped, 0.80 of 3.51 million groups ended there (rounds 6.85 -> 5.93 million per batch), the other groups pay the test twice: mapping 373 ms against 353;
+* in the group of the expected optimum, a first round that takes the 64 states AROUND the optimum instead of the first 64 in slide order (so that the begins
+  left over are as far from it as can be on both sides): 11.76 ms per dispatch against 11.48 -- the left-overs on the left were evaluated for free before;
 * what the phase cuts promised and the A/Bs gave: ordering by counting, cluster alone: -5.5 ms of mapping (cut: 14 of 28); with strays -7.5 more; the L1 scan skipped for a run
   with strays: -1.4 (the cut's L1 phase is 21 ms, most of it the candidate's hand-over through LDS, which stays); in the sparse kernel the hits marked by position and one
   comparison per entry and hit instead of three: 3.39 -> 3.28 ms per batch, the end of a begin's last window taken from the next begin's search and the hit's
-  allowance computed once per begin instead of once per pair of states: 3.30 -> 3.16; `postings_kernel`'s contig from a per-block table instead of a search: 19.2 -> 18.1 ms; the host's
+  allowance computed once per begin instead of once per pair of states: 3.30 -> 3.16, the one lane's own search done by the wave: -> 3.06, and the groups of
+  begins between two tying begins left out (only the first and the last tying state count): -> 2.78, the hits' prefix counts scanned four hits at a time in rows of sixteen lanes and the
+  second state of a pair counted from the first: -> 2.63; `postings_kernel`'s contig from a per-block table instead of a search: 19.2 -> 18.1 ms; the host's
   fragment bookkeeping done while the minimizer kernel runs and its k-dependent tables made once per context: -6 ms per run.
 
 '''
