@@ -921,8 +921,8 @@ def also_fragani(engine, arena, args, n_total, lengths) -> dict:
             out["roofline_sparse"] = {
                 "kernel": "map_sparse_kernel", "bound": "valu-issue", "frac": sc.get("frac"), "frac_what": sc.get("frac_what"), "valu_busy": sc.get("valu_busy"),
                 "valu_instructions_per_segment": sc.get("valu_instructions_per_segment"), "valu_instructions_per_state_evaluated": sc.get("valu_instructions_per_state_evaluated"),
-                "events_per_dispatch": sc.get("events_per_dispatch"), "avg_ms_per_dispatch": sc.get("avg_ms_per_dispatch"), "waves_per_simd": sc.get("waves_per_simd"),
-                "source": sc.get("source"),
+                "events_per_dispatch": sc.get("events_per_dispatch"), "groups_of_begins_per_segment": sc.get("groups_per_segment"),
+                "avg_ms_per_dispatch": sc.get("avg_ms_per_dispatch"), "waves_per_simd": sc.get("waves_per_simd"), "source": sc.get("source"),
             }
         ic = (counters or {}).get("minimizer_kernel", {})
         if ic:

@@ -1134,10 +1134,11 @@ def test_work_based_roofline_is_reproducible_from_the_committed_profiles():
     # the product build's own counter pass agrees with the tools build's uncut run within the cut checks' few instructions
     product = tool.parse(prof / f"{tag}_pmc_map_segments_summary.txt")["SQ_INSTS_VALU"]
     assert committed["map_segments_kernel"]["valu_instructions"] == product and abs(product / v[9] - 1.0) < 0.03
-    # ---- map_sparse_kernel: states of the begins that tie / states evaluated
+    # ---- map_sparse_kernel: groups that hold a candidate's first or last tying begin / groups evaluated
     sp = committed["map_sparse_kernel"]
     se = ev["sparse"]
-    assert abs(sp["frac"] - se["begins_tying_when_folded"] / se["begins"]) < 1e-12 and 0.3 < sp["frac"] <= 1.0 and sp["valu_busy"] > 0.8
+    assert abs(sp["frac"] - se["groups_with_the_first_or_last_tie"] / se["groups"]) < 1e-12 and 0.3 < sp["frac"] <= 1.0 and sp["valu_busy"] > 0.8
+    assert se["candidates"] <= se["groups_with_the_first_or_last_tie"] <= 2 * se["candidates"]  # one or two per candidate
     # ---- minimizer_kernel: the two hashes per position / instructions issued per position
     mi = committed["minimizer_kernel"]
     issued = tool.parse(prof / f"{tag}_pmc_minimizer_summary.txt")["SQ_INSTS_VALU"] * 64 / (1000 * 5_000_064)

@@ -95,7 +95,7 @@ The product build's own counter pass ({ms["valu_instructions"]:.4g}) sits 2 % be
 
 Other kernels of the path (`fragani_counters.json`):
 
-* `map_sparse_kernel` (`roofline_sparse`): VALUBusy {sp["valu_busy"]:.2f} -- instructions are time --, {sp["valu_instructions_per_segment"]:.0f} vector instructions per segment = {sp["valu_instructions_per_state_evaluated"]:.2f} per state evaluated ({sp["events_per_dispatch"]["states"]:.4g} states of {sp["events_per_dispatch"]["begins"]:.4g} begins in {sp["events_per_dispatch"]["groups"]:.4g} groups per dispatch).  Work-based `frac` = the states of the begins that tie their candidate's best when their group is folded / states evaluated = **{sp["frac"]:.2f}**: with two to eight hits nearly every window that holds them ties, which is why no bound helps this kernel and why its price per segment is a general segment's.
+* `map_sparse_kernel` (`roofline_sparse`): VALUBusy {sp["valu_busy"]:.2f} -- instructions are time --, {sp["valu_instructions_per_segment"]:.0f} vector instructions per segment = {sp["valu_instructions_per_state_evaluated"]:.2f} per state evaluated ({sp["events_per_dispatch"]["states"]:.4g} states of {sp["events_per_dispatch"]["begins"]:.4g} begins in {sp["events_per_dispatch"]["groups"]:.4g} groups per dispatch).  Work-based `frac` = groups that hold a candidate's first or last tying begin / groups evaluated = **{sp["frac"]:.2f}** ({sp["groups_per_segment"]:.1f} groups per segment, 3.9 at the start of the round): with two to eight hits nearly every window that holds them ties, and of the ties only the first and the last decide the position -- the kernel now starts at the first hit's group and leaves out the begins between two known ties unless they hold more hits than those share.  What is left: in two candidates of three one of the hits is shared by no window (its hash lies too high in the union), so the begins that hold every hit could share more by the count of their hits and are all evaluated; ruling them out needs the hit's count over every window, which is the evaluation.
 * `minimizer_kernel<16>` (`roofline_index`): {mi["valu_instructions_per_position"]:.0f} vector instructions per position of which the two MurmurHash3 are 126 (the kernel's own hashing loop) -> `frac` **{mi["frac"]:.2f}**, VALUBusy {mi["valu_busy"]:.2f}; 0.2 TB/s of algorithmic bytes: not an HBM kernel.
 * `bucket_hits_staged_kernel` (`roofline_seeding`): 18 algorithmic bytes per hit / {bh["avg_ms_per_dispatch"]:.2f} ms = {bh["algorithmic_gbs"] / 1000:.2f} TB/s = **{bh["algorithmic_gbs"] / 8000:.3f} of the HBM roof**; traffic: FETCH_SIZE {bh["fetch_bytes_per_hit_as_counted"]:.1f} counted bytes per hit x {bh["fetch_calibration"]["line_bytes_per_counted_byte"]:.3f} (the calibration's lines per counted byte for this mix of 2- and 8-byte runs) = {bh["fetch_bytes_per_hit_calibrated"]:.1f} + WRITE_SIZE {bh["write_bytes_per_hit"]:.1f} = **{bh["counter_bytes_per_hit"]:.1f} bytes per hit = {bh["traffic_over_algorithmic"]:.2f} x algorithmic** -- one calibrated number where round 5 gave two (1.13 x as counted, 1.81 x doubled).  The excess is the lines' unused halves: a run of eighteen 2-byte genomes is 36 bytes in a 64-byte line.
 

@@ -91,6 +91,9 @@ def parse_events(path: Path) -> dict:
         m = re.search(r"sparse stats: (\d+) segments with a candidate, (\d+) candidates, (\d+) groups of begins evaluated, (\d+) begins, (\d+) states, (\d+) begins tying", sparse[-1])
         if m:
             ev["sparse"] = dict(zip(("segments_with_a_candidate", "candidates", "groups", "begins", "states", "begins_tying_when_folded"), (float(x) for x in m.groups())))
+        m = re.search(r"(\d+) groups that hold a candidate's first or last tying begin", sparse[-1])
+        if m and "sparse" in ev:
+            ev["sparse"]["groups_with_the_first_or_last_tie"] = float(m.group(1))
     m = re.search(r"(\d+) segments of at most 8 hits in the sparse kernel, (\d+) of them handed on", text)
     if m:
         ev.setdefault("sparse", {})["segments"] = float(m.group(1))
@@ -192,15 +195,18 @@ def build(tag: str, root: Path = ROOT) -> dict:
             entry["segments_per_dispatch"] = se["segments"]
             entry["valu_instructions_per_segment"] = sp["SQ_INSTS_VALU"] / se["segments"]
         if se.get("states"):
-            # work-based: the states a perfect bound still evaluates are those of the begins that tie their candidate's best (every one of
-            # them decides the mapping's position); the kernel evaluates every state of every begin that holds enough hits
+            # work-based, in groups of 64 begins (the unit the kernel loads a stretch and builds its bit masks for): of the states that
+            # tie a candidate's best only the first and the last decide the mapping's position, so what any order of evaluation has to
+            # load is the one or two groups that hold them; the kernel also evaluates the groups it cannot rule out beforehand
             entry["events_per_dispatch"] = se
             entry["valu_instructions_per_state_evaluated"] = sp["SQ_INSTS_VALU"] / se["states"]
             entry["states_per_begin"] = se["states"] / se["begins"]
-            tying_states = se["begins_tying_when_folded"] * se["states"] / se["begins"]
-            entry["frac"] = tying_states / se["states"]
-            entry["frac_what"] = ("work-based, in states: states of the begins that tie their candidate's best when their group is folded (what no bound can spare: their positions "
-                                  "decide the mapping's) / states evaluated; the kernel's instructions are proportional to the states it evaluates (valu_busy is the pipe's share)")
+            entry["groups_per_segment"] = se["groups"] / se["segments_with_a_candidate"]
+            if se.get("groups_with_the_first_or_last_tie"):
+                entry["frac"] = se["groups_with_the_first_or_last_tie"] / se["groups"]
+                entry["frac_what"] = ("work-based, in groups of 64 begins: groups that hold a candidate's first or last tying begin (the two states that decide the mapping's "
+                                      "position: what any order of evaluation has to load) / groups evaluated; the kernel's instructions are proportional to the groups it "
+                                      "evaluates (valu_busy is the pipe's share)")
         out["map_sparse_kernel"] = entry
     mi_file = root / f"{tag}_pmc_minimizer_summary.txt"
     if mi_file.is_file():
