@@ -1169,8 +1169,8 @@ static int fragani_ex_impl(pa_ctx *c, const uint32_t *d_packed, const uint32_t *
                 st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], st[9], st[10], st[11], st[12], st[13], st[14], st[15], st[16], st[17],
                 st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27], st[28], st[29], st[30], st[31], st[32], st[33], st[40], st[39], st[37], st[38], st[41], st[42], st[46], st[43], st[44], st[45]);
         fprintf(stderr, "pa_fragani: sparse stats: %u segments with a candidate, %u candidates, %u groups of begins evaluated, %u begins, %u states, %u begins tying "
-                        "their candidate's best when folded; %u one-run segments with strays; %u begins with enough hits left out because they lie between two tying begins and hold no more hits than those share, %u groups between the ties passed over unseen, %u groups that hold a candidate's first or last tying begin\n",
-                st[48], st[49], st[50], st[51], st[52], st[53], st[47], st[58], st[59], st[54]);
+                        "their candidate's best when folded; %u one-run segments with strays; %u begins with enough hits left out because they lie between two tying begins and hold no more hits than those share, %u groups between the ties passed over unseen, %u groups that hold a candidate's first or last tying begin, %u candidates whose first hit lies past the batch of 512 window ids\n",
+                st[48], st[49], st[50], st[51], st[52], st[53], st[47], st[58], st[59], st[54], st[55]);
       }
 #endif
     }

@@ -989,3 +989,52 @@ def test_sparse_segments_equal_the_general_kernel(tools_engine, monkeypatch):
     total, matched, _ = _check_against_oracle(engine, texts, contig_lists)
     assert matched[0, 4] > 0 and matched[4, 0] > 0  # the most diverged pair still maps fragments: through the sparse kernel
     _check_against_oracle(engine, texts, contig_lists, frag=1000, k=15)
+
+
+@pytest.mark.gpu
+def test_sparse_segments_next_to_low_complexity_sequence(tools_engine, monkeypatch):
+    """The sparse kernel starts a candidate at the group of begins at its first seed hit, which it finds among the 512 window
+    ids it loads from the start of the candidate's range -- or, when the range holds more minimizers than that before the
+    hit, through the bucket index.  Random sequence never does (a fragment holds ~240 minimizers whatever its length); a
+    homopolymer run or an array of a short unit in the REFERENCE does, one minimizer per position.  Diverged pairs (a handful
+    of hits per fragment) with such runs a few hundred to two thousand residues before the matching sequence: the same
+    integers and float sums with and without the sparse kernel, and the oracle's."""
+    engine = tools_engine
+    from pyani_plus_amd.engine import pack_genomes
+
+    rng = np.random.default_rng(626)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n: int) -> np.ndarray:
+        return rng.choice(acgt, size=n)
+
+    def run_of(unit: bytes, n: int) -> np.ndarray:
+        return np.frombuffer((unit * (n // len(unit) + 1))[:n], dtype=np.uint8)
+
+    parts, marks = [], []
+    for unit, n, gap in ((b"A", 1_500, 300), (b"AC", 1_400, 1_200), (b"T", 2_600, 2_000), (b"AAC", 900, 100), (b"G", 700, 2_600)):
+        parts += [rnd(int(rng.integers(4_000, 9_000))), run_of(unit, n)]
+        marks.append(gap)
+    parts.append(rnd(8_000))
+    root = np.concatenate(parts)
+    genomes = [root]
+    for rate in (0.14, 0.18, 0.22):
+        seq = root.copy()
+        hit = rng.random(seq.size) < rate
+        seq[hit] = acgt[rng.integers(0, 4, size=int(hit.sum()))]
+        genomes.append(seq)
+    texts = [b">g%d\n" % i + g.tobytes() + b"\n" for i, g in enumerate(genomes)]
+    contig_lists = [[g.tobytes()] for g in genomes]
+    arena = pack_genomes(texts)
+    dev = engine.upload(arena)
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PA_FRAGANI_SPARSE", mode)
+        results[mode] = engine.fragani(dev, arena.contig_start, arena.contig_len, arena.contig_genome, K, FRAG)
+    for a, b in zip(results["1"], results["0"]):
+        assert np.array_equal(a, b)
+    monkeypatch.setenv("PA_FRAGANI_SPARSE", "1")
+    total, matched, _ = _check_against_oracle(engine, texts, contig_lists)
+    assert matched[3, 0] > 0 and matched[0, 3] > 0
+    _check_against_oracle(engine, texts, contig_lists, frag=1000, k=14)
+
